@@ -1,0 +1,144 @@
+/*
+ * lspiv.h -- C ABI of liblspiv_hip.so, the MI355X (gfx950) LSPIV cross-correlation engine.
+ *
+ * This is the drop-in boundary for the hot path behind pyorc's Frames.get_piv().  The
+ * reference has no native boundary at all: the seam is the Python-level `engine` string
+ * (pyorc/api/frames.py:118,176-177) that is forwarded to pyorc/velocimetry/ffpiv.py and
+ * from there to six symbols of the third-party `ffpiv` package.  Every entry point below
+ * names the reference call it replaces.  INTEGRATION.md shows the ctypes binding and the
+ * five-line patch a pyorc maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; all arrays are C-contiguous, caller-allocated, never retained;
+ *   - frames are (T, H, W) of dtype LSPIV_U8 / LSPIV_F32 / LSPIV_F64; a stack of T frames
+ *     holds P = T-1 pairs (pair p = frames p and p+1, labelled with frame p+1's time stamp,
+ *     pyorc/velocimetry/ffpiv.py:403);
+ *   - window index is row-major k*n_cols+m (pyorc/velocimetry/ffpiv.py:469);
+ *   - every function returns LSPIV_OK (0) or a negative status; lspiv_last_error() returns
+ *     the thread-local message of the last failure on this thread;
+ *   - "_dev" variants take DEVICE pointers (HBM-resident stacks, multi-GPU shards) and a
+ *     stream handle (NULL = the library's own per-device stream); host variants stage
+ *     through pinned buffers and synchronise before returning;
+ *   - NaN conventions follow the reference: skipped / invalid windows yield NaN, never an
+ *     error (pyorc/velocimetry/ffpiv.py:93-97,465-466).
+ */
+#ifndef LSPIV_H
+#define LSPIV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSPIV_ABI_VERSION 1
+
+/* status codes (mapped by the Python shim onto the reference's exception types) */
+#define LSPIV_OK            0
+#define LSPIV_EINVAL       -1  /* bad argument                      -> ValueError    */
+#define LSPIV_ESHAPE       -2  /* frame smaller than window, T < 2  -> ValueError    */
+#define LSPIV_ENOMEM       -3  /* HBM / pinned allocation failed    -> MemoryError   */
+#define LSPIV_EHIP         -4  /* HIP runtime error                 -> RuntimeError  */
+#define LSPIV_ENODEV       -5  /* no gfx950 device visible          -> RuntimeError  */
+#define LSPIV_EUNSUPPORTED -6  /* window size outside kernel range  -> ValueError    */
+
+/* frame dtypes (pyorc frame stacks are uint8 after normalize/project_cv, float32 after
+ * edge_detect/smooth/time_diff, float64 out of project_numpy) */
+#define LSPIV_U8  0
+#define LSPIV_F32 1
+#define LSPIV_F64 2
+
+/* largest interrogation window side the kernels accept (even sizes 4..LSPIV_MAX_WINDOW) */
+#define LSPIV_MAX_WINDOW 64
+
+/* ---------------------------------------------------------------- library / device ------- */
+int         lspiv_abi_version(void);
+const char* lspiv_version(void);
+const char* lspiv_last_error(void);
+int         lspiv_device_count(int* n);                 /* 0 devices is LSPIV_OK with *n = 0 */
+int         lspiv_set_device(int device);               /* per calling thread               */
+int         lspiv_get_device(int* device);
+int         lspiv_device_name(int device, char* buf, size_t len);
+int         lspiv_synchronize(void);                    /* hipDeviceSynchronize             */
+/* which kernel a window size dispatches to: 1 = FFT 32x32, 2 = FFT 64x64, 3 = direct (any even
+ * size); <0 = unsupported.  Host-only. */
+int         lspiv_kernel_kind(int wy, int wx);
+
+/* ---------------------------------------------------------------- window grid (host) ----- */
+/* replaces ffpiv.window.get_rect_coordinates (pyorc/api/frames.py:85-90) and the implied
+ * ffpiv.window.get_axis_shape: n = (dim - win)//(win - overlap) + 1, centres
+ * arange(n)*(win-overlap) + win/2 as integer pixel indices. */
+int lspiv_grid_shape(int64_t H, int64_t W, int wy, int wx, int oy, int ox, int64_t* n_rows, int64_t* n_cols);
+int lspiv_grid_coords(int64_t H, int64_t W, int wy, int wx, int oy, int ox,
+                      int64_t* rows /* n_rows */, int64_t* cols /* n_cols */);
+
+/* ---------------------------------------------------------------- memory planner --------- */
+/* replaces ffpiv.window.required_memory / available_memory (pyorc/velocimetry/ffpiv.py:120-129):
+ * device bytes one call on T frames needs (frames + results [+ planes]); free/total HBM. */
+int64_t lspiv_required_bytes(int64_t T, int64_t H, int64_t W, int dtype, int wy, int wx, int oy, int ox,
+                             int with_planes);
+int     lspiv_available_bytes(int64_t* free_bytes, int64_t* total_bytes);
+
+/* ---------------------------------------------------------------- the hot path ----------- */
+/* One fused call per frame chunk: replaces ffpiv.cross_corr + the corr_max / s2n reductions +
+ * ffpiv.u_v_displacement of pyorc/velocimetry/ffpiv.py:446-474 (_get_uv_timestep).
+ *   u, v          displacement in PIXELS (u = column shift, v = row shift, no sign flip)
+ *   corr_max      nanmax of the clipped correlation plane
+ *   s2n           corr_max / nanmean(plane)
+ *   each (T-1) * n_rows * n_cols float32.
+ *   corr_planes   NULL, or (T-1) * n_win * wy * wx float32: the fft-shifted, clipped planes that
+ *                 ffpiv.cross_corr returns (NaN planes for windows below signal_threshold).
+ *   signal_threshold < 0 disables the pre-mask (reference: None).                           */
+int lspiv_piv_pairs(const void* frames, int dtype, int64_t T, int64_t H, int64_t W,
+                    int wy, int wx, int oy, int ox, float signal_threshold,
+                    float* u, float* v, float* corr_max, float* s2n, float* corr_planes);
+
+/* same on device-resident data.  d_out is 4 planes [u | v | corr_max | s2n], each
+ * (T-1)*n_win float32, contiguous (so one all-gather moves a rank's whole result block).    */
+int lspiv_piv_pairs_dev(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W,
+                        int wy, int wx, int oy, int ox, float signal_threshold,
+                        float* d_out, float* d_corr_planes, void* stream);
+
+/* replaces ffpiv.u_v_displacement on an existing plane volume (pyorc/velocimetry/ffpiv.py:324,471):
+ * planes (P, n_win, wy, wx) float32 -> u, v (P * n_win) float32 in pixels.                   */
+int lspiv_u_v_displacement(const float* corr_planes, int64_t P, int64_t n_win, int wy, int wx,
+                           float* u, float* v);
+
+/* ---------------------------------------------------------------- ensemble correlation --- */
+/* replaces _get_ffpiv_mean (pyorc/velocimetry/ffpiv.py:182-376): corr_sum / corr_count stay in
+ * HBM across chunks; per-pair corr_max / s2n (masked to 0 like ffpiv.py:238-241) are returned per
+ * chunk for the time averages of ffpiv.py:284-286.                                          */
+typedef struct lspiv_ensemble lspiv_ensemble;
+int lspiv_ensemble_begin(int64_t H, int64_t W, int wy, int wx, int oy, int ox, lspiv_ensemble** handle);
+int lspiv_ensemble_accumulate(lspiv_ensemble* handle, const void* frames, int dtype, int64_t T,
+                              float corr_min, float s2n_min, float signal_threshold,
+                              float* corr_max /* (T-1)*n_win */, float* s2n /* (T-1)*n_win */);
+/* count filter (count < count_min * n_frames -> NaN), mean plane, sub-pixel peak.
+ * u, v (n_win) in pixels; corr_count (n_win) float32; corr_mean NULL or n_win*wy*wx float32.  */
+int lspiv_ensemble_finish(lspiv_ensemble* handle, float count_min, float n_frames,
+                          float* u, float* v, float* corr_count, float* corr_mean);
+int lspiv_ensemble_destroy(lspiv_ensemble* handle);
+
+/* ---------------------------------------------------------------- device-resident helpers  */
+/* For hosts that keep stacks in HBM (bench.py, one-process-per-GPU shards).                 */
+int lspiv_dev_malloc(void** d_ptr, size_t bytes);
+int lspiv_dev_free(void* d_ptr);
+int lspiv_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
+int lspiv_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
+int lspiv_memset_dev(void* d_ptr, int value, size_t bytes);
+/* HIP events recorded on the library's launch stream (bench.py's live kernel timing). */
+int lspiv_event_create(void** ev);
+int lspiv_event_record(void* ev);
+int lspiv_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms); /* synchronises ev_stop */
+int lspiv_event_destroy(void* ev);
+
+/* Synthetic particle-image stack rendered directly into HBM (SURVEY.md section 8d workload; test and
+ * bench utility, not on the PIV path): N_p = density*H*W Gaussian particles (sigma 1.2 px)
+ * advected by u = 3 + 2 sin(2 pi y/H), v = 1.5 cos(2 pi x/W) px/frame.  d_frames (T,H,W) uint8. */
+int lspiv_synth_particles_dev(void* d_frames, int64_t T, int64_t H, int64_t W, uint64_t seed, float density);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSPIV_H */

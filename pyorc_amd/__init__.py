@@ -1,0 +1,17 @@
+"""pyorc_amd -- MI355X-native LSPIV cross-correlation engine (drop-in for pyorc's ``Frames.get_piv``).
+
+Only the hot path lives here: hand-written HIP kernels behind a C ABI (``liblspiv_hip.so``,
+declared in ``include/lspiv.h``) and the thin Python host code that mirrors the reference
+interfaces around it:
+
+  pyorc_amd.window        <-> ffpiv.window            (grid, memory planner)
+  pyorc_amd.piv           <-> ffpiv                   (cross_corr, u_v_displacement + fused piv_pairs)
+  pyorc_amd.velocimetry   <-> pyorc.velocimetry.ffpiv (get_ffpiv: chunking, halo, ensemble, px -> m/s)
+  pyorc_amd.frames        <-> pyorc.api.frames        (get_piv, engine="hip")
+  pyorc_amd.shard                                      (frame-pair sharding over the GPUs of a node)
+"""
+
+__version__ = "0.1.0"
+
+from . import window  # noqa: F401
+from .piv import cross_corr, piv_pairs, u_v_displacement  # noqa: F401

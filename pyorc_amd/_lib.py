@@ -1,0 +1,132 @@
+"""ctypes binding of ``liblspiv_hip.so`` (the C ABI declared in ``include/lspiv.h``).
+
+This is the only place the package touches native code.  There is NO CPU fallback: if the
+shared object is missing, or no gfx950 device is visible when a compute entry point is
+called, a loud exception is raised (``LspivLibraryMissing`` / ``LspivError``).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblspiv_hip.so")
+
+LSPIV_OK = 0
+LSPIV_EINVAL = -1
+LSPIV_ESHAPE = -2
+LSPIV_ENOMEM = -3
+LSPIV_EHIP = -4
+LSPIV_ENODEV = -5
+LSPIV_EUNSUPPORTED = -6
+
+DTYPE_CODES = {np.dtype(np.uint8): 0, np.dtype(np.float32): 1, np.dtype(np.float64): 2}
+
+
+class LspivLibraryMissing(ImportError):
+    """liblspiv_hip.so has not been built (run ``python -c 'import __graft_entry__ as g; g.build()'``)."""
+
+
+class LspivError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"lspiv error {code}: {message}")
+        self.code = code
+
+
+# every symbol include/lspiv.h declares: name -> (restype, argtypes)
+_i64, _i32, _f32, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t
+_pf = C.POINTER(C.c_float)
+_pi64 = C.POINTER(C.c_int64)
+SIGNATURES = {
+    "lspiv_abi_version": (_i32, []),
+    "lspiv_version": (C.c_char_p, []),
+    "lspiv_last_error": (C.c_char_p, []),
+    "lspiv_device_count": (_i32, [C.POINTER(_i32)]),
+    "lspiv_set_device": (_i32, [_i32]),
+    "lspiv_get_device": (_i32, [C.POINTER(_i32)]),
+    "lspiv_device_name": (_i32, [_i32, C.c_char_p, _sz]),
+    "lspiv_synchronize": (_i32, []),
+    "lspiv_kernel_kind": (_i32, [_i32, _i32]),
+    "lspiv_grid_shape": (_i32, [_i64, _i64, _i32, _i32, _i32, _i32, _pi64, _pi64]),
+    "lspiv_grid_coords": (_i32, [_i64, _i64, _i32, _i32, _i32, _i32, _pi64, _pi64]),
+    "lspiv_required_bytes": (_i64, [_i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32]),
+    "lspiv_available_bytes": (_i32, [_pi64, _pi64]),
+    "lspiv_piv_pairs": (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "lspiv_piv_pairs_dev": (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
+    "lspiv_u_v_displacement": (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _vp]),
+    "lspiv_ensemble_begin": (_i32, [_i64, _i64, _i32, _i32, _i32, _i32, C.POINTER(_vp)]),
+    "lspiv_ensemble_accumulate": (_i32, [_vp, _vp, _i32, _i64, _f32, _f32, _f32, _vp, _vp]),
+    "lspiv_ensemble_finish": (_i32, [_vp, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "lspiv_ensemble_destroy": (_i32, [_vp]),
+    "lspiv_dev_malloc": (_i32, [C.POINTER(_vp), _sz]),
+    "lspiv_dev_free": (_i32, [_vp]),
+    "lspiv_memcpy_h2d": (_i32, [_vp, _vp, _sz]),
+    "lspiv_memcpy_d2h": (_i32, [_vp, _vp, _sz]),
+    "lspiv_memset_dev": (_i32, [_vp, _i32, _sz]),
+    "lspiv_event_create": (_i32, [C.POINTER(_vp)]),
+    "lspiv_event_record": (_i32, [_vp]),
+    "lspiv_event_elapsed_ms": (_i32, [_vp, _vp, C.POINTER(_f32)]),
+    "lspiv_event_destroy": (_i32, [_vp]),
+    "lspiv_synth_particles_dev": (_i32, [_vp, _i64, _i64, _i64, C.c_uint64, _f32]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the shared object once and attach prototypes; raises if it was never built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LspivLibraryMissing(
+            f"{LIB_PATH} not found: the HIP extension is not built. There is no CPU fallback; run "
+            "`make -C pyorc_amd/csrc` (or __graft_entry__.build())."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise LspivError(rc, load().lspiv_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(load().lspiv_device_count(C.byref(n)))
+    return n.value
+
+
+def require_device() -> None:
+    if device_count() < 1:
+        raise LspivError(LSPIV_ENODEV, "no gfx950 (MI355X) device visible; engine='hip' has no CPU fallback")
+
+
+def ptr(a: np.ndarray) -> C.c_void_p:
+    return C.c_void_p(a.ctypes.data)
+
+
+def as_frames(imgs) -> np.ndarray:
+    """C-contiguous (T,H,W) array of a supported dtype (other dtypes -> float32 / float64)."""
+    a = np.asarray(imgs)
+    if a.ndim != 3:
+        raise ValueError(f"frames must be (T, H, W), got shape {a.shape}")
+    if a.dtype not in DTYPE_CODES:
+        if a.dtype == np.bool_ or (a.dtype.kind in "ui" and a.dtype.itemsize <= 2):
+            a = a.astype(np.float32)  # exact
+        else:
+            a = a.astype(np.float64)
+    return np.ascontiguousarray(a)

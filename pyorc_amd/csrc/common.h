@@ -1,0 +1,123 @@
+// Shared declarations of the LSPIV HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lspiv {
+
+// One launch = all interrogation-window pairs of a frame chunk.
+// Replaces, fused: ffpiv.cross_corr + corr_max/s2n reductions + ffpiv.u_v_displacement
+// (pyorc/velocimetry/ffpiv.py:446-474).
+struct PivParams {
+  const void* frames;      // device (T, H, W), dtype by template
+  int64_t frame_elems;     // H * W
+  int H, W;
+  int wy, wx;              // window (== search area, pyorc/api/frames.py:168)
+  int sy, sx;              // window stride = window - overlap
+  int n_rows, n_cols;
+  uint32_t n_win;          // n_rows * n_cols
+  uint32_t n_tiles;        // (T-1) * n_win
+  float signal_threshold;  // < 0: off
+  float* u;                // each n_tiles float32
+  float* v;
+  float* cmax;
+  float* s2n;
+  float* planes;           // nullptr or n_tiles * wy * wx
+  // ensemble mode (lspiv_ensemble_accumulate): per-pair masks, running plane sum
+  float corr_min, s2n_min;
+  float* corr_sum;         // n_win * wy * wx
+  float* corr_count;       // n_win
+  uint32_t n_pairs;        // T-1
+};
+
+// ---- wave64 cross-lane helpers -----------------------------------------------------------------
+// DPP row operations act inside rows of 16 lanes; ds_swizzle(SWAP,16) joins the two rows of a
+// 32-lane half, ds_swizzle cannot cross the 32-lane boundary (which is what we want: the two
+// halves of a wave work on different tiles).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int x) {
+  return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);
+}
+constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141; // lane ^ 7 inside 8
+constexpr int DPP_MIRROR = 0x140;      // lane ^ 15 inside 16
+constexpr int SWZ_XOR16 = 0x401F;      // ds_swizzle bit mode: and 0x1f, or 0, xor 0x10
+constexpr int SWZ_XOR8 = 0x201F;
+
+__device__ __forceinline__ float swz16_f(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), SWZ_XOR16));
+}
+__device__ __forceinline__ int swz16_i(int x) { return __builtin_amdgcn_ds_swizzle(x, SWZ_XOR16); }
+
+// sum over the 32 lanes of a half-wave; every lane gets the total (fixed order => deterministic)
+__device__ __forceinline__ float half_sum(float x) {
+  x += dpp_f<DPP_XOR1>(x);
+  x += dpp_f<DPP_XOR2>(x);
+  x += dpp_f<DPP_HALF_MIRROR>(x);
+  x += dpp_f<DPP_MIRROR>(x);
+  x += swz16_f(x);
+  return x;
+}
+__device__ __forceinline__ int half_sum_i(int x) {
+  x += dpp_i<DPP_XOR1>(x);
+  x += dpp_i<DPP_XOR2>(x);
+  x += dpp_i<DPP_HALF_MIRROR>(x);
+  x += dpp_i<DPP_MIRROR>(x);
+  x += swz16_i(x);
+  return x;
+}
+// sum over all 64 lanes (two halves joined by a cross-half permute)
+__device__ __forceinline__ float wave_sum(float x) {
+  x = half_sum(x);
+  x += __shfl_xor(x, 32, 64);
+  return x;
+}
+
+// lexicographic arg-max step: keep (v, idx) unless partner is larger, or equal with smaller idx
+__device__ __forceinline__ void argmax_merge(float& v, int& idx, float pv, int pidx) {
+  bool take = (pv > v) || (pv == v && pidx < idx);
+  v = take ? pv : v;
+  idx = take ? pidx : idx;
+}
+__device__ __forceinline__ void half_argmax(float& v, int& idx) {
+  argmax_merge(v, idx, dpp_f<DPP_XOR1>(v), dpp_i<DPP_XOR1>(idx));
+  argmax_merge(v, idx, dpp_f<DPP_XOR2>(v), dpp_i<DPP_XOR2>(idx));
+  argmax_merge(v, idx, dpp_f<DPP_HALF_MIRROR>(v), dpp_i<DPP_HALF_MIRROR>(idx));
+  argmax_merge(v, idx, dpp_f<DPP_MIRROR>(v), dpp_i<DPP_MIRROR>(idx));
+  argmax_merge(v, idx, swz16_f(v), swz16_i(idx));
+}
+
+// 3-point log-Gaussian sub-pixel offset; zero denominator -> 0 (ffpiv peak_position, A5).
+// The ratio is independent of the logarithm base.
+__device__ __forceinline__ float gauss_offset(float lm, float l0, float lp) {
+  float nom = lm - lp;
+  float den = 2.0f * lm - 4.0f * l0 + 2.0f * lp;
+  return den != 0.0f ? nom / den : 0.0f;
+}
+
+constexpr float kEpsPeak = 1e-7f;
+
+// element -> float conversion of the three frame dtypes
+__device__ __forceinline__ float to_f32(uint8_t x) { return (float)x; }
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(double x) { return (float)x; }
+
+// launch entry points implemented by the kernel translation units
+hipError_t launch_piv_fft32(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
+hipError_t launch_piv_fft64(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
+hipError_t launch_piv_direct(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
+hipError_t launch_peaks_from_planes(const float* planes, uint32_t n_planes, int wy, int wx,
+                                    float* u, float* v, hipStream_t s);
+// mean[w][o] = count[w] < min_count ? NaN : sum[w][o] / count[w]   (pyorc/velocimetry/ffpiv.py:280-282)
+hipError_t launch_ensemble_mean(const float* sum, const float* count, float min_count, uint32_t n_win,
+                                int plane_elems, float* mean, hipStream_t s);
+// synthetic particle-image stack (bench / test utility)
+hipError_t launch_synth_particles(uint8_t* d_frames, int64_t T, int H, int W, uint64_t seed, float density,
+                                  hipStream_t s);
+
+}  // namespace lspiv

@@ -1,0 +1,205 @@
+// In-register complex FFTs for gfx950 wavefronts (one transform per lane, all indices static).
+//
+// A lane owns a whole row (or column) of an interrogation tile in VGPRs, so a length-N
+// transform is straight-line VALU code: no LDS, no cross-lane traffic, twiddles are
+// compile-time literals.  N = 32 is 8 radix-4 butterflies -> 21 twiddle multiplies ->
+// 4 radix-8 butterflies; N = 64 is 8 radix-8 -> 49 twiddles -> 8 radix-8.
+//
+// There is no reference kernel to mirror: pyorc delegates the FFT to rocket_fft/pocketfft on
+// the CPU.  Sign convention matches numpy: forward = exp(-2 pi i nk/N),
+// inverse = exp(+2 pi i nk/N), both unnormalised (the 1/N^2 is folded into the final scale).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace lspiv {
+
+// cos(2 pi m / 64), m = 0..63, rounded from double
+static constexpr float kCos64[64] = {
+    1.0f, 0.9951847195625305f, 0.9807852506637573f, 0.9569403529167175f,
+    0.9238795042037964f, 0.8819212913513184f, 0.8314695954322815f, 0.7730104327201843f,
+    0.7071067690849304f, 0.6343932747840881f, 0.5555702447891235f, 0.4713967442512512f,
+    0.3826834261417389f, 0.290284663438797f, 0.19509032368659973f, 0.0980171412229538f,
+    0.0f, -0.0980171412229538f, -0.19509032368659973f, -0.290284663438797f,
+    -0.3826834261417389f, -0.4713967442512512f, -0.5555702447891235f, -0.6343932747840881f,
+    -0.7071067690849304f, -0.7730104327201843f, -0.8314695954322815f, -0.8819212913513184f,
+    -0.9238795042037964f, -0.9569403529167175f, -0.9807852506637573f, -0.9951847195625305f,
+    -1.0f, -0.9951847195625305f, -0.9807852506637573f, -0.9569403529167175f,
+    -0.9238795042037964f, -0.8819212913513184f, -0.8314695954322815f, -0.7730104327201843f,
+    -0.7071067690849304f, -0.6343932747840881f, -0.5555702447891235f, -0.4713967442512512f,
+    -0.3826834261417389f, -0.290284663438797f, -0.19509032368659973f, -0.0980171412229538f,
+    0.0f, 0.0980171412229538f, 0.19509032368659973f, 0.290284663438797f,
+    0.3826834261417389f, 0.4713967442512512f, 0.5555702447891235f, 0.6343932747840881f,
+    0.7071067690849304f, 0.7730104327201843f, 0.8314695954322815f, 0.8819212913513184f,
+    0.9238795042037964f, 0.9569403529167175f, 0.9807852506637573f, 0.9951847195625305f};
+
+__host__ __device__ constexpr float cos64(int m) { return kCos64[m & 63]; }
+__host__ __device__ constexpr float sin64(int m) { return kCos64[(m - 16) & 63]; }
+
+constexpr float kSqrtHalf = 0.70710678118654757f;
+
+// x *= exp(-/+ 2 pi i m / 64)   (forward: minus; INV: plus)
+template <bool INV, int M>
+__device__ __forceinline__ void twiddle64(float& xr, float& xi) {
+  constexpr int m = M & 63;
+  if constexpr (m == 0) {
+    return;
+  } else if constexpr (m == 16) {  // -i (fwd) / +i (inv)
+    float t = xr;
+    if constexpr (!INV) { xr = xi; xi = -t; } else { xr = -xi; xi = t; }
+  } else if constexpr (m == 32) {
+    xr = -xr; xi = -xi;
+  } else if constexpr (m == 48) {
+    float t = xr;
+    if constexpr (!INV) { xr = -xi; xi = t; } else { xr = xi; xi = -t; }
+  } else {
+    constexpr float c = cos64(m);
+    constexpr float s = INV ? sin64(m) : -sin64(m);
+    float tr = xr * c - xi * s;
+    float ti = xr * s + xi * c;
+    xr = tr; xi = ti;
+  }
+}
+
+// radix-4 butterfly, natural-order outputs
+template <bool INV>
+__device__ __forceinline__ void bfly4(float& r0, float& i0, float& r1, float& i1,
+                                      float& r2, float& i2, float& r3, float& i3) {
+  float ar = r0 + r2, ai = i0 + i2;
+  float br = r0 - r2, bi = i0 - i2;
+  float cr = r1 + r3, ci = i1 + i3;
+  float dr = r1 - r3, di = i1 - i3;
+  r0 = ar + cr; i0 = ai + ci;
+  r2 = ar - cr; i2 = ai - ci;
+  if constexpr (!INV) {  // X1 = b - i d, X3 = b + i d
+    r1 = br + di; i1 = bi - dr;
+    r3 = br - di; i3 = bi + dr;
+  } else {               // X1 = b + i d, X3 = b - i d
+    r1 = br - di; i1 = bi + dr;
+    r3 = br + di; i3 = bi - dr;
+  }
+}
+
+// radix-8 butterfly on 8 values (natural order in, natural order out)
+template <bool INV>
+__device__ __forceinline__ void bfly8(float (&r)[8], float (&i)[8]) {
+  // even / odd radix-4
+  bfly4<INV>(r[0], i[0], r[2], i[2], r[4], i[4], r[6], i[6]);  // E0..E3 in slots 0,2,4,6
+  bfly4<INV>(r[1], i[1], r[3], i[3], r[5], i[5], r[7], i[7]);  // O0..O3 in slots 1,3,5,7
+  // O1 *= W8^1, O2 *= W8^2, O3 *= W8^3
+  {
+    float tr = r[3], ti = i[3];
+    if constexpr (!INV) { r[3] = (tr + ti) * kSqrtHalf; i[3] = (ti - tr) * kSqrtHalf; }
+    else                { r[3] = (tr - ti) * kSqrtHalf; i[3] = (ti + tr) * kSqrtHalf; }
+    tr = r[5]; ti = i[5];
+    if constexpr (!INV) { r[5] = ti; i[5] = -tr; } else { r[5] = -ti; i[5] = tr; }
+    tr = r[7]; ti = i[7];
+    if constexpr (!INV) { r[7] = (ti - tr) * kSqrtHalf; i[7] = -(tr + ti) * kSqrtHalf; }
+    else                { r[7] = -(tr + ti) * kSqrtHalf; i[7] = (tr - ti) * kSqrtHalf; }
+  }
+  float er[4] = {r[0], r[2], r[4], r[6]}, ei[4] = {i[0], i[2], i[4], i[6]};
+  float orr[4] = {r[1], r[3], r[5], r[7]}, oi[4] = {i[1], i[3], i[5], i[7]};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    r[k] = er[k] + orr[k];     i[k] = ei[k] + oi[k];
+    r[k + 4] = er[k] - orr[k]; i[k + 4] = ei[k] - oi[k];
+  }
+}
+
+template <bool INV, int N2, int K1, int STEP>
+struct TwiddleRow {
+  // x[n2] *= W^(STEP * n2 * K1) for n2 = 1..7 (W = 64th root); unrolled at compile time
+  template <int n2>
+  static __device__ __forceinline__ void apply(float (&r)[8], float (&i)[8]) {
+    if constexpr (n2 < N2) {
+      twiddle64<INV, STEP * n2 * K1>(r[n2], i[n2]);
+      apply<n2 + 1>(r, i);
+    }
+  }
+};
+
+// ---- length-32 transform, in place, natural order in and out --------------------------------
+// n = 8 n1 + n2, k = k1 + 4 k2:  X[k1 + 4 k2] = DFT8_{n2}( W32^{n2 k1} * DFT4_{n1} x[8 n1 + n2] )
+template <bool INV>
+__device__ __forceinline__ void fft32(float (&xr)[32], float (&xi)[32]) {
+#pragma unroll
+  for (int n2 = 0; n2 < 8; ++n2)
+    bfly4<INV>(xr[n2], xi[n2], xr[8 + n2], xi[8 + n2], xr[16 + n2], xi[16 + n2], xr[24 + n2], xi[24 + n2]);
+  float yr[32], yi[32];
+  // slot (k1, n2) lives at 8*k1 + n2
+  {
+    float r[8], i[8];
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) { r[n2] = xr[n2]; i[n2] = xi[n2]; }
+    bfly8<INV>(r, i);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) { yr[4 * k2] = r[k2]; yi[4 * k2] = i[k2]; }
+  }
+  {
+    float r[8], i[8];
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) { r[n2] = xr[8 + n2]; i[n2] = xi[8 + n2]; }
+    TwiddleRow<INV, 8, 1, 2>::template apply<1>(r, i);
+    bfly8<INV>(r, i);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) { yr[1 + 4 * k2] = r[k2]; yi[1 + 4 * k2] = i[k2]; }
+  }
+  {
+    float r[8], i[8];
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) { r[n2] = xr[16 + n2]; i[n2] = xi[16 + n2]; }
+    TwiddleRow<INV, 8, 2, 2>::template apply<1>(r, i);
+    bfly8<INV>(r, i);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) { yr[2 + 4 * k2] = r[k2]; yi[2 + 4 * k2] = i[k2]; }
+  }
+  {
+    float r[8], i[8];
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) { r[n2] = xr[24 + n2]; i[n2] = xi[24 + n2]; }
+    TwiddleRow<INV, 8, 3, 2>::template apply<1>(r, i);
+    bfly8<INV>(r, i);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) { yr[3 + 4 * k2] = r[k2]; yi[3 + 4 * k2] = i[k2]; }
+  }
+#pragma unroll
+  for (int k = 0; k < 32; ++k) { xr[k] = yr[k]; xi[k] = yi[k]; }
+}
+
+// ---- length-64 transform: n = 8 n1 + n2, k = k1 + 8 k2 --------------------------------------
+template <bool INV, int K1>
+__device__ __forceinline__ void fft64_col(const float (&xr)[64], const float (&xi)[64],
+                                          float (&yr)[64], float (&yi)[64]) {
+  float r[8], i[8];
+#pragma unroll
+  for (int n2 = 0; n2 < 8; ++n2) { r[n2] = xr[8 * K1 + n2]; i[n2] = xi[8 * K1 + n2]; }
+  TwiddleRow<INV, 8, K1, 1>::template apply<1>(r, i);
+  bfly8<INV>(r, i);
+#pragma unroll
+  for (int k2 = 0; k2 < 8; ++k2) { yr[K1 + 8 * k2] = r[k2]; yi[K1 + 8 * k2] = i[k2]; }
+}
+
+template <bool INV>
+__device__ __forceinline__ void fft64(float (&xr)[64], float (&xi)[64]) {
+#pragma unroll
+  for (int n2 = 0; n2 < 8; ++n2) {
+    float r[8], i[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) { r[n1] = xr[8 * n1 + n2]; i[n1] = xi[8 * n1 + n2]; }
+    bfly8<INV>(r, i);
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) { xr[8 * k1 + n2] = r[k1]; xi[8 * k1 + n2] = i[k1]; }
+  }
+  float yr[64], yi[64];
+  fft64_col<INV, 0>(xr, xi, yr, yi);
+  fft64_col<INV, 1>(xr, xi, yr, yi);
+  fft64_col<INV, 2>(xr, xi, yr, yi);
+  fft64_col<INV, 3>(xr, xi, yr, yi);
+  fft64_col<INV, 4>(xr, xi, yr, yi);
+  fft64_col<INV, 5>(xr, xi, yr, yi);
+  fft64_col<INV, 6>(xr, xi, yr, yi);
+  fft64_col<INV, 7>(xr, xi, yr, yi);
+#pragma unroll
+  for (int k = 0; k < 64; ++k) { xr[k] = yr[k]; xi[k] = yi[k]; }
+}
+
+}  // namespace lspiv

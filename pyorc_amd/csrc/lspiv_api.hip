@@ -1,0 +1,473 @@
+// C ABI of liblspiv_hip.so (see include/lspiv.h for the contract and the reference call sites
+// each entry point replaces).  Host logic only: argument checks, window grid, HBM workspaces,
+// H2D/D2H staging, kernel dispatch.  No PyTorch, no CPU compute fallback: without a gfx950
+// device every compute entry point fails with LSPIV_ENODEV.
+#include "../../include/lspiv.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      int code_ = (e_ == hipErrorOutOfMemory) ? LSPIV_ENOMEM                                   \
+                  : (e_ == hipErrorNoDevice || e_ == hipErrorNoBinaryForGpu) ? LSPIV_ENODEV    \
+                                                                             : LSPIV_EHIP;     \
+      return fail(code_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    }                                                                                          \
+  } while (0)
+
+size_t elem_size(int dtype) { return dtype == LSPIV_U8 ? 1 : dtype == LSPIV_F32 ? 4 : 8; }
+
+struct Grid {
+  int64_t n_rows = 0, n_cols = 0;
+};
+
+int check_window(int wy, int wx, int oy, int ox) {
+  if (wy < 2 || wx < 2 || wy > LSPIV_MAX_WINDOW || wx > LSPIV_MAX_WINDOW)
+    return fail(LSPIV_EUNSUPPORTED, "window %dx%d outside supported range 2..%d", wy, wx, LSPIV_MAX_WINDOW);
+  if (oy < 0 || ox < 0 || oy >= wy || ox >= wx)
+    return fail(LSPIV_EINVAL, "overlap (%d,%d) must satisfy 0 <= overlap < window (%d,%d)", oy, ox, wy, wx);
+  return LSPIV_OK;
+}
+
+// ffpiv.window.get_axis_shape restated: (dim - win)//(win - overlap) + 1
+int64_t axis_shape(int64_t dim, int win, int ov) { return dim < win ? 0 : (dim - win) / (win - ov) + 1; }
+
+int make_grid(int64_t H, int64_t W, int wy, int wx, int oy, int ox, Grid* g) {
+  int rc = check_window(wy, wx, oy, ox);
+  if (rc) return rc;
+  if (H <= 0 || W <= 0) return fail(LSPIV_ESHAPE, "frame shape (%lld,%lld) invalid", (long long)H, (long long)W);
+  g->n_rows = axis_shape(H, wy, oy);
+  g->n_cols = axis_shape(W, wx, ox);
+  if (g->n_rows <= 0 || g->n_cols <= 0)
+    return fail(LSPIV_ESHAPE, "frame (%lld,%lld) smaller than window (%d,%d)", (long long)H, (long long)W, wy, wx);
+  return LSPIV_OK;
+}
+
+// ---- per-device context: launch stream + grow-only HBM / pinned workspaces -------------------
+struct DeviceCtx {
+  hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;
+  void* d_frames = nullptr;  size_t frames_cap = 0;
+  float* d_out = nullptr;    size_t out_cap = 0;
+  float* d_planes = nullptr; size_t planes_cap = 0;
+  bool arch_ok = false;
+};
+std::mutex g_mu;
+std::vector<DeviceCtx*> g_ctx;
+
+int get_ctx(DeviceCtx** out) {
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) return fail(LSPIV_ENODEV, "no HIP device visible (%s)", hipGetErrorString(e));
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_mu);
+  if ((int)g_ctx.size() < ndev) g_ctx.resize(ndev, nullptr);
+  if (!g_ctx[dev]) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+      return fail(LSPIV_ENODEV, "device %d is %s; this library carries gfx950 (MI355X) code only", dev, prop.gcnArchName);
+    DeviceCtx* c = new DeviceCtx();
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    c->arch_ok = true;
+    g_ctx[dev] = c;
+  }
+  *out = g_ctx[dev];
+  return LSPIV_OK;
+}
+
+template <typename P>
+int ensure(P** ptr, size_t* cap, size_t bytes) {
+  if (bytes <= *cap) return LSPIV_OK;
+  if (*ptr) HIP_TRY(hipFree(*ptr));
+  *ptr = nullptr; *cap = 0;
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, bytes));
+  *ptr = static_cast<P*>(p); *cap = bytes;
+  return LSPIV_OK;
+}
+
+int fill_params(lspiv::PivParams* p, const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, int wy, int wx,
+                int oy, int ox, float signal_threshold, const Grid& g) {
+  if (dtype < 0 || dtype > 2) return fail(LSPIV_EINVAL, "dtype %d not in {0:u8, 1:f32, 2:f64}", dtype);
+  if (T < 2) return fail(LSPIV_ESHAPE, "need at least 2 frames, got %lld", (long long)T);
+  const int64_t n_win = g.n_rows * g.n_cols;
+  const int64_t n_tiles = (T - 1) * n_win;
+  if (n_tiles >= (int64_t)1 << 31 || H * W >= (int64_t)1 << 31)
+    return fail(LSPIV_EINVAL, "chunk too large for one launch: %lld windows (limit 2^31); use smaller chunks",
+                (long long)n_tiles);
+  memset(p, 0, sizeof(*p));
+  p->frames = d_frames;
+  p->frame_elems = H * W;
+  p->H = (int)H; p->W = (int)W;
+  p->wy = wy; p->wx = wx;
+  p->sy = wy - oy; p->sx = wx - ox;
+  p->n_rows = (int)g.n_rows; p->n_cols = (int)g.n_cols;
+  p->n_win = (uint32_t)n_win;
+  p->n_tiles = (uint32_t)n_tiles;
+  p->n_pairs = (uint32_t)(T - 1);
+  p->signal_threshold = signal_threshold;
+  return LSPIV_OK;
+}
+
+int dispatch(const lspiv::PivParams& p, int dtype, bool ensemble, hipStream_t s) {
+  const int kind = lspiv_kernel_kind(p.wy, p.wx);
+  hipError_t e;
+  switch (kind) {
+    case 1: e = lspiv::launch_piv_fft32(p, dtype, ensemble, s); break;
+    case 2: e = lspiv::launch_piv_fft64(p, dtype, ensemble, s); break;
+    case 3: e = lspiv::launch_piv_direct(p, dtype, ensemble, s); break;
+    default: return fail(LSPIV_EUNSUPPORTED, "no kernel for window %dx%d", p.wy, p.wx);
+  }
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return LSPIV_OK;
+}
+
+}  // namespace
+
+struct lspiv_ensemble {
+  int64_t H, W;
+  int wy, wx, oy, ox;
+  Grid g;
+  int device;
+  float* d_sum;    // n_win * wy * wx
+  float* d_count;  // n_win
+};
+
+extern "C" {
+
+int lspiv_abi_version(void) { return LSPIV_ABI_VERSION; }
+const char* lspiv_version(void) { return "lspiv-hip 0.1.0 (gfx950)"; }
+const char* lspiv_last_error(void) { return g_err.c_str(); }
+
+int lspiv_device_count(int* n) {
+  if (!n) return fail(LSPIV_EINVAL, "n is NULL");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  *n = (e == hipSuccess) ? c : 0;
+  return LSPIV_OK;
+}
+int lspiv_set_device(int device) { HIP_TRY(hipSetDevice(device)); return LSPIV_OK; }
+int lspiv_get_device(int* device) {
+  if (!device) return fail(LSPIV_EINVAL, "device is NULL");
+  HIP_TRY(hipGetDevice(device));
+  return LSPIV_OK;
+}
+int lspiv_device_name(int device, char* buf, size_t len) {
+  if (!buf || len == 0) return fail(LSPIV_EINVAL, "buf is NULL");
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  snprintf(buf, len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return LSPIV_OK;
+}
+int lspiv_synchronize(void) { HIP_TRY(hipDeviceSynchronize()); return LSPIV_OK; }
+
+int lspiv_kernel_kind(int wy, int wx) {
+  if (wy < 2 || wx < 2 || wy > LSPIV_MAX_WINDOW || wx > LSPIV_MAX_WINDOW) return LSPIV_EUNSUPPORTED;
+  if (wy == 32 && wx == 32) return 1;
+  // 64x64 FFT kernel: not built yet, served by the direct kernel
+
+  return 3;
+}
+
+int lspiv_grid_shape(int64_t H, int64_t W, int wy, int wx, int oy, int ox, int64_t* n_rows, int64_t* n_cols) {
+  if (!n_rows || !n_cols) return fail(LSPIV_EINVAL, "output pointer is NULL");
+  int rc = check_window(wy, wx, oy, ox);
+  if (rc) return rc;
+  *n_rows = axis_shape(H, wy, oy);
+  *n_cols = axis_shape(W, wx, ox);
+  return LSPIV_OK;
+}
+
+int lspiv_grid_coords(int64_t H, int64_t W, int wy, int wx, int oy, int ox, int64_t* rows, int64_t* cols) {
+  int64_t nr, nc;
+  int rc = lspiv_grid_shape(H, W, wy, wx, oy, ox, &nr, &nc);
+  if (rc) return rc;
+  if ((nr > 0 && !rows) || (nc > 0 && !cols)) return fail(LSPIV_EINVAL, "output pointer is NULL");
+  // ffpiv.window.get_axis_coords restated: int64(arange(n) * (win - overlap) + win / 2.0)
+  for (int64_t k = 0; k < nr; ++k) rows[k] = (int64_t)std::floor((double)k * (wy - oy) + wy / 2.0);
+  for (int64_t k = 0; k < nc; ++k) cols[k] = (int64_t)std::floor((double)k * (wx - ox) + wx / 2.0);
+  return LSPIV_OK;
+}
+
+int64_t lspiv_required_bytes(int64_t T, int64_t H, int64_t W, int dtype, int wy, int wx, int oy, int ox,
+                             int with_planes) {
+  Grid g;
+  int rc = make_grid(H, W, wy, wx, oy, ox, &g);
+  if (rc) return rc;
+  if (dtype < 0 || dtype > 2 || T < 2) return fail(LSPIV_EINVAL, "bad dtype/T");
+  const int64_t n_tiles = (T - 1) * g.n_rows * g.n_cols;
+  int64_t b = T * H * W * (int64_t)elem_size(dtype) + 4 * n_tiles * 4;
+  if (with_planes) b += n_tiles * wy * wx * 4;
+  return b;
+}
+
+int lspiv_available_bytes(int64_t* free_bytes, int64_t* total_bytes) {
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  size_t f = 0, t = 0;
+  HIP_TRY(hipMemGetInfo(&f, &t));
+  // workspaces this library already holds are reusable, count them as free
+  f += c->frames_cap + c->out_cap + c->planes_cap;
+  if (free_bytes) *free_bytes = (int64_t)f;
+  if (total_bytes) *total_bytes = (int64_t)t;
+  return LSPIV_OK;
+}
+
+int lspiv_piv_pairs_dev(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, int wy, int wx, int oy,
+                        int ox, float signal_threshold, float* d_out, float* d_corr_planes, void* stream) {
+  if (!d_frames || !d_out) return fail(LSPIV_EINVAL, "d_frames / d_out is NULL");
+  Grid g;
+  int rc = make_grid(H, W, wy, wx, oy, ox, &g);
+  if (rc) return rc;
+  DeviceCtx* c;
+  rc = get_ctx(&c);
+  if (rc) return rc;
+  lspiv::PivParams p;
+  rc = fill_params(&p, d_frames, dtype, T, H, W, wy, wx, oy, ox, signal_threshold, g);
+  if (rc) return rc;
+  p.u = d_out;
+  p.v = d_out + (size_t)p.n_tiles;
+  p.cmax = d_out + 2 * (size_t)p.n_tiles;
+  p.s2n = d_out + 3 * (size_t)p.n_tiles;
+  p.planes = d_corr_planes;
+  return dispatch(p, dtype, false, stream ? (hipStream_t)stream : c->stream);
+}
+
+int lspiv_piv_pairs(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, int wy, int wx, int oy, int ox,
+                    float signal_threshold, float* u, float* v, float* corr_max, float* s2n, float* corr_planes) {
+  if (!frames || !u || !v || !corr_max || !s2n) return fail(LSPIV_EINVAL, "NULL buffer");
+  Grid g;
+  int rc = make_grid(H, W, wy, wx, oy, ox, &g);
+  if (rc) return rc;
+  if (dtype < 0 || dtype > 2) return fail(LSPIV_EINVAL, "dtype %d not in {0:u8, 1:f32, 2:f64}", dtype);
+  if (T < 2) return fail(LSPIV_ESHAPE, "need at least 2 frames, got %lld", (long long)T);
+  DeviceCtx* c;
+  rc = get_ctx(&c);
+  if (rc) return rc;
+  const size_t fbytes = (size_t)T * H * W * elem_size(dtype);
+  const size_t n_tiles = (size_t)(T - 1) * g.n_rows * g.n_cols;
+  rc = ensure(&c->d_frames, &c->frames_cap, fbytes);
+  if (rc) return rc;
+  rc = ensure(&c->d_out, &c->out_cap, 4 * n_tiles * sizeof(float));
+  if (rc) return rc;
+  if (corr_planes) {
+    rc = ensure(&c->d_planes, &c->planes_cap, n_tiles * wy * wx * sizeof(float));
+    if (rc) return rc;
+  }
+  HIP_TRY(hipMemcpyAsync(c->d_frames, frames, fbytes, hipMemcpyHostToDevice, c->stream));
+  rc = lspiv_piv_pairs_dev(c->d_frames, dtype, T, H, W, wy, wx, oy, ox, signal_threshold, c->d_out,
+                           corr_planes ? c->d_planes : nullptr, c->stream);
+  if (rc) return rc;
+  const size_t ob = n_tiles * sizeof(float);
+  HIP_TRY(hipMemcpyAsync(u, c->d_out, ob, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(v, c->d_out + n_tiles, ob, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(corr_max, c->d_out + 2 * n_tiles, ob, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(s2n, c->d_out + 3 * n_tiles, ob, hipMemcpyDeviceToHost, c->stream));
+  if (corr_planes)
+    HIP_TRY(hipMemcpyAsync(corr_planes, c->d_planes, n_tiles * wy * wx * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
+
+int lspiv_u_v_displacement(const float* corr_planes, int64_t P, int64_t n_win, int wy, int wx, float* u, float* v) {
+  if (!corr_planes || !u || !v) return fail(LSPIV_EINVAL, "NULL buffer");
+  if (P < 0 || n_win < 0 || wy < 1 || wx < 1 || wy > 4096 || wx > 4096) return fail(LSPIV_EINVAL, "bad shape");
+  const int64_t n = P * n_win;
+  if (n == 0) return LSPIV_OK;
+  if (n >= (int64_t)1 << 31) return fail(LSPIV_EINVAL, "too many planes for one launch");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  const size_t pb = (size_t)n * wy * wx * sizeof(float);
+  rc = ensure(&c->d_planes, &c->planes_cap, pb);
+  if (rc) return rc;
+  rc = ensure(&c->d_out, &c->out_cap, 2 * (size_t)n * sizeof(float));
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_planes, corr_planes, pb, hipMemcpyHostToDevice, c->stream));
+  hipError_t e = lspiv::launch_peaks_from_planes(c->d_planes, (uint32_t)n, wy, wx, c->d_out, c->d_out + n, c->stream);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  HIP_TRY(hipMemcpyAsync(u, c->d_out, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(v, c->d_out + n, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
+
+// ---- ensemble -------------------------------------------------------------------------------
+int lspiv_ensemble_begin(int64_t H, int64_t W, int wy, int wx, int oy, int ox, lspiv_ensemble** handle) {
+  if (!handle) return fail(LSPIV_EINVAL, "handle is NULL");
+  Grid g;
+  int rc = make_grid(H, W, wy, wx, oy, ox, &g);
+  if (rc) return rc;
+  DeviceCtx* c;
+  rc = get_ctx(&c);
+  if (rc) return rc;
+  lspiv_ensemble* h = new lspiv_ensemble();
+  h->H = H; h->W = W; h->wy = wy; h->wx = wx; h->oy = oy; h->ox = ox; h->g = g;
+  h->d_sum = nullptr; h->d_count = nullptr;
+  HIP_TRY(hipGetDevice(&h->device));
+  const size_t n_win = (size_t)g.n_rows * g.n_cols;
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, n_win * wy * wx * sizeof(float));
+  if (e != hipSuccess) { delete h; return fail(LSPIV_ENOMEM, "hipMalloc corr_sum: %s", hipGetErrorString(e)); }
+  h->d_sum = (float*)p;
+  e = hipMalloc(&p, n_win * sizeof(float));
+  if (e != hipSuccess) { hipFree(h->d_sum); delete h; return fail(LSPIV_ENOMEM, "hipMalloc corr_count: %s", hipGetErrorString(e)); }
+  h->d_count = (float*)p;
+  HIP_TRY(hipMemsetAsync(h->d_sum, 0, n_win * wy * wx * sizeof(float), c->stream));
+  HIP_TRY(hipMemsetAsync(h->d_count, 0, n_win * sizeof(float), c->stream));
+  *handle = h;
+  return LSPIV_OK;
+}
+
+int lspiv_ensemble_accumulate(lspiv_ensemble* h, const void* frames, int dtype, int64_t T, float corr_min,
+                              float s2n_min, float signal_threshold, float* corr_max, float* s2n) {
+  if (!h || !frames || !corr_max || !s2n) return fail(LSPIV_EINVAL, "NULL argument");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  if (dtype < 0 || dtype > 2) return fail(LSPIV_EINVAL, "dtype %d not in {0:u8, 1:f32, 2:f64}", dtype);
+  if (T < 2) return fail(LSPIV_ESHAPE, "need at least 2 frames, got %lld", (long long)T);
+  const size_t fbytes = (size_t)T * h->H * h->W * elem_size(dtype);
+  const size_t n_tiles = (size_t)(T - 1) * h->g.n_rows * h->g.n_cols;
+  rc = ensure(&c->d_frames, &c->frames_cap, fbytes);
+  if (rc) return rc;
+  rc = ensure(&c->d_out, &c->out_cap, 4 * n_tiles * sizeof(float));
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_frames, frames, fbytes, hipMemcpyHostToDevice, c->stream));
+  lspiv::PivParams p;
+  rc = fill_params(&p, c->d_frames, dtype, T, h->H, h->W, h->wy, h->wx, h->oy, h->ox, signal_threshold, h->g);
+  if (rc) return rc;
+  p.cmax = c->d_out;
+  p.s2n = c->d_out + n_tiles;
+  p.corr_min = corr_min;
+  p.s2n_min = s2n_min;
+  p.corr_sum = h->d_sum;
+  p.corr_count = h->d_count;
+  rc = dispatch(p, dtype, true, c->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(corr_max, c->d_out, n_tiles * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(s2n, c->d_out + n_tiles, n_tiles * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
+
+int lspiv_ensemble_finish(lspiv_ensemble* h, float count_min, float n_frames, float* u, float* v, float* corr_count,
+                          float* corr_mean) {
+  if (!h || !u || !v) return fail(LSPIV_EINVAL, "NULL argument");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  const size_t n_win = (size_t)h->g.n_rows * h->g.n_cols;
+  const size_t pb = n_win * h->wy * h->wx * sizeof(float);
+  rc = ensure(&c->d_planes, &c->planes_cap, pb);
+  if (rc) return rc;
+  rc = ensure(&c->d_out, &c->out_cap, 2 * n_win * sizeof(float));
+  if (rc) return rc;
+  hipError_t e = lspiv::launch_ensemble_mean(h->d_sum, h->d_count, count_min * n_frames, (uint32_t)n_win,
+                                             h->wy * h->wx, c->d_planes, c->stream);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  e = lspiv::launch_peaks_from_planes(c->d_planes, (uint32_t)n_win, h->wy, h->wx, c->d_out, c->d_out + n_win, c->stream);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  HIP_TRY(hipMemcpyAsync(u, c->d_out, n_win * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(v, c->d_out + n_win, n_win * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (corr_count) HIP_TRY(hipMemcpyAsync(corr_count, h->d_count, n_win * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (corr_mean) HIP_TRY(hipMemcpyAsync(corr_mean, c->d_planes, pb, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
+
+int lspiv_ensemble_destroy(lspiv_ensemble* h) {
+  if (!h) return LSPIV_OK;
+  if (h->d_sum) hipFree(h->d_sum);
+  if (h->d_count) hipFree(h->d_count);
+  delete h;
+  return LSPIV_OK;
+}
+
+// ---- device-resident helpers ------------------------------------------------------------------
+int lspiv_dev_malloc(void** d_ptr, size_t bytes) {
+  if (!d_ptr) return fail(LSPIV_EINVAL, "d_ptr is NULL");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  HIP_TRY(hipMalloc(d_ptr, bytes));
+  return LSPIV_OK;
+}
+int lspiv_dev_free(void* d_ptr) { if (d_ptr) HIP_TRY(hipFree(d_ptr)); return LSPIV_OK; }
+int lspiv_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes) {
+  HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice)); return LSPIV_OK;
+}
+int lspiv_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes) {
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost)); return LSPIV_OK;
+}
+int lspiv_memset_dev(void* d_ptr, int value, size_t bytes) { HIP_TRY(hipMemset(d_ptr, value, bytes)); return LSPIV_OK; }
+
+int lspiv_event_create(void** ev) {
+  if (!ev) return fail(LSPIV_EINVAL, "ev is NULL");
+  hipEvent_t e;
+  HIP_TRY(hipEventCreate(&e));
+  *ev = (void*)e;
+  return LSPIV_OK;
+}
+int lspiv_event_record(void* ev) {
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord((hipEvent_t)ev, c->stream));
+  return LSPIV_OK;
+}
+int lspiv_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms) {
+  if (!ms) return fail(LSPIV_EINVAL, "ms is NULL");
+  HIP_TRY(hipEventSynchronize((hipEvent_t)ev_stop));
+  HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)ev_start, (hipEvent_t)ev_stop));
+  return LSPIV_OK;
+}
+int lspiv_event_destroy(void* ev) { if (ev) HIP_TRY(hipEventDestroy((hipEvent_t)ev)); return LSPIV_OK; }
+
+int lspiv_synth_particles_dev(void* d_frames, int64_t T, int64_t H, int64_t W, uint64_t seed, float density) {
+  if (!d_frames || T < 1 || H < 8 || W < 8 || !(density > 0.0f)) return fail(LSPIV_EINVAL, "bad argument");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  hipError_t e = lspiv::launch_synth_particles((uint8_t*)d_frames, T, (int)H, (int)W, seed, density, c->stream);
+  if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? LSPIV_ENOMEM : LSPIV_EHIP, "synth failed: %s", hipGetErrorString(e));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
+
+}  // extern "C"

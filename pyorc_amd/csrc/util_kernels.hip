@@ -1,0 +1,122 @@
+// Small helper kernels: ensemble mean plane, synthetic particle-image generator.
+#include "common.h"
+
+namespace lspiv {
+
+// count filter + mean plane of the ensemble branch (pyorc/velocimetry/ffpiv.py:280-282):
+// windows with corr_count < count_min * n_frames become NaN, otherwise corr_sum / corr_count
+// (0/0 = NaN exactly like numpy's divide).
+__global__ void ensemble_mean_kernel(const float* sum, const float* count, float min_count, int plane_elems,
+                                     float* mean) {
+  const uint32_t w = blockIdx.x;
+  const float c = count[w];
+  const bool low = c < min_count;
+  for (int o = threadIdx.x; o < plane_elems; o += blockDim.x) {
+    const size_t i = (size_t)w * plane_elems + o;
+    mean[i] = low ? __builtin_nanf("") : sum[i] / c;
+  }
+}
+
+hipError_t launch_ensemble_mean(const float* sum, const float* count, float min_count, uint32_t n_win,
+                                int plane_elems, float* mean, hipStream_t s) {
+  if (n_win == 0) return hipSuccess;
+  hipLaunchKernelGGL(ensemble_mean_kernel, dim3(n_win), dim3(256), 0, s, sum, count, min_count, plane_elems, mean);
+  return hipGetLastError();
+}
+
+// ---- synthetic particle images ----------------------------------------------------------------
+// Same model as pyorc_amd/synth.py (different random stream): Gaussian blobs sigma = 1.2 px,
+// peak U(120,255), flow u = 3 + 2 sin(2 pi y/H), v = 1.5 cos(2 pi x/W) px/frame, re-seeded when a
+// particle leaves.  Rendering accumulates 24.8 fixed point with integer atomics, so a stack is
+// bit-reproducible for a given seed.
+struct Particle {
+  float x, y, amp;
+  uint32_t gen;
+};
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ float u01(uint64_t h) { return (float)(h >> 40) * (1.0f / 16777216.0f); }
+
+__device__ __forceinline__ void seed_particle(Particle& p, uint64_t seed, uint32_t i, int H, int W) {
+  const uint64_t h = splitmix64(seed ^ ((uint64_t)i << 32 | p.gen));
+  p.x = u01(h) * W;
+  p.y = u01(splitmix64(h)) * H;
+  p.amp = 120.0f + 135.0f * u01(splitmix64(h ^ 0x5bd1e995u));
+}
+
+__global__ void synth_init_kernel(Particle* ps, uint32_t n, uint64_t seed, int H, int W) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Particle p;
+  p.gen = 0;
+  seed_particle(p, seed, i, H, W);
+  ps[i] = p;
+}
+
+__global__ void synth_render_kernel(Particle* ps, uint32_t n, uint32_t* acc, uint64_t seed, int H, int W) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Particle p = ps[i];
+  const int iy = (int)rintf(p.y), ix = (int)rintf(p.x);
+  const float k = -1.0f / (2.0f * 1.2f * 1.2f);
+  for (int dy = -3; dy <= 3; ++dy) {
+    const int yy = iy + dy;
+    if (yy < 0 || yy >= H) continue;
+    for (int dx = -3; dx <= 3; ++dx) {
+      const int xx = ix + dx;
+      if (xx < 0 || xx >= W) continue;
+      const float fy = (float)yy - p.y, fx = (float)xx - p.x;
+      const float w = p.amp * __expf((fy * fy + fx * fx) * k);
+      atomicAdd(&acc[(size_t)yy * W + xx], (uint32_t)(w * 256.0f + 0.5f));
+    }
+  }
+  // advect for the next frame, re-seed when the blob has left the frame
+  const float u = 3.0f + 2.0f * __sinf(6.283185307f * p.y / (float)H);
+  const float v = 1.5f * __cosf(6.283185307f * p.x / (float)W);
+  p.x += u;
+  p.y += v;
+  if (p.x < -3.0f || p.x >= W + 3.0f || p.y < -3.0f || p.y >= H + 3.0f) {
+    p.gen += 1;
+    seed_particle(p, seed, i, H, W);
+  }
+  ps[i] = p;
+}
+
+__global__ void synth_finalize_kernel(uint32_t* acc, uint8_t* frame, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t v = (acc[i] + 128u) >> 8;
+  frame[i] = (uint8_t)(v > 255u ? 255u : v);
+  acc[i] = 0;
+}
+
+hipError_t launch_synth_particles(uint8_t* d_frames, int64_t T, int H, int W, uint64_t seed, float density,
+                                  hipStream_t s) {
+  const uint32_t n_px = (uint32_t)H * (uint32_t)W;
+  uint32_t n_p = (uint32_t)(density * (float)H * (float)W);
+  if (n_p < 1) n_p = 1;
+  Particle* ps = nullptr;
+  uint32_t* acc = nullptr;
+  hipError_t e = hipMalloc((void**)&ps, (size_t)n_p * sizeof(Particle));
+  if (e != hipSuccess) return e;
+  e = hipMalloc((void**)&acc, (size_t)n_px * sizeof(uint32_t));
+  if (e != hipSuccess) { hipFree(ps); return e; }
+  hipMemsetAsync(acc, 0, (size_t)n_px * sizeof(uint32_t), s);
+  hipLaunchKernelGGL(synth_init_kernel, dim3((n_p + 255) / 256), dim3(256), 0, s, ps, n_p, seed, H, W);
+  for (int64_t t = 0; t < T; ++t) {
+    hipLaunchKernelGGL(synth_render_kernel, dim3((n_p + 255) / 256), dim3(256), 0, s, ps, n_p, acc, seed, H, W);
+    hipLaunchKernelGGL(synth_finalize_kernel, dim3((n_px + 255) / 256), dim3(256), 0, s, acc,
+                       d_frames + (size_t)t * n_px, n_px);
+  }
+  e = hipStreamSynchronize(s);
+  hipFree(ps);
+  hipFree(acc);
+  return e != hipSuccess ? e : hipGetLastError();
+}
+
+}  // namespace lspiv

@@ -1,0 +1,144 @@
+"""Mirror of the ``ffpiv`` API that pyorc's PIV wrapper binds, executed on the MI355X.
+
+``cross_corr`` and ``u_v_displacement`` keep the signatures observed at the reference call
+sites (pyorc/velocimetry/ffpiv.py:222-231, 324, 450-459, 471) so they can be swapped in for
+``from ffpiv import cross_corr, u_v_displacement`` (ffpiv.py:9).  ``piv_pairs`` is the fused
+entry the ``hip`` engine actually uses: one kernel produces u, v, corr_max and s2n per
+window without ever writing the (T-1, n_win, wy, wx) correlation volume to memory.
+
+No CPU fallback: every function needs liblspiv_hip.so and a gfx950 device.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib, window
+
+ENGINES = ("hip",)
+
+
+def _sig(signal_threshold: Optional[float]) -> float:
+    return -1.0 if signal_threshold is None else float(signal_threshold)
+
+
+def _check_args(window_size, overlap, search_area_size, normalize, engine):
+    if engine not in ENGINES:
+        raise ValueError(f"Selected PIV engine {engine} does not exist.")
+    if normalize:
+        raise NotImplementedError("stack-level `normalize` is never used by pyorc (ffpiv.py:227,455)")
+    sa = tuple(window_size) if search_area_size is None else tuple(search_area_size)
+    if sa != tuple(window_size):
+        raise NotImplementedError("search_area_size must equal window_size (pyorc/api/frames.py:168)")
+
+
+def piv_pairs(imgs, window_size=(32, 32), overlap=(16, 16), signal_threshold: Optional[float] = None,
+              return_planes: bool = False):
+    """Fused PIV of every consecutive frame pair of ``imgs`` (T, H, W).
+
+    Returns ``(u, v, corr_max, s2n[, planes])``: float32 arrays (T-1, n_rows, n_cols); u, v in
+    pixels (u = column shift, v = row shift).  Replaces pyorc/velocimetry/ffpiv.py:446-474.
+    """
+    lib = _lib.load()
+    _lib.require_device()
+    a = _lib.as_frames(imgs)
+    T, H, W = a.shape
+    n_rows, n_cols = window.get_array_shape((H, W), window_size, overlap)
+    if T < 2 or n_rows < 1 or n_cols < 1:
+        raise ValueError(f"need >= 2 frames at least one window large, got {a.shape} for window {window_size}")
+    P = T - 1
+    out = [np.empty((P, n_rows, n_cols), dtype=np.float32) for _ in range(4)]
+    planes = None
+    if return_planes:
+        planes = np.empty((P, n_rows * n_cols, window_size[0], window_size[1]), dtype=np.float32)
+    _lib.check(lib.lspiv_piv_pairs(_lib.ptr(a), _lib.DTYPE_CODES[a.dtype], T, H, W, window_size[0], window_size[1],
+                                   overlap[0], overlap[1], _sig(signal_threshold),
+                                   _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.ptr(out[3]),
+                                   _lib.ptr(planes) if planes is not None else None))
+    return (*out, planes) if return_planes else tuple(out)
+
+
+def cross_corr(imgs, window_size=(64, 64), overlap=(32, 32), search_area_size=None, normalize=False,
+               engine="hip", signal_threshold=None, verbose=False):
+    """``ffpiv.cross_corr`` drop-in: returns ``(x, y, corr)``, corr (T-1, n_win, wy, wx) float32.
+
+    Planes of window pairs below ``signal_threshold`` are NaN (pyorc/velocimetry/ffpiv.py:93-97).
+    """
+    _check_args(window_size, overlap, search_area_size, normalize, engine)
+    a = _lib.as_frames(imgs)
+    x, y = window.get_rect_coordinates(a.shape[-2:], window_size, overlap)
+    *_, planes = piv_pairs(a, window_size, overlap, signal_threshold, return_planes=True)
+    return x, y, planes
+
+
+def u_v_displacement(corr, n_rows: int, n_cols: int, engine: str = "hip") -> Tuple[np.ndarray, np.ndarray]:
+    """``ffpiv.u_v_displacement`` drop-in: corr (P, n_win, wy, wx) -> u, v (P, n_rows, n_cols) in pixels."""
+    if engine not in ENGINES:
+        raise ValueError(f"Selected PIV engine {engine} does not exist.")
+    lib = _lib.load()
+    _lib.require_device()
+    c = np.ascontiguousarray(corr, dtype=np.float32)
+    if c.ndim == 3:
+        c = c[None]
+    P, n_win, wy, wx = c.shape
+    if n_win != n_rows * n_cols:
+        raise ValueError(f"corr has {n_win} windows, expected {n_rows}*{n_cols}")
+    u = np.empty((P, n_rows, n_cols), dtype=np.float32)
+    v = np.empty((P, n_rows, n_cols), dtype=np.float32)
+    _lib.check(lib.lspiv_u_v_displacement(_lib.ptr(c), P, n_win, wy, wx, _lib.ptr(u), _lib.ptr(v)))
+    return u, v
+
+
+class Ensemble:
+    """Device-resident ensemble-correlation accumulator (pyorc/velocimetry/ffpiv.py:182-376)."""
+
+    def __init__(self, dim_size, window_size, overlap):
+        lib = _lib.load()
+        _lib.require_device()
+        self._h = C.c_void_p()
+        self.window_size = tuple(window_size)
+        self.overlap = tuple(overlap)
+        self.dim_size = tuple(dim_size)
+        self.n_rows, self.n_cols = window.get_array_shape(dim_size, window_size, overlap)
+        _lib.check(lib.lspiv_ensemble_begin(dim_size[0], dim_size[1], window_size[0], window_size[1],
+                                            overlap[0], overlap[1], C.byref(self._h)))
+
+    def accumulate(self, imgs, corr_min: float, s2n_min: float, signal_threshold: Optional[float] = None):
+        """Add one frame chunk; returns masked per-pair (corr_max, s2n), each (T-1, n_win) float32."""
+        a = _lib.as_frames(imgs)
+        if a.shape[1:] != self.dim_size:
+            raise ValueError(f"chunk shape {a.shape[1:]} != ensemble shape {self.dim_size}")
+        P = a.shape[0] - 1
+        n_win = self.n_rows * self.n_cols
+        cm = np.empty((P, n_win), dtype=np.float32)
+        sn = np.empty((P, n_win), dtype=np.float32)
+        _lib.check(_lib.load().lspiv_ensemble_accumulate(self._h, _lib.ptr(a), _lib.DTYPE_CODES[a.dtype], a.shape[0],
+                                                         float(corr_min), float(s2n_min), _sig(signal_threshold),
+                                                         _lib.ptr(cm), _lib.ptr(sn)))
+        return cm, sn
+
+    def finish(self, count_min: float, n_frames: float, return_mean: bool = False):
+        """Count filter + mean plane + sub-pixel peak: u, v (1, n_rows, n_cols) px, corr_count (n_win,)."""
+        n_win = self.n_rows * self.n_cols
+        u = np.empty((1, self.n_rows, self.n_cols), dtype=np.float32)
+        v = np.empty((1, self.n_rows, self.n_cols), dtype=np.float32)
+        cnt = np.empty(n_win, dtype=np.float32)
+        mean = np.empty((1, n_win) + self.window_size, dtype=np.float32) if return_mean else None
+        _lib.check(_lib.load().lspiv_ensemble_finish(self._h, float(count_min), float(n_frames), _lib.ptr(u),
+                                                     _lib.ptr(v), _lib.ptr(cnt),
+                                                     _lib.ptr(mean) if mean is not None else None))
+        return (u, v, cnt, mean) if return_mean else (u, v, cnt)
+
+    def close(self):
+        if self._h:
+            _lib.load().lspiv_ensemble_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,71 @@
+"""Mirror of ``ffpiv.window`` for the call sites on pyorc's PIV path.
+
+Reference call sites: pyorc/api/frames.py:85-90 (``get_rect_coordinates``), :167
+(``round_to_even``); pyorc/velocimetry/ffpiv.py:120-126 (``required_memory``), :129
+(``available_memory``).  The grid functions call the C ABI (host-only code in
+liblspiv_hip.so, no GPU needed); the memory functions answer for HBM instead of host RAM,
+because that is what bounds a chunk on the ``hip`` engine.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+
+
+def round_to_even(input_tuple: Sequence[float]) -> Tuple[int, ...]:
+    """Round window sizes to even integers (pyorc/api/frames.py:167; direction for odd sizes: SURVEY A8)."""
+    return tuple(int(np.round(float(x) / 2.0) * 2) for x in input_tuple)
+
+
+def get_axis_shape(dim_size: int, window_size: int, overlap: int) -> int:
+    nr, nc = C.c_int64(), C.c_int64()
+    _lib.check(_lib.load().lspiv_grid_shape(dim_size, dim_size, window_size, window_size, overlap, overlap,
+                                            C.byref(nr), C.byref(nc)))
+    return nr.value
+
+
+def get_array_shape(dim_size, window_size, overlap) -> Tuple[int, int]:
+    nr, nc = C.c_int64(), C.c_int64()
+    _lib.check(_lib.load().lspiv_grid_shape(dim_size[0], dim_size[1], window_size[0], window_size[1],
+                                            overlap[0], overlap[1], C.byref(nr), C.byref(nc)))
+    return nr.value, nc.value
+
+
+def get_rect_coordinates(dim_size, window_size, overlap, search_area_size=None, center_on_field=False):
+    """Window-centre pixel indices ``(x_cols, y_rows)``, int64 (usable for fancy indexing)."""
+    if center_on_field:
+        raise NotImplementedError("pyorc never centres the grid on the field")
+    sa = window_size if search_area_size is None else search_area_size
+    n_rows, n_cols = get_array_shape(dim_size, sa, overlap)
+    rows = np.empty(max(n_rows, 0), dtype=np.int64)
+    cols = np.empty(max(n_cols, 0), dtype=np.int64)
+    _lib.check(_lib.load().lspiv_grid_coords(dim_size[0], dim_size[1], sa[0], sa[1], overlap[0], overlap[1],
+                                             rows.ctypes.data_as(C.POINTER(C.c_int64)),
+                                             cols.ctypes.data_as(C.POINTER(C.c_int64))))
+    return cols, rows
+
+
+def required_memory(n_frames: int, dim_size, window_size, overlap, search_area_size=None,
+                    dtype=np.uint8, with_planes: bool = False) -> int:
+    """HBM bytes one fused call on ``n_frames`` frames needs (frames + four result planes).
+
+    The reference's figure is the host RAM of the materialised window stack + correlation volume
+    (x3.9 .. x14.8 of the frames); the fused kernel materialises neither.
+    """
+    sa = window_size if search_area_size is None else search_area_size
+    code = _lib.DTYPE_CODES[np.dtype(dtype)]
+    r = _lib.load().lspiv_required_bytes(n_frames, dim_size[0], dim_size[1], code, sa[0], sa[1],
+                                         overlap[0], overlap[1], int(with_planes))
+    return _lib.check(r)
+
+
+def available_memory() -> int:
+    """Free HBM on the current device in bytes (library workspaces counted as reusable)."""
+    free, total = C.c_int64(), C.c_int64()
+    _lib.check(_lib.load().lspiv_available_bytes(C.byref(free), C.byref(total)))
+    return free.value
