@@ -1,0 +1,58 @@
+"""CPU-baseline leg of bench.py: times the C oracle (all host cores) on a bounded sample.  TEST INFRASTRUCTURE.
+
+The figure is "own restatement of the ffpiv semantics" (kind = "port"), NOT ffpiv itself: neither ffpiv,
+rocket_fft nor numba exist on the GPU box, and nothing of /root/reference travels there.
+"""
+
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+
+from . import c_oracle
+
+
+def default_sample_pairs(H: int, W: int, ws) -> int:
+    """About 10-30 s of CPU work: ~50 us per 32x32 window pair per core (measured), scaled by area."""
+    cores = max(1, min(c_oracle.max_threads(), os.cpu_count() or 1))
+    n_win = ((H - ws[0]) // (ws[0] // 2) + 1) * ((W - ws[1]) // (ws[1] // 2) + 1)
+    per_pair_s = n_win * 50e-6 * (ws[0] * ws[1] / 1024.0) ** 1.2 / cores
+    return int(max(2, min(200, round(15.0 / max(per_pair_s, 1e-6)))))
+
+
+def run(frames_sample: np.ndarray, ws, ov, gpu_block=None) -> dict:
+    """Time the oracle on ``frames_sample`` (T,H,W); compare with the GPU block (4, T-1, n_rows, n_cols)."""
+    cores = max(1, min(c_oracle.max_threads(), os.cpu_count() or 1))
+    n_pairs = frames_sample.shape[0] - 1
+    c_oracle.piv_pairs(frames_sample[:2], ws, ov, nthreads=cores)  # warm-up (thread pool, page faults)
+    t0 = time.perf_counter()
+    u, v, cm, sn = c_oracle.piv_pairs(frames_sample, ws, ov, nthreads=cores)
+    dt = time.perf_counter() - t0
+    if gpu_block is not None:  # untimed: grade the windows (argmax gap, neighbourhood floor) for the parity line
+        *_, cond = c_oracle.piv_pairs(frames_sample, ws, ov, nthreads=cores, return_cond=True)
+        ok = c_oracle.well_posed(cond)
+    out = {
+        "value": round(n_pairs / dt, 3),
+        "unit": "frame-pairs/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"first {n_pairs} frame-pairs of the benchmark stack ({frames_sample.shape[1]}x"
+                  f"{frames_sample.shape[2]}, {ws[0]}x{ws[1]} windows), C/OpenMP float64 restatement of the ffpiv "
+                  f"semantics (oracle/piv_oracle.c), {dt:.1f} s wall",
+    }
+    if gpu_block is not None:
+        worst = 0.0
+        nan_mismatch = 0
+        for g, r in zip(gpu_block, (u, v, cm, sn)):
+            nan_mismatch += int((np.isnan(g) != np.isnan(r))[ok].sum())
+            with np.errstate(all="ignore"):
+                e = (np.abs(g - r) / np.maximum(np.abs(r), 0.05))[ok]
+            if np.isfinite(e).any():
+                worst = max(worst, float(np.nanmax(e)))
+        out["parity_max_rel_err_vs_oracle"] = float(f"{worst:.3e}")
+        out["parity_nan_mismatch"] = nan_mismatch
+        out["parity_windows_checked"] = int(ok.sum())
+        out["parity_windows_ill_posed"] = int((~ok).sum())
+    return out

@@ -168,7 +168,7 @@ template <typename T>
 __device__ __forceinline__ void correlate_job(const PivParams& p, const TileRef (&t)[2], float* buf, int l32,
                                               int partner_byte, float (&xr)[32], float (&xi)[32], bool (&skip)[2]) {
   float Rr[32], Ri[32];
-  float scale[2];
+  float scale[2], hi[2];  // hi = clip ceiling: 1, or 0 for a zero-variance window (plane exactly 0)
   const T* frames = static_cast<const T*>(p.frames);
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -187,7 +187,17 @@ __device__ __forceinline__ void correlate_job(const PivParams& p, const TileRef 
     const float inv_a = center_clip(xr, finite);
     const float inv_b = center_clip(xi, finite);
     skip[k] = skip[k] || !finite;
-    scale[k] = inv_a * inv_b * (1.0f / (4.0f * 1024.0f * 1024.0f));
+    // Balance the packed pair: b is rescaled to a's variance so |A| ~ |B| and the
+    // |Z[k]|^2 - |Z[-k]|^2 difference in cross_spectrum() does not cancel catastrophically when
+    // one window is much fainter than the other.  corr = inv_a inv_b corr(a'', b'') =
+    // inv_a^2 corr(a'', rho b'') with rho = inv_b / inv_a.  A zero-variance window gives an
+    // exactly-zero plane (scale 0), like the reference's zeros-if-std-is-0 rule (A3).
+    const bool dead = (inv_a == 0.0f) || (inv_b == 0.0f);
+    const float rho = dead ? 0.0f : inv_b / inv_a;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) xi[j] *= rho;
+    scale[k] = dead ? 0.0f : inv_a * inv_a * (1.0f / (4.0f * 1024.0f * 1024.0f));
+    hi[k] = dead ? 0.0f : 1.0f;
     __builtin_amdgcn_sched_barrier(0);
     fft32<false>(xr, xi);            // along x
     __builtin_amdgcn_sched_barrier(0);
@@ -197,15 +207,19 @@ __device__ __forceinline__ void correlate_job(const PivParams& p, const TileRef 
     __builtin_amdgcn_sched_barrier(0);
     cross_spectrum(partner_byte, xr, xi);
     __builtin_amdgcn_sched_barrier(0);
+    // The per-window scale goes onto R BEFORE the two windows are packed into one inverse
+    // transform: both planes then peak at <= 1, so float32 rounding of the shared inverse is
+    // relative to O(1) for each of them.  (Scaling after the inverse lets a bright window's
+    // rounding noise, ~1e-7 of ITS magnitude, swamp a faint neighbour packed with it.)
     if (k == 0) {
 #pragma unroll
-      for (int j = 0; j < 32; ++j) { Rr[j] = xr[j]; Ri[j] = xi[j]; }
+      for (int j = 0; j < 32; ++j) { Rr[j] = xr[j] * scale[0]; Ri[j] = xi[j] * scale[0]; }
     } else {
 #pragma unroll
-      for (int j = 0; j < 32; ++j) {  // Q = R1 + i R2
-        float r2r = xr[j], r2i = xi[j];
-        xr[j] = Rr[j] - r2i;
-        xi[j] = Ri[j] + r2r;
+      for (int j = 0; j < 32; ++j) {  // Q = s1 R1 + i s2 R2
+        const float r2r = xr[j], r2i = xi[j];
+        xr[j] = fmaf(-r2i, scale[1], Rr[j]);
+        xi[j] = fmaf(r2r, scale[1], Ri[j]);
       }
     }
   }
@@ -218,8 +232,8 @@ __device__ __forceinline__ void correlate_job(const PivParams& p, const TileRef 
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int j = 0; j < 32; ++j) {
-    xr[j] = fminf(fmaxf(xr[j] * scale[0], 0.0f), 1.0f);
-    xi[j] = fminf(fmaxf(xi[j] * scale[1], 0.0f), 1.0f);
+    xr[j] = fminf(fmaxf(xr[j], 0.0f), hi[0]);
+    xi[j] = fminf(fmaxf(xi[j], 0.0f), hi[1]);
   }
 }
 
