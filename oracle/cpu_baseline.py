@@ -14,17 +14,45 @@ import numpy as np
 from . import c_oracle
 
 
+def effective_cores() -> int:
+    """Host cores this process may really use: min(online CPUs, affinity mask, cgroup CPU quota).
+
+    The GPU boxes expose 256 logical CPUs but cap the container at 16 via cgroup cpu.max; running 256 OpenMP
+    threads there is 6x SLOWER than 16, so the baseline uses the quota and reports it as ``cores``.
+    """
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            n = min(n, max(1, q // per))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, c_oracle.max_threads()))
+
+
 def default_sample_pairs(H: int, W: int, ws) -> int:
-    """About 10-30 s of CPU work: ~50 us per 32x32 window pair per core (measured), scaled by area."""
-    cores = max(1, min(c_oracle.max_threads(), os.cpu_count() or 1))
+    """About 10-30 s of CPU work: ~20-50 us per 32x32 window pair per core (measured), scaled by area."""
+    cores = effective_cores()
     n_win = ((H - ws[0]) // (ws[0] // 2) + 1) * ((W - ws[1]) // (ws[1] // 2) + 1)
-    per_pair_s = n_win * 50e-6 * (ws[0] * ws[1] / 1024.0) ** 1.2 / cores
-    return int(max(2, min(200, round(15.0 / max(per_pair_s, 1e-6)))))
+    per_pair_s = n_win * 30e-6 * (ws[0] * ws[1] / 1024.0) ** 1.2 / cores
+    return int(max(2, min(1000, round(15.0 / max(per_pair_s, 1e-6)))))
 
 
 def run(frames_sample: np.ndarray, ws, ov, gpu_block=None) -> dict:
     """Time the oracle on ``frames_sample`` (T,H,W); compare with the GPU block (4, T-1, n_rows, n_cols)."""
-    cores = max(1, min(c_oracle.max_threads(), os.cpu_count() or 1))
+    cores = effective_cores()
     n_pairs = frames_sample.shape[0] - 1
     c_oracle.piv_pairs(frames_sample[:2], ws, ov, nthreads=cores)  # warm-up (thread pool, page faults)
     t0 = time.perf_counter()

@@ -1,0 +1,110 @@
+"""Frame-pair sharding over the GPUs of one node (one process per GPU).
+
+PIV pairs are independent (docs/user-guide/velocimetry/index.rst:12-13 of the reference), and the
+reference already splits the time axis into chunks with a 1-frame halo
+(pyorc/velocimetry/ffpiv.py:140).  Sharding is the same cut, one level up: rank r of R owns the
+contiguous pair block [r P / R, (r+1) P / R) and therefore reads frames [r P / R, (r+1) P / R] --
+the halo frame is read redundantly, never communicated.  The only exchange is ONE all-gather of each
+rank's packed (4, p_local, n_rows, n_cols) float32 result block (u | v | corr_max | s2n) at the end
+(RCCL over xGMI with the "nccl" backend; "gloo" in the CPU tests).  Ensemble mode instead needs a
+sum all-reduce of corr_sum / corr_count, provided by ``allreduce_sum``.
+
+torch.distributed is plumbing here (rendezvous + collectives); the compute callable is injected.
+"""
+
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+
+
+def pair_block(n_pairs: int, rank: int, world: int) -> Tuple[int, int]:
+    """[start, stop) of the pairs owned by ``rank``; blocks are contiguous, ordered, sizes differ by <= 1."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    return (n_pairs * rank) // world, (n_pairs * (rank + 1)) // world
+
+
+def frame_block(n_pairs: int, rank: int, world: int) -> Tuple[int, int]:
+    """[start, stop) of the FRAMES rank needs: its pairs plus the one-frame halo."""
+    a, b = pair_block(n_pairs, rank, world)
+    return (a, b + 1) if b > a else (a, a)
+
+
+def block_sizes(n_pairs: int, world: int) -> List[int]:
+    return [pair_block(n_pairs, r, world)[1] - pair_block(n_pairs, r, world)[0] for r in range(world)]
+
+
+def _dist():
+    import torch
+    import torch.distributed as dist
+
+    return torch, dist
+
+
+def gather_blocks(local: np.ndarray, n_pairs: int, group=None, device=None) -> np.ndarray:
+    """All-gather per-rank result blocks (4, p_local, n_rows, n_cols) into (4, n_pairs, n_rows, n_cols).
+
+    Blocks may differ by one pair; they are padded to the largest block so that a single
+    ``all_gather_into_tensor`` moves everything (one large collective, not one per variable).
+    """
+    torch, dist = _dist()
+    world = dist.get_world_size(group)
+    sizes = block_sizes(n_pairs, world)
+    pmax = max(sizes)
+    k, p_local, n_rows, n_cols = local.shape
+    if p_local != sizes[dist.get_rank(group)]:
+        raise ValueError(f"rank {dist.get_rank(group)} holds {p_local} pairs, expected {sizes[dist.get_rank(group)]}")
+    dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    send = torch.full((k, pmax, n_rows, n_cols), float("nan"), dtype=torch.float32, device=dev)
+    send[:, :p_local] = torch.as_tensor(np.ascontiguousarray(local, dtype=np.float32)).to(dev)
+    recv = torch.empty((world,) + tuple(send.shape), dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
+    recv = recv.cpu().numpy()
+    return np.concatenate([recv[r][:, :sizes[r]] for r in range(world)], axis=1)
+
+
+def allreduce_sum(arr: np.ndarray, group=None, device=None) -> np.ndarray:
+    """Sum an array over ranks (ensemble corr_sum / corr_count), same dtype and shape back."""
+    torch, dist = _dist()
+    dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    t = torch.as_tensor(np.ascontiguousarray(arr)).to(dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu().numpy()
+
+
+def sharded_piv(load_frames: Callable[[int, int], np.ndarray], n_pairs: int, window_size, overlap,
+                compute: Optional[Callable] = None, signal_threshold=None, group=None) -> np.ndarray:
+    """Every rank computes its pair block and all ranks receive the full (4, n_pairs, n_rows, n_cols) block.
+
+    ``load_frames(start, stop)`` returns frames [start, stop) as (T, H, W) -- each rank only ever touches its
+    own time block (+ halo).  ``compute(frames, window_size, overlap, signal_threshold)`` -> (u, v, corr_max,
+    s2n); default is the HIP engine (``pyorc_amd.piv.piv_pairs``).
+    """
+    torch, dist = _dist()
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if compute is None:
+        from . import piv
+
+        compute = piv.piv_pairs
+    f0, f1 = frame_block(n_pairs, rank, world)
+    if f1 - f0 >= 2:
+        u, v, cm, sn = compute(load_frames(f0, f1), window_size, overlap, signal_threshold)
+        local = np.stack([u, v, cm, sn]).astype(np.float32)
+        shape = np.array(local.shape[2:], dtype=np.int64)
+    else:
+        local, shape = None, np.zeros(2, dtype=np.int64)
+    # ranks without pairs (n_pairs < world) learn the grid shape from the others
+    shape = allreduce_max(shape, group)
+    if local is None:
+        local = np.empty((4, 0, int(shape[0]), int(shape[1])), dtype=np.float32)
+    return gather_blocks(local, n_pairs, group)
+
+
+def allreduce_max(arr: np.ndarray, group=None) -> np.ndarray:
+    torch, dist = _dist()
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.as_tensor(np.ascontiguousarray(arr)).to(dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t.cpu().numpy()

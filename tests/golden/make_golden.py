@@ -1,0 +1,103 @@
+"""Generate the golden fixtures under tests/golden/ from the numpy oracle (oracle/piv_oracle.py).
+
+    python tests/golden/make_golden.py
+
+** These are NOT reference outputs. **  The reference path (ffpiv + rocket_fft + numba) cannot be imported
+or run in the build container and its only numeric test needs a video that is absent, so
+the vectors pin this repository's own restatement of the ffpiv semantics: they freeze the oracle (a
+regression in it fails tests/test_oracle.py) and give the GPU tests inputs + expected outputs that travel to
+the GPU box.  Regenerate and diff against a real ffpiv the moment one is importable.
+
+Contents of piv_golden.npz (G1..G3 of SURVEY.md section 8c):
+  g1_*   single 32x32 window pairs: Gaussian speckle field shifted by known integer / fractional (dx, dy)
+  g2_*   degenerate windows: constant, all zero, single bright pixel, peak on the plane border
+  g3_*   128 x 160 x 5 mini stack, 32x32/16 and 64x64/48, uint8 and signed float32
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import piv_oracle as po  # noqa: E402
+from pyorc_amd.synth import particle_stack  # noqa: E402
+
+SHIFTS = [(0.0, 0.0), (1.0, 0.0), (0.0, -1.0), (3.25, -3.25), (-7.5, 7.5), (2.0, 5.0), (-4.6, -2.2)]
+
+
+def speckle_pair(dx, dy, seed, n=32, pad=24):
+    """Two n x n windows cut from one smooth random field, the second displaced by (dx, dy) pixels."""
+    rng = np.random.default_rng(seed)
+    size = n + 2 * pad
+    npart = 90
+    py, px = rng.uniform(0, size, npart), rng.uniform(0, size, npart)
+    amp = rng.uniform(120, 255, npart)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float64)
+
+    def render(oy, ox):
+        img = np.zeros((size, size))
+        for y0, x0, a in zip(py + oy, px + ox, amp):
+            img += a * np.exp(-((yy - y0) ** 2 + (xx - x0) ** 2) / (2 * 1.6**2))
+        return np.clip(np.rint(img), 0, 255).astype(np.uint8)[pad:pad + n, pad:pad + n]
+
+    return render(0.0, 0.0), render(dy, dx)
+
+
+def run(frames, ws, ov, thr=None):
+    x, y, corr = po.cross_corr(frames, ws, ov, signal_threshold=thr)
+    u, v, cm, sn = po.get_uv_timestep(frames, len(x), len(y), ws, ov, thr)
+    return dict(u=u.astype(np.float32), v=v.astype(np.float32), corr=cm, s2n=sn)
+
+
+def main():
+    out = {}
+    # G1: known shifts
+    g1_in, g1_out = [], []
+    for k, (dx, dy) in enumerate(SHIFTS):
+        a, b = speckle_pair(dx, dy, seed=100 + k)
+        fr = np.stack([a, b])
+        r = run(fr, (32, 32), (16, 16))
+        g1_in.append(fr)
+        g1_out.append([r["u"][0, 0, 0], r["v"][0, 0, 0], r["corr"][0, 0, 0], r["s2n"][0, 0, 0]])
+    out["g1_frames"] = np.array(g1_in)
+    out["g1_shifts"] = np.array(SHIFTS)
+    out["g1_expected"] = np.array(g1_out, dtype=np.float32)
+    # G2: degenerate windows (one 32x32 window each)
+    rng = np.random.default_rng(7)
+    base = rng.integers(0, 255, (32, 32)).astype(np.uint8)
+    const = np.full((32, 32), 9, np.uint8)
+    zero = np.zeros((32, 32), np.uint8)
+    single = zero.copy(); single[5, 7] = 200
+    border_b = np.roll(base, 15, axis=1)  # displacement 15 px -> peak in the last plane column (border)
+    cases = {"const_a": (const, base), "zero_b": (base, zero), "both_zero": (zero, zero),
+             "single_px": (single, np.roll(single, (2, 3), (0, 1))), "border": (base, border_b), "self": (base, base)}
+    g2_in, g2_out = [], []
+    for name, (a, b) in cases.items():
+        fr = np.stack([a, b])
+        r = run(fr, (32, 32), (16, 16))
+        g2_in.append(fr)
+        g2_out.append([r["u"][0, 0, 0], r["v"][0, 0, 0], r["corr"][0, 0, 0], r["s2n"][0, 0, 0]])
+    out["g2_names"] = np.array(list(cases))
+    out["g2_frames"] = np.array(g2_in)
+    out["g2_expected"] = np.array(g2_out, dtype=np.float32)
+    # G3: mini stack
+    stack = particle_stack(5, 128, 160, seed=20260927)
+    out["g3_frames_u8"] = stack
+    f32 = stack.astype(np.float32)
+    f32 -= f32.mean(axis=0, keepdims=True)
+    out["g3_frames_f32"] = f32
+    for tag, fr in (("u8", stack), ("f32", f32)):
+        for ws, ov in (((32, 32), (16, 16)), ((64, 64), (48, 48))):
+            r = run(fr, ws, ov)
+            for k, v in r.items():
+                out[f"g3_{tag}_{ws[0]}_{k}"] = v
+    r = run(stack, (32, 32), (16, 16), thr=0.3)
+    for k, v in r.items():
+        out[f"g3_u8_32_thr03_{k}"] = v
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "piv_golden.npz"), **out)
+    print({k: getattr(v, "shape", None) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

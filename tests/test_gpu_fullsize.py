@@ -1,0 +1,128 @@
+"""GPU tests at the BASELINE.json sizes: 1080p x 1000 pairs (config 2), 64x64@75% (config 3), 4K (config 4).
+
+The oracle cannot finish these sizes in seconds, so they are checked through size-independent properties:
+  * a sample of pairs spread over the stack equals the oracle (same gate as the small tests);
+  * determinism: two launches give bit-identical results;
+  * chunk invariance: the stack processed in time chunks (1-frame halo) equals the single launch bit for bit;
+  * round trip: a stack made of circular shifts of one frame returns that shift in every window.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from pyorc_amd import _lib, window
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def rel_err(got, ref, floor=0.05):
+    with np.errstate(all="ignore"):
+        e = np.abs(np.asarray(got, dtype=np.float64) - ref) / np.maximum(np.abs(ref), floor)
+    return float(np.nanmax(e)) if np.isfinite(e).any() else 0.0
+
+
+class DeviceStack:
+    def __init__(self, lib, T, H, W, seed):
+        self.lib, self.T, self.H, self.W = lib, T, H, W
+        self.d = C.c_void_p()
+        _lib.check(lib.lspiv_dev_malloc(C.byref(self.d), T * H * W))
+        _lib.check(lib.lspiv_synth_particles_dev(self.d, T, H, W, seed, 0.02))
+
+    def run(self, ws, ov, first=0, n_frames=None):
+        n_frames = self.T - first if n_frames is None else n_frames
+        nr, nc = window.get_array_shape((self.H, self.W), ws, ov)
+        P = n_frames - 1
+        d_out = C.c_void_p()
+        _lib.check(self.lib.lspiv_dev_malloc(C.byref(d_out), 4 * P * nr * nc * 4))
+        try:
+            src = C.c_void_p(self.d.value + first * self.H * self.W)
+            _lib.check(self.lib.lspiv_piv_pairs_dev(src, 0, n_frames, self.H, self.W, ws[0], ws[1], ov[0], ov[1], -1.0,
+                                                    d_out, None, None))
+            out = np.empty((4, P, nr, nc), np.float32)
+            _lib.check(self.lib.lspiv_memcpy_d2h(_lib.ptr(out), d_out, out.nbytes))
+        finally:
+            self.lib.lspiv_dev_free(d_out)
+        return out
+
+    def frames(self, first, n):
+        a = np.empty((n, self.H, self.W), np.uint8)
+        src = C.c_void_p(self.d.value + first * self.H * self.W)
+        _lib.check(self.lib.lspiv_memcpy_d2h(_lib.ptr(a), src, a.nbytes))
+        return a
+
+    def free(self):
+        self.lib.lspiv_dev_free(self.d)
+
+
+def check_sample(stack, out, ws, ov, starts):
+    for s in starts:
+        fr = stack.frames(s, 3)
+        uo, vo, cmo, sno, cond = c_oracle.piv_pairs(fr, ws, ov, return_cond=True)
+        ok = c_oracle.well_posed(cond)
+        g = out[:, s:s + 2]
+        for k, r in enumerate((uo, vo, cmo, sno)):
+            assert np.array_equal(np.isnan(g[k]), np.isnan(r)), (s, k)
+        assert rel_err(g[2], cmo.astype(np.float64)) <= TOL and rel_err(g[3], sno.astype(np.float64)) <= TOL
+        assert ok.mean() > 0.9
+        assert rel_err(g[0][ok], uo[ok].astype(np.float64)) <= TOL
+        assert rel_err(g[1][ok], vo[ok].astype(np.float64)) <= TOL
+
+
+def test_config2_1080p_1000_pairs(gpu):
+    st = DeviceStack(gpu, 1001, 1080, 1920, seed=20260929)
+    try:
+        ws, ov = (32, 32), (16, 16)
+        out = st.run(ws, ov)
+        assert out.shape == (4, 1000, 66, 119)
+        again = st.run(ws, ov)
+        assert np.array_equal(out, again, equal_nan=True)                       # deterministic
+        check_sample(st, out, ws, ov, starts=[0, 499, 998])                     # oracle on a spread sample
+        for first, n in ((0, 334), (333, 334), (666, 335)):                     # time chunks with a 1-frame halo
+            part = st.run(ws, ov, first=first, n_frames=n)
+            assert np.array_equal(part, out[:, first:first + n - 1], equal_nan=True)
+        u = out[0]
+        assert 2.5 < np.nanmedian(u) < 3.5 and np.isnan(u).mean() < 0.05       # flow 3 + 2 sin(.) px/frame
+    finally:
+        st.free()
+
+
+def test_config3_64x64_overlap48(gpu):
+    st = DeviceStack(gpu, 41, 1080, 1920, seed=20260930)
+    try:
+        ws, ov = (64, 64), (48, 48)
+        out = st.run(ws, ov)
+        assert out.shape == (4, 40, 64, 117)
+        check_sample(st, out, ws, ov, starts=[0, 38])
+        assert np.array_equal(out[:, 10:20], st.run(ws, ov, first=10, n_frames=11), equal_nan=True)
+    finally:
+        st.free()
+
+
+def test_config4_4k(gpu):
+    st = DeviceStack(gpu, 101, 2160, 3840, seed=20260931)
+    try:
+        ws, ov = (32, 32), (16, 16)
+        out = st.run(ws, ov)
+        assert out.shape == (4, 100, 134, 239)
+        check_sample(st, out, ws, ov, starts=[0, 98])
+        assert np.array_equal(out[:, 50:75], st.run(ws, ov, first=50, n_frames=26), equal_nan=True)
+    finally:
+        st.free()
+
+
+def test_round_trip_circular_shift_full_frame(gpu):
+    """frames[t] = roll(frames[0], t * (dy, dx)): every interior window must report exactly (dx, dy)."""
+    import pyorc_amd
+
+    rng = np.random.default_rng(5)
+    base = (rng.random((1080, 1920)) ** 6 * 255).astype(np.uint8)
+    dy, dx = 2, -5
+    fr = np.stack([np.roll(base, (t * dy, t * dx), (0, 1)) for t in range(4)])
+    u, v, cm, sn = pyorc_amd.piv_pairs(fr, (32, 32), (16, 16))
+    # the window content moves rigidly; integer shift => symmetric peak => sub-pixel offset ~ 0
+    assert np.nanmax(np.abs(u - dx)) < 0.05 and np.nanmax(np.abs(v - dy)) < 0.05
+    assert not np.isnan(u).any()
+    assert np.array_equal(u[0], u[0]) and np.abs(u[0] - u[1]).max() < 0.1

@@ -1,0 +1,171 @@
+"""CPU tests of the host side: C-ABI surface, window grid, chunk planner, parameter resolution, loud failure
+without a GPU.  No compute entry point is exercised here (there is no GPU and no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import piv_oracle as po
+from pyorc_amd import _lib, frames, shard, velocimetry, window
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "lspiv.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(lspiv_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_header_symbol(lib):
+    syms = header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/lspiv.h but not exported by liblspiv_hip.so"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes prototype in pyorc_amd/_lib.py"
+    assert sorted(_lib.SIGNATURES) == syms
+    assert lib.lspiv_abi_version() == 1
+    assert b"gfx950" in lib.lspiv_version()
+
+
+def test_library_contains_gfx950_code_object_only():
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"amdgcn-amd-amdhsa--gfx950" in blob
+    for other in (b"gfx942", b"gfx90a", b"gfx1100", b"sm_90", b"nvptx"):
+        assert other not in blob, other  # no second backend, no compatibility layer
+
+
+@pytest.mark.parametrize("dim,win,ov", [((1080, 1920), (32, 32), (16, 16)), ((1080, 1920), (64, 64), (48, 48)),
+                                        ((2160, 3840), (32, 32), (16, 16)), ((785, 875), (32, 32), (16, 16)),
+                                        ((475, 371), (10, 10), (5, 5)), ((100, 90), (24, 16), (12, 8)),
+                                        ((40, 40), (26, 26), (13, 13))])
+def test_grid_matches_oracle(dim, win, ov):
+    x, y = window.get_rect_coordinates(dim, win, ov)
+    xo, yo = po.get_rect_coordinates(dim, win, ov)
+    assert np.array_equal(x, xo) and np.array_equal(y, yo) and x.dtype == np.int64
+    assert window.get_array_shape(dim, win, ov) == (len(yo), len(xo))
+
+
+def test_grid_errors_map_to_status_codes(lib):
+    nr, nc = C.c_int64(), C.c_int64()
+    assert lib.lspiv_grid_shape(100, 100, 32, 32, 32, 16, C.byref(nr), C.byref(nc)) == _lib.LSPIV_EINVAL
+    assert b"overlap" in lib.lspiv_last_error()
+    assert lib.lspiv_grid_shape(100, 100, 66, 66, 0, 0, C.byref(nr), C.byref(nc)) == _lib.LSPIV_EUNSUPPORTED
+    assert lib.lspiv_grid_shape(10, 100, 32, 32, 16, 16, C.byref(nr), C.byref(nc)) == 0 and nr.value == 0
+    with pytest.raises(_lib.LspivError):
+        window.get_rect_coordinates((100, 100), (32, 32), (40, 16))
+
+
+def test_kernel_dispatch_table(lib):
+    assert lib.lspiv_kernel_kind(32, 32) == 1
+    assert lib.lspiv_kernel_kind(10, 10) == 3 and lib.lspiv_kernel_kind(24, 16) == 3
+    assert lib.lspiv_kernel_kind(64, 64) in (2, 3)
+    assert lib.lspiv_kernel_kind(128, 128) == _lib.LSPIV_EUNSUPPORTED
+
+
+def test_required_memory_counts_frames_and_results():
+    b = window.required_memory(1001, (1080, 1920), (32, 32), (16, 16), dtype=np.uint8)
+    assert b == 1001 * 1080 * 1920 + 4 * 4 * 1000 * 66 * 119
+    bp = window.required_memory(3, (64, 64), (32, 32), (16, 16), dtype=np.float32, with_planes=True)
+    assert bp == 3 * 64 * 64 * 4 + 16 * 2 * 9 + 2 * 9 * 1024 * 4
+
+
+def test_no_gpu_means_loud_failure_not_fallback(lib):
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    import pyorc_amd
+
+    with pytest.raises(_lib.LspivError) as ei:
+        pyorc_amd.piv_pairs(np.zeros((2, 64, 64), np.uint8))
+    assert ei.value.code == _lib.LSPIV_ENODEV
+    u = np.zeros(9, np.float32)
+    rc = lib.lspiv_piv_pairs(_lib.ptr(np.zeros((2, 64, 64), np.uint8)), 0, 2, 64, 64, 32, 32, 16, 16, -1.0,
+                             _lib.ptr(u), _lib.ptr(u), _lib.ptr(u), _lib.ptr(u), None)
+    assert rc == _lib.LSPIV_ENODEV and b"device" in lib.lspiv_last_error()
+    with pytest.raises(_lib.LspivError):
+        window.available_memory()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "pyorc_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "piv_oracle" not in txt, f
+    code = "import sys; import pyorc_amd, pyorc_amd.velocimetry, pyorc_amd.frames, pyorc_amd.shard; " \
+           "assert not any(m.startswith('oracle') for m in sys.modules)"
+    subprocess.check_call([sys.executable, "-c", code], cwd=ROOT)
+
+
+def test_missing_library_raises(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "liblspiv_hip.so"))
+    with pytest.raises(_lib.LspivLibraryMissing):
+        _lib.load()
+
+
+def test_resolve_window_matches_reference_rules():
+    for ws in (32, 10, 25, 64, (32, 64)):
+        assert frames.resolve_window(ws) == po.resolve_piv_args(ws)
+    assert frames.resolve_window(32, (8, 24)) == ((32, 32), (32, 32), (8, 24))
+    with pytest.raises(ValueError, match="does not exist"):
+        frames.get_piv(np.zeros((3, 64, 64), np.uint8), 32, engine="numba")  # same message as frames.py:177
+    with pytest.raises(ValueError, match="does not exist"):
+        velocimetry.get_ffpiv(np.zeros((3, 64, 64)), [0], [0], [1, 1], (32, 32), (16, 16), (32, 32), 1, 1,
+                              engine="openpiv")
+
+
+@pytest.mark.parametrize("n,req,avail,cs", [(21, 1e9, 1e12, None), (21, 4e9, 1e9, None), (11, 0, 1, 5), (11, 0, 1, 10),
+                                            (10, 0, 1, 10), (1001, 9e9, 1e9, None), (7, 0, 1, 2)])
+def test_chunk_planner_matches_oracle(n, req, avail, cs):
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, got = velocimetry.plan_chunks(n, req, avail, cs, "hip")
+    assert got == po.plan_chunks(n, req, avail, cs)
+    assert sum(b - a - 1 for a, b in got) == n - 1  # every pair exactly once
+
+
+def test_chunk_planner_warning_and_error():
+    with pytest.warns(UserWarning, match="Memory availability is poor"):
+        cs, _ = velocimetry.plan_chunks(100, 1e12, 1e9, None, "hip")
+    assert cs == 5
+    with pytest.raises(OverflowError, match="Chunk size"):
+        velocimetry.plan_chunks(10, 0, 1, 1, "hip")
+    cs, sl = velocimetry.plan_chunks(1001, 0, 1, 1001, "hip", n_win=2**29)  # 32-bit window index per launch
+    assert cs == 3 and all(b - a <= 4 for a, b in sl)
+
+
+def test_shard_blocks_partition_pairs():
+    for n, w in [(1000, 8), (8000, 8), (7, 2), (5, 8), (1, 1), (0, 2)]:
+        blocks = [shard.pair_block(n, r, w) for r in range(w)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == n
+        assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
+        assert max(b - a for a, b in blocks) - min(b - a for a, b in blocks) <= 1
+        for r in range(w):
+            a, b = shard.pair_block(n, r, w)
+            assert shard.frame_block(n, r, w) == ((a, b + 1) if b > a else (a, a))
+    with pytest.raises(ValueError):
+        shard.pair_block(10, 2, 2)
+
+
+def test_int16_encoding_matches_oracle():
+    a = np.array([0.1234, -1.005, np.nan, 327.0, 1e6])
+    assert frames.encode_int16(a)[:4].tolist() == po.encode_int16(a[:4]).tolist()
+    assert frames.encode_int16(a)[4] == 32767
+
+
+def test_as_frames_dtype_rules():
+    assert _lib.as_frames(np.zeros((2, 4, 4), np.uint8)).dtype == np.uint8
+    assert _lib.as_frames(np.zeros((2, 4, 4), np.float32)).dtype == np.float32
+    assert _lib.as_frames(np.zeros((2, 4, 4), np.int16)).dtype == np.float32
+    assert _lib.as_frames(np.zeros((2, 4, 4), np.int64)).dtype == np.float64
+    assert _lib.as_frames(np.zeros((4, 4, 2), np.uint8).transpose(2, 0, 1)).flags.c_contiguous
+    with pytest.raises(ValueError):
+        _lib.as_frames(np.zeros((4, 4)))

@@ -1,0 +1,178 @@
+"""CPU tests of the oracle itself: golden vectors, analytic known answers, C port vs numpy restatement.
+
+The reference's own numeric test of this path (tests/test_frames.py:139-153) cannot run here (video and
+ffpiv absent), so the oracle is pinned by analytic answers and by the fixtures of tests/golden/ -- see the
+"parity unpinned" note in oracle/piv_oracle.py.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from oracle import piv_oracle as po
+from pyorc_amd.synth import flow_field, particle_stack
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "piv_golden.npz"))
+
+
+def rel_err(got, ref, floor=0.05):
+    with np.errstate(all="ignore"):
+        e = np.abs(np.asarray(got, dtype=np.float64) - ref) / np.maximum(np.abs(ref), floor)
+    return float(np.nanmax(e)) if np.isfinite(e).any() else 0.0
+
+
+@pytest.mark.parametrize("dim,win,ov,n", [
+    ((1080, 1920), (32, 32), (16, 16), (66, 119)),   # BASELINE config 2
+    ((1080, 1920), (64, 64), (48, 48), (64, 117)),   # config 3
+    ((2160, 3840), (32, 32), (16, 16), (134, 239)),  # config 4
+    ((785, 875), (32, 32), (16, 16), (48, 53)),      # config 1 (Ngwerere geometry)
+    ((32, 32), (32, 32), (16, 16), (1, 1)),
+])
+def test_grid_shapes_of_baseline_configs(dim, win, ov, n):
+    x, y = po.get_rect_coordinates(dim, win, ov)
+    assert (len(y), len(x)) == n
+    assert y[0] == win[0] // 2 and x[0] == win[1] // 2
+    assert np.all(np.diff(x) == win[1] - ov[1]) or len(x) == 1
+    assert x.dtype == np.int64 and y.dtype == np.int64  # used for fancy indexing (pyorc/helpers.py:166-167)
+
+
+def test_round_to_even_and_default_overlap():
+    assert po.round_to_even((32, 64)) == (32, 64)
+    ws, sa, ov = po.resolve_piv_args(32)
+    assert ws == sa == (32, 32) and ov == (16, 16)
+    ws, sa, ov = po.resolve_piv_args(10)  # the reference's own test size
+    assert ws == (10, 10) and ov == (5, 5)
+
+
+def test_g1_known_shifts_golden_and_analytic():
+    for fr, (dx, dy), exp in zip(GOLD["g1_frames"], GOLD["g1_shifts"], GOLD["g1_expected"]):
+        u, v, cm, sn = po.get_uv_timestep(fr, 1, 1, (32, 32), (16, 16))
+        got = np.array([u[0, 0, 0], v[0, 0, 0], cm[0, 0, 0], sn[0, 0, 0]])
+        assert np.allclose(got, exp, rtol=1e-6, atol=1e-6)        # frozen oracle output
+        assert abs(got[0] - dx) < 0.55 and abs(got[1] - dy) < 0.55  # analytic: single-window PIV bias < 0.55 px
+        assert 0.0 < got[2] <= 1.0 and got[3] > 1.0
+
+
+def test_integer_roll_is_recovered_exactly():
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 255, (32, 32)).astype(np.uint8)
+    for dy, dx in [(0, 0), (1, 2), (-5, 7), (9, -11), (14, 14), (-15, 3)]:
+        b = np.roll(a, (dy, dx), (0, 1))
+        u, v, cm, sn = po.get_uv_timestep(np.stack([a, b]), 1, 1, (32, 32), (16, 16))
+        # circular shift of the same window: the plane is the autocorrelation moved by (dy, dx)
+        assert abs(u[0, 0, 0] - dx) < 1e-6 and abs(v[0, 0, 0] - dy) < 1e-6
+        u0, v0, cm0, _ = po.get_uv_timestep(np.stack([a, a]), 1, 1, (32, 32), (16, 16))
+        assert abs(cm[0, 0, 0] - cm0[0, 0, 0]) < 1e-6
+
+
+def test_g2_degenerate_windows():
+    names = list(GOLD["g2_names"])
+    for name, fr, exp in zip(names, GOLD["g2_frames"], GOLD["g2_expected"]):
+        u, v, cm, sn = po.get_uv_timestep(fr, 1, 1, (32, 32), (16, 16))
+        got = np.array([u[0, 0, 0], v[0, 0, 0], cm[0, 0, 0], sn[0, 0, 0]])
+        assert np.array_equal(np.isnan(got), np.isnan(exp)), name
+        assert np.allclose(got, exp, rtol=1e-6, atol=1e-9, equal_nan=True), name
+    k = names.index("zero_b")
+    assert np.isnan(GOLD["g2_expected"][k][[0, 1, 3]]).all() and GOLD["g2_expected"][k][2] == 0.0
+    k = names.index("border")  # 15 px shift -> peak in the last plane column -> NaN displacement, valid corr
+    assert np.isnan(GOLD["g2_expected"][k][:2]).all() and GOLD["g2_expected"][k][2] > 0.3
+
+
+@pytest.mark.parametrize("tag,ws,ov", [("u8", (32, 32), (16, 16)), ("u8", (64, 64), (48, 48)),
+                                       ("f32", (32, 32), (16, 16)), ("f32", (64, 64), (48, 48))])
+def test_g3_mini_stack_golden(tag, ws, ov):
+    fr = GOLD[f"g3_frames_{tag}"]
+    x, y = po.get_rect_coordinates(fr.shape[1:], ws, ov)
+    u, v, cm, sn = po.get_uv_timestep(fr, len(x), len(y), ws, ov)
+    for k, got in (("u", u), ("v", v), ("corr", cm), ("s2n", sn)):
+        exp = GOLD[f"g3_{tag}_{ws[0]}_{k}"]
+        assert np.array_equal(np.isnan(got), np.isnan(exp))
+        assert rel_err(got, exp.astype(np.float64)) < 1e-5, k
+
+
+def test_signal_threshold_masks_window_pairs():
+    fr = GOLD["g3_frames_u8"]
+    x, y, corr = po.cross_corr(fr, (32, 32), (16, 16), signal_threshold=0.3)
+    stack = po.sliding_window_stack(fr, (32, 32), (16, 16))
+    frac = np.count_nonzero(stack, axis=(-1, -2)) / 1024.0
+    keep = (frac[:-1] >= 0.3) & (frac[1:] >= 0.3)
+    assert np.array_equal(np.isnan(corr).all(axis=(-1, -2)), ~keep)
+    assert 0 < (~keep).sum() < keep.size  # the case exercises both branches
+    exp = GOLD["g3_u8_32_thr03_u"]
+    assert np.array_equal(np.isnan(exp).reshape(keep.shape) | keep, np.ones_like(keep))
+
+
+def test_flow_is_recovered_on_particle_images():
+    fr = particle_stack(3, 256, 320, seed=11)
+    x, y = po.get_rect_coordinates(fr.shape[1:], (32, 32), (16, 16))
+    u, v, cm, sn = po.get_uv_timestep(fr, len(x), len(y), (32, 32), (16, 16))
+    ut, vt = flow_field(256, 320, y[:, None].astype(float), x[None, :].astype(float))
+    assert np.nanmedian(np.abs(u[0] - ut)) < 0.15 and np.nanmedian(np.abs(v[0] - vt)) < 0.15
+    assert np.nanmedian(cm) > 0.4 and np.nanmedian(sn) > 3
+
+
+@pytest.mark.parametrize("ws,ov", [((32, 32), (16, 16)), ((10, 10), (5, 5)), ((24, 16), (12, 8)), ((64, 64), (48, 48))])
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32, np.float64])
+def test_c_port_matches_numpy_oracle(ws, ov, dtype):
+    fr = particle_stack(3, 160, 192, seed=5, dtype=np.uint8)
+    fr = fr if dtype == np.uint8 else (fr.astype(dtype) - 17.5)
+    u, v, cm, sn, planes, cond = c_oracle.piv_pairs(fr, ws, ov, return_planes=True, return_cond=True)
+    x, y, corr = po.cross_corr(fr, ws, ov)
+    uo, vo, cmo, sno = po.get_uv_timestep(fr, len(x), len(y), ws, ov)
+    assert np.nanmax(np.abs(planes - corr)) < 1e-12
+    ok = c_oracle.well_posed(cond, min_gap=1e-9, min_neighbour=0.0)  # float64 vs float64: only exact ties differ
+    assert ok.mean() > 0.5
+    assert np.array_equal(np.isnan(u)[ok], np.isnan(uo)[ok])
+    assert rel_err(u[ok], uo[ok]) < 1e-5 and rel_err(v[ok], vo[ok]) < 1e-5
+    assert rel_err(cm, cmo.astype(np.float64)) < 1e-6
+    assert np.array_equal(np.isnan(sn), np.isnan(sno)) and rel_err(sn, sno.astype(np.float64)) < 1e-6
+
+
+def test_c_port_signal_threshold_and_zero_windows():
+    fr = GOLD["g3_frames_u8"].copy()
+    fr[:, :48, :48] = 0
+    u, v, cm, sn = c_oracle.piv_pairs(fr, (32, 32), (16, 16), signal_threshold=0.3)
+    uo, vo, cmo, sno = po.get_uv_timestep(fr, u.shape[2], u.shape[1], (32, 32), (16, 16), 0.3)
+    for g, r in ((u, uo), (v, vo), (cm, cmo), (sn, sno)):
+        assert np.array_equal(np.isnan(g), np.isnan(r))
+    u, v, cm, sn = c_oracle.piv_pairs(fr, (32, 32), (16, 16))
+    assert cm[0, 0, 0] == 0.0 and np.isnan(sn[0, 0, 0]) and np.isnan(u[0, 0, 0])  # exact zeros, like numpy's rfft2(0)
+
+
+def test_chunked_equals_whole_stack_g4():
+    """Chunk / halo equivalence: any chunking of the time axis gives bit-identical results."""
+    fr = GOLD["g3_frames_u8"]
+    dt = np.full(4, 1 / 30)
+    whole = po.get_ffpiv(fr, dt, (32, 32), (16, 16), 0.01, 0.01)
+    for cs in (2, 3, 4):
+        part = po.get_ffpiv(fr, dt, (32, 32), (16, 16), 0.01, 0.01, chunksize=cs)
+        for k in ("v_x", "v_y", "corr", "s2n", "pair_index"):
+            assert np.array_equal(whole[k], part[k], equal_nan=True), (cs, k)
+    assert whole["v_x"].dtype == np.float32 and whole["pair_index"].tolist() == [1, 2, 3, 4]
+
+
+def test_chunk_planner_follows_reference_rules():
+    # pyorc/velocimetry/ffpiv.py:127-142: floor of 5, halo frame, chunks shorter than 2 frames dropped
+    assert po.plan_chunks(21, 1e9, 1e12) == [(0, 21)]
+    assert po.plan_chunks(21, 4e9, 1e9) == [(0, 5), (4, 10), (9, 15), (14, 20), (19, 21)]
+    assert po.plan_chunks(11, 0, 1, chunksize=5) == [(0, 5), (4, 10), (9, 11)]
+    assert po.plan_chunks(11, 0, 1, chunksize=10) == [(0, 10), (9, 11)]
+    assert po.plan_chunks(10, 0, 1, chunksize=10) == [(0, 10)]
+    with pytest.raises(OverflowError):
+        po.plan_chunks(10, 0, 1, chunksize=1)
+
+
+def test_ensemble_branch_runs_and_masks():
+    fr = GOLD["g3_frames_u8"]
+    dt = np.full(4, 1 / 30)
+    ens = po.get_ffpiv(fr, dt, (32, 32), (16, 16), 0.01, 0.01, ensemble_corr=True, corr_min=0.0, s2n_min=0.0,
+                       count_min=0.0)
+    assert ens["v_x"].shape == (1, 7, 9) and np.isfinite(ens["v_x"]).mean() > 0.8
+    hard = po.get_ffpiv(fr, dt, (32, 32), (16, 16), 0.01, 0.01, ensemble_corr=True, corr_min=2.0)
+    assert np.isnan(hard["v_x"]).all()  # nothing passes corr_min = 2 -> count 0 -> 0/0 -> NaN
+
+
+def test_int16_encoding_of_results():
+    a = np.array([0.1234, -1.005, np.nan, 327.0])
+    assert po.encode_int16(a).tolist() == [12, -100, -9999, 32700]
