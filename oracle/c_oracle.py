@@ -41,8 +41,9 @@ def piv_pairs(frames, window_size, overlap, signal_threshold=None, return_planes
               return_cond=False):
     """(u, v, corr_max, s2n[, planes][, cond]) for every consecutive pair of frames (T,H,W); u, v in pixels.
 
-    cond (T-1, n_rows, n_cols, 2): [..., 0] relative gap between the plane maximum and the runner-up,
-    [..., 1] smallest peak-neighbourhood value / maximum -- see ``well_posed``."""
+    cond (T-1, n_rows, n_cols, 3): [..., 0] relative gap between the plane maximum and the runner-up,
+    [..., 1] smallest peak-neighbourhood value / maximum, [..., 2] smallest log-curvature of the peak --
+    see ``well_posed``."""
     a = np.ascontiguousarray(frames)
     if a.dtype not in _CODES:
         a = a.astype(np.float64)
@@ -54,7 +55,7 @@ def piv_pairs(frames, window_size, overlap, signal_threshold=None, return_planes
     out = [np.empty((T - 1, n_rows, n_cols), dtype=np.float32) for _ in range(4)]
     planes = np.empty((T - 1, n_rows * n_cols, wy, wx), dtype=np.float64) if return_planes else None
     thr = -1.0 if signal_threshold is None else float(signal_threshold)
-    cond = np.zeros((T - 1, n_rows, n_cols, 2), dtype=np.float32) if return_cond else None
+    cond = np.zeros((T - 1, n_rows, n_cols, 3), dtype=np.float32) if return_cond else None
     rc = load().piv_oracle_pairs(a.ctypes.data, _CODES[a.dtype], T, H, W, wy, wx, oy, ox, thr,
                                  out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, out[3].ctypes.data,
                                  planes.ctypes.data if planes is not None else None,
@@ -69,12 +70,19 @@ def piv_pairs(frames, window_size, overlap, signal_threshold=None, return_planes
     return tuple(res)
 
 
-def well_posed(cond, min_gap=1e-5, min_neighbour=0.02):
+def unique_peak(cond, min_gap=1e-5):
+    """Windows whose arg-max (hence whether the peak is on the border => NaN) is unique under float32 noise."""
+    return cond[..., 0] >= min_gap
+
+
+def well_posed(cond, min_gap=1e-5, min_neighbour=0.02, min_curvature=0.05):
     """Windows whose sub-pixel result is stable under float32 rounding of the correlation plane.
 
     A plane is computed to ~1e-7 of its maximum in float32.  The arg-max is unique under that noise when the
     runner-up is >= ``min_gap`` below the maximum, and the log-Gaussian fit moves by < 1e-5 px when every
-    neighbour of the peak is >= ``min_neighbour`` of the maximum.  Ill-posed windows (empty / single-speckle
-    windows at the frame edge) are excluded from the 1e-4 parity gate and counted separately.
+    neighbour of the peak is >= ``min_neighbour`` of the maximum and the peak is not a flat ridge (log-curvature
+    2 ln c- - 4 ln c0 + 2 ln c+ at least ``min_curvature`` in both directions: the fit divides by it).  Ill-posed
+    windows (empty / single-speckle windows at the frame edge, flat ridges) are excluded from the 1e-4 parity
+    gate on u, v and counted separately; their NaN mask, corr_max and s2n are still gated.
     """
-    return (cond[..., 0] >= min_gap) & (cond[..., 1] >= min_neighbour)
+    return (cond[..., 0] >= min_gap) & (cond[..., 1] >= min_neighbour) & (cond[..., 2] >= min_curvature)

@@ -138,9 +138,11 @@ static int normalize_part(cpx* z, int n, int part, int* dead) {
 
 /*
  * frames (T,H,W); outputs (T-1)*n_rows*n_cols float32 each; planes NULL or (T-1)*n_win*wy*wx float64.
- * signal_threshold < 0: off.  cond: NULL or 2 floats per window that grade how well-posed the window is for a
+ * signal_threshold < 0: off.  cond: NULL or 3 floats per window that grade how well-posed the window is for a
  * float32 implementation: [0] (max - runner-up)/max over the whole plane (argmax stability), [1] smallest of the
- * five peak-neighbourhood values / max (log-Gaussian sensitivity); both 0 for border peaks / NaN planes.
+ * five peak-neighbourhood values / max (log-Gaussian sensitivity; 1 for a border peak, whose result is NaN
+ * anyway), [2] min(|den_row|, |den_col|) of the log-Gaussian fit (a flat ridge divides rounding noise by a tiny
+ * curvature; 1 for a border peak); all 0 for NaN / all-zero planes.
  * Returns 0, or -1 on bad arguments.
  */
 int piv_oracle_pairs(const void* frames, int dtype, long T, long H, long W, int wy, int wx, int oy, int ox,
@@ -225,8 +227,8 @@ int piv_oracle_pairs(const void* frames, int dtype, long T, long H, long W, int 
       }
       u[g] = uo; v[g] = vo; cmax[g] = cm; s2n[g] = sn;
       if (cond) {
-        float gap = 0.0f, mnb = 0.0f;
-        if (!skip && uo == uo && cm > 0.0f) {
+        float gap = 0.0f, mnb = 0.0f, curv = 0.0f;
+        if (!skip && cm > 0.0f) {
           const double mx = cm;
           int imax = 0;
           double best = -1.0, second = -1.0;
@@ -234,14 +236,23 @@ int piv_oracle_pairs(const void* frames, int dtype, long T, long H, long W, int 
           for (int i = 0; i < n; ++i) if (i != imax && pl[i] > second) second = pl[i];
           gap = (float)((best - second) / best);
           const int i = imax / wx, j = imax % wx;
-          double m = pl[imax];
-          if (pl[(i - 1) * wx + j] < m) m = pl[(i - 1) * wx + j];
-          if (pl[(i + 1) * wx + j] < m) m = pl[(i + 1) * wx + j];
-          if (pl[i * wx + j - 1] < m) m = pl[i * wx + j - 1];
-          if (pl[i * wx + j + 1] < m) m = pl[i * wx + j + 1];
-          mnb = (float)(m / mx);
+          if (i > 0 && i < wy - 1 && j > 0 && j < wx - 1) {
+            double m = pl[imax];
+            if (pl[(i - 1) * wx + j] < m) m = pl[(i - 1) * wx + j];
+            if (pl[(i + 1) * wx + j] < m) m = pl[(i + 1) * wx + j];
+            if (pl[i * wx + j - 1] < m) m = pl[i * wx + j - 1];
+            if (pl[i * wx + j + 1] < m) m = pl[i * wx + j + 1];
+            mnb = (float)(m / mx);
+            const double l0 = log(pl[imax] + EPS_PEAK);
+            const double d1 = fabs(2 * log(pl[(i - 1) * wx + j] + EPS_PEAK) - 4 * l0 + 2 * log(pl[(i + 1) * wx + j] + EPS_PEAK));
+            const double d2 = fabs(2 * log(pl[i * wx + j - 1] + EPS_PEAK) - 4 * l0 + 2 * log(pl[i * wx + j + 1] + EPS_PEAK));
+            curv = (float)(d1 < d2 ? d1 : d2);
+          } else {
+            mnb = 1.0f; /* border peak: the result is NaN whatever the neighbours are */
+            curv = 1.0f;
+          }
         }
-        cond[2 * g] = gap; cond[2 * g + 1] = mnb;
+        cond[3 * g] = gap; cond[3 * g + 1] = mnb; cond[3 * g + 2] = curv;
       }
       if (planes) {
         double* dst = planes + (size_t)g * n;

@@ -305,16 +305,22 @@ __global__ __launch_bounds__(BLOCK, 2) void piv_fft32_kernel(PivParams p) {
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const uint32_t blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 
-  const uint32_t job = (blk * WAVES_PER_BLOCK + wave) * 2 + half;
+  // A job is windows (2j, 2j+1) of ONE frame pair: a window's partner in the shared inverse
+  // transform is then fixed by the window grid alone, so results do not depend on how the time
+  // axis was chunked (bit-identical chunk / halo equivalence).  An odd last window pairs with
+  // itself.  Jobs past the end recompute the last job and store nothing.
+  const uint32_t jobs_per_pair = (p.n_win + 1) >> 1;
+  uint32_t job = (blk * WAVES_PER_BLOCK + wave) * 2 + half;
+  const bool job_valid = job < p.n_pairs * jobs_per_pair;
+  job = job_valid ? job : p.n_pairs * jobs_per_pair - 1;
+  const uint32_t pair = job / jobs_per_pair;
+  const uint32_t w0 = (job - pair * jobs_per_pair) * 2;
   TileRef t[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    uint32_t g = job * 2 + k;
-    t[k].valid = g < p.n_tiles;
-    g = t[k].valid ? g : p.n_tiles - 1;
-    t[k].pair = g / p.n_win;
-    t[k].win = g - t[k].pair * p.n_win;
-  }
+  t[0].pair = t[1].pair = pair;
+  t[0].win = w0;
+  t[0].valid = job_valid;
+  t[1].valid = job_valid && (w0 + 1 < p.n_win);
+  t[1].win = (w0 + 1 < p.n_win) ? w0 + 1 : w0;
   float xr[32], xi[32];
   bool skip[2];
   correlate_job<T>(p, t, buf, l32, partner_byte, xr, xi, skip);
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(BLOCK, 2) void piv_fft32_kernel(PivParams p) {
     float sn = vmax[k] / (sum[k] * (1.0f / 1024.0f));
     if (skip[k]) u = v = cm = sn = __builtin_nanf("");
     if (t[k].valid && l32 == 0) {
-      const uint32_t g = job * 2 + k;
+      const uint32_t g = t[k].pair * p.n_win + t[k].win;
       p.u[g] = u;
       p.v[g] = v;
       p.cmax[g] = cm;
@@ -349,8 +355,8 @@ __global__ __launch_bounds__(BLOCK, 2) void piv_fft32_kernel(PivParams p) {
     }
   }
   if constexpr (PLANES) {
-    if (t[0].valid) store_plane_rows(p.planes + (size_t)(job * 2 + 0) * 1024, l32, xr, skip[0]);
-    if (t[1].valid) store_plane_rows(p.planes + (size_t)(job * 2 + 1) * 1024, l32, xi, skip[1]);
+    if (t[0].valid) store_plane_rows(p.planes + ((size_t)t[0].pair * p.n_win + t[0].win) * 1024, l32, xr, skip[0]);
+    if (t[1].valid) store_plane_rows(p.planes + ((size_t)t[1].pair * p.n_win + t[1].win) * 1024, l32, xi, skip[1]);
   }
   __builtin_amdgcn_wave_barrier();
 }
@@ -434,7 +440,7 @@ static hipError_t launch_t(const PivParams& p, bool ensemble, hipStream_t s) {
     hipLaunchKernelGGL(piv_fft32_ensemble_kernel<T>, dim3(blocks), dim3(BLOCK), LDS_BYTES, s, p);
     return hipGetLastError();
   }
-  const uint32_t jobs = (p.n_tiles + 1) / 2;
+  const uint32_t jobs = p.n_pairs * ((p.n_win + 1) / 2);
   const uint32_t blocks = (jobs + 2 * WAVES_PER_BLOCK - 1) / (2 * WAVES_PER_BLOCK);
   if (p.planes)
     hipLaunchKernelGGL((piv_fft32_kernel<T, true>), dim3(blocks), dim3(BLOCK), LDS_BYTES, s, p);
