@@ -1,0 +1,42 @@
+"""Summarise a tools/profile.sh output directory into profiles/<tag>_summary.json (per-launch means of the dominant kernel).
+
+    python tools/summarize_profile.py gpurun_out/prof_r1d r01_v3
+
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE are collected in
+separate --pmc passes, are in KiB, and on gfx950 FETCH_SIZE reports half of the bytes of 16-byte-per-lane reads
+(which is what the window gather issues), so fetch bytes = 2 * FETCH_SIZE * 1024.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(list)
+for f in glob.glob(os.path.join(src, "pmc_*counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        if "piv_" in r["Kernel_Name"]:
+            acc[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+kernels = sorted({k for k, _ in acc})
+stats = {}
+for r in csv.DictReader(open(os.path.join(src, "trace_kernel_stats.csv"))):
+    if "piv_" in r["Name"]:
+        stats[r["Name"]] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"])}
+out = {"tag": tag, "source": src, "kernels": {}}
+for k in kernels:
+    c = {n: sum(v) / len(v) for (kk, n), v in acc.items() if kk == k}
+    d = {"counters_mean_per_launch": c, "trace": stats.get(k)}
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        d["hbm_fetch_bytes"] = 2.0 * c["FETCH_SIZE"] * 1024.0
+        d["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024.0
+        d["hbm_traffic_bytes"] = d["hbm_fetch_bytes"] + d["hbm_write_bytes"]
+    if "SQ_INSTS_VALU" in c and "GRBM_GUI_ACTIVE" in c:
+        cycles = c["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
+        d["valu_inst_per_simd_per_4cyc"] = c["SQ_INSTS_VALU"] / (1024.0 * cycles / 4.0)
+        d["valu_inst_per_wave"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
+    out["kernels"][k] = d
+dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"{tag}_summary.json")
+json.dump(out, open(dst, "w"), indent=1)
+print(json.dumps(out, indent=1)[:1500])
