@@ -86,17 +86,25 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {a.gpus} != WORLD_SIZE {world}")
 
-    lib = _lib.load()
-    _lib.require_device()
-    _lib.check(lib.lspiv_set_device(local_rank))
-
+    if os.environ.get("LSPIV_BENCH_SAME_DEVICE"):  # plumbing test of the N>1 path on a 1-GPU box (not a measurement)
+        local_rank = 0
     dist = torch = None
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("LSPIV_BENCH_FORCE_DIST"))  # FORCE_DIST: 1-rank plumbing test
+    if use_dist:
+        # torch FIRST: its wheel bundles its own libamdhip64 (SONAME libamdhip64.so.7).  Loaded first, the dynamic
+        # loader hands the same copy to liblspiv_hip.so; loaded second, the process would hold two HIP runtimes and
+        # the second one finds no GPU.
         import torch
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    lib = _lib.load()
+    _lib.require_device()
+    _lib.check(lib.lspiv_set_device(local_rank))
 
     H, W, T = a.height, a.width, a.pairs + 1
     ws, ov = (a.window, a.window), (a.overlap, a.overlap)
@@ -106,7 +114,7 @@ def main():
 
     # ---- device-resident synthetic stack + result block -------------------------------------
     d_frames, d_out = C.c_void_p(), C.c_void_p()
-    if world > 1:
+    if use_dist:
         t_frames = torch.empty(T * H * W, dtype=torch.uint8, device="cuda")
         t_out = torch.empty(4 * n_tiles, dtype=torch.float32, device="cuda")
         t_all = torch.empty(world * 4 * n_tiles, dtype=torch.float32, device="cuda")
@@ -119,7 +127,7 @@ def main():
     def launch_all():
         _lib.check(lib.lspiv_piv_pairs_dev(d_frames, 0, T, H, W, ws[0], ws[1], ov[0], ov[1], -1.0, d_out, None, None))
 
-    if world == 1:
+    if not use_dist:
         step = launch_all
 
         def sync():
@@ -131,23 +139,27 @@ def main():
         # sub-chunked: kernel k+1 runs while the result block of sub-chunk k is all-gathered
         S = max(1, min(a.subchunks, a.pairs))
         bounds = [(a.pairs * k) // S for k in range(S + 1)]
-        stream = torch.cuda.current_stream()
+        # a dedicated (non-default) torch stream carries the PIV kernels: its handle is passed through the C ABI,
+        # and RCCL's stream orders itself after it when the collective is issued under `with torch.cuda.stream`
+        stream = torch.cuda.Stream()
+        assert stream.cuda_stream != 0
         esz = H * W
 
         def step():
             works = []
-            for k in range(S):
-                p0, p1 = bounds[k], bounds[k + 1]
-                # sub-chunk k: frames p0 .. p1 (one halo frame), its own 4-plane result block
-                sub_out = t_out[4 * p0 * n_win: 4 * p1 * n_win]
-                _lib.check(lib.lspiv_piv_pairs_dev(C.c_void_p(t_frames.data_ptr() + p0 * esz), 0, p1 - p0 + 1, H, W,
-                                                   ws[0], ws[1], ov[0], ov[1], -1.0,
-                                                   C.c_void_p(sub_out.data_ptr()), None,
-                                                   C.c_void_p(stream.cuda_stream)))
-                dst = t_all[world * 4 * p0 * n_win: world * 4 * p1 * n_win]
-                works.append(dist.all_gather_into_tensor(dst, sub_out, async_op=True))
-            for w in works:
-                w.wait()
+            with torch.cuda.stream(stream):
+                for k in range(S):
+                    p0, p1 = bounds[k], bounds[k + 1]
+                    # sub-chunk k: frames p0 .. p1 (one halo frame), its own 4-plane result block
+                    sub_out = t_out[4 * p0 * n_win: 4 * p1 * n_win]
+                    _lib.check(lib.lspiv_piv_pairs_dev(C.c_void_p(t_frames.data_ptr() + p0 * esz), 0, p1 - p0 + 1,
+                                                       H, W, ws[0], ws[1], ov[0], ov[1], -1.0,
+                                                       C.c_void_p(sub_out.data_ptr()), None,
+                                                       C.c_void_p(stream.cuda_stream)))
+                    dst = t_all[world * 4 * p0 * n_win: world * 4 * p1 * n_win]
+                    works.append(dist.all_gather_into_tensor(dst, sub_out, async_op=True))
+                for w in works:
+                    w.wait()
 
         def sync():
             torch.cuda.synchronize()
@@ -163,10 +175,12 @@ def main():
         step()
     sync(); barrier(); sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+
+    gathered = t_all.clone() if use_dist else None
 
     # ---- live kernel timing with HIP events on the launch stream (roofline leg, N-independent) --
     ev0, ev1 = C.c_void_p(), C.c_void_p()
@@ -182,8 +196,20 @@ def main():
     _lib.check(lib.lspiv_event_elapsed_ms(ev0, ev1, C.byref(ms)))
     kernel_ms = ms.value / reps
 
+    dist_check = None
+    if use_dist:
+        # the all-gathered sub-chunk blocks of THIS rank must equal its single-launch result bit for bit
+        # (window pairing is chunk-invariant); cheap, outside the timed region
+        torch.cuda.synchronize()
+        whole = t_out.view(4, a.pairs, n_win)
+        dist_check = True
+        for k in range(S):
+            p0, p1 = bounds[k], bounds[k + 1]
+            blk = gathered[world * 4 * p0 * n_win: world * 4 * p1 * n_win].view(world, 4, p1 - p0, n_win)[rank]
+            same = (blk == whole[:, p0:p1]) | (blk.isnan() & whole[:, p0:p1].isnan())
+            dist_check = dist_check and bool(same.all().item())
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -211,7 +237,8 @@ def main():
             "frame_dtype": "u8",
             "windows_per_pair": n_win,
             "mvectors_per_s": round(pairs_per_s * n_win / 1e6, 3),
-            "parallelism": f"time-block shard x{world}, RCCL all-gather of (4,t,y,x) result" if world > 1 else "single GPU",
+            "parallelism": f"time-block shard x{world}, RCCL all-gather of (4,t,y,x) result" if use_dist else "single GPU",
+            **({"allgather_matches_single_launch": dist_check} if use_dist else {}),
         },
         "roofline": {
             "bound": "hbm",
@@ -249,7 +276,7 @@ def main():
         if base.get("value"):
             out["config"]["speedup_vs_cpu_baseline"] = round(pairs_per_s / base["value"], 1)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
