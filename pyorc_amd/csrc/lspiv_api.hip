@@ -196,7 +196,7 @@ int lspiv_synchronize(void) { HIP_TRY(hipDeviceSynchronize()); return LSPIV_OK; 
 int lspiv_kernel_kind(int wy, int wx) {
   if (wy < 2 || wx < 2 || wy > LSPIV_MAX_WINDOW || wx > LSPIV_MAX_WINDOW) return LSPIV_EUNSUPPORTED;
   if (wy == 32 && wx == 32) return 1;
-  // 64x64 FFT kernel: not built yet, served by the direct kernel
+  if (wy == 64 && wx == 64) return 2;
 
   return 3;
 }

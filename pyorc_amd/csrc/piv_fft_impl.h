@@ -1,0 +1,639 @@
+// Fused N x N interrogation-window kernels for gfx950 (CDNA4, wave64), N = 32 or 64.
+//
+// Replaces, in ONE launch per frame chunk, what the reference does in three passes over a
+// (T-1, n_win, N, N) float volume (pyorc/velocimetry/ffpiv.py:446-474):
+//   ffpiv.cross_corr       window gather, per-window normalise, rfft2 . conj-mul . irfft2,
+//                          fftshift, /N^2, clip[0,1]                     
+//   numpy reductions       corr_max = nanmax(plane), s2n = corr_max / nanmean(plane)     (K6)
+//   ffpiv.u_v_displacement argmax + 3-point log-Gaussian sub-pixel fit                   (K7)
+// The correlation planes never leave the CU unless the caller asks for them.
+//
+// Mapping (there is no reference kernel; this is an MI355X design):
+//   * a "job" is TWO windows of one frame pair processed by a group of N lanes (a half-wave for
+//     N = 32, a whole wave for N = 64), lane = tile row (tile column after a transpose), the N
+//     complex values of that row in VGPRs;
+//   * window pair (a from frame t, b from frame t+1) is packed z = a + i b, so the two real
+//     forward FFTs cost one complex 2-D FFT;  R = conj(A) B follows from Z[k], Z[-k]:
+//         4 R[k] = 2 Im(Z[k] Z[-k]) - i (|Z[k]|^2 - |Z[-k]|^2)
+//     R is Hermitian (the correlation is real), bit-exactly so in this formula, therefore a lane
+//     computes and keeps only R[ky][kx] for ky = 0..N/2; the rest is the conjugate of what the
+//     mirrored lane (-kx) holds;
+//   * the two windows of a job share ONE inverse transform: IFFT(R1 + i R2) = c1 + i c2;
+//   * length-N transforms are straight-line register code (fft_regs.h); the 2-D transposes go
+//     through a padded per-group LDS tile, real and imaginary plane one after the other (N = 32:
+//     four 4-wave workgroups fit the 160 KB of a CU); Z[-k] comes from the mirrored lane with
+//     ds_bpermute; per-window mean / variance / max / argmax / sum are DPP reductions;
+//   * a wave can issue one VALU instruction every 4 cycles while a SIMD retires ~1.6 from >= 3
+//     waves (tools/ubench/valu_rate.hip), so N = 32 is built for THREE+ waves per SIMD (<= 168 VGPRs,
+//     9 KB of LDS per wave); N = 64 needs 254 VGPRs and runs two.
+// MFMA is deliberately unused: this is FFT + pointwise work (BASELINE.json north_star).
+#pragma once
+#include <cstdlib>
+
+#include "common.h"
+#include "fft_regs.h"
+
+namespace lspiv {
+
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int BLOCK = 64 * WAVES_PER_BLOCK;
+
+template <int N>
+struct Geo {
+  static constexpr int NN = N * N;                  // samples per window
+  static constexpr int HALF = N / 2;
+  static constexpr int GROUPS = 64 / N;             // jobs per wave
+  static constexpr int LDS_ROW = N + 4;             // dwords per padded row: 16-byte aligned, (N/4+1) l mod 16 slots
+  static constexpr int LDS_JOB = N * LDS_ROW;       // dwords per group buffer
+  static constexpr int LDS_BYTES = WAVES_PER_BLOCK * GROUPS * LDS_JOB * 4;
+  static constexpr int LOG2N = N == 32 ? 5 : 6;
+};
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_u __attribute__((aligned(1)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef f32x4 f32x4_u __attribute__((aligned(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef f64x2 f64x2_u __attribute__((aligned(8)));
+
+// ---- reductions over the N lanes of a group ----------------------------------------------------
+template <int N> __device__ __forceinline__ float group_sum(float x) { return N == 32 ? half_sum(x) : wave_sum(x); }
+template <int N> __device__ __forceinline__ int group_sum_i(int x) {
+  x = half_sum_i(x);
+  if (N == 64) x += __shfl_xor(x, 32, 64);
+  return x;
+}
+template <int N> __device__ __forceinline__ float group_max(float x) {
+  x = half_max(x);
+  if (N == 64) x = fmaxf(x, __shfl_xor(x, 32, 64));
+  return x;
+}
+template <int N> __device__ __forceinline__ int group_min_i(int x) {
+  x = half_min_i(x);
+  if (N == 64) x = min(x, __shfl_xor(x, 32, 64));
+  return x;
+}
+
+// pairwise (tree) sum of a register row: exact for constant rows, short dependency chains
+template <int N>
+__device__ __forceinline__ float tree_sum(const float (&x)[N]) {
+  float s[N / 2];
+#pragma unroll
+  for (int k = 0; k < N / 2; ++k) s[k] = x[2 * k] + x[2 * k + 1];
+#pragma unroll
+  for (int w = N / 4; w >= 1; w >>= 1) {
+#pragma unroll
+    for (int k = 0; k < w; ++k) s[k] = s[2 * k] + s[2 * k + 1];
+  }
+  return s[0];
+}
+
+// ---- one tile row as fetched from HBM -----------------------------------------------------------
+// uint8 rows are N/4 dwords, cheap enough to prefetch for BOTH windows of a job before any arithmetic
+// starts; float rows are N..2N dwords, so only their address is kept and the load is issued where the
+// samples are consumed (the other waves of the SIMD cover that latency).
+template <typename T, int N>
+struct RowRaw {
+  const T* p;
+  __device__ __forceinline__ void fetch(const T* q) { p = q; }
+};
+template <int N>
+struct RowRaw<uint8_t, N> {
+  uint32_t w[N / 4];
+  __device__ __forceinline__ void fetch(const uint8_t* q) {
+#pragma unroll
+    for (int k = 0; k < N / 16; ++k) {
+      const u32x4 v = *reinterpret_cast<const u32x4_u*>(q + 16 * k);
+      w[4 * k] = v[0]; w[4 * k + 1] = v[1]; w[4 * k + 2] = v[2]; w[4 * k + 3] = v[3];
+    }
+  }
+};
+
+struct RowStats {
+  float mean;     // window mean
+  float inv_std;  // 1 / population std, 0 for a zero-variance window
+};
+
+// ffpiv normalize_intensity (A3): (a - mean)/std (0 if std == 0), clipped to >= 0.
+// uint8: sum and sum of squares are exact integers (v_dot4_u32_u8 on the packed bytes), variance from
+// n sum(x^2) - (sum x)^2 in 64 bits -- no per-sample arithmetic besides convert / fma / clip.
+template <int N>
+__device__ __forceinline__ RowStats stats_u8(const RowRaw<uint8_t, N>& raw, bool want_nz, int& nonzero) {
+  constexpr int NN = Geo<N>::NN;
+  uint32_t s = 0, q = 0;
+#pragma unroll
+  for (int k = 0; k < N / 4; ++k) {
+    s = __builtin_amdgcn_udot4(raw.w[k], 0x01010101u, s, false);
+    q = __builtin_amdgcn_udot4(raw.w[k], raw.w[k], q, false);
+  }
+  if (want_nz) {
+    int nz = 0;
+#pragma unroll
+    for (int k = 0; k < N / 4; ++k) {  // 0x80 in every zero byte
+      const uint32_t t = ~(((raw.w[k] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | raw.w[k] | 0x7F7F7F7Fu);
+      nz += 4 - __builtin_popcount(t);
+    }
+    nonzero = group_sum_i<N>(nz);
+  }
+  const uint32_t S = (uint32_t)group_sum_i<N>((int)s);  // <= 255 N^2
+  const uint32_t Q = (uint32_t)group_sum_i<N>((int)q);  // <= 255^2 N^2 < 2^31 for N <= 64
+  RowStats st;
+  st.mean = (float)S * (1.0f / NN);                      // exact
+  const uint64_t n2var = (uint64_t)Q * NN - (uint64_t)S * (uint64_t)S;
+  const float var = (float)n2var * (1.0f / ((float)NN * (float)NN));
+  st.inv_std = n2var != 0 ? __builtin_amdgcn_rsqf(var) : 0.0f;
+  return st;
+}
+
+// x = max((byte - mean) * g, 0), g >= 0: convert + fma + max per sample
+template <int N>
+__device__ __forceinline__ void center_u8(const RowRaw<uint8_t, N>& raw, float mean, float g, float (&x)[N]) {
+  const float off = -mean * g;
+#pragma unroll
+  for (int k = 0; k < N / 4; ++k) {
+    const uint32_t w = raw.w[k];
+    x[4 * k + 0] = fmaxf(fmaf((float)(w & 0xffu), g, off), 0.0f);
+    x[4 * k + 1] = fmaxf(fmaf((float)((w >> 8) & 0xffu), g, off), 0.0f);
+    x[4 * k + 2] = fmaxf(fmaf((float)((w >> 16) & 0xffu), g, off), 0.0f);
+    x[4 * k + 3] = fmaxf(fmaf((float)(w >> 24), g, off), 0.0f);
+  }
+}
+
+// float rows: pairwise sum (a constant window gives its value, hence zero variance, exactly)
+template <int N>
+__device__ __forceinline__ float center_clip_f(float (&x)[N], bool want_nz, int& nonzero, bool& finite) {
+  constexpr float inv_nn = 1.0f / Geo<N>::NN;
+  if (want_nz) {
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) c += (x[k] != 0.0f) ? 1 : 0;
+    nonzero = group_sum_i<N>(c);
+  }
+  const float s = group_sum<N>(tree_sum<N>(x));
+  const float mean = s * inv_nn;
+  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const float d = x[k] - mean;
+    acc[k & 3] = fmaf(d, d, acc[k & 3]);
+    x[k] = fmaxf(d, 0.0f);
+  }
+  const float ssq = group_sum<N>((acc[0] + acc[1]) + (acc[2] + acc[3]));
+  finite = finite && (fabsf(s) <= 3.0e38f) && (ssq <= 3.0e38f);
+  const float var = ssq * inv_nn;
+  return var > 0.0f ? __builtin_amdgcn_rsqf(var) : 0.0f;
+}
+template <int N>
+__device__ __forceinline__ float load_center(const RowRaw<float, N>& raw, float (&x)[N], bool want_nz, int& nonzero,
+                                             bool& finite) {
+#pragma unroll
+  for (int k = 0; k < N / 4; ++k) {
+    const f32x4 v = *reinterpret_cast<const f32x4_u*>(raw.p + 4 * k);
+    x[4 * k + 0] = v[0]; x[4 * k + 1] = v[1]; x[4 * k + 2] = v[2]; x[4 * k + 3] = v[3];
+  }
+  return center_clip_f<N>(x, want_nz, nonzero, finite);
+}
+template <int N>
+__device__ __forceinline__ float load_center(const RowRaw<double, N>& raw, float (&x)[N], bool want_nz, int& nonzero,
+                                             bool& finite) {
+#pragma unroll
+  for (int k = 0; k < N / 2; ++k) {
+    const f64x2 v = *reinterpret_cast<const f64x2_u*>(raw.p + 2 * k);
+    x[2 * k + 0] = (float)v[0]; x[2 * k + 1] = (float)v[1];
+  }
+  return center_clip_f<N>(x, want_nz, nonzero, finite);
+}
+
+// Both windows of a pair -> xr = a'' (mean-offset, zero-clipped), xi = rho b''.
+// Balance: b is rescaled to a's variance (rho = inv_b / inv_a) so |A| ~ |B| and the
+// |Z[k]|^2 - |Z[-k]|^2 difference of the cross spectrum does not cancel catastrophically when one
+// window is much fainter than the other; corr = inv_a inv_b corr(a'', b'') = inv_a^2 corr(a'', rho b'').
+// `scale` (= inv_a^2 / (4 N^4)) goes onto R BEFORE the two windows of a job are packed into one inverse
+// transform: both planes then peak at <= 1, so float32 rounding of the shared inverse is relative to
+// O(1) for each of them (scaling after the inverse lets a bright window's rounding noise swamp a faint
+// neighbour packed with it).  A zero-variance window gives an exactly-zero plane (scale 0, clip ceiling
+// hi = 0), the reference's zeros-if-std-is-0 rule (A3).
+template <int N>
+__device__ __forceinline__ void finish_pair(float inv_a, float inv_b, float& rho, float& scale, float& hi) {
+  constexpr float k = 1.0f / (4.0f * (float)Geo<N>::NN * (float)Geo<N>::NN);
+  const bool dead = (inv_a == 0.0f) || (inv_b == 0.0f);
+  rho = dead ? 0.0f : inv_b * __builtin_amdgcn_rcpf(inv_a);
+  scale = dead ? 0.0f : inv_a * inv_a * k;
+  hi = dead ? 0.0f : 1.0f;
+}
+template <int N>
+__device__ __forceinline__ bool below_threshold(int nza, int nzb, float thr) {
+  constexpr float inv_nn = 1.0f / Geo<N>::NN;
+  const float fa = (float)nza * inv_nn, fb = (float)nzb * inv_nn;
+  return !(fa >= thr && fb >= thr);
+}
+template <int N>
+__device__ __forceinline__ void prepare_pair(const RowRaw<uint8_t, N>& ra, const RowRaw<uint8_t, N>& rb,
+                                             float (&xr)[N], float (&xi)[N], bool want_nz, float thr, float& scale,
+                                             float& hi, bool& skip) {
+  int nza = Geo<N>::NN, nzb = Geo<N>::NN;
+  const RowStats sa = stats_u8<N>(ra, want_nz, nza);
+  const RowStats sb = stats_u8<N>(rb, want_nz, nzb);
+  float rho;
+  finish_pair<N>(sa.inv_std, sb.inv_std, rho, scale, hi);
+  center_u8<N>(ra, sa.mean, 1.0f, xr);
+  center_u8<N>(rb, sb.mean, rho, xi);  // the balance factor rides on the conversion
+  skip = want_nz && below_threshold<N>(nza, nzb, thr);
+}
+template <typename T, int N>
+__device__ __forceinline__ void prepare_pair(const RowRaw<T, N>& ra, const RowRaw<T, N>& rb, float (&xr)[N],
+                                             float (&xi)[N], bool want_nz, float thr, float& scale, float& hi,
+                                             bool& skip) {
+  bool finite = true;
+  int nza = Geo<N>::NN, nzb = Geo<N>::NN;
+  const float inv_a = load_center<N>(ra, xr, want_nz, nza, finite);
+  const float inv_b = load_center<N>(rb, xi, want_nz, nzb, finite);
+  float rho;
+  finish_pair<N>(inv_a, inv_b, rho, scale, hi);
+#pragma unroll
+  for (int j = 0; j < N; ++j) xi[j] *= rho;
+  skip = !finite || (want_nz && below_threshold<N>(nza, nzb, thr));
+}
+
+// LDS transpose of one real N x N plane held as lane = row: lane r scatters its row down column r of
+// the buffer (ds_write_b32, the lanes of a group hit consecutive banks), then reads buffer row r =
+// tile column r with ds_read_b128 (row stride N+4 dwords: 16-byte aligned, and the 16 lanes of a b128
+// group land on 16 distinct 4-bank slots since (N/4+1) l mod 16 is a bijection).
+template <int N>
+__device__ __forceinline__ void transpose_plane(float* buf, int lg, float (&x)[N]) {
+  constexpr int LR = Geo<N>::LDS_ROW;
+  float* wcol = buf + lg;
+#pragma unroll
+  for (int j = 0; j < N; ++j) wcol[j * LR] = x[j];
+  __builtin_amdgcn_wave_barrier();  // same wave: LDS ops execute in order, this only pins the compiler
+  const f32x4* rrow = reinterpret_cast<const f32x4*>(buf + lg * LR);
+#pragma unroll
+  for (int q = 0; q < N / 4; ++q) {
+    const f32x4 v = rrow[q];
+    x[4 * q] = v[0]; x[4 * q + 1] = v[1]; x[4 * q + 2] = v[2]; x[4 * q + 3] = v[3];
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+template <int N>
+__device__ __forceinline__ void transpose2(float* buf, int lg, float (&xr)[N], float (&xi)[N]) {
+  transpose_plane<N>(buf, lg, xr);
+  transpose_plane<N>(buf, lg, xi);
+}
+
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[32], float (&xi)[32]) { fft32<INV>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[64], float (&xi)[64]) { fft64<INV>(xr, xi); }
+
+__device__ __forceinline__ float bperm_f(int addr, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
+}
+
+// lane = kx, registers = ky hold Z = FFT2(a + i b).  Writes s * 4 conj(A) B for ky = 0..N/2 into
+// (rr, ri); Z[-k] = mirrored lane's Z[N - ky].
+template <int N>
+__device__ __forceinline__ void cross_spectrum_half(int partner_byte, const float (&zr)[N], const float (&zi)[N],
+                                                    float s, float (&rr)[N / 2 + 1], float (&ri)[N / 2 + 1]) {
+#pragma unroll
+  for (int ky = 0; ky <= N / 2; ++ky) {
+    const int kn = (N - ky) & (N - 1);
+    const float wr = bperm_f(partner_byte, zr[kn]);
+    const float wi = bperm_f(partner_byte, zi[kn]);
+    const float ar = zr[ky], ai = zi[ky];
+    rr[ky] = (2.0f * s) * (ar * wi + ai * wr);
+    ri[ky] = s * ((wr * wr + wi * wi) - (ar * ar + ai * ai));
+  }
+}
+
+struct TileRef {
+  uint32_t pair;   // frame pair index inside the chunk
+  uint32_t win;    // window index k * n_cols + m
+  bool valid;
+};
+
+// Everything between "two window pairs" and "two clipped correlation planes in registers".
+// On return xr = plane of tile 0, xi = plane of tile 1, natural (un-shifted) order: lane = row y,
+// register = column x;  skip[k] = plane k is NaN (signal pre-mask / non-finite input).
+template <typename T, int N, bool WANT_NZ>
+__device__ __forceinline__ void correlate_job(const PivParams& p, const TileRef (&t)[2], float* buf, int lg,
+                                              int partner_byte, float (&xr)[N], float (&xi)[N], bool (&skip)[2]) {
+  constexpr int H = N / 2;
+  float R1r[H + 1], R1i[H + 1];  // s1 * 4 conj(A1) B1, ky = 0..N/2 (Hermitian half)
+  float hi[2];                   // clip ceiling: 1, or 0 for a zero-variance window (plane exactly 0)
+  const T* frames = static_cast<const T*>(p.frames);
+  constexpr bool want_nz = WANT_NZ;  // compile-time: a run-time branch here splits the pipeline into basic
+                                     // blocks and the register allocator spills across them
+  RowRaw<T, N> raw[2][2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const uint32_t wrow = p.div_ncols.div(t[k].win);
+    const uint32_t wcol = t[k].win - wrow * (uint32_t)p.n_cols;
+    const int64_t off = ((int64_t)t[k].pair * p.H + (int64_t)(wrow * p.sy + lg)) * p.W + (int64_t)wcol * p.sx;
+    raw[k][0].fetch(frames + off);
+    raw[k][1].fetch(frames + off + p.frame_elems);
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    // keep the two windows' register-hungry phases apart: the scheduler otherwise interleaves window 1's
+    // conversion with window 0's column FFT and spills
+    __builtin_amdgcn_sched_barrier(0);
+    float scale;
+    prepare_pair(raw[k][0], raw[k][1], xr, xi, want_nz, p.signal_threshold, scale, hi[k], skip[k]);
+    fft_n<false>(xr, xi);              // along x
+    transpose2<N>(buf, lg, xr, xi);    // lane = kx, regs = y
+    fft_n<false>(xr, xi);              // along y -> Z[ky][kx]
+    if (k == 0) {
+      cross_spectrum_half<N>(partner_byte, xr, xi, scale, R1r, R1i);
+    } else {
+      float R2r[H + 1], R2i[H + 1];
+      cross_spectrum_half<N>(partner_byte, xr, xi, scale, R2r, R2i);
+      // Q = R1 + i R2 for ky = 0..N/2 directly; for ky > N/2 use R[ky][kx] = conj(R[N-ky][-kx]):
+      // Q[ky][kx] = conj( (R1 - i R2)[N-ky][-kx] ), fetched from the mirrored lane.
+#pragma unroll
+      for (int ky = 0; ky <= H; ++ky) {
+        xr[ky] = R1r[ky] - R2i[ky];
+        xi[ky] = R1i[ky] + R2r[ky];
+      }
+#pragma unroll
+      for (int ky = 1; ky < H; ++ky) {
+        const float mr = R1r[ky] + R2i[ky];   // (R1 - i R2).re
+        const float mi = R1i[ky] - R2r[ky];   // (R1 - i R2).im
+        xr[N - ky] = bperm_f(partner_byte, mr);
+        xi[N - ky] = -bperm_f(partner_byte, mi);
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  fft_n<true>(xr, xi);                 // along ky
+  transpose2<N>(buf, lg, xr, xi);      // lane = y, regs = kx
+  fft_n<true>(xr, xi);                 // along kx -> c1 + i c2
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    xr[j] = __builtin_amdgcn_fmed3f(xr[j], 0.0f, hi[0]);
+    xi[j] = __builtin_amdgcn_fmed3f(xi[j], 0.0f, hi[1]);
+  }
+}
+
+// max / first-argmax (in fft-shifted row-major order) / sum of one plane held as lane = y, reg = x.
+// The maximum is a v_max3 tree + DPP reduction; the arg-max is the smallest shifted flat index whose
+// value equals it (np.argmax: first occurrence), found by an equality scan and a DPP min-reduction.
+template <int N>
+__device__ __forceinline__ void plane_stats(const float (&c)[N], int lg, float& vmax, int& imax, float& sum) {
+  float m[N / 2];  // v_max3_f32 tree (short dependency chains)
+#pragma unroll
+  for (int k = 0; k < N / 2; ++k) m[k] = fmaxf(c[2 * k], c[2 * k + 1]);
+#pragma unroll
+  for (int w = N / 2; w > 1;) {
+    const int t = w / 3, rem = w - 3 * t;
+#pragma unroll
+    for (int k = 0; k < t; ++k) m[k] = fmaxf(fmaxf(m[3 * k], m[3 * k + 1]), m[3 * k + 2]);
+    if (rem >= 1) m[t] = m[3 * t];
+    if (rem == 2) m[t] = fmaxf(m[t], m[3 * t + 1]);
+    w = t + (rem ? 1 : 0);
+  }
+  const float r = m[0];
+  vmax = group_max<N>(r);
+  int bj = 1 << 12;  // "not in this row"
+#pragma unroll
+  for (int jj = N - 1; jj >= 0; --jj) bj = (c[(jj + N / 2) & (N - 1)] == vmax) ? jj : bj;  // ends on the smallest jj
+  imax = group_min_i<N>((((lg + N / 2) & (N - 1)) << Geo<N>::LOG2N) + bj);
+  sum = group_sum<N>(tree_sum<N>(c));
+}
+
+// park one plane in LDS (row y at buf[y * LDS_ROW + x]) and fit the peak: u, v in pixels
+template <int N>
+__device__ __forceinline__ void subpixel(float* buf, int lg, const float (&c)[N], int imax, float& u, float& v) {
+  constexpr int LR = Geo<N>::LDS_ROW;
+  constexpr int M = N - 1, C = N / 2;
+  f32x4* wrow = reinterpret_cast<f32x4*>(buf + lg * LR);
+#pragma unroll
+  for (int q = 0; q < N / 4; ++q) {
+    const f32x4 w = {c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
+    wrow[q] = w;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int ip = imax >> Geo<N>::LOG2N, jp = imax & M;  // shifted coordinates
+  const bool border = (ip == 0 || ip == M || jp == 0 || jp == M);
+  const int y = (ip + C) & M, x = (jp + C) & M;
+  const int ym = (ip + C - 1) & M, yp = (ip + C + 1) & M;
+  const int xm = (jp + C - 1) & M, xp = (jp + C + 1) & M;
+  const float c0 = buf[y * LR + x] + kEpsPeak;
+  const float cl = buf[ym * LR + x] + kEpsPeak;
+  const float cr = buf[yp * LR + x] + kEpsPeak;
+  const float cd = buf[y * LR + xm] + kEpsPeak;
+  const float cu = buf[y * LR + xp] + kEpsPeak;
+  __builtin_amdgcn_wave_barrier();
+  // the fit is a ratio of log differences, so any base works: v_log_f32 (log2, 1 ulp) on inputs >= 1e-7
+  const float l0 = __builtin_amdgcn_logf(c0);
+  v = (float)ip + gauss_offset_fast(__builtin_amdgcn_logf(cl), l0, __builtin_amdgcn_logf(cr)) - (float)C;
+  u = (float)jp + gauss_offset_fast(__builtin_amdgcn_logf(cd), l0, __builtin_amdgcn_logf(cu)) - (float)C;
+  if (border) u = v = __builtin_nanf("");
+}
+
+template <int N>
+__device__ __forceinline__ void store_plane_rows(float* dst, int lg, const float (&c)[N], bool nan_plane) {
+  // shifted row i' = (y + N/2) % N receives columns x = N/2..N-1, 0..N/2-1
+  float* row = dst + ((lg + N / 2) & (N - 1)) * N;
+  const float nanv = __builtin_nanf("");
+#pragma unroll
+  for (int q = 0; q < N / 4; ++q) {
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = nan_plane ? nanv : c[(4 * q + e + N / 2) & (N - 1)];
+    *reinterpret_cast<f32x4*>(row + 4 * q) = v;
+  }
+}
+
+// registers decide the occupancy: 32x32 uint8 runs three waves per SIMD (<= 168 VGPRs, no scratch; at the 128 of
+// four waves it spills two dwords and measures 1.5 % slower -- the VALU is saturated from three waves on);
+// 32x32 float rows are loaded where they are consumed and need a few more; 64x64 holds 128 + 66 + temporaries
+// (two waves, 254 VGPRs)
+#ifndef LSPIV_WAVES_32U8
+#define LSPIV_WAVES_32U8 3
+#endif
+template <typename T, int N>
+constexpr int kWavesPerSimd = (N == 32 && sizeof(T) == 1) ? LSPIV_WAVES_32U8 : 2;
+
+// ---- per-timestep kernel: one job (two neighbouring windows of one pair) per lane group ---------
+template <typename T, int N, bool PLANES, bool WANT_NZ>
+__global__ __launch_bounds__(BLOCK, (kWavesPerSimd<T, N>)) void piv_fft_kernel(PivParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using G = Geo<N>;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int grp = lane / N;
+  const int lg = lane & (N - 1);
+  float* buf = smem + (wave * G::GROUPS + grp) * G::LDS_JOB;
+  const int partner_byte = ((lane & ~(N - 1)) | ((N - lg) & (N - 1))) << 2;
+
+  // XCD-aware block order: block b runs on XCD b % 8; give every XCD one contiguous range of
+  // jobs (= contiguous frame pairs) so a frame is pulled into one L2, not eight.
+  const uint32_t nb = gridDim.x;
+  const uint32_t q = nb >> 3, r = nb & 7u;
+  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const uint32_t blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+
+  // A job is windows (2j, 2j+1) of ONE frame pair: a window's partner in the shared inverse
+  // transform is then fixed by the window grid alone, so results do not depend on how the time
+  // axis was chunked (bit-identical chunk / halo equivalence).  An odd last window pairs with
+  // itself.  Jobs past the end recompute the last job and store nothing.
+  const uint32_t jobs_per_pair = (p.n_win + 1) >> 1;
+  uint32_t job = (blk * WAVES_PER_BLOCK + wave) * G::GROUPS + grp;
+  const bool job_valid = job < p.n_pairs * jobs_per_pair;
+  job = job_valid ? job : p.n_pairs * jobs_per_pair - 1;
+  const uint32_t pair = p.div_jobs.div(job);
+  const uint32_t w0 = (job - pair * jobs_per_pair) * 2;
+  TileRef t[2];
+  t[0].pair = t[1].pair = pair;
+  t[0].win = w0;
+  t[0].valid = job_valid;
+  t[1].valid = job_valid && (w0 + 1 < p.n_win);
+  t[1].win = (w0 + 1 < p.n_win) ? w0 + 1 : w0;
+
+  float xr[N], xi[N];
+  bool skip[2];
+  correlate_job<T, N, WANT_NZ>(p, t, buf, lg, partner_byte, xr, xi, skip);
+
+  const float nanv = __builtin_nanf("");
+  constexpr float inv_nn = 1.0f / G::NN;
+  {
+    float vmax, sum, u, v;
+    int imax;
+    plane_stats<N>(xr, lg, vmax, imax, sum);
+    subpixel<N>(buf, lg, xr, imax, u, v);
+    float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(sum * inv_nn);
+    if (skip[0]) u = v = cm = sn = nanv;
+    if (t[0].valid && lg == 0) {
+      const uint32_t g = t[0].pair * p.n_win + t[0].win;
+      p.u[g] = u; p.v[g] = v; p.cmax[g] = cm; p.s2n[g] = sn;
+    }
+  }
+  {
+    float vmax, sum, u, v;
+    int imax;
+    plane_stats<N>(xi, lg, vmax, imax, sum);
+    subpixel<N>(buf, lg, xi, imax, u, v);
+    float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(sum * inv_nn);
+    if (skip[1]) u = v = cm = sn = nanv;
+    if (t[1].valid && lg == 0) {
+      const uint32_t g = t[1].pair * p.n_win + t[1].win;
+      p.u[g] = u; p.v[g] = v; p.cmax[g] = cm; p.s2n[g] = sn;
+    }
+  }
+  if constexpr (PLANES) {
+    if (t[0].valid) store_plane_rows<N>(p.planes + ((size_t)t[0].pair * p.n_win + t[0].win) * G::NN, lg, xr, skip[0]);
+    if (t[1].valid) store_plane_rows<N>(p.planes + ((size_t)t[1].pair * p.n_win + t[1].win) * G::NN, lg, xi, skip[1]);
+  }
+}
+
+// ---- ensemble kernel: a job owns two windows and walks all pairs of the chunk in order ---------
+// (pyorc/velocimetry/ffpiv.py:222-241,361-363): planes failing corr_min / s2n_min / finite are
+// zeroed, corr_sum += plane, corr_count += (corr_max > 1e-6).  The accumulation order is the
+// pair order, one owner per window => bit-reproducible, no atomics.  The running sums live in HBM
+// (L2-resident read-modify-write by their single owner) so the kernel keeps the register budget of the
+// per-timestep kernel.
+template <int N>
+__device__ __forceinline__ void accumulate_plane(float* dst, int lg, const float (&c)[N], bool first) {
+  // corr_sum is kept in fft-shifted layout (what u_v_displacement expects)
+  float* row = dst + ((lg + N / 2) & (N - 1)) * N;
+#pragma unroll
+  for (int qd = 0; qd < N / 4; ++qd) {
+    f32x4 acc = *reinterpret_cast<f32x4*>(row + 4 * qd);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += c[(4 * qd + e + N / 2) & (N - 1)];
+    *reinterpret_cast<f32x4*>(row + 4 * qd) = acc;
+  }
+}
+
+template <typename T, int N, bool WANT_NZ>
+__global__ __launch_bounds__(BLOCK, 2) void piv_fft_ensemble_kernel(PivParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using G = Geo<N>;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int grp = lane / N;
+  const int lg = lane & (N - 1);
+  float* buf = smem + (wave * G::GROUPS + grp) * G::LDS_JOB;
+  const int partner_byte = ((lane & ~(N - 1)) | ((N - lg) & (N - 1))) << 2;
+  const uint32_t job = (blockIdx.x * WAVES_PER_BLOCK + wave) * G::GROUPS + grp;
+  uint32_t w[2];
+  bool valid[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    w[k] = job * 2 + k;
+    valid[k] = w[k] < p.n_win;
+    w[k] = valid[k] ? w[k] : p.n_win - 1;
+  }
+  constexpr float inv_nn = 1.0f / G::NN;
+  float cnt0 = 0.0f, cnt1 = 0.0f;
+  for (uint32_t pair = 0; pair < p.n_pairs; ++pair) {
+    TileRef t[2] = {{pair, w[0], valid[0]}, {pair, w[1], valid[1]}};
+    float xr[N], xi[N];
+    bool skip[2];
+    correlate_job<T, N, WANT_NZ>(p, t, buf, lg, partner_byte, xr, xi, skip);
+    float vmax, sum;
+    int imax;
+    plane_stats<N>(xr, lg, vmax, imax, sum);
+    {
+      float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(sum * inv_nn);
+      const bool keep = !skip[0] && (cm >= p.corr_min) && (sn >= p.s2n_min);  // NaN s2n compares false
+      cm = keep ? cm : 0.0f;
+      sn = keep ? sn : 0.0f;
+      cnt0 += (cm > 1e-6f) ? 1.0f : 0.0f;
+      if (valid[0] && lg == 0) {
+        p.cmax[(size_t)pair * p.n_win + w[0]] = cm;
+        p.s2n[(size_t)pair * p.n_win + w[0]] = sn;
+      }
+      if (valid[0] && keep) accumulate_plane<N>(p.corr_sum + (size_t)w[0] * G::NN, lg, xr, pair == 0);
+    }
+    plane_stats<N>(xi, lg, vmax, imax, sum);
+    {
+      float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(sum * inv_nn);
+      const bool keep = !skip[1] && (cm >= p.corr_min) && (sn >= p.s2n_min);
+      cm = keep ? cm : 0.0f;
+      sn = keep ? sn : 0.0f;
+      cnt1 += (cm > 1e-6f) ? 1.0f : 0.0f;
+      if (valid[1] && lg == 0) {
+        p.cmax[(size_t)pair * p.n_win + w[1]] = cm;
+        p.s2n[(size_t)pair * p.n_win + w[1]] = sn;
+      }
+      if (valid[1] && keep) accumulate_plane<N>(p.corr_sum + (size_t)w[1] * G::NN, lg, xi, pair == 0);
+    }
+  }
+  if (lg == 0) {
+    if (valid[0]) p.corr_count[w[0]] += cnt0;
+    if (valid[1]) p.corr_count[w[1]] += cnt1;
+  }
+}
+
+template <typename T, int N, bool WANT_NZ>
+static hipError_t launch_t(const PivParams& p, bool ensemble, hipStream_t s) {
+  using G = Geo<N>;
+  constexpr uint32_t jobs_per_block = WAVES_PER_BLOCK * G::GROUPS;
+  if (ensemble) {
+    const uint32_t jobs = (p.n_win + 1) / 2;
+    const uint32_t blocks = (jobs + jobs_per_block - 1) / jobs_per_block;
+    hipLaunchKernelGGL((piv_fft_ensemble_kernel<T, N, WANT_NZ>), dim3(blocks), dim3(BLOCK), G::LDS_BYTES, s, p);
+    return hipGetLastError();
+  }
+  const uint32_t jobs = p.n_pairs * ((p.n_win + 1) / 2);
+  const uint32_t blocks = (jobs + jobs_per_block - 1) / jobs_per_block;
+  // LSPIV_DEBUG_EXTRA_LDS: occupancy experiments only (pads the LDS request so fewer blocks fit a CU)
+  static const int extra_lds = getenv("LSPIV_DEBUG_EXTRA_LDS") ? atoi(getenv("LSPIV_DEBUG_EXTRA_LDS")) : 0;
+  if (p.planes)
+    hipLaunchKernelGGL((piv_fft_kernel<T, N, true, WANT_NZ>), dim3(blocks), dim3(BLOCK), G::LDS_BYTES + extra_lds, s, p);
+  else
+    hipLaunchKernelGGL((piv_fft_kernel<T, N, false, WANT_NZ>), dim3(blocks), dim3(BLOCK), G::LDS_BYTES + extra_lds, s, p);
+  return hipGetLastError();
+}
+
+template <int N>
+static hipError_t launch_fft(const PivParams& p, int dtype, bool ensemble, hipStream_t s) {
+  const bool nz = p.signal_threshold >= 0.0f;
+  switch (dtype) {
+    case 0: return nz ? launch_t<uint8_t, N, true>(p, ensemble, s) : launch_t<uint8_t, N, false>(p, ensemble, s);
+    case 1: return nz ? launch_t<float, N, true>(p, ensemble, s) : launch_t<float, N, false>(p, ensemble, s);
+    case 2: return nz ? launch_t<double, N, true>(p, ensemble, s) : launch_t<double, N, false>(p, ensemble, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace lspiv
