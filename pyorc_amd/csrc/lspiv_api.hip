@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -77,6 +78,8 @@ struct DeviceCtx {
   void* d_frames = nullptr;  size_t frames_cap = 0;
   float* d_out = nullptr;    size_t out_cap = 0;
   float* d_planes = nullptr; size_t planes_cap = 0;
+  void* pinned[2] = {nullptr, nullptr}; size_t pinned_cap = 0;  // H2D staging ring
+  hipEvent_t staged[2] = {nullptr, nullptr};
   bool arch_ok = false;
 };
 std::mutex g_mu;
@@ -102,6 +105,24 @@ int get_ctx(DeviceCtx** out) {
     g_ctx[dev] = c;
   }
   *out = g_ctx[dev];
+  return LSPIV_OK;
+}
+
+// two pinned staging slots of >= one frame each (LSPIV_STAGE_BYTES per slot, default 32 MiB)
+int stage_ring(DeviceCtx* c, size_t frame_bytes) {
+  const size_t want = getenv("LSPIV_STAGE_BYTES") ? (size_t)atoll(getenv("LSPIV_STAGE_BYTES")) : ((size_t)32 << 20);
+  const size_t need = std::max(want, frame_bytes);
+  if (c->pinned_cap >= need && c->pinned_cap < 2 * need + frame_bytes) return LSPIV_OK;
+  for (int i = 0; i < 2; ++i) {
+    if (c->pinned[i]) HIP_TRY(hipHostFree(c->pinned[i]));
+    c->pinned[i] = nullptr;
+  }
+  c->pinned_cap = 0;
+  for (int i = 0; i < 2; ++i) {
+    HIP_TRY(hipHostMalloc(&c->pinned[i], need, hipHostMallocDefault));
+    if (!c->staged[i]) HIP_TRY(hipEventCreateWithFlags(&c->staged[i], hipEventDisableTiming));
+  }
+  c->pinned_cap = need;
   return LSPIV_OK;
 }
 
@@ -287,10 +308,44 @@ int lspiv_piv_pairs(const void* frames, int dtype, int64_t T, int64_t H, int64_t
     rc = ensure(&c->d_planes, &c->planes_cap, n_tiles * wy * wx * sizeof(float));
     if (rc) return rc;
   }
-  HIP_TRY(hipMemcpyAsync(c->d_frames, frames, fbytes, hipMemcpyHostToDevice, c->stream));
-  rc = lspiv_piv_pairs_dev(c->d_frames, dtype, T, H, W, wy, wx, oy, ox, signal_threshold, c->d_out,
-                           corr_planes ? c->d_planes : nullptr, c->stream);
+  // Pipelined upload: the stack is copied through a two-slot pinned ring in sub-batches of whole frames; the
+  // kernel for the pairs of sub-batch k runs while sub-batch k+1 is staged and DMA'd.  Window pairing is
+  // chunk-invariant, so this equals one launch over the whole stack bit for bit.
+  lspiv::PivParams base;
+  rc = fill_params(&base, c->d_frames, dtype, T, H, W, wy, wx, oy, ox, signal_threshold, g);
   if (rc) return rc;
+  const size_t n_win = (size_t)g.n_rows * g.n_cols;
+  const size_t frame_bytes = (size_t)H * W * elem_size(dtype);
+  rc = stage_ring(c, frame_bytes);
+  if (rc) return rc;
+  const int64_t fpb = std::max<int64_t>(1, (int64_t)(c->pinned_cap / frame_bytes));
+  int batch = 0;
+  for (int64_t f0 = 0; f0 < T; ++batch) {
+    const int64_t f1 = std::min<int64_t>(T, f0 + fpb);
+    const int slot = batch & 1;
+    if (batch >= 2) HIP_TRY(hipEventSynchronize(c->staged[slot]));  // the slot's previous DMA has drained
+    const size_t nb = (size_t)(f1 - f0) * frame_bytes;
+    memcpy(c->pinned[slot], (const char*)frames + (size_t)f0 * frame_bytes, nb);
+    HIP_TRY(hipMemcpyAsync((char*)c->d_frames + (size_t)f0 * frame_bytes, c->pinned[slot], nb, hipMemcpyHostToDevice,
+                           c->copy_stream));
+    HIP_TRY(hipEventRecord(c->staged[slot], c->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->staged[slot], 0));
+    const int64_t p0 = std::max<int64_t>(f0 - 1, 0), p1 = f1 - 1;  // pairs whose two frames are resident
+    if (p1 > p0) {
+      lspiv::PivParams p = base;
+      p.frames = (const char*)c->d_frames + (size_t)p0 * frame_bytes;
+      p.n_pairs = (uint32_t)(p1 - p0);
+      p.n_tiles = (uint32_t)((p1 - p0) * n_win);
+      p.u = c->d_out + p0 * n_win;
+      p.v = c->d_out + n_tiles + p0 * n_win;
+      p.cmax = c->d_out + 2 * n_tiles + p0 * n_win;
+      p.s2n = c->d_out + 3 * n_tiles + p0 * n_win;
+      p.planes = corr_planes ? c->d_planes + (size_t)p0 * n_win * wy * wx : nullptr;
+      rc = dispatch(p, dtype, false, c->stream);
+      if (rc) return rc;
+    }
+    f0 = f1;
+  }
   const size_t ob = n_tiles * sizeof(float);
   HIP_TRY(hipMemcpyAsync(u, c->d_out, ob, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(v, c->d_out + n_tiles, ob, hipMemcpyDeviceToHost, c->stream));

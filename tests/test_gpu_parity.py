@@ -270,6 +270,26 @@ def test_ensemble_other_window_size(gpu):
     assert rel_err(got["v_x"], ref["v_x"].astype(np.float64)) <= 2e-4
 
 
+def test_pipelined_upload_equals_single_batch(gpu, monkeypatch):
+    """Host entry point: staging the stack in sub-batches of frames (two pinned slots, compute overlapped with
+    the next DMA) must equal one batch bit for bit, for every batch geometry including 1 frame per batch."""
+    import pyorc_amd
+
+    fr = particle_stack(12, 96, 128, seed=41)
+    monkeypatch.setenv("LSPIV_STAGE_BYTES", str(1 << 30))
+    ref = pyorc_amd.piv_pairs(fr, (32, 32), (16, 16), return_planes=True)
+    for stage in (1, 96 * 128 * 2 + 5, 96 * 128 * 5, 96 * 128 * 11):
+        monkeypatch.setenv("LSPIV_STAGE_BYTES", str(stage))
+        got = pyorc_amd.piv_pairs(fr, (32, 32), (16, 16), return_planes=True)
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b, equal_nan=True), stage
+        got = pyorc_amd.piv_pairs(fr.astype(np.float64), (24, 24), (12, 12))
+        monkeypatch.setenv("LSPIV_STAGE_BYTES", str(1 << 30))
+        ref2 = pyorc_amd.piv_pairs(fr.astype(np.float64), (24, 24), (12, 12))
+        for a, b in zip(ref2, got):
+            assert np.array_equal(a, b, equal_nan=True), stage
+
+
 # ------------------------------------------------------------------ errors --------------------------
 def test_error_mapping(gpu):
     import pyorc_amd
