@@ -242,7 +242,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "piv_fft32_kernel<u8>",
+            "kernel": f"piv_fft_kernel<unsigned char, {a.window}, false, false>",
             "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -256,7 +256,7 @@ def main():
                           "achieved_tflops": round(0.66e9 * a.pairs / (kernel_ms * 1e-3) / 1e12, 2), "peak_tflops": 157.3},
         },
     }
-    tr = measured_traffic("piv_fft32_kernel<unsigned char", a.pairs, H, W) if (a.window, a.overlap) == (32, 16) else None
+    tr = measured_traffic("piv_fft_kernel<unsigned char, 32", a.pairs, H, W) if (a.window, a.overlap) == (32, 16) else None
     if tr:
         out["roofline"]["traffic"] = tr["bytes"]
         out["roofline"]["traffic_source"] = f"profiles/{tr['source']} (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"

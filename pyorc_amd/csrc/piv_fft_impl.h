@@ -24,7 +24,7 @@
 //     four 4-wave workgroups fit the 160 KB of a CU); Z[-k] comes from the mirrored lane with
 //     ds_bpermute; per-window mean / variance / max / argmax / sum are DPP reductions;
 //   * a wave can issue one VALU instruction every 4 cycles while a SIMD retires ~1.6 from >= 3
-//     waves (tools/ubench/valu_rate.hip), so N = 32 is built for THREE+ waves per SIMD (<= 168 VGPRs,
+//     waves (tools/ubench/valu_rate.hip), so N = 32 is built for FOUR waves per SIMD (<= 128 VGPRs,
 //     9 KB of LDS per wave); N = 64 needs 254 VGPRs and runs two.
 // MFMA is deliberately unused: this is FFT + pointwise work (BASELINE.json north_star).
 #pragma once
@@ -314,7 +314,8 @@ struct TileRef {
 // register = column x;  skip[k] = plane k is NaN (signal pre-mask / non-finite input).
 template <typename T, int N, bool WANT_NZ>
 __device__ __forceinline__ void correlate_job(const PivParams& p, const TileRef (&t)[2], float* buf, int lg,
-                                              int partner_byte, float (&xr)[N], float (&xi)[N], bool (&skip)[2]) {
+                                              int partner_byte, float (&xr)[N], float (&xi)[N], bool (&skip)[2],
+                                              float (&mean)[2]) {
   constexpr int H = N / 2;
   float R1r[H + 1], R1i[H + 1];  // s1 * 4 conj(A1) B1, ky = 0..N/2 (Hermitian half)
   float hi[2];                   // clip ceiling: 1, or 0 for a zero-variance window (plane exactly 0)
@@ -361,6 +362,12 @@ __device__ __forceinline__ void correlate_job(const PivParams& p, const TileRef 
       }
     }
   }
+  // mean of a plane = its DC bin: sum_x IFFT(Q)[x] = N^2 Q[0][0], and Q[0][0] = s1 R1[0][0] + i s2 R2[0][0] sits
+  // in lane kx = 0 of the group, register ky = 0.  (The reference averages the CLIPPED plane; the clip only
+  // removes float rounding below zero -- a ~1e-8 relative difference, measured in the parity tests.)
+  const int lane0_byte = (int)((threadIdx.x & 63u) & ~(unsigned)(N - 1)) << 2;
+  mean[0] = bperm_f(lane0_byte, xr[0]);
+  mean[1] = bperm_f(lane0_byte, xi[0]);
   __builtin_amdgcn_sched_barrier(0);
   fft_n<true>(xr, xi);                 // along ky
   transpose2<N>(buf, lg, xr, xi);      // lane = y, regs = kx
@@ -372,12 +379,10 @@ __device__ __forceinline__ void correlate_job(const PivParams& p, const TileRef 
   }
 }
 
-// max / first-argmax (in fft-shifted row-major order) / sum of one plane held as lane = y, reg = x.
-// The maximum is a v_max3 tree + DPP reduction; the arg-max is the smallest shifted flat index whose
-// value equals it (np.argmax: first occurrence), found by an equality scan and a DPP min-reduction.
+// Row maximum of a plane held as lane = y, reg = x (v_max3 tree) reduced over the group -> plane maximum.
 template <int N>
-__device__ __forceinline__ void plane_stats(const float (&c)[N], int lg, float& vmax, int& imax, float& sum) {
-  float m[N / 2];  // v_max3_f32 tree (short dependency chains)
+__device__ __forceinline__ float plane_max(const float (&c)[N], float& row_max) {
+  float m[N / 2];
 #pragma unroll
   for (int k = 0; k < N / 2; ++k) m[k] = fmaxf(c[2 * k], c[2 * k + 1]);
 #pragma unroll
@@ -389,20 +394,19 @@ __device__ __forceinline__ void plane_stats(const float (&c)[N], int lg, float& 
     if (rem == 2) m[t] = fmaxf(m[t], m[3 * t + 1]);
     w = t + (rem ? 1 : 0);
   }
-  const float r = m[0];
-  vmax = group_max<N>(r);
-  int bj = 1 << 12;  // "not in this row"
-#pragma unroll
-  for (int jj = N - 1; jj >= 0; --jj) bj = (c[(jj + N / 2) & (N - 1)] == vmax) ? jj : bj;  // ends on the smallest jj
-  imax = group_min_i<N>((((lg + N / 2) & (N - 1)) << Geo<N>::LOG2N) + bj);
-  sum = group_sum<N>(tree_sum<N>(c));
+  row_max = m[0];
+  return group_max<N>(row_max);
 }
 
-// park one plane in LDS (row y at buf[y * LDS_ROW + x]) and fit the peak: u, v in pixels
+// Peak of one plane: parks the plane in LDS (row y at buf[y * LDS_ROW + x]), finds np.argmax of the
+// fft-shifted plane (first maximum in row-major order: smallest shifted row holding the maximum, then the
+// smallest shifted column of that row -- one lane per column compares its LDS sample, DPP min-reductions),
+// and fits the 3-point log-Gaussian.  u, v in pixels; NaN when the peak sits on the plane border.
 template <int N>
-__device__ __forceinline__ void subpixel(float* buf, int lg, const float (&c)[N], int imax, float& u, float& v) {
+__device__ __forceinline__ void find_peak(float* buf, int lg, const float (&c)[N], float vmax, float row_max,
+                                          float& u, float& v) {
   constexpr int LR = Geo<N>::LDS_ROW;
-  constexpr int M = N - 1, C = N / 2;
+  constexpr int M = N - 1, C = N / 2, NONE = 1 << 12;
   f32x4* wrow = reinterpret_cast<f32x4*>(buf + lg * LR);
 #pragma unroll
   for (int q = 0; q < N / 4; ++q) {
@@ -410,12 +414,15 @@ __device__ __forceinline__ void subpixel(float* buf, int lg, const float (&c)[N]
     wrow[q] = w;
   }
   __builtin_amdgcn_wave_barrier();
-  const int ip = imax >> Geo<N>::LOG2N, jp = imax & M;  // shifted coordinates
+  const int sh = (lg + C) & M;                                           // this lane's shifted row AND column
+  const int ip = group_min_i<N>(row_max == vmax ? sh : NONE);            // first shifted row with the maximum
+  const int y = (ip + C) & M;
+  const int jp = group_min_i<N>(buf[y * LR + lg] == vmax ? sh : NONE);   // first shifted column in that row
   const bool border = (ip == 0 || ip == M || jp == 0 || jp == M);
-  const int y = (ip + C) & M, x = (jp + C) & M;
+  const int x = (jp + C) & M;
   const int ym = (ip + C - 1) & M, yp = (ip + C + 1) & M;
   const int xm = (jp + C - 1) & M, xp = (jp + C + 1) & M;
-  const float c0 = buf[y * LR + x] + kEpsPeak;
+  const float c0 = vmax + kEpsPeak;
   const float cl = buf[ym * LR + x] + kEpsPeak;
   const float cr = buf[yp * LR + x] + kEpsPeak;
   const float cd = buf[y * LR + xm] + kEpsPeak;
@@ -442,12 +449,12 @@ __device__ __forceinline__ void store_plane_rows(float* dst, int lg, const float
   }
 }
 
-// registers decide the occupancy: 32x32 uint8 runs three waves per SIMD (<= 168 VGPRs, no scratch; at the 128 of
-// four waves it spills two dwords and measures 1.5 % slower -- the VALU is saturated from three waves on);
+// registers decide the occupancy: 32x32 uint8 fits 127 VGPRs, no scratch -> FOUR waves per SIMD (interleaved A/B on
+// one box: 111.0 k pairs/s at 4 waves vs 103-104 k at the 129 VGPRs = 3 waves of an otherwise identical build);
 // 32x32 float rows are loaded where they are consumed and need a few more; 64x64 holds 128 + 66 + temporaries
 // (two waves, 254 VGPRs)
 #ifndef LSPIV_WAVES_32U8
-#define LSPIV_WAVES_32U8 3
+#define LSPIV_WAVES_32U8 4
 #endif
 template <typename T, int N>
 constexpr int kWavesPerSimd = (N == 32 && sizeof(T) == 1) ? LSPIV_WAVES_32U8 : 2;
@@ -488,18 +495,16 @@ __global__ __launch_bounds__(BLOCK, (kWavesPerSimd<T, N>)) void piv_fft_kernel(P
   t[1].valid = job_valid && (w0 + 1 < p.n_win);
   t[1].win = (w0 + 1 < p.n_win) ? w0 + 1 : w0;
 
-  float xr[N], xi[N];
+  float xr[N], xi[N], mean[2];
   bool skip[2];
-  correlate_job<T, N, WANT_NZ>(p, t, buf, lg, partner_byte, xr, xi, skip);
+  correlate_job<T, N, WANT_NZ>(p, t, buf, lg, partner_byte, xr, xi, skip, mean);
 
   const float nanv = __builtin_nanf("");
-  constexpr float inv_nn = 1.0f / G::NN;
   {
-    float vmax, sum, u, v;
-    int imax;
-    plane_stats<N>(xr, lg, vmax, imax, sum);
-    subpixel<N>(buf, lg, xr, imax, u, v);
-    float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(sum * inv_nn);
+    float row_max, u, v;
+    const float vmax = plane_max<N>(xr, row_max);
+    find_peak<N>(buf, lg, xr, vmax, row_max, u, v);
+    float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean[0]);
     if (skip[0]) u = v = cm = sn = nanv;
     if (t[0].valid && lg == 0) {
       const uint32_t g = t[0].pair * p.n_win + t[0].win;
@@ -507,11 +512,10 @@ __global__ __launch_bounds__(BLOCK, (kWavesPerSimd<T, N>)) void piv_fft_kernel(P
     }
   }
   {
-    float vmax, sum, u, v;
-    int imax;
-    plane_stats<N>(xi, lg, vmax, imax, sum);
-    subpixel<N>(buf, lg, xi, imax, u, v);
-    float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(sum * inv_nn);
+    float row_max, u, v;
+    const float vmax = plane_max<N>(xi, row_max);
+    find_peak<N>(buf, lg, xi, vmax, row_max, u, v);
+    float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean[1]);
     if (skip[1]) u = v = cm = sn = nanv;
     if (t[1].valid && lg == 0) {
       const uint32_t g = t[1].pair * p.n_win + t[1].win;
@@ -562,18 +566,16 @@ __global__ __launch_bounds__(BLOCK, 2) void piv_fft_ensemble_kernel(PivParams p)
     valid[k] = w[k] < p.n_win;
     w[k] = valid[k] ? w[k] : p.n_win - 1;
   }
-  constexpr float inv_nn = 1.0f / G::NN;
   float cnt0 = 0.0f, cnt1 = 0.0f;
   for (uint32_t pair = 0; pair < p.n_pairs; ++pair) {
     TileRef t[2] = {{pair, w[0], valid[0]}, {pair, w[1], valid[1]}};
-    float xr[N], xi[N];
+    float xr[N], xi[N], mean[2];
     bool skip[2];
-    correlate_job<T, N, WANT_NZ>(p, t, buf, lg, partner_byte, xr, xi, skip);
-    float vmax, sum;
-    int imax;
-    plane_stats<N>(xr, lg, vmax, imax, sum);
+    correlate_job<T, N, WANT_NZ>(p, t, buf, lg, partner_byte, xr, xi, skip, mean);
+    float vmax, row_max;
+    vmax = plane_max<N>(xr, row_max);
     {
-      float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(sum * inv_nn);
+      float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean[0]);
       const bool keep = !skip[0] && (cm >= p.corr_min) && (sn >= p.s2n_min);  // NaN s2n compares false
       cm = keep ? cm : 0.0f;
       sn = keep ? sn : 0.0f;
@@ -584,9 +586,9 @@ __global__ __launch_bounds__(BLOCK, 2) void piv_fft_ensemble_kernel(PivParams p)
       }
       if (valid[0] && keep) accumulate_plane<N>(p.corr_sum + (size_t)w[0] * G::NN, lg, xr, pair == 0);
     }
-    plane_stats<N>(xi, lg, vmax, imax, sum);
+    vmax = plane_max<N>(xi, row_max);
     {
-      float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(sum * inv_nn);
+      float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean[1]);
       const bool keep = !skip[1] && (cm >= p.corr_min) && (sn >= p.s2n_min);
       cm = keep ? cm : 0.0f;
       sn = keep ? sn : 0.0f;
