@@ -120,6 +120,30 @@ int lspiv_ensemble_finish(lspiv_ensemble* handle, float count_min, float n_frame
                           float* u, float* v, float* corr_count, float* corr_mean);
 int lspiv_ensemble_destroy(lspiv_ensemble* handle);
 
+/* ---------------------------------------------------------------- next rows */
+/* N1 -- orthoprojection: replaces pyorc.project.img_to_ortho applied per frame by project_numpy
+ * (pyorc/project.py:123-230), the numba group average (:19-53) and Frames.project's fillna(0.0)
+ * (pyorc/api/frames.py:265).  The index maps are the outputs of CameraConfig.map_idx_img_ortho /
+ * map_mean_idx_img_ortho (pyorc/api/cameraconfig.py:739-860):
+ *   idx_img[K], idx_ortho[K]   nearest neighbour: out[idx_ortho[k]] = img[idx_img[k]] (flat indices; later k wins)
+ *   src_idx[M], norm_idx[M]    group means: sample img[src_idx[i]] belongs to group norm_idx[i] (0..G-1)
+ *   uidx[G]                    flat output index of every group; M = 0 disables the mean step (reducer != "mean")
+ * Output: (T, dst_h, dst_w) float32, the values the reference returns (widened to float64 there).            */
+typedef struct lspiv_projection lspiv_projection;
+int lspiv_projection_create(int64_t src_h, int64_t src_w, int64_t dst_h, int64_t dst_w,
+                            const int64_t* idx_img, const int64_t* idx_ortho, int64_t K,
+                            const int64_t* src_idx, const int64_t* norm_idx, int64_t M,
+                            const int64_t* uidx, int64_t G, lspiv_projection** handle);
+int lspiv_project_frames(lspiv_projection* handle, const void* frames, int dtype, int64_t T, float* out);
+int lspiv_project_frames_dev(lspiv_projection* handle, const void* d_frames, int dtype, int64_t T, float* d_out,
+                             void* stream);
+int lspiv_projection_destroy(lspiv_projection* handle);
+
+/* N4 -- on-disk packing of the result variables (pyorc/const.py:80-83: int16, scale_factor 0.01,
+ * _FillValue -9999; arithmetic of xarray's encoder: float32 x / float32 scale, NaN -> fill, round half even). */
+int lspiv_pack_int16(const float* values, int64_t n, float scale, int fill, int16_t* packed);
+int lspiv_pack_int16_dev(const float* d_values, int64_t n, float scale, int fill, int16_t* d_packed, void* stream);
+
 /* ---------------------------------------------------------------- device-resident helpers  */
 /* For hosts that keep stacks in HBM (bench.py, one-process-per-GPU shards).                 */
 int lspiv_dev_malloc(void** d_ptr, size_t bytes);

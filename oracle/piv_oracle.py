@@ -385,6 +385,9 @@ def resolve_piv_args(window_size, overlap=None):
 
 
 def encode_int16(a: np.ndarray, scale=0.01, fill=-9999) -> np.ndarray:
-    """On-disk packing of pyorc/const.py:80 (int16, scale 0.01, fill -9999), netCDF4 rounding."""
-    q = np.where(np.isfinite(a), np.rint(a / scale), fill)
-    return q.astype(np.int16)
+    """On-disk packing of pyorc/const.py:80 (int16, scale 0.01, fill -9999) with the arithmetic xarray's CF encoder
+    applies to float32 variables: float32 data / float32(scale), NaN -> fill, np.around (half to even), int16."""
+    a = np.asarray(a, dtype=np.float32)
+    q = a / np.float32(scale)
+    q = np.where(np.isnan(q), np.float32(fill), np.around(q))
+    return np.clip(q, -32768, 32767).astype(np.int16)

@@ -64,6 +64,12 @@ SIGNATURES = {
     "lspiv_ensemble_accumulate": (_i32, [_vp, _vp, _i32, _i64, _f32, _f32, _f32, _vp, _vp]),
     "lspiv_ensemble_finish": (_i32, [_vp, _f32, _f32, _vp, _vp, _vp, _vp]),
     "lspiv_ensemble_destroy": (_i32, [_vp]),
+    "lspiv_projection_create": (_i32, [_i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, C.POINTER(_vp)]),
+    "lspiv_project_frames": (_i32, [_vp, _vp, _i32, _i64, _vp]),
+    "lspiv_project_frames_dev": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp]),
+    "lspiv_projection_destroy": (_i32, [_vp]),
+    "lspiv_pack_int16": (_i32, [_vp, _i64, _f32, _i32, _vp]),
+    "lspiv_pack_int16_dev": (_i32, [_vp, _i64, _f32, _i32, _vp, _vp]),
     "lspiv_dev_malloc": (_i32, [C.POINTER(_vp), _sz]),
     "lspiv_dev_free": (_i32, [_vp]),
     "lspiv_memcpy_h2d": (_i32, [_vp, _vp, _sz]),

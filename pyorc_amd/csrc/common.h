@@ -176,6 +176,11 @@ hipError_t launch_peaks_from_planes(const float* planes, uint32_t n_planes, int 
 // mean[w][o] = count[w] < min_count ? NaN : sum[w][o] / count[w]   (pyorc/velocimetry/ffpiv.py:280-282)
 hipError_t launch_ensemble_mean(const float* sum, const float* count, float min_count, uint32_t n_win,
                                 int plane_elems, float* mean, hipStream_t s);
+// orthoprojection gather (project.hip) and int16 result packing
+hipError_t launch_project(const void* frames, int dtype, int64_t src_elems, int n_frames, const int* nn_src,
+                          const int* grp_of, const int* grp_off, const int* grp_src, float* out, int n_out,
+                          hipStream_t s);
+hipError_t launch_pack_int16(const float* in, int64_t n, float scale, int fill, int16_t* out, hipStream_t s);
 // synthetic particle-image stack (bench / test utility)
 hipError_t launch_synth_particles(uint8_t* d_frames, int64_t T, int H, int W, uint64_t seed, float density,
                                   hipStream_t s);

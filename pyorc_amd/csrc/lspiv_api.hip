@@ -177,6 +177,12 @@ int dispatch(const lspiv::PivParams& p, int dtype, bool ensemble, hipStream_t s)
 
 }  // namespace
 
+struct lspiv_projection {
+  int64_t src_h, src_w, dst_h, dst_w;
+  int device;
+  int *d_nn, *d_grp_of, *d_grp_off, *d_grp_src;
+};
+
 struct lspiv_ensemble {
   int64_t H, W;
   int wy, wx, oy, ox;
@@ -469,6 +475,138 @@ int lspiv_ensemble_destroy(lspiv_ensemble* h) {
   if (h->d_sum) hipFree(h->d_sum);
   if (h->d_count) hipFree(h->d_count);
   delete h;
+  return LSPIV_OK;
+}
+
+// ---- orthoprojection (N1) and int16 packing (N4) -------------------------------------------------
+int lspiv_projection_create(int64_t src_h, int64_t src_w, int64_t dst_h, int64_t dst_w, const int64_t* idx_img,
+                            const int64_t* idx_ortho, int64_t K, const int64_t* src_idx, const int64_t* norm_idx,
+                            int64_t M, const int64_t* uidx, int64_t G, lspiv_projection** handle) {
+  if (!handle) return fail(LSPIV_EINVAL, "handle is NULL");
+  if (src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0 || K < 0 || M < 0 || G < 0)
+    return fail(LSPIV_ESHAPE, "bad projection shape");
+  const int64_t n_src = src_h * src_w, n_out = dst_h * dst_w;
+  if (n_src >= (int64_t)1 << 31 || n_out >= (int64_t)1 << 31 || M >= (int64_t)1 << 31)
+    return fail(LSPIV_EINVAL, "projection too large for 32-bit indices");
+  if ((K > 0 && (!idx_img || !idx_ortho)) || (M > 0 && (!src_idx || !norm_idx)) || (G > 0 && !uidx))
+    return fail(LSPIV_EINVAL, "NULL index array");
+  if (M > 0 && G == 0) return fail(LSPIV_EINVAL, "group samples without groups");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  // host plan: nearest source per cell; CSR of group members in their ORIGINAL order (stable counting sort)
+  std::vector<int> nn((size_t)n_out, -1), grp_of((size_t)n_out, -1), off((size_t)G + 1, 0), members((size_t)M);
+  for (int64_t k = 0; k < K; ++k) {
+    if (idx_ortho[k] < 0 || idx_ortho[k] >= n_out || idx_img[k] < 0 || idx_img[k] >= n_src)
+      return fail(LSPIV_EINVAL, "nearest-neighbour index %lld out of range", (long long)k);
+    nn[(size_t)idx_ortho[k]] = (int)idx_img[k];
+  }
+  for (int64_t g = 0; g < G; ++g) {
+    if (uidx[g] < 0 || uidx[g] >= n_out) return fail(LSPIV_EINVAL, "uidx[%lld] out of range", (long long)g);
+    grp_of[(size_t)uidx[g]] = (int)g;
+  }
+  for (int64_t i = 0; i < M; ++i) {
+    if (norm_idx[i] < 0 || norm_idx[i] >= G || src_idx[i] < 0 || src_idx[i] >= n_src)
+      return fail(LSPIV_EINVAL, "group sample %lld out of range", (long long)i);
+    off[(size_t)norm_idx[i] + 1]++;
+  }
+  for (int64_t g = 0; g < G; ++g) off[(size_t)g + 1] += off[(size_t)g];
+  {
+    std::vector<int> cur(off.begin(), off.end() - 1);
+    for (int64_t i = 0; i < M; ++i) members[(size_t)cur[(size_t)norm_idx[i]]++] = (int)src_idx[i];
+  }
+  lspiv_projection* h = new lspiv_projection();
+  h->src_h = src_h; h->src_w = src_w; h->dst_h = dst_h; h->dst_w = dst_w;
+  h->d_nn = h->d_grp_of = h->d_grp_off = h->d_grp_src = nullptr;
+  HIP_TRY(hipGetDevice(&h->device));
+  auto up = [&](int** d, const std::vector<int>& v) -> hipError_t {
+    const size_t b = std::max<size_t>(v.size(), 1) * sizeof(int);
+    hipError_t e = hipMalloc((void**)d, b);
+    if (e != hipSuccess) return e;
+    return v.empty() ? hipSuccess : hipMemcpy(*d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice);
+  };
+  hipError_t e = up(&h->d_nn, nn);
+  if (e == hipSuccess) e = up(&h->d_grp_of, grp_of);
+  if (e == hipSuccess) e = up(&h->d_grp_off, off);
+  if (e == hipSuccess) e = up(&h->d_grp_src, members);
+  if (e != hipSuccess) {
+    lspiv_projection_destroy(h);
+    return fail(e == hipErrorOutOfMemory ? LSPIV_ENOMEM : LSPIV_EHIP, "projection plan upload: %s", hipGetErrorString(e));
+  }
+  *handle = h;
+  return LSPIV_OK;
+}
+
+int lspiv_project_frames_dev(lspiv_projection* h, const void* d_frames, int dtype, int64_t T, float* d_out, void* stream) {
+  if (!h || !d_frames || !d_out) return fail(LSPIV_EINVAL, "NULL argument");
+  if (dtype < 0 || dtype > 2) return fail(LSPIV_EINVAL, "dtype %d not in {0:u8, 1:f32, 2:f64}", dtype);
+  if (T < 0 || T >= (int64_t)1 << 28) return fail(LSPIV_ESHAPE, "bad frame count");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  hipError_t e = lspiv::launch_project(d_frames, dtype, h->src_h * h->src_w, (int)T, h->d_nn, h->d_grp_of, h->d_grp_off,
+                                       h->d_grp_src, d_out, (int)(h->dst_h * h->dst_w), stream ? (hipStream_t)stream : c->stream);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return LSPIV_OK;
+}
+
+int lspiv_project_frames(lspiv_projection* h, const void* frames, int dtype, int64_t T, float* out) {
+  if (!h || !frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
+  if (dtype < 0 || dtype > 2) return fail(LSPIV_EINVAL, "dtype %d not in {0:u8, 1:f32, 2:f64}", dtype);
+  if (T <= 0) return LSPIV_OK;
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  const size_t ib = (size_t)T * h->src_h * h->src_w * elem_size(dtype);
+  const size_t ob = (size_t)T * h->dst_h * h->dst_w * sizeof(float);
+  rc = ensure(&c->d_frames, &c->frames_cap, ib);
+  if (rc) return rc;
+  rc = ensure(&c->d_planes, &c->planes_cap, ob);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_frames, frames, ib, hipMemcpyHostToDevice, c->stream));
+  rc = lspiv_project_frames_dev(h, c->d_frames, dtype, T, c->d_planes, c->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out, c->d_planes, ob, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
+
+int lspiv_projection_destroy(lspiv_projection* h) {
+  if (!h) return LSPIV_OK;
+  if (h->d_nn) hipFree(h->d_nn);
+  if (h->d_grp_of) hipFree(h->d_grp_of);
+  if (h->d_grp_off) hipFree(h->d_grp_off);
+  if (h->d_grp_src) hipFree(h->d_grp_src);
+  delete h;
+  return LSPIV_OK;
+}
+
+int lspiv_pack_int16_dev(const float* d_values, int64_t n, float scale, int fill, int16_t* d_packed, void* stream) {
+  if (!d_values || !d_packed) return fail(LSPIV_EINVAL, "NULL argument");
+  if (n < 0 || !(scale > 0.0f) || fill < -32768 || fill > 32767) return fail(LSPIV_EINVAL, "bad argument");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  hipError_t e = lspiv::launch_pack_int16(d_values, n, scale, fill, d_packed, stream ? (hipStream_t)stream : c->stream);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return LSPIV_OK;
+}
+
+int lspiv_pack_int16(const float* values, int64_t n, float scale, int fill, int16_t* packed) {
+  if (!values || !packed) return fail(LSPIV_EINVAL, "NULL argument");
+  if (n <= 0) return n == 0 ? LSPIV_OK : fail(LSPIV_EINVAL, "bad n");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  rc = ensure(&c->d_planes, &c->planes_cap, (size_t)n * sizeof(float));
+  if (rc) return rc;
+  rc = ensure(&c->d_out, &c->out_cap, (size_t)n * sizeof(int16_t));
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_planes, values, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  rc = lspiv_pack_int16_dev(c->d_planes, n, scale, fill, (int16_t*)c->d_out, c->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(packed, c->d_out, (size_t)n * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   return LSPIV_OK;
 }
 

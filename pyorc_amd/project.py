@@ -1,0 +1,94 @@
+"""Mirror of ``pyorc/project.py`` (``img_to_ortho`` / ``project_numpy``) on the MI355X -- SURVEY.md section 8f row N1.
+
+The camera-geometry part stays in pyorc: ``CameraConfig.map_idx_img_ortho`` and ``map_mean_idx_img_ortho``
+(pyorc/api/cameraconfig.py:739-860) produce the index maps; this module consumes them.  ``Projection`` uploads the
+maps once; ``project_frames`` then turns a (T, Hc, Wc) stack of camera frames into the (T, Ho, Wo) float32 stack
+the PIV engine reads -- one gather kernel per call, bit-identical to the reference's numba loop, NaN -> 0 like
+``Frames.project`` (pyorc/api/frames.py:265).  With ``device=True`` the projected stack stays in HBM and is handed
+to ``lspiv_piv_pairs_dev`` directly: the only host->device traffic is then the raw uint8 camera frames.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+
+
+def _i64(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a).ravel(), dtype=np.int64)
+
+
+class Projection:
+    """Device-resident projection plan for one camera configuration / water level."""
+
+    def __init__(self, src_shape, dst_shape, idx_img, idx_ortho, src_idx=None, uidx=None, norm_idx=None):
+        lib = _lib.load()
+        _lib.require_device()
+        self.src_shape = (int(src_shape[0]), int(src_shape[1]))
+        self.dst_shape = (int(dst_shape[0]), int(dst_shape[1]))
+        idx_ortho = np.asarray(idx_ortho)
+        if idx_ortho.dtype == np.bool_:  # the reference passes a mask: new_arr[mask] = img[idx_img] (project.py:154)
+            idx_ortho = np.flatnonzero(idx_ortho.ravel())
+        ii, io = _i64(idx_img), _i64(idx_ortho)
+        if ii.shape != io.shape:
+            raise ValueError(f"idx_img has {ii.size} entries, idx_ortho selects {io.size}")
+        if src_idx is None:  # reducer != "mean": nearest neighbour only (project.py:196-199)
+            si = ni = ui = np.zeros(0, np.int64)
+        else:
+            si, ni, ui = _i64(src_idx), _i64(norm_idx), _i64(uidx)
+            if si.shape != ni.shape:
+                raise ValueError("src_idx and norm_idx must have the same length")
+        self._h = C.c_void_p()
+        _lib.check(lib.lspiv_projection_create(self.src_shape[0], self.src_shape[1], self.dst_shape[0], self.dst_shape[1],
+                                               _lib.ptr(ii), _lib.ptr(io), ii.size, _lib.ptr(si), _lib.ptr(ni), si.size,
+                                               _lib.ptr(ui), ui.size, C.byref(self._h)))
+
+    def project_frames(self, frames) -> np.ndarray:
+        """(T, Hc, Wc) or (Hc, Wc) camera frames -> (T, Ho, Wo) float32 (``project_numpy`` + ``fillna(0)``)."""
+        a = np.asarray(frames)
+        single = a.ndim == 2
+        a = _lib.as_frames(a[None] if single else a)
+        if a.shape[1:] != self.src_shape:
+            raise ValueError(f"frames are {a.shape[1:]}, projection expects {self.src_shape}")
+        out = np.empty((a.shape[0],) + self.dst_shape, dtype=np.float32)
+        _lib.check(_lib.load().lspiv_project_frames(self._h, _lib.ptr(a), _lib.DTYPE_CODES[a.dtype], a.shape[0], _lib.ptr(out)))
+        return out[0] if single else out
+
+    def project_frames_dev(self, d_frames: int, dtype, T: int, d_out: int, stream: Optional[int] = None) -> None:
+        """Device pointers in, device pointer out (see bench / tools/project_bench.py)."""
+        _lib.check(_lib.load().lspiv_project_frames_dev(self._h, C.c_void_p(d_frames), _lib.DTYPE_CODES[np.dtype(dtype)], T,
+                                                        C.c_void_p(d_out), C.c_void_p(stream) if stream else None))
+
+    def close(self):
+        if self._h:
+            _lib.load().lspiv_projection_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def img_to_ortho(img, x, y, idx_img, idx_ortho, src_idx=None, uidx=None, norm_idx=None) -> np.ndarray:
+    """``pyorc.project.img_to_ortho`` drop-in (same arguments, project.py:123); returns float32 instead of float64."""
+    img = np.asarray(img)
+    p = Projection(img.shape, (len(y), len(x)), idx_img, idx_ortho, src_idx, uidx, norm_idx)
+    try:
+        return p.project_frames(img)
+    finally:
+        p.close()
+
+
+def pack_int16(values, scale: float = 0.01, fill: int = -9999) -> np.ndarray:
+    """On-device int16 packing of a result variable (pyorc/const.py:80-83), SURVEY.md section 8f row N4."""
+    a = np.ascontiguousarray(values, dtype=np.float32)
+    out = np.empty(a.shape, dtype=np.int16)
+    _lib.require_device()
+    _lib.check(_lib.load().lspiv_pack_int16(_lib.ptr(a), a.size, float(scale), int(fill), _lib.ptr(out)))
+    return out

@@ -71,3 +71,38 @@ def particle_stack(T: int, H: int, W: int, seed: int = 20260927, density: float 
     f = out.astype(np.float32)
     f -= f.mean(axis=0, keepdims=True)
     return f.astype(dtype)
+
+
+def projection_maps(src_shape, dst_shape, tilt: float = 0.35, seed: int = 0):
+    """Index maps with the structure of CameraConfig.map_idx_img_ortho / map_mean_idx_img_ortho
+    (pyorc/api/cameraconfig.py:739-860) for a synthetic pin-hole view: a plane seen under perspective, so the near
+    part of the ortho grid is oversampled (several camera pixels per cell -> group means) and the far part is
+    undersampled (nearest neighbour only).  Returns (idx_img, idx_ortho_mask, src_idx, uidx, norm_idx).
+    """
+    Hc, Wc = src_shape
+    Ho, Wo = dst_shape
+    rng = np.random.default_rng(seed)
+    # homography ortho (col, row, 1) -> camera (u, v, w): perspective foreshortening along rows
+    sx, sy = Wc / Wo, Hc / Ho
+    Hm = np.array([[0.9 * sx, 0.12 * sx, 0.03 * Wc], [0.02 * sy, 0.8 * sy, 0.08 * Hc], [0.0, tilt / Ho, 1.0]])
+    Hm[:2] *= 1.0 + tilt * 0.5
+    Hm[0, 2] += rng.uniform(-2, 2)
+    cols, rows = np.meshgrid(np.arange(Wo), np.arange(Ho))
+    p = Hm @ np.stack([cols.ravel(), rows.ravel(), np.ones(Wo * Ho)])
+    pc = np.int64(np.round(p[:2] / p[2]))
+    inside = (pc[0] > 0) & (pc[0] < Wc) & (pc[1] > 0) & (pc[1] < Hc)            # cameraconfig.py:771-779
+    idx_img = pc[1][inside] * Wc + pc[0][inside]                                # :791
+    # camera pixels -> ortho cells (the inverse map), groups with more than one sample
+    Hi = np.linalg.inv(Hm)
+    coli, rowi = np.meshgrid(np.arange(Wc), np.arange(Hc))
+    q = Hi @ np.stack([coli.ravel(), rowi.ravel(), np.ones(Wc * Hc)])
+    ix = np.int64(np.floor(q[0] / q[2] + 0.5))
+    iy = np.int64(np.floor(q[1] / q[2] + 0.5))
+    ok = (iy >= 0) & (iy < Ho) & (ix >= 0) & (ix < Wo)                          # :829
+    idx = iy[ok] * Wo + ix[ok]                                                  # :833
+    src = (rowi.ravel()[ok] * Wc + coli.ravel()[ok])
+    u, counts = np.unique(idx, return_counts=True)                              # :836
+    keep = np.isin(idx, u[counts > 1])                                          # :839-841
+    src_idx = src[keep]                                                         # :844
+    uidx, norm_idx = np.unique(idx[keep], return_inverse=True)                  # :851
+    return idx_img, inside, src_idx, uidx, norm_idx

@@ -101,3 +101,23 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def make_projection_golden():
+    """project_golden.npz: synthetic index maps + two camera frames + the oracle's ortho frames (N1)."""
+    from oracle import project_oracle as pro
+    from pyorc_amd.synth import projection_maps
+
+    src, dst = (120, 160), (96, 112)
+    idx_img, mask, src_idx, uidx, norm_idx = projection_maps(src, dst, seed=3)
+    rng = np.random.default_rng(11)
+    fr = rng.integers(0, 256, (2,) + src).astype(np.uint8)
+    out = pro.project_frames(fr, dst, idx_img, mask, src_idx, uidx, norm_idx).astype(np.float32)
+    nn = pro.project_frames(fr, dst, idx_img, mask).astype(np.float32)
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "project_golden.npz"),
+                        frames=fr, idx_img=idx_img, idx_ortho=mask, src_idx=src_idx, uidx=uidx, norm_idx=norm_idx,
+                        expected_mean=out, expected_nn=nn, dst_shape=np.array(dst))
+
+
+if __name__ == "__main__":
+    make_projection_golden()
