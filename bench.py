@@ -7,7 +7,7 @@ A "step" is one pass of the hot path (lspiv_piv_pairs_dev: window gather + norma
 cross-correlation + corr_max / s2n + sub-pixel peak, fused) over ONE batch of 1000 frame pairs
 per GPU that is already resident in HBM (BASELINE.json configs[1]).  With N > 1 every rank owns
 its own 1000-pair time block (weak scaling, BASELINE.json configs[4]); the only exchange is the
-RCCL all-gather of the packed (4, t, y, x) result block, overlapped with compute per sub-chunk.
+RCCL all-gather of the packed (4, t, y, x) result block, software-pipelined one step behind the kernel.
 
 Prints ONE JSON line on rank 0 (see the task contract).  No PyTorch is needed for N = 1; for
 N > 1 torch.distributed is plumbing for the rendezvous, the barrier and the all-gather only.
@@ -42,7 +42,6 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--window", type=int, default=32)
     ap.add_argument("--overlap", type=int, default=16)
-    ap.add_argument("--subchunks", type=int, default=4, help="N>1: result all-gather granularity per step")
     ap.add_argument("--cpu-pairs", type=int, default=-1, help="pairs of the CPU-baseline sample (-1: auto, 0: skip)")
     ap.add_argument("--seed", type=int, default=20260927 + 2)
     return ap.parse_args()
@@ -130,36 +129,47 @@ def main():
     if not use_dist:
         step = launch_all
 
+        def drain():
+            pass
+
         def sync():
             _lib.check(lib.lspiv_synchronize())
 
         def barrier():
             pass
     else:
-        # sub-chunked: kernel k+1 runs while the result block of sub-chunk k is all-gathered
-        S = max(1, min(a.subchunks, a.pairs))
-        bounds = [(a.pairs * k) // S for k in range(S + 1)]
-        # a dedicated (non-default) torch stream carries the PIV kernels: its handle is passed through the C ABI,
-        # and RCCL's stream orders itself after it when the collective is issued under `with torch.cuda.stream`
-        stream = torch.cuda.Stream()
-        assert stream.cuda_stream != 0
-        esz = H * W
+        # Software pipeline over steps: step k's kernel (all 1000 pairs, one launch) runs while step k-1's result
+        # block is all-gathered over RCCL on a second stream.  Two result buffers; before a buffer is overwritten
+        # (two steps later) the compute stream waits for its gather.  Every gather issued inside the timed region
+        # completes inside it (drain() before the closing synchronize), so K steps = K kernels + K all-gathers.
+        comp = torch.cuda.Stream()   # non-default: its handle goes through the C ABI
+        comm = torch.cuda.Stream()
+        assert comp.cuda_stream != 0
+        outs = [t_out, torch.empty_like(t_out)]
+        alls = [t_all, torch.empty_like(t_all)]
+        pending = [None, None]
+        state = {"k": 0}
 
         def step():
-            works = []
-            with torch.cuda.stream(stream):
-                for k in range(S):
-                    p0, p1 = bounds[k], bounds[k + 1]
-                    # sub-chunk k: frames p0 .. p1 (one halo frame), its own 4-plane result block
-                    sub_out = t_out[4 * p0 * n_win: 4 * p1 * n_win]
-                    _lib.check(lib.lspiv_piv_pairs_dev(C.c_void_p(t_frames.data_ptr() + p0 * esz), 0, p1 - p0 + 1,
-                                                       H, W, ws[0], ws[1], ov[0], ov[1], -1.0,
-                                                       C.c_void_p(sub_out.data_ptr()), None,
-                                                       C.c_void_p(stream.cuda_stream)))
-                    dst = t_all[world * 4 * p0 * n_win: world * 4 * p1 * n_win]
-                    works.append(dist.all_gather_into_tensor(dst, sub_out, async_op=True))
-                for w in works:
+            b = state["k"] & 1
+            with torch.cuda.stream(comp):
+                if pending[b] is not None:
+                    pending[b].wait()            # stream-level: comp waits until gather k-2 has read outs[b]
+                _lib.check(lib.lspiv_piv_pairs_dev(d_frames, 0, T, H, W, ws[0], ws[1], ov[0], ov[1], -1.0,
+                                                   C.c_void_p(outs[b].data_ptr()), None, C.c_void_p(comp.cuda_stream)))
+                ev = torch.cuda.Event()
+                ev.record(comp)
+            with torch.cuda.stream(comm):
+                comm.wait_event(ev)
+                pending[b] = dist.all_gather_into_tensor(alls[b], outs[b], async_op=True)
+            state["k"] += 1
+
+        def drain():
+            for w in pending:
+                if w is not None:
                     w.wait()
+            torch.cuda.current_stream().wait_stream(comp)
+            torch.cuda.current_stream().wait_stream(comm)
 
         def sync():
             torch.cuda.synchronize()
@@ -169,18 +179,18 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    sync(); barrier(); sync()
+    drain(); sync(); barrier(); sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
-    sync(); barrier(); sync()
+    drain(); sync(); barrier(); sync()
     dt = time.perf_counter() - t0
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    gathered = t_all.clone() if use_dist else None
+    gathered = alls[(state["k"] - 1) & 1].clone() if use_dist else None
 
     # ---- live kernel timing with HIP events on the launch stream (roofline leg, N-independent) --
     ev0, ev1 = C.c_void_p(), C.c_void_p()
@@ -201,13 +211,10 @@ def main():
         # the all-gathered sub-chunk blocks of THIS rank must equal its single-launch result bit for bit
         # (window pairing is chunk-invariant); cheap, outside the timed region
         torch.cuda.synchronize()
-        whole = t_out.view(4, a.pairs, n_win)
-        dist_check = True
-        for k in range(S):
-            p0, p1 = bounds[k], bounds[k + 1]
-            blk = gathered[world * 4 * p0 * n_win: world * 4 * p1 * n_win].view(world, 4, p1 - p0, n_win)[rank]
-            same = (blk == whole[:, p0:p1]) | (blk.isnan() & whole[:, p0:p1].isnan())
-            dist_check = dist_check and bool(same.all().item())
+        whole = t_out.view(-1)                          # launch_all (kernel-timing loop) wrote the same stack here
+        mine = gathered.view(world, -1)[rank]
+        same = (mine == whole) | (mine.isnan() & whole.isnan())
+        dist_check = bool(same.all().item())
     if rank != 0:
         if use_dist:
             dist.barrier()
