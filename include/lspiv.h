@@ -139,6 +139,21 @@ int lspiv_project_frames_dev(lspiv_projection* handle, const void* d_frames, int
                              void* stream);
 int lspiv_projection_destroy(lspiv_projection* handle);
 
+/* N2 -- element-wise pre-processing filters the reference writes in plain numpy (bit-reproducible):
+ *   lspiv_time_diff   Frames.time_diff (pyorc/api/frames.py:409-436): out (T-1,H,W) float32 = f32(frame t+1) - f32(frame t),
+ *                     values <= thres and NaN -> 0, |.| if use_abs
+ *   lspiv_minmax      Frames.minmax (:344-362) on float32 frames: maximum(minimum(x, hi), lo), NaN propagates
+ *   lspiv_normalize   Frames.normalize (:279-306) on uint8 frames: float32 mean of frames [::round(T/samples)] removed,
+ *                     per-frame ((x - min) / (max - min) * 255) -> uint8
+ * (edge_detect / smooth are cv2.GaussianBlur calls and are not covered.)  Host pointers; *_dev take device pointers. */
+int lspiv_time_diff(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, float thres, int use_abs, float* out);
+int lspiv_time_diff_dev(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, float thres, int use_abs,
+                        float* d_out, void* stream);
+int lspiv_minmax(const float* frames, int64_t n, float lo, float hi, float* out);
+int lspiv_minmax_dev(const float* d_frames, int64_t n, float lo, float hi, float* d_out, void* stream);
+int lspiv_normalize(const uint8_t* frames, int64_t T, int64_t H, int64_t W, int samples, uint8_t* out);
+int lspiv_normalize_dev(const uint8_t* d_frames, int64_t T, int64_t H, int64_t W, int samples, uint8_t* d_out, void* stream);
+
 /* N4 -- on-disk packing of the result variables (pyorc/const.py:80-83: int16, scale_factor 0.01,
  * _FillValue -9999; arithmetic of xarray's encoder: float32 x / float32 scale, NaN -> fill, round half even). */
 int lspiv_pack_int16(const float* values, int64_t n, float scale, int fill, int16_t* packed);

@@ -68,6 +68,12 @@ SIGNATURES = {
     "lspiv_project_frames": (_i32, [_vp, _vp, _i32, _i64, _vp]),
     "lspiv_project_frames_dev": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp]),
     "lspiv_projection_destroy": (_i32, [_vp]),
+    "lspiv_time_diff": (_i32, [_vp, _i32, _i64, _i64, _i64, _f32, _i32, _vp]),
+    "lspiv_time_diff_dev": (_i32, [_vp, _i32, _i64, _i64, _i64, _f32, _i32, _vp, _vp]),
+    "lspiv_minmax": (_i32, [_vp, _i64, _f32, _f32, _vp]),
+    "lspiv_minmax_dev": (_i32, [_vp, _i64, _f32, _f32, _vp, _vp]),
+    "lspiv_normalize": (_i32, [_vp, _i64, _i64, _i64, _i32, _vp]),
+    "lspiv_normalize_dev": (_i32, [_vp, _i64, _i64, _i64, _i32, _vp, _vp]),
     "lspiv_pack_int16": (_i32, [_vp, _i64, _f32, _i32, _vp]),
     "lspiv_pack_int16_dev": (_i32, [_vp, _i64, _f32, _i32, _vp, _vp]),
     "lspiv_dev_malloc": (_i32, [C.POINTER(_vp), _sz]),

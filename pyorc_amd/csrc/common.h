@@ -181,6 +181,12 @@ hipError_t launch_project(const void* frames, int dtype, int64_t src_elems, int 
                           const int* grp_of, const int* grp_off, const int* grp_src, float* out, int n_out,
                           hipStream_t s);
 hipError_t launch_pack_int16(const float* in, int64_t n, float scale, int fill, int16_t* out, hipStream_t s);
+// element-wise pre-processing filters (filters.hip)
+hipError_t launch_time_diff(const void* frames, int dtype, int64_t frame_elems, int64_t n_frames, float thres, int use_abs,
+                            float* out, hipStream_t s);
+hipError_t launch_minmax(const float* in, int64_t n, float lo, float hi, float* out, hipStream_t s);
+hipError_t launch_normalize(const uint8_t* frames, int64_t frame_elems, int n_frames, int interval, float* d_mean,
+                            int* d_mn, int* d_mx, uint8_t* out, hipStream_t s);
 // synthetic particle-image stack (bench / test utility)
 hipError_t launch_synth_particles(uint8_t* d_frames, int64_t T, int H, int W, uint64_t seed, float density,
                                   hipStream_t s);

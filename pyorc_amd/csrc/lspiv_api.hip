@@ -610,6 +610,111 @@ int lspiv_pack_int16(const float* values, int64_t n, float scale, int fill, int1
   return LSPIV_OK;
 }
 
+// ---- element-wise filters (N2) ---------------------------------------------------------------------
+int lspiv_time_diff_dev(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, float thres, int use_abs,
+                        float* d_out, void* stream) {
+  if (!d_frames || !d_out) return fail(LSPIV_EINVAL, "NULL argument");
+  if (dtype < 0 || dtype > 2) return fail(LSPIV_EINVAL, "dtype %d not in {0:u8, 1:f32, 2:f64}", dtype);
+  if (T < 2 || H <= 0 || W <= 0) return fail(LSPIV_ESHAPE, "need >= 2 frames of positive size");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  hipError_t e = lspiv::launch_time_diff(d_frames, dtype, H * W, T, thres, use_abs, d_out, stream ? (hipStream_t)stream : c->stream);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return LSPIV_OK;
+}
+
+int lspiv_time_diff(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, float thres, int use_abs, float* out) {
+  if (!frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
+  if (dtype < 0 || dtype > 2) return fail(LSPIV_EINVAL, "dtype %d not in {0:u8, 1:f32, 2:f64}", dtype);
+  if (T < 2 || H <= 0 || W <= 0) return fail(LSPIV_ESHAPE, "need >= 2 frames of positive size");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  const size_t ib = (size_t)T * H * W * elem_size(dtype), ob = (size_t)(T - 1) * H * W * sizeof(float);
+  rc = ensure(&c->d_frames, &c->frames_cap, ib);
+  if (rc) return rc;
+  rc = ensure(&c->d_planes, &c->planes_cap, ob);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_frames, frames, ib, hipMemcpyHostToDevice, c->stream));
+  rc = lspiv_time_diff_dev(c->d_frames, dtype, T, H, W, thres, use_abs, c->d_planes, c->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out, c->d_planes, ob, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
+
+int lspiv_minmax_dev(const float* d_frames, int64_t n, float lo, float hi, float* d_out, void* stream) {
+  if (!d_frames || !d_out) return fail(LSPIV_EINVAL, "NULL argument");
+  if (n < 0) return fail(LSPIV_EINVAL, "bad n");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  hipError_t e = lspiv::launch_minmax(d_frames, n, lo, hi, d_out, stream ? (hipStream_t)stream : c->stream);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return LSPIV_OK;
+}
+
+int lspiv_minmax(const float* frames, int64_t n, float lo, float hi, float* out) {
+  if (!frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
+  if (n <= 0) return n == 0 ? LSPIV_OK : fail(LSPIV_EINVAL, "bad n");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  const size_t b = (size_t)n * sizeof(float);
+  rc = ensure(&c->d_planes, &c->planes_cap, b);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_planes, frames, b, hipMemcpyHostToDevice, c->stream));
+  rc = lspiv_minmax_dev(c->d_planes, n, lo, hi, c->d_planes, c->stream);  // in place
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out, c->d_planes, b, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
+
+int lspiv_normalize_dev(const uint8_t* d_frames, int64_t T, int64_t H, int64_t W, int samples, uint8_t* d_out, void* stream) {
+  if (!d_frames || !d_out) return fail(LSPIV_EINVAL, "NULL argument");
+  if (T < 1 || H <= 0 || W <= 0 || samples < 1 || T >= 65536) return fail(LSPIV_ESHAPE, "bad shape");
+  const long interval = std::lround((double)T / (double)samples);  // Python round(): half to even
+  const double ratio = (double)T / (double)samples;
+  long iv = interval;
+  if (ratio - std::floor(ratio) == 0.5) iv = ((long)std::floor(ratio) % 2 == 0) ? (long)std::floor(ratio) : (long)std::floor(ratio) + 1;
+  if (iv == 0) return fail(LSPIV_EINVAL, "Amount of frames is too small to provide %d samples", samples);
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  float* d_mean = nullptr;
+  int* d_mm = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_mean, (size_t)H * W * sizeof(float)));
+  hipError_t e = hipMalloc((void**)&d_mm, (size_t)2 * T * sizeof(int));
+  if (e == hipSuccess) e = lspiv::launch_normalize(d_frames, H * W, (int)T, (int)iv, d_mean, d_mm, d_mm + T, d_out, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);  // the temporaries are freed below
+  hipFree(d_mean);
+  if (d_mm) hipFree(d_mm);
+  if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? LSPIV_ENOMEM : LSPIV_EHIP, "normalize failed: %s", hipGetErrorString(e));
+  return LSPIV_OK;
+}
+
+int lspiv_normalize(const uint8_t* frames, int64_t T, int64_t H, int64_t W, int samples, uint8_t* out) {
+  if (!frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
+  if (T < 1 || H <= 0 || W <= 0) return fail(LSPIV_ESHAPE, "bad shape");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  const size_t b = (size_t)T * H * W;
+  rc = ensure(&c->d_frames, &c->frames_cap, b);
+  if (rc) return rc;
+  rc = ensure(&c->d_planes, &c->planes_cap, b);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_frames, frames, b, hipMemcpyHostToDevice, c->stream));
+  rc = lspiv_normalize_dev((const uint8_t*)c->d_frames, T, H, W, samples, (uint8_t*)c->d_planes, c->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out, c->d_planes, b, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
+
 // ---- device-resident helpers ------------------------------------------------------------------
 int lspiv_dev_malloc(void** d_ptr, size_t bytes) {
   if (!d_ptr) return fail(LSPIV_EINVAL, "d_ptr is NULL");

@@ -1,0 +1,45 @@
+"""Mirror of the element-wise ``Frames`` filters of pyorc on the MI355X.
+
+``normalize`` (pyorc/api/frames.py:279-306), ``minmax`` (:344-362) and ``time_diff`` (:409-436) are plain
+numpy/xarray arithmetic in the reference and are reproduced bit for bit; ``edge_detect`` / ``smooth`` are
+``cv2.GaussianBlur`` calls (pyorc/cv.py:142-183) and are not covered (cv2 cannot be installed here to pin them).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+
+
+def time_diff(frames, thres: float = 0.0, abs: bool = False) -> np.ndarray:
+    """``Frames.time_diff``: (T, H, W) -> (T-1, H, W) float32; values <= thres (and NaN) become 0."""
+    a = _lib.as_frames(frames)
+    _lib.require_device()
+    out = np.empty((a.shape[0] - 1,) + a.shape[1:], dtype=np.float32)
+    _lib.check(_lib.load().lspiv_time_diff(_lib.ptr(a), _lib.DTYPE_CODES[a.dtype], a.shape[0], a.shape[1], a.shape[2],
+                                           float(thres), int(bool(abs)), _lib.ptr(out)))
+    return out
+
+
+def minmax(frames, min=-np.inf, max=np.inf) -> np.ndarray:
+    """``Frames.minmax`` on float32 frames: ``np.maximum(np.minimum(x, max), min)`` (NaN propagates)."""
+    a = np.ascontiguousarray(frames, dtype=np.float32)
+    _lib.require_device()
+    out = np.empty_like(a)
+    _lib.check(_lib.load().lspiv_minmax(_lib.ptr(a), a.size, float(min), float(max), _lib.ptr(out)))
+    return out
+
+
+def normalize(frames, samples: int = 15) -> np.ndarray:
+    """``Frames.normalize`` on uint8 frames: sampled temporal mean removed, per-frame stretch to uint8."""
+    a = np.asarray(frames)
+    if a.dtype != np.uint8 or a.ndim != 3:
+        raise ValueError("normalize expects a (T, H, W) uint8 stack (grayscale camera frames)")
+    if round(len(a) / samples) == 0:
+        raise AssertionError(f"Amount of frames is too small to provide {samples} samples")
+    a = np.ascontiguousarray(a)
+    _lib.require_device()
+    out = np.empty_like(a)
+    _lib.check(_lib.load().lspiv_normalize(_lib.ptr(a), a.shape[0], a.shape[1], a.shape[2], int(samples), _lib.ptr(out)))
+    return out

@@ -1,0 +1,89 @@
+"""N2 element-wise filters: oracle behaviour on CPU, bit-exact parity on the GPU."""
+import numpy as np
+import pytest
+
+from oracle import filters_oracle as fo
+from pyorc_amd.synth import particle_stack
+
+
+def test_oracle_filters_follow_reference_arithmetic():
+    fr = particle_stack(31, 48, 64, seed=2)
+    n = fo.normalize(fr, samples=15)
+    assert n.dtype == np.uint8 and n.shape == fr.shape
+    assert (n.reshape(31, -1).max(axis=1) == 255).all() and (n.reshape(31, -1).min(axis=1) == 0).all()
+    iv = round(31 / 15)
+    mean = fr[::iv].mean(axis=0).astype("float32")
+    red = fr.astype("float32") - mean
+    k = 7
+    exp = ((red[k] - red[k].min()) / (red[k].max() - red[k].min()) * 255).astype("uint8")
+    assert np.array_equal(n[k], exp)
+    d = fo.time_diff(fr, thres=3.0)
+    assert d.dtype == np.float32 and d.shape == (30, 48, 64) and ((d == 0) | (d > 3.0)).all()
+    raw = np.diff(fr.astype(np.float32), axis=0)
+    assert np.array_equal(d, np.where(raw > 3.0, raw, 0))
+    f = raw.copy(); f[0, 0, 0] = np.nan
+    m = fo.minmax(f, -5, 5)
+    assert np.isnan(m[0, 0, 0]) and np.nanmin(m) == -5 and np.nanmax(m) == 5
+    with pytest.raises(AssertionError):
+        fo.normalize(fr[:5], samples=15)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32, np.float64])
+def test_gpu_time_diff_bit_exact(gpu, dtype):
+    from pyorc_amd import filters
+
+    fr = particle_stack(9, 130, 171, seed=4)
+    fr = fr if dtype == np.uint8 else fr.astype(dtype) * 0.37 - 3.0
+    if dtype != np.uint8:
+        fr[3, 5, 7] = np.nan
+    for thres, ab in ((0.0, False), (2.5, False), (-1.0, True)):
+        got = filters.time_diff(fr, thres, ab)
+        assert got.dtype == np.float32 and np.array_equal(got, fo.time_diff(fr, thres, ab))
+
+
+@pytest.mark.gpu
+def test_gpu_minmax_and_normalize_bit_exact(gpu):
+    from pyorc_amd import _lib, filters
+
+    rng = np.random.default_rng(3)
+    f = (rng.standard_normal((4, 77, 93)) * 6).astype(np.float32)
+    f[1, 2, 3] = np.nan
+    for lo, hi in ((-5, 5), (-np.inf, 2.0), (0.0, np.inf)):
+        assert np.array_equal(filters.minmax(f, lo, hi), fo.minmax(f, lo, hi), equal_nan=True)
+    fr = particle_stack(31, 120, 160, seed=6)
+    fr[5] = 17  # a constant frame: 0/0 -> 0
+    for samples in (15, 4, 31):
+        assert np.array_equal(filters.normalize(fr, samples), fo.normalize(fr, samples)), samples
+    with pytest.raises(AssertionError):
+        filters.normalize(fr[:5], 15)
+    with pytest.raises(ValueError):
+        filters.normalize(fr.astype(np.float32))
+
+
+@pytest.mark.gpu
+def test_gpu_recipe_chain_normalize_project_piv(gpu):
+    """The Ngwerere recipe order (examples/ngwerere/ngwerere.yml:5-11, minus the cv2 edge filter): normalize ->
+    project -> get_piv, every stage on the GPU, against the oracle chain."""
+    import pyorc_amd
+    from oracle import c_oracle, project_oracle as pro
+    from pyorc_amd import filters
+    from pyorc_amd.project import Projection
+    from pyorc_amd.synth import projection_maps
+
+    src, dst = (240, 320), (128, 160)
+    cam = particle_stack(16, src[0], src[1], seed=8, density=0.04)
+    cam = (cam * 0.6 + 60).astype(np.uint8)  # static background offset that normalize removes
+    maps = projection_maps(src, dst, tilt=0.25, seed=2)
+    norm = filters.normalize(cam, samples=15)
+    assert np.array_equal(norm, fo.normalize(cam, 15))
+    p = Projection(src, dst, *maps)
+    ortho = p.project_frames(norm)
+    p.close()
+    ref_ortho = pro.project_frames(fo.normalize(cam, 15), dst, *maps)
+    assert np.array_equal(ortho.astype(np.float64), ref_ortho)
+    u, v, cm, sn = pyorc_amd.piv_pairs(ortho, (32, 32), (16, 16))
+    uo, vo, cmo, sno, cond = c_oracle.piv_pairs(ref_ortho, (32, 32), (16, 16), return_cond=True)
+    ok = c_oracle.well_posed(cond)
+    e = lambda g, r: float(np.nanmax(np.abs(g - r) / np.maximum(np.abs(r), 0.05)))
+    assert ok.mean() > 0.5 and e(cm, cmo) <= 1e-4 and e(u[ok], uo[ok]) <= 1e-4 and e(v[ok], vo[ok]) <= 1e-4

@@ -127,3 +127,25 @@ def test_round_trip_circular_shift_full_frame(gpu):
     assert np.nanmax(np.abs(u - dx)) < 0.25 and np.nanmax(np.abs(v - dy)) < 0.25
     assert abs(np.mean(u) - dx) < 0.01 and abs(np.mean(v) - dy) < 0.01
     assert not np.isnan(u).any()
+
+
+def test_config1_ngwerere_geometry(gpu):
+    """BASELINE.json configs[0] geometry (785 x 875, 21 frames, 32x32 @ 50 % -> 48 x 53) through get_piv on the GPU,
+    chunked like the reference would on a small machine, against the C oracle."""
+    from pyorc_amd import frames as F
+    from pyorc_amd.synth import particle_stack
+
+    fr = particle_stack(21, 785, 875, seed=20260927 + 1)
+    t = np.arange(21) / 30.0
+    ds = F.get_piv(fr, 32, time=t, resolution=0.01, chunksize=5)
+    assert ds["v_x"].shape == (20, 48, 53) and np.array_equal(ds.coords["time"], t[1:])
+    assert np.array_equal(ds.coords["x"], np.arange(875)[16::16][:53])
+    whole = F.get_piv(fr, 32, time=t, resolution=0.01)
+    for k in ds:
+        assert np.array_equal(ds[k], whole[k], equal_nan=True)
+    uo, vo, cmo, sno, cond = c_oracle.piv_pairs(fr, (32, 32), (16, 16), return_cond=True)
+    ok = c_oracle.well_posed(cond)
+    assert ok.mean() > 0.9
+    assert rel_err(ds["corr"], cmo.astype(np.float64)) <= TOL and rel_err(ds["s2n"], sno.astype(np.float64)) <= TOL
+    vx_ref = (uo.astype(np.float64) * 0.01 * 30.0)
+    assert rel_err(ds["v_x"][ok], vx_ref[ok], floor=0.05 * 0.3) <= TOL

@@ -176,3 +176,27 @@ def test_ensemble_branch_runs_and_masks():
 def test_int16_encoding_of_results():
     a = np.array([0.1234, -1.005, np.nan, 327.0])
     assert po.encode_int16(a).tolist() == [12, -100, -9999, 32700]
+
+
+def test_config1_ngwerere_geometry_cpu_plumbing():
+    """BASELINE.json configs[0]: the Ngwerere clip's geometry (bbox 8.75 m x 7.85 m at 0.01 m -> 785 x 875 frames,
+    examples/ngwerere/ngwerere.json; 32x32 windows at 50 % -> 48 x 53 = 2 544 vectors per pair) through the CPU path:
+    the real clip is absent (.MISSING_LARGE_BLOBS), so a synthetic stand-in of the same shape runs through the
+    oracle's get_ffpiv (chunked like the reference: 21 frames, memory floor of 5 frames per chunk)."""
+    fr = particle_stack(21, 785, 875, seed=20260927 + 1)
+    dt = np.full(20, 1 / 30)
+    u, v, cm, sn = c_oracle.piv_pairs(fr, (32, 32), (16, 16))
+    assert u.shape == (20, 48, 53)
+    # the chunk planner on this stack: poor memory -> 5-frame chunks with a 1-frame halo, every pair exactly once
+    chunks = po.plan_chunks(21, 1e12, 1e9)
+    assert chunks == [(0, 5), (4, 10), (9, 15), (14, 20), (19, 21)]
+    got = np.concatenate([c_oracle.piv_pairs(fr[a:b], (32, 32), (16, 16))[0] for a, b in chunks])
+    assert np.array_equal(got, u, equal_nan=True)
+    # numpy oracle (the primary checker) on the first chunk agrees with the C port used above
+    ref = po.get_ffpiv(fr[:3], dt[:2], (32, 32), (16, 16), 0.01, 0.01)
+    assert ref["v_x"].shape == (2, 48, 53)
+    vx = (u[:2].astype(np.float64) * 0.01 / dt[:2, None, None]).astype(np.float32)
+    ok = np.isfinite(ref["v_x"]) & np.isfinite(vx)
+    assert ok.mean() > 0.95 and np.abs(ref["v_x"][ok] - vx[ok]).max() < 1e-4
+    ut, _ = flow_field(785, 875, (np.arange(48)[:, None] * 16 + 16.0), (np.arange(53)[None, :] * 16 + 16.0))
+    assert np.nanmedian(np.abs(u[0] - ut)) < 0.15
