@@ -1,0 +1,25 @@
+"""N2 measurement: element-wise filters on a device-resident 1080p uint8 stack (HBM-bound streaming kernels)."""
+import ctypes as C, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from pyorc_amd import _lib
+lib = _lib.load(); _lib.require_device()
+H, W, T = 1080, 1920, int(sys.argv[1]) if len(sys.argv) > 1 else 401
+n = H * W
+d_f, d_o, d_o2, d_n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+_lib.check(lib.lspiv_dev_malloc(C.byref(d_f), T * n)); _lib.check(lib.lspiv_dev_malloc(C.byref(d_o), (T - 1) * n * 4))
+_lib.check(lib.lspiv_dev_malloc(C.byref(d_o2), (T - 1) * n * 4)); _lib.check(lib.lspiv_dev_malloc(C.byref(d_n), T * n))
+_lib.check(lib.lspiv_synth_particles_dev(d_f, T, H, W, 3, 0.02))
+def timed(fn, reps=5):
+    fn(); _lib.check(lib.lspiv_synchronize()); t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    _lib.check(lib.lspiv_synchronize()); return (time.perf_counter() - t0) / reps
+t = timed(lambda: _lib.check(lib.lspiv_time_diff_dev(d_f, 0, T, H, W, 0.0, 0, d_o, None)))
+b = (T - 1) * n * (2 * 1 + 4)
+print(f"time_diff  u8->f32: {t*1e3:.2f} ms / {T-1} frames, {b/t/1e9:.0f} GB/s algorithmic (2 u8 reads + 1 f32 write per px) = {b/t/8e12*100:.1f}% of 8 TB/s")
+t = timed(lambda: _lib.check(lib.lspiv_minmax_dev(d_o, (T - 1) * n, -5.0, 5.0, d_o2, None)))
+b = (T - 1) * n * 8
+print(f"minmax     f32    : {t*1e3:.2f} ms, {b/t/1e9:.0f} GB/s = {b/t/8e12*100:.1f}% of 8 TB/s")
+t = timed(lambda: _lib.check(lib.lspiv_normalize_dev(d_f, T, H, W, 15, d_n, None)), 3)
+b = T * n * (1 + 1 + 1)  # min/max pass read, normalise pass read + write (mean plane is L2-resident)
+print(f"normalize  u8->u8 : {t*1e3:.2f} ms / {T} frames, {b/t/1e9:.0f} GB/s algorithmic = {b/t/8e12*100:.1f}% of 8 TB/s (incl. 2 hipMalloc/hipFree + sync)")
