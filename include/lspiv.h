@@ -118,6 +118,11 @@ int lspiv_ensemble_accumulate(lspiv_ensemble* handle, const void* frames, int dt
  * u, v (n_win) in pixels; corr_count (n_win) float32; corr_mean NULL or n_win*wy*wx float32.  */
 int lspiv_ensemble_finish(lspiv_ensemble* handle, float count_min, float n_frames,
                           float* u, float* v, float* corr_count, float* corr_mean);
+/* running state out of / into HBM: corr_sum (n_win*wy*wx, fft-shifted planes) and corr_count (n_win).  Multi-GPU
+ * ensemble = every rank accumulates its own time block, the states are summed (one all-reduce) and
+ * imported on the rank that calls lspiv_ensemble_finish.  `add` != 0 adds to the current state instead of replacing. */
+int lspiv_ensemble_export(lspiv_ensemble* handle, float* corr_sum, float* corr_count);
+int lspiv_ensemble_import(lspiv_ensemble* handle, const float* corr_sum, const float* corr_count, int add);
 int lspiv_ensemble_destroy(lspiv_ensemble* handle);
 
 /* ---------------------------------------------------------------- next rows */

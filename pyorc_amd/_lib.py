@@ -63,6 +63,8 @@ SIGNATURES = {
     "lspiv_ensemble_begin": (_i32, [_i64, _i64, _i32, _i32, _i32, _i32, C.POINTER(_vp)]),
     "lspiv_ensemble_accumulate": (_i32, [_vp, _vp, _i32, _i64, _f32, _f32, _f32, _vp, _vp]),
     "lspiv_ensemble_finish": (_i32, [_vp, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "lspiv_ensemble_export": (_i32, [_vp, _vp, _vp]),
+    "lspiv_ensemble_import": (_i32, [_vp, _vp, _vp, _i32]),
     "lspiv_ensemble_destroy": (_i32, [_vp]),
     "lspiv_projection_create": (_i32, [_i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, C.POINTER(_vp)]),
     "lspiv_project_frames": (_i32, [_vp, _vp, _i32, _i64, _vp]),

@@ -83,6 +83,7 @@ struct DeviceCtx {
   bool arch_ok = false;
 };
 std::mutex g_mu;
+std::mutex g_host_mu;  // host-pointer entry points share one set of workspaces per device: serialise them
 std::vector<DeviceCtx*> g_ctx;
 
 int get_ctx(DeviceCtx** out) {
@@ -295,6 +296,7 @@ int lspiv_piv_pairs_dev(const void* d_frames, int dtype, int64_t T, int64_t H, i
 
 int lspiv_piv_pairs(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, int wy, int wx, int oy, int ox,
                     float signal_threshold, float* u, float* v, float* corr_max, float* s2n, float* corr_planes) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
   if (!frames || !u || !v || !corr_max || !s2n) return fail(LSPIV_EINVAL, "NULL buffer");
   Grid g;
   int rc = make_grid(H, W, wy, wx, oy, ox, &g);
@@ -364,6 +366,7 @@ int lspiv_piv_pairs(const void* frames, int dtype, int64_t T, int64_t H, int64_t
 }
 
 int lspiv_u_v_displacement(const float* corr_planes, int64_t P, int64_t n_win, int wy, int wx, float* u, float* v) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
   if (!corr_planes || !u || !v) return fail(LSPIV_EINVAL, "NULL buffer");
   if (P < 0 || n_win < 0 || wy < 1 || wx < 1 || wy > 4096 || wx > 4096) return fail(LSPIV_EINVAL, "bad shape");
   const int64_t n = P * n_win;
@@ -415,6 +418,7 @@ int lspiv_ensemble_begin(int64_t H, int64_t W, int wy, int wx, int oy, int ox, l
 
 int lspiv_ensemble_accumulate(lspiv_ensemble* h, const void* frames, int dtype, int64_t T, float corr_min,
                               float s2n_min, float signal_threshold, float* corr_max, float* s2n) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
   if (!h || !frames || !corr_max || !s2n) return fail(LSPIV_EINVAL, "NULL argument");
   DeviceCtx* c;
   int rc = get_ctx(&c);
@@ -447,6 +451,7 @@ int lspiv_ensemble_accumulate(lspiv_ensemble* h, const void* frames, int dtype, 
 
 int lspiv_ensemble_finish(lspiv_ensemble* h, float count_min, float n_frames, float* u, float* v, float* corr_count,
                           float* corr_mean) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
   if (!h || !u || !v) return fail(LSPIV_EINVAL, "NULL argument");
   DeviceCtx* c;
   int rc = get_ctx(&c);
@@ -468,6 +473,39 @@ int lspiv_ensemble_finish(lspiv_ensemble* h, float count_min, float n_frames, fl
   if (corr_mean) HIP_TRY(hipMemcpyAsync(corr_mean, c->d_planes, pb, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return LSPIV_OK;
+}
+
+int lspiv_ensemble_export(lspiv_ensemble* h, float* corr_sum, float* corr_count) {
+  if (!h || !corr_sum || !corr_count) return fail(LSPIV_EINVAL, "NULL argument");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  const size_t n_win = (size_t)h->g.n_rows * h->g.n_cols;
+  HIP_TRY(hipMemcpyAsync(corr_sum, h->d_sum, n_win * h->wy * h->wx * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(corr_count, h->d_count, n_win * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
+
+int lspiv_ensemble_import(lspiv_ensemble* h, const float* corr_sum, const float* corr_count, int add) {
+  if (!h || !corr_sum || !corr_count) return fail(LSPIV_EINVAL, "NULL argument");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  const size_t n_win = (size_t)h->g.n_rows * h->g.n_cols, np = n_win * h->wy * h->wx;
+  if (!add) {
+    HIP_TRY(hipMemcpyAsync(h->d_sum, corr_sum, np * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_count, corr_count, n_win * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LSPIV_OK;
+  }
+  // add on the host side of the boundary: export, sum, import (a few tens of MB, once per video)
+  std::vector<float> s(np), k(n_win);
+  rc = lspiv_ensemble_export(h, s.data(), k.data());
+  if (rc) return rc;
+  for (size_t i = 0; i < np; ++i) s[i] += corr_sum[i];
+  for (size_t i = 0; i < n_win; ++i) k[i] += corr_count[i];
+  return lspiv_ensemble_import(h, s.data(), k.data(), 0);
 }
 
 int lspiv_ensemble_destroy(lspiv_ensemble* h) {
@@ -551,6 +589,7 @@ int lspiv_project_frames_dev(lspiv_projection* h, const void* d_frames, int dtyp
 }
 
 int lspiv_project_frames(lspiv_projection* h, const void* frames, int dtype, int64_t T, float* out) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
   if (!h || !frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
   if (dtype < 0 || dtype > 2) return fail(LSPIV_EINVAL, "dtype %d not in {0:u8, 1:f32, 2:f64}", dtype);
   if (T <= 0) return LSPIV_OK;
@@ -593,6 +632,7 @@ int lspiv_pack_int16_dev(const float* d_values, int64_t n, float scale, int fill
 }
 
 int lspiv_pack_int16(const float* values, int64_t n, float scale, int fill, int16_t* packed) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
   if (!values || !packed) return fail(LSPIV_EINVAL, "NULL argument");
   if (n <= 0) return n == 0 ? LSPIV_OK : fail(LSPIV_EINVAL, "bad n");
   DeviceCtx* c;
@@ -625,6 +665,7 @@ int lspiv_time_diff_dev(const void* d_frames, int dtype, int64_t T, int64_t H, i
 }
 
 int lspiv_time_diff(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, float thres, int use_abs, float* out) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
   if (!frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
   if (dtype < 0 || dtype > 2) return fail(LSPIV_EINVAL, "dtype %d not in {0:u8, 1:f32, 2:f64}", dtype);
   if (T < 2 || H <= 0 || W <= 0) return fail(LSPIV_ESHAPE, "need >= 2 frames of positive size");
@@ -656,6 +697,7 @@ int lspiv_minmax_dev(const float* d_frames, int64_t n, float lo, float hi, float
 }
 
 int lspiv_minmax(const float* frames, int64_t n, float lo, float hi, float* out) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
   if (!frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
   if (n <= 0) return n == 0 ? LSPIV_OK : fail(LSPIV_EINVAL, "bad n");
   DeviceCtx* c;
@@ -697,6 +739,7 @@ int lspiv_normalize_dev(const uint8_t* d_frames, int64_t T, int64_t H, int64_t W
 }
 
 int lspiv_normalize(const uint8_t* frames, int64_t T, int64_t H, int64_t W, int samples, uint8_t* out) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
   if (!frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
   if (T < 1 || H <= 0 || W <= 0) return fail(LSPIV_ESHAPE, "bad shape");
   DeviceCtx* c;

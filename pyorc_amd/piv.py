@@ -132,6 +132,23 @@ class Ensemble:
                                                      _lib.ptr(mean) if mean is not None else None))
         return (u, v, cnt, mean) if return_mean else (u, v, cnt)
 
+    def export_state(self):
+        """(corr_sum (n_win, wy, wx) float32 in fft-shifted layout, corr_count (n_win,) float32) from HBM."""
+        n_win = self.n_rows * self.n_cols
+        s = np.empty((n_win,) + self.window_size, dtype=np.float32)
+        k = np.empty(n_win, dtype=np.float32)
+        _lib.check(_lib.load().lspiv_ensemble_export(self._h, _lib.ptr(s), _lib.ptr(k)))
+        return s, k
+
+    def import_state(self, corr_sum, corr_count, add: bool = False):
+        """Replace (or add to) the running state, e.g. with the all-reduced sums of every rank's time block."""
+        s = np.ascontiguousarray(corr_sum, dtype=np.float32)
+        k = np.ascontiguousarray(corr_count, dtype=np.float32)
+        n_win = self.n_rows * self.n_cols
+        if s.size != n_win * self.window_size[0] * self.window_size[1] or k.size != n_win:
+            raise ValueError("state shape does not match this ensemble")
+        _lib.check(_lib.load().lspiv_ensemble_import(self._h, _lib.ptr(s), _lib.ptr(k), int(bool(add))))
+
     def close(self):
         if self._h:
             _lib.load().lspiv_ensemble_destroy(self._h)

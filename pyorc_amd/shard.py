@@ -108,3 +108,33 @@ def allreduce_max(arr: np.ndarray, group=None) -> np.ndarray:
     t = torch.as_tensor(np.ascontiguousarray(arr)).to(dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return t.cpu().numpy()
+
+
+def sharded_ensemble(load_frames: Callable[[int, int], np.ndarray], n_pairs: int, make_ensemble: Callable[[], object],
+                     corr_min: float, s2n_min: float, count_min: float, signal_threshold=None, group=None):
+    """Ensemble correlation over the GPUs of a node (pyorc/velocimetry/ffpiv.py:182-376 sharded in time).
+
+    Every rank accumulates its own pair block into its own ensemble object (``make_ensemble()`` -> an object with
+    ``accumulate / export_state / import_state / finish``, e.g. ``pyorc_amd.piv.Ensemble``); corr_sum and corr_count
+    are summed with ONE all-reduce each; every rank imports the total and finishes, so all ranks return the same
+    (u, v, corr_count, corr_max (P, n_win), s2n (P, n_win)).  ``n_frames`` of the count filter is the number of
+    ranks that contributed a chunk -- the reference counts CHUNKS there (quirk Q3, ffpiv.py:373).
+    """
+    torch, dist = _dist()
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ens = make_ensemble()
+    f0, f1 = frame_block(n_pairs, rank, world)
+    if f1 - f0 >= 2:
+        cm, sn = ens.accumulate(load_frames(f0, f1), corr_min, s2n_min, signal_threshold)
+    else:
+        cm = sn = None
+    s, k = ens.export_state()
+    s = allreduce_sum(s, group)
+    k = allreduce_sum(k, group)
+    ens.import_state(s, k)
+    n_chunks = int(allreduce_sum(np.array([1.0 if cm is not None else 0.0], dtype=np.float32), group)[0])
+    u, v, cnt = ens.finish(count_min, n_chunks)
+    n_win = k.size
+    local = np.stack([cm, sn]).astype(np.float32)[:, :, None, :] if cm is not None else np.empty((2, 0, 1, n_win), np.float32)
+    per_pair = gather_blocks(local, n_pairs, group)  # (2, n_pairs, 1, n_win)
+    return u, v, cnt, per_pair[0, :, 0], per_pair[1, :, 0]

@@ -290,6 +290,38 @@ def test_pipelined_upload_equals_single_batch(gpu, monkeypatch):
             assert np.array_equal(a, b, equal_nan=True), stage
 
 
+def test_ensemble_state_export_import_merges_time_blocks(gpu):
+    """Multi-GPU ensemble = per-rank accumulate + summed state: two half-stack ensembles merged through
+    export_state / import_state must equal one ensemble over the whole stack."""
+    import pyorc_amd.piv as P
+
+    fr = particle_stack(11, 96, 128, seed=51)
+    kw = dict(corr_min=0.1, s2n_min=1.5)
+    whole = P.Ensemble(fr.shape[1:], (32, 32), (16, 16))
+    cm_w, sn_w = whole.accumulate(fr, **kw)
+    a = P.Ensemble(fr.shape[1:], (32, 32), (16, 16))
+    b = P.Ensemble(fr.shape[1:], (32, 32), (16, 16))
+    cm_a, _ = a.accumulate(fr[:6], **kw)      # pairs 0..4
+    cm_b, _ = b.accumulate(fr[5:], **kw)      # pairs 5..9 (one halo frame)
+    assert np.array_equal(np.concatenate([cm_a, cm_b]), cm_w)
+    sa, ka = a.export_state()
+    sb, kb = b.export_state()
+    sw, kw_ = whole.export_state()
+    assert np.array_equal(ka + kb, kw_) and np.abs((sa + sb) - sw).max() < 1e-5
+    a.import_state(sb, kb, add=True)
+    u1, v1, c1 = a.finish(0.2, 1)
+    u0, v0, c0 = whole.finish(0.2, 1)
+    assert np.array_equal(c1, c0) and np.array_equal(np.isnan(u1), np.isnan(u0))
+    assert np.nanmax(np.abs(u1 - u0)) < 1e-4 and np.nanmax(np.abs(v1 - v0)) < 1e-4
+    b.import_state(sw, kw_)                   # replace
+    u2, v2, _ = b.finish(0.2, 1)
+    assert np.array_equal(u2, u0, equal_nan=True) and np.array_equal(v2, v0, equal_nan=True)
+    with pytest.raises(ValueError):
+        b.import_state(sw[:3], kw_)
+    for e in (whole, a, b):
+        e.close()
+
+
 # ------------------------------------------------------------------ errors --------------------------
 def test_error_mapping(gpu):
     import pyorc_amd
