@@ -127,6 +127,35 @@ def test_other_window_sizes_vs_oracle(gpu, ws, ov):
     check_against_oracle(fr, ws, ov, min_ok=0.02 if min(ws) < 10 else 0.3, min_neighbour=0.2 if min(ws) < 10 else 0.02)
 
 
+@pytest.mark.parametrize("ws,ov,shape", [((32, 32), (31, 31), (40, 45)), ((32, 32), (31, 0), (34, 100)),
+                                         ((64, 64), (63, 60), (70, 80)), ((12, 12), (11, 11), (20, 24))])
+def test_extreme_overlaps(gpu, ws, ov, shape):
+    """Stride-1 grids (overlap = window - 1): every pixel shift is its own window; exercises odd grids and the
+    window-index arithmetic of all three kernels."""
+    fr = particle_stack(3, shape[0], shape[1], seed=12, density=0.05)
+    check_against_oracle(fr, ws, ov, min_ok=0.2)
+
+
+def test_input_layouts_and_dtypes(gpu):
+    """Whatever numpy hands over: non-contiguous views, Fortran order, small integer types, bool, T = 2."""
+    import pyorc_amd
+
+    base = particle_stack(4, 96, 128, seed=14)
+    ref = pyorc_amd.piv_pairs(base, (32, 32), (16, 16))
+    wide = np.zeros((4, 96, 256), np.uint8); wide[:, :, ::2] = base
+    for view in (wide[:, :, ::2], np.asfortranarray(base), base.astype(np.int16), base.astype(np.uint16),
+                 base.astype(np.float64), base.astype(np.float32)):
+        got = pyorc_amd.piv_pairs(view, (32, 32), (16, 16))
+        for a, b in zip(ref, got):
+            assert np.array_equal(np.isnan(a), np.isnan(b)) and rel_err(b, a.astype(np.float64)) <= TOL
+    two = pyorc_amd.piv_pairs(base[:2], (32, 32), (16, 16))
+    assert two[0].shape == (1, 5, 7) and np.array_equal(two[0][0], ref[0][0], equal_nan=True)
+    b = pyorc_amd.piv_pairs(base > 40, (32, 32), (16, 16))
+    uo, vo, cmo, sno = c_oracle.piv_pairs((base > 40).astype(np.float64), (32, 32), (16, 16))
+    assert rel_err(b[2], cmo.astype(np.float64)) <= TOL
+    check_against_oracle(base.astype(np.float64) - 9.5, (64, 64), (48, 48), thr=0.2, min_ok=0.0)
+
+
 def test_signal_threshold_vs_oracle(gpu):
     fr = particle_stack(4, 160, 224, seed=5)
     fr[:, :, :64] = 0  # empty band: skipped windows
