@@ -1,0 +1,14 @@
+#!/bin/bash
+# kernel-trace stats for the other kernels (64x64 FFT, projection, filters) -> gpurun_out/prof_extra_<tag>/
+R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-r1}
+OUT=$R/gpurun_out/prof_extra_$TAG
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+run() { name=$1; shift; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/px_$name -o $name -- "$@" > $OUT/$name.log 2>&1; \
+        find /tmp/px_$name -name "*kernel_stats.csv" -exec cp {} $OUT/ \; ; }
+run fft64 python $R/bench.py --steps 3 --warmup 1 --cpu-pairs 0 --window 64 --overlap 48 --pairs 300
+run project python $R/tools/project_bench.py 201
+run filters python $R/tools/filters_bench.py 201
+run dtypes python $R/tools/dtype_bench.py 100
+for f in $OUT/*kernel_stats.csv; do echo == $f; grep -v "synth_" $f | cut -c1-170; done
