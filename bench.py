@@ -101,6 +101,9 @@ def main():
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
+        _warm = torch.zeros(1, device="cuda")
+        dist.all_reduce(_warm)  # build the RCCL communicator now, whatever --warmup says
+        torch.cuda.synchronize()
     lib = _lib.load()
     _lib.require_device()
     _lib.check(lib.lspiv_set_device(local_rank))
@@ -208,8 +211,8 @@ def main():
 
     dist_check = None
     if use_dist:
-        # the all-gathered sub-chunk blocks of THIS rank must equal its single-launch result bit for bit
-        # (window pairing is chunk-invariant); cheap, outside the timed region
+        # this rank's slice of the all-gathered block must equal its own single-launch result bit for bit;
+        # cheap, outside the timed region
         torch.cuda.synchronize()
         whole = t_out.view(-1)                          # launch_all (kernel-timing loop) wrote the same stack here
         mine = gathered.view(world, -1)[rank]
