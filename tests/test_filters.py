@@ -87,3 +87,33 @@ def test_gpu_recipe_chain_normalize_project_piv(gpu):
     ok = c_oracle.well_posed(cond)
     e = lambda g, r: float(np.nanmax(np.abs(g - r) / np.maximum(np.abs(r), 0.05)))
     assert ok.mean() > 0.5 and e(cm, cmo) <= 1e-4 and e(u[ok], uo[ok]) <= 1e-4 and e(v[ok], vo[ok]) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_gpu_camera_to_velocity_chain_equals_stage_by_stage(gpu):
+    """pipeline.CameraToVelocity (one H2D, every stage a *_dev call, one D2H) == the stand-alone mirrors, bit for bit."""
+    import pyorc_amd
+    from oracle import piv_oracle as po
+    from pyorc_amd import filters
+    from pyorc_amd.pipeline import CameraToVelocity
+    from pyorc_amd.project import Projection
+    from pyorc_amd.synth import projection_maps
+
+    src, dst = (240, 320), (128, 160)
+    cam = (particle_stack(16, src[0], src[1], seed=18, density=0.04) * 0.6 + 50).astype(np.uint8)
+    maps = projection_maps(src, dst, tilt=0.25, seed=5)
+    p = Projection(src, dst, *maps)
+    for samples in (None, 15):
+        staged = filters.normalize(cam, samples) if samples else cam
+        ref = pyorc_amd.piv_pairs(p.project_frames(staged), (32, 32), (16, 16))
+        with CameraToVelocity(src, dst, *maps, window_size=(32, 32), overlap=(16, 16), normalize_samples=samples) as chain:
+            got = chain.run(cam)
+            for a, b in zip(ref, got):
+                assert np.array_equal(a, b, equal_nan=True)
+            pk = chain.run(cam, packed=True)
+            for a, b in zip(ref, pk):
+                assert b.dtype == np.int16 and np.array_equal(b, po.encode_int16(a))
+            assert chain.run(cam[:9])[0].shape == (8, 7, 9)   # buffers are reused for a shorter chunk
+            with pytest.raises(ValueError):
+                chain.run(cam.astype(np.float32))
+    p.close()

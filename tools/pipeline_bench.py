@@ -1,0 +1,19 @@
+"""End-to-end: raw uint8 camera frames in host memory -> velocities in host memory, every stage on the GPU
+(pipeline.CameraToVelocity).  PCIe-inclusive; compares with the host-fed PIV-only rate and the CPU oracle chain."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from pyorc_amd.pipeline import CameraToVelocity
+from pyorc_amd.synth import projection_maps
+
+src, dst, T = (1080, 1920), (1080, 1920), int(sys.argv[1]) if len(sys.argv) > 1 else 201
+maps = projection_maps(src, dst, tilt=0.3, seed=1)
+rng = np.random.default_rng(0)
+base = (rng.random(src) ** 6 * 255).astype(np.uint8)
+cam = np.stack([np.roll(base, (2 * t, -5 * t), (0, 1)) for t in range(T)])
+for samples, packed in ((None, False), (15, False), (15, True)):
+    with CameraToVelocity(src, dst, *maps, normalize_samples=samples) as chain:
+        chain.run(cam[:31])
+        best = min((lambda t0: (chain.run(cam, packed=packed), time.perf_counter() - t0)[1])(time.perf_counter()) for _ in range(3))
+    print(f"normalize={samples} packed={packed}: {T-1} pairs in {best*1e3:.1f} ms -> {(T-1)/best:.0f} pairs/s host-to-host "
+          f"({cam.nbytes/best/1e9:.1f} GB/s of camera frames)")
