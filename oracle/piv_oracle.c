@@ -112,14 +112,17 @@ static double load_px(const void* frames, int dtype, size_t idx) {
 
 /* normalise one window in place (re or im part of z); returns count of non-zero raw samples */
 static int normalize_part(cpx* z, int n, int part, int* dead) {
+  /* mean as x0 + mean(x - x0): algebraically the mean, and exactly x0 for a constant window, so that "zeros if
+     std == 0" (A3) does not depend on whether n * c happens to be representable */
+  const double x0 = part ? z[0].im : z[0].re;
   double s = 0.0;
   int nz = 0;
   for (int i = 0; i < n; ++i) {
     const double v = part ? z[i].im : z[i].re;
-    s += v;
+    s += v - x0;
     nz += (v != 0.0);
   }
-  const double mean = s / n;
+  const double mean = x0 + s / n;
   double ss = 0.0;
   for (int i = 0; i < n; ++i) {
     const double d = (part ? z[i].im : z[i].re) - mean;

@@ -29,17 +29,21 @@ __device__ __forceinline__ void wave_argmax(float& v, int& idx) {
   argmax_merge(v, idx, pv, pi);
 }
 
-// stage one window into LDS as float, return its sum (deterministic lane-strided order)
+// stage one window into LDS as float, return the sum of (x - x0), x0 = its first sample (deterministic
+// lane-strided order).  Summing offsets from x0 makes a constant window come out with an exactly-zero sum, hence
+// mean == x0 and zero variance, for ANY window size -- the FFT kernels get the same from pairwise sums of 2^k terms.
 template <typename T>
-__device__ __forceinline__ float stage_window(const T* src, int W, int wy, int wx, float* dst, int lane, int& nonzero) {
+__device__ __forceinline__ float stage_window(const T* src, int W, int wy, int wx, float* dst, int lane, int& nonzero,
+                                              float& x0) {
   const int n = wy * wx;
+  x0 = to_f32(src[0]);
   float s = 0.0f;
   int nz = 0;
   for (int o = lane; o < n; o += 64) {
     const int y = o / wx, x = o - y * wx;
     const float v = to_f32(src[(int64_t)y * W + x]);
     dst[o] = v;
-    s += v;
+    s += v - x0;
     nz += (v != 0.0f) ? 1 : 0;
   }
   nonzero = half_sum_i(nz);
@@ -48,8 +52,8 @@ __device__ __forceinline__ float stage_window(const T* src, int W, int wy, int w
 }
 
 // mean-offset / variance / clip in LDS; returns 1/std (0 if std == 0)
-__device__ __forceinline__ float normalize_window(float* w, int n, float sum, int lane, bool& finite) {
-  const float mean = sum / (float)n;
+__device__ __forceinline__ float normalize_window(float* w, int n, float sum_off, float x0, int lane, bool& finite) {
+  const float mean = x0 + sum_off / (float)n;
   float ssq = 0.0f;
   for (int o = lane; o < n; o += 64) {
     const float d = w[o] - mean;
@@ -57,7 +61,7 @@ __device__ __forceinline__ float normalize_window(float* w, int n, float sum, in
     w[o] = fmaxf(d, 0.0f);
   }
   ssq = wave_sum(ssq);
-  finite = finite && (fabsf(sum) <= 3.0e38f) && (ssq <= 3.0e38f);
+  finite = finite && (fabsf(mean) <= 3.0e38f) && (ssq <= 3.0e38f);
   const float var = ssq / (float)n;
   return var > 0.0f ? 1.0f / sqrtf(var) : 0.0f;
 }
@@ -130,12 +134,13 @@ __device__ __forceinline__ bool direct_pair(const PivParams& p, uint32_t pair, u
   const int64_t off = ((int64_t)pair * p.H + (int64_t)wrow * p.sy) * p.W + (int64_t)wcol * p.sx;
   const int n = p.wy * p.wx;
   int nza, nzb;
-  const float sa = stage_window(frames + off, p.W, p.wy, p.wx, a, lane, nza);
-  const float sb = stage_window(frames + off + p.frame_elems, p.W, p.wy, p.wx, b, lane, nzb);
+  float a0, b0;
+  const float sa = stage_window(frames + off, p.W, p.wy, p.wx, a, lane, nza, a0);
+  const float sb = stage_window(frames + off + p.frame_elems, p.W, p.wy, p.wx, b, lane, nzb, b0);
   __builtin_amdgcn_wave_barrier();
   bool finite = true;
-  const float inv_a = normalize_window(a, n, sa, lane, finite);
-  const float inv_b = normalize_window(b, n, sb, lane, finite);
+  const float inv_a = normalize_window(a, n, sa, a0, lane, finite);
+  const float inv_b = normalize_window(b, n, sb, b0, lane, finite);
   __builtin_amdgcn_wave_barrier();
   bool ok = finite;
   if (p.signal_threshold >= 0.0f) {

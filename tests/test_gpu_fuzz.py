@@ -1,0 +1,18 @@
+"""Randomised differential test on the GPU: tools/fuzz_parity.py (random shapes, dtypes, windows, overlaps, thresholds,
+constant patches, empty frames) must report zero gate violations against the C oracle."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [11, 12])
+def test_fuzz_parity(gpu, seed):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), str(seed), "40"],
+                         capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "40 cases, 0 failures" in out.stdout

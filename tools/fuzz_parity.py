@@ -1,0 +1,44 @@
+"""Randomised differential test: the HIP path vs the C oracle over random shapes / dtypes / windows / overlaps /
+thresholds.  Prints one line per case and a summary; exits non-zero on any gate violation."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import pyorc_amd
+from oracle import c_oracle
+from pyorc_amd.synth import particle_stack
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+bad = 0
+t_start = time.time()
+for case in range(n_cases):
+    ws = int(rng.choice([32, 32, 32, 64, 64, 16, 24, 10, 48]))
+    wsy = ws if rng.random() < 0.8 else int(rng.choice([8, 16, 20, 32]))
+    ov = (int(rng.integers(0, wsy)), int(rng.integers(0, ws)))
+    H = int(rng.integers(wsy, wsy * 4 + 7)); W = int(rng.integers(ws, ws * 5 + 9)); T = int(rng.integers(2, 6))
+    dtype = rng.choice([np.uint8, np.float32, np.float64])
+    thr = None if rng.random() < 0.6 else float(rng.uniform(0, 0.6))
+    fr = particle_stack(T, H, W, seed=int(rng.integers(1 << 30)), density=float(rng.uniform(0.01, 0.08)))
+    if dtype != np.uint8:
+        fr = (fr.astype(dtype) * float(rng.uniform(0.1, 3)) - float(rng.uniform(0, 50)))
+    if rng.random() < 0.3:
+        fr[:, : H // 3, : W // 3] = 7 if dtype == np.uint8 else float(rng.choice([0.0, 7.0, -2.5, 0.1]))  # masked area
+    if rng.random() < 0.2:
+        fr[rng.integers(T)] = 0                           # an empty frame
+    u, v, cm, sn = pyorc_amd.piv_pairs(fr, (wsy, ws), ov, thr)
+    uo, vo, cmo, sno, cond = c_oracle.piv_pairs(fr, (wsy, ws), ov, thr, return_cond=True)
+    ok = c_oracle.well_posed(cond, min_neighbour=0.05 if min(ws, wsy) >= 16 else 0.2)
+    uniq = c_oracle.unique_peak(cond) | (cmo == 0) | np.isnan(cmo)
+    def err(g, r, m=None):
+        with np.errstate(all="ignore"):
+            e = np.abs(g - r) / np.maximum(np.abs(r), 0.05)
+        e = e if m is None else e[m]
+        return float(np.nanmax(e)) if np.isfinite(e).any() else 0.0
+    nan_bad = int((np.isnan(cm) != np.isnan(cmo)).sum() + (np.isnan(sn) != np.isnan(sno)).sum() + (np.isnan(u) != np.isnan(uo))[uniq].sum())
+    e_c, e_s, e_u, e_v = err(cm, cmo), err(sn, sno), err(u, uo, ok), err(v, vo, ok)
+    fail = nan_bad > 0 or max(e_c, e_s, e_u, e_v) > 1e-4
+    bad += fail
+    print(f"{'FAIL' if fail else 'ok  '} {case:3d} win ({wsy},{ws}) ov {ov} frame ({T},{H},{W}) {np.dtype(dtype).name:7s} thr {thr} "
+          f"well-posed {ok.mean():.2f} errs c {e_c:.1e} s {e_s:.1e} u {e_u:.1e} v {e_v:.1e} nan {nan_bad}", flush=True)
+print(f"{n_cases} cases, {bad} failures, {time.time()-t_start:.1f} s")
+sys.exit(1 if bad else 0)
