@@ -150,7 +150,17 @@ int lspiv_projection_destroy(lspiv_projection* handle);
  *   lspiv_minmax      Frames.minmax (:344-362) on float32 frames: maximum(minimum(x, hi), lo), NaN propagates
  *   lspiv_normalize   Frames.normalize (:279-306) on uint8 frames: float32 mean of frames [::round(T/samples)] removed,
  *                     per-frame ((x - min) / (max - min) * 255) -> uint8
- * (edge_detect / smooth are cv2.GaussianBlur calls and are not covered.)  Host pointers; *_dev take device pointers. */
+ *   lspiv_gaussian_blur / lspiv_edge_detect   Frames.smooth (:438-467) / Frames.edge_detect (:308-342): pyorc calls
+ *                     cv2.GaussianBlur(float32, (k, k), 0) (pyorc/cv.py:142-183); OpenCV's published algorithm is
+ *                     restated (coefficient tables for k <= 7, separable, BORDER_REFLECT_101): NOT bit-pinned, ~1e-6.
+ *                     out (T,H,W) float32; ksize odd, 1..31; edge = blur(ksize_2) - blur(ksize_1).
+ * Host pointers; *_dev take device pointers. */
+int lspiv_gaussian_blur(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, int ksize, float* out);
+int lspiv_gaussian_blur_dev(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, int ksize, float* d_out,
+                            void* stream);
+int lspiv_edge_detect(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, int ksize_1, int ksize_2, float* out);
+int lspiv_edge_detect_dev(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, int ksize_1, int ksize_2,
+                          float* d_out, void* stream);
 int lspiv_time_diff(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, float thres, int use_abs, float* out);
 int lspiv_time_diff_dev(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, float thres, int use_abs,
                         float* d_out, void* stream);

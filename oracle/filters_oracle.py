@@ -40,3 +40,66 @@ def time_diff(frames: np.ndarray, thres: float = 0.0, abs: bool = False) -> np.n
     with np.errstate(invalid="ignore"):
         d = np.where(d > np.float32(thres), d, np.float32(0.0))  # .where(d > thres) -> NaN, then .fillna(0.0)
     return np.abs(d) if abs else d
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# cv2.GaussianBlur-based filters -- THIRD-PARTY ALGORITHM RESTATED, UNPINNED
+# ---------------------------------------------------------------------------------------------------------------------
+# Frames.smooth (pyorc/api/frames.py:438-467 -> pyorc/cv.py:142-158) and Frames.edge_detect (frames.py:308-342 ->
+# cv.py:162-183) call cv2.GaussianBlur(img.astype("float32"), (k, k), 0).  OpenCV (opencv-python, unpinned in
+# pyproject.toml) is not installable here, so its published algorithm is restated:
+#   * kernel for sigma <= 0: fixed tables for k = 1, 3, 5, 7 ([1], [.25 .5 .25], [.0625 .25 .375 .25 .0625],
+#     [.03125 .109375 .21875 .28125 ...]); otherwise sigma = 0.3*((k-1)*0.5 - 1) + 0.8 and exp(-x^2 / 2 sigma^2)
+#     normalised to sum 1, coefficients stored as float32 (getGaussianKernel, ktype CV_32F);
+#   * separable: rows first, then columns, float32 intermediates; borders BORDER_REFLECT_101 (gfedcb|abcdefgh|gfedcba);
+#   * symmetric evaluation k0*x0 + sum_j kj*(x[-j] + x[+j]).
+# OpenCV's SIMD paths may fuse multiply-adds, so agreement with a real cv2 is expected to ~1e-6 relative, not bitwise.
+_SMALL_TAB = {1: [1.0], 3: [0.25, 0.5, 0.25], 5: [0.0625, 0.25, 0.375, 0.25, 0.0625],
+              7: [0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125]}
+
+
+def gaussian_kernel(ksize: int) -> np.ndarray:
+    if ksize in _SMALL_TAB:
+        return np.asarray(_SMALL_TAB[ksize], dtype=np.float32)
+    sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
+    x = np.arange(ksize, dtype=np.float64) - (ksize - 1) * 0.5
+    k = np.exp(-(x * x) / (2.0 * sigma * sigma))
+    return (k / k.sum()).astype(np.float32)
+
+
+def _reflect101(i: np.ndarray, n: int) -> np.ndarray:
+    if n == 1:
+        return np.zeros_like(i)
+    p = 2 * (n - 1)
+    i = np.mod(i, p)
+    return np.where(i >= n, p - i, i)
+
+
+def gaussian_blur(img: np.ndarray, ksize: int) -> np.ndarray:
+    """cv2.GaussianBlur(img.astype(float32), (ksize, ksize), 0) restated; img (H, W) -> float32 (H, W)."""
+    a = np.asarray(img).astype(np.float32)
+    k = gaussian_kernel(ksize)
+    r = ksize // 2
+    H, W = a.shape
+
+    def pass1d(x, axis):
+        n = x.shape[axis]
+        idx = np.arange(n)
+        out = np.take(x, idx, axis=axis) * k[r]
+        for j in range(1, r + 1):
+            lo = np.take(x, _reflect101(idx - j, n), axis=axis)
+            hi = np.take(x, _reflect101(idx + j, n), axis=axis)
+            out = out + k[r + j] * (lo + hi)          # float32 throughout
+        return out.astype(np.float32)
+
+    return pass1d(pass1d(a, 1), 0)
+
+
+def smooth(frames: np.ndarray, wdw: int = 1) -> np.ndarray:
+    """Frames.smooth: stride = 2*wdw + 1 (frames.py:455)."""
+    return np.stack([gaussian_blur(f, 2 * wdw + 1) for f in np.asarray(frames)])
+
+
+def edge_detect(frames: np.ndarray, wdw_1: int = 1, wdw_2: int = 2) -> np.ndarray:
+    """Frames.edge_detect: blur(stride_2) - blur(stride_1) (cv.py:180-183)."""
+    return np.stack([gaussian_blur(f, 2 * wdw_2 + 1) - gaussian_blur(f, 2 * wdw_1 + 1) for f in np.asarray(frames)])

@@ -76,6 +76,10 @@ SIGNATURES = {
     "lspiv_minmax_dev": (_i32, [_vp, _i64, _f32, _f32, _vp, _vp]),
     "lspiv_normalize": (_i32, [_vp, _i64, _i64, _i64, _i32, _vp]),
     "lspiv_normalize_dev": (_i32, [_vp, _i64, _i64, _i64, _i32, _vp, _vp]),
+    "lspiv_gaussian_blur": (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _vp]),
+    "lspiv_gaussian_blur_dev": (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _vp, _vp]),
+    "lspiv_edge_detect": (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp]),
+    "lspiv_edge_detect_dev": (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp, _vp]),
     "lspiv_pack_int16": (_i32, [_vp, _i64, _f32, _i32, _vp]),
     "lspiv_pack_int16_dev": (_i32, [_vp, _i64, _f32, _i32, _vp, _vp]),
     "lspiv_dev_malloc": (_i32, [C.POINTER(_vp), _sz]),

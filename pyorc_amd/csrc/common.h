@@ -187,6 +187,9 @@ hipError_t launch_time_diff(const void* frames, int dtype, int64_t frame_elems, 
 hipError_t launch_minmax(const float* in, int64_t n, float lo, float hi, float* out, hipStream_t s);
 hipError_t launch_normalize(const uint8_t* frames, int64_t frame_elems, int n_frames, int interval, float* d_mean,
                             int* d_mn, int* d_mx, uint8_t* out, hipStream_t s);
+// Gaussian blur (ksize_b == 0) or band filter blur(ksize_b) - blur(ksize_a); odd sizes 1..31
+hipError_t launch_blur(const void* frames, int dtype, int n_frames, int H, int W, int ksize_a, int ksize_b, float* out,
+                       hipStream_t s);
 // synthetic particle-image stack (bench / test utility)
 hipError_t launch_synth_particles(uint8_t* d_frames, int64_t T, int H, int W, uint64_t seed, float density,
                                   hipStream_t s);

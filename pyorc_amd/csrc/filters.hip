@@ -3,6 +3,9 @@
 //   Frames.time_diff  pyorc/api/frames.py:409-436    Frames.minmax  :344-362    Frames.normalize  :279-306
 // (edge_detect / smooth are cv2.GaussianBlur calls and are not covered).  All are HBM-bound streaming kernels:
 // 16-byte accesses per lane, grid-stride over the stack.
+#include <algorithm>
+#include <cmath>
+
 #include "common.h"
 
 namespace lspiv {
@@ -108,6 +111,202 @@ hipError_t launch_normalize(const uint8_t* frames, int64_t frame_elems, int n_fr
   const unsigned bx = (unsigned)std::min<int64_t>((frame_elems + 255) / 256, 64);
   hipLaunchKernelGGL(frame_minmax_kernel, dim3(bx, n_frames), dim3(256), 0, s, frames, d_mean, frame_elems, d_mn, d_mx);
   hipLaunchKernelGGL(normalize_kernel, dim3(bx * 4, n_frames), dim3(256), 0, s, frames, d_mean, frame_elems, d_mn, d_mx, out);
+  return hipGetLastError();
+}
+
+}  // namespace lspiv
+
+// ---- Gaussian blur / band-pass edge filter (Frames.smooth, Frames.edge_detect) -----------------------------------------
+// pyorc calls cv2.GaussianBlur(img.astype("float32"), (k, k), 0) (pyorc/cv.py:142-183).  OpenCV is a third-party
+// dependency that is absent here; its published algorithm is restated (oracle/filters_oracle.py): fixed coefficient
+// tables for k <= 7, separable float32 filter, rows first, BORDER_REFLECT_101, symmetric evaluation
+// k0 x0 + sum_j kj (x[-j] + x[+j]).  One fused kernel per call: a 16 x 64 output tile, its halo staged in LDS once,
+// row pass into a second LDS buffer, column pass to HBM -- each frame is read once and written once.
+// EDGE: out = blur(kernel B) - blur(kernel A) from the same staged tile (edge_detect's band filter).
+namespace lspiv {
+
+constexpr int BLUR_TW = 64, BLUR_MAXR = 15;   // tile width; tile height TH = 64 (unrolled radii) or 16 (run-time radii)
+
+struct BlurTaps {
+  int r;                        // radius, ksize = 2 r + 1
+  float k[BLUR_MAXR + 1];       // k[0] centre, k[j] = coefficient at distance j
+};
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  // one reflection covers every halo that is narrower than the frame; the loop only runs for frames smaller than it
+  while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+  return i;
+}
+
+// symmetric taps around c with element stride S; R > 0: compile-time radius (unrolled), R == 0: run-time radius
+template <int R, int S>
+__device__ __forceinline__ float taps(const float* c, const BlurTaps& k) {
+  float s = c[0] * k.k[0];
+  if (R > 0) {
+#pragma unroll
+    for (int j = 1; j <= R; ++j) s += k.k[j] * (c[-j * S] + c[j * S]);
+  } else {
+    for (int j = 1; j <= k.r; ++j) s += k.k[j] * (c[-j * S] + c[j * S]);
+  }
+  return s;
+}
+
+template <typename T, bool EDGE, int RA, int RB, int BLUR_TH>
+__global__ __launch_bounds__(256) void blur_kernel(const T* __restrict__ frames, int H, int W, BlurTaps ka, BlurTaps kb,
+                                                   float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int R = EDGE ? (RB > 0 ? RB : kb.r) : (RA > 0 ? RA : ka.r);   // halo = the larger radius
+  const int tw = BLUR_TW + 2 * R, th = BLUR_TH + 2 * R;
+  float* tile = lds;                                   // th x tw
+  float* rowa = tile + th * tw;                        // th x BLUR_TW   (kernel A row pass)
+  float* rowb = rowa + th * BLUR_TW;                   // th x BLUR_TW   (kernel B row pass, EDGE only)
+  const int x0 = blockIdx.x * BLUR_TW, y0 = blockIdx.y * BLUR_TH;
+  const T* img = frames + (int64_t)blockIdx.z * H * W;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // stage the tile: a wave per row, lanes along x; the two source columns of a lane are resolved once
+  const int cx0 = reflect101(x0 + lane - R, W);
+  const int cx1 = lane + 64 < tw ? reflect101(x0 + lane + 64 - R, W) : -1;
+  for (int ty = wv; ty < th; ty += 4) {
+    const T* row = img + (int64_t)reflect101(y0 + ty - R, H) * W;
+    tile[ty * tw + lane] = to_f32(row[cx0]);
+    if (cx1 >= 0) tile[ty * tw + lane + 64] = to_f32(row[cx1]);
+  }
+  __syncthreads();
+  for (int ty = wv; ty < th; ty += 4) {
+    const float* c = tile + ty * tw + lane + R;
+    rowa[ty * BLUR_TW + lane] = taps<RA, 1>(c, ka);
+    if (EDGE) rowb[ty * BLUR_TW + lane] = taps<RB, 1>(c, kb);
+  }
+  __syncthreads();
+  const int x = x0 + lane;
+  if (x >= W) return;
+  float* dst = out + (int64_t)blockIdx.z * H * W + x;
+  // a wave owns BLUR_TH / 4 consecutive rows: unrolled, the LDS column reads are shared between neighbouring outputs
+#pragma unroll
+  for (int i = 0; i < BLUR_TH / 4; ++i) {
+    const int ty = wv * (BLUR_TH / 4) + i;
+    const int y = y0 + ty;
+    if (y >= H) break;
+    float res = taps<RA, BLUR_TW>(rowa + (ty + R) * BLUR_TW + lane, ka);
+    if (EDGE) res = taps<RB, BLUR_TW>(rowb + (ty + R) * BLUR_TW + lane, kb) - res;
+    dst[(int64_t)y * W] = res;
+  }
+}
+
+// Unrolled radii (<= 3, i.e. pyorc's wdw 1..3): one WAVE per 64-column x BLUR_TS-row strip, no block barriers.  Rows
+// stream through: global row -> wave-private LDS row (for the x neighbours) -> row filter -> a register window of the
+// last 2R+1 row-filtered values per lane -> column filter -> HBM.  Every pixel is loaded once (+ 2R halo rows per
+// strip), touches LDS once, and the fully unrolled row loop lets the compiler issue the global loads far ahead.
+constexpr int BLUR_TS = 32;
+
+template <typename T, bool EDGE, int RA, int RB>
+__global__ __launch_bounds__(256) void blur_strip_kernel(const T* __restrict__ frames, int H, int W, BlurTaps ka,
+                                                         BlurTaps kb, float* __restrict__ out) {
+  constexpr int R = EDGE ? RB : RA;
+  constexpr int TWW = BLUR_TW + 2 * R;
+  __shared__ float rowbuf[4][TWW + 2];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int x0 = blockIdx.x * BLUR_TW, y0 = (blockIdx.y * 4 + wv) * BLUR_TS;
+  if (y0 >= H) return;
+  const T* img = frames + (int64_t)blockIdx.z * H * W;
+  const int x = x0 + lane;
+  float* dst = out + (int64_t)blockIdx.z * H * W + x;
+  const int cx0 = reflect101(x - R, W);
+  const int cx1 = lane < 2 * R ? reflect101(x + 64 - R, W) : 0;
+  float* buf = rowbuf[wv];
+  float wa[2 * R + 1], wb[2 * R + 1];
+  T p0[BLUR_TS + 2 * R], p1[BLUR_TS + 2 * R];   // every global load of the strip is issued before the first use
+#pragma unroll
+  for (int i = 0; i < BLUR_TS + 2 * R; ++i) {
+    const T* row = img + (int64_t)reflect101(y0 - R + i, H) * W;
+    p0[i] = row[cx0];
+    p1[i] = row[cx1];
+  }
+#pragma unroll
+  for (int i = 0; i < BLUR_TS + 2 * R; ++i) {
+    __builtin_amdgcn_wave_barrier();  // same wave: LDS ops execute in order, this only pins the compiler
+    buf[lane] = to_f32(p0[i]);
+    if (lane < 2 * R) buf[lane + 64] = to_f32(p1[i]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 2 * R; ++j) { wa[j] = wa[j + 1]; wb[j] = wb[j + 1]; }
+    wa[2 * R] = taps<RA, 1>(buf + lane + R, ka);
+    if (EDGE) wb[2 * R] = taps<RB, 1>(buf + lane + R, kb);
+    if (i >= 2 * R) {
+      const int y = y0 + i - 2 * R;
+      float res = wa[R] * ka.k[0];
+#pragma unroll
+      for (int j = 1; j <= RA; ++j) res += ka.k[j] * (wa[R - j] + wa[R + j]);
+      if (EDGE) {
+        float sb = wb[R] * kb.k[0];
+#pragma unroll
+        for (int j = 1; j <= RB; ++j) sb += kb.k[j] * (wb[R - j] + wb[R + j]);
+        res = sb - res;
+      }
+      if (y < H && x < W) dst[(int64_t)y * W] = res;
+    }
+  }
+}
+
+// getGaussianKernel(ksize, sigma <= 0, CV_32F)
+static BlurTaps make_taps(int ksize) {
+  BlurTaps t;
+  t.r = ksize / 2;
+  static const float t3[] = {0.5f, 0.25f}, t5[] = {0.375f, 0.25f, 0.0625f}, t7[] = {0.28125f, 0.21875f, 0.109375f, 0.03125f};
+  for (int j = 0; j <= BLUR_MAXR; ++j) t.k[j] = 0.0f;
+  if (ksize == 1) { t.k[0] = 1.0f; return t; }
+  if (ksize == 3 || ksize == 5 || ksize == 7) {
+    const float* s = ksize == 3 ? t3 : ksize == 5 ? t5 : t7;
+    for (int j = 0; j <= t.r; ++j) t.k[j] = s[j];
+    return t;
+  }
+  const double sigma = 0.3 * ((ksize - 1) * 0.5 - 1.0) + 0.8;
+  double sum = 0.0, v[2 * BLUR_MAXR + 1];
+  for (int i = 0; i < ksize; ++i) { const double x = i - (ksize - 1) * 0.5; v[i] = std::exp(-(x * x) / (2.0 * sigma * sigma)); sum += v[i]; }
+  for (int j = 0; j <= t.r; ++j) t.k[j] = (float)(v[t.r + j] / sum);
+  return t;
+}
+
+hipError_t launch_blur(const void* frames, int dtype, int n_frames, int H, int W, int ksize_a, int ksize_b, float* out,
+                       hipStream_t s) {
+  if (n_frames <= 0) return hipSuccess;
+  const bool edge = ksize_b > 0;
+  const BlurTaps ka = make_taps(ksize_a), kb = edge ? make_taps(ksize_b) : ka;
+  const int R = edge ? kb.r : ka.r;
+  const bool unrolled = edge ? (kb.r <= 3 && ka.r >= 1 && ka.r < kb.r) : (ka.r >= 1 && ka.r <= 3);
+  if (unrolled) {
+    const int strips = (H + BLUR_TS - 1) / BLUR_TS;
+    const dim3 grid((W + BLUR_TW - 1) / BLUR_TW, (strips + 3) / 4, n_frames);
+#define LSPIV_STRIP4(T, E, A, B) hipLaunchKernelGGL((blur_strip_kernel<T, E, A, B>), grid, dim3(256), 0, s, (const T*)frames, H, W, ka, kb, out)
+#define LSPIV_STRIP(T)                                                                     \
+  if (!edge) {                                                                             \
+    if (ka.r == 1) LSPIV_STRIP4(T, false, 1, 0); else if (ka.r == 2) LSPIV_STRIP4(T, false, 2, 0); else LSPIV_STRIP4(T, false, 3, 0); \
+  } else {                                                                                 \
+    if (kb.r == 2) LSPIV_STRIP4(T, true, 1, 2); else if (ka.r == 1) LSPIV_STRIP4(T, true, 1, 3); else LSPIV_STRIP4(T, true, 2, 3); \
+  }
+    switch (dtype) {
+      case 0: LSPIV_STRIP(uint8_t) break;
+      case 1: LSPIV_STRIP(float) break;
+      case 2: LSPIV_STRIP(double) break;
+      default: return hipErrorInvalidValue;
+    }
+#undef LSPIV_STRIP
+#undef LSPIV_STRIP4
+    return hipGetLastError();
+  }
+  // run-time radii: block kernel, 16 x 64 tiles
+  const int TH = 16;
+  const size_t lds = ((size_t)(TH + 2 * R) * (BLUR_TW + 2 * R) + (size_t)(edge ? 2 : 1) * (TH + 2 * R) * BLUR_TW) * sizeof(float);
+  const dim3 grid((W + BLUR_TW - 1) / BLUR_TW, (H + TH - 1) / TH, n_frames);
+#define LSPIV_BLUR(T, E) hipLaunchKernelGGL((blur_kernel<T, E, 0, 0, 16>), grid, dim3(256), lds, s, (const T*)frames, H, W, ka, kb, out)
+  switch (dtype) {
+    case 0: if (edge) LSPIV_BLUR(uint8_t, true); else LSPIV_BLUR(uint8_t, false); break;
+    case 1: if (edge) LSPIV_BLUR(float, true); else LSPIV_BLUR(float, false); break;
+    case 2: if (edge) LSPIV_BLUR(double, true); else LSPIV_BLUR(double, false); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef LSPIV_BLUR
   return hipGetLastError();
 }
 

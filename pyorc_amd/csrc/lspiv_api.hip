@@ -776,6 +776,59 @@ int lspiv_normalize(const uint8_t* frames, int64_t T, int64_t H, int64_t W, int 
   return LSPIV_OK;
 }
 
+static int blur_common_dev(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, int k1, int k2, float* d_out,
+                           void* stream) {
+  if (!d_frames || !d_out) return fail(LSPIV_EINVAL, "NULL argument");
+  if (dtype < 0 || dtype > 2) return fail(LSPIV_EINVAL, "dtype %d not in {0:u8, 1:f32, 2:f64}", dtype);
+  if (T < 1 || H <= 0 || W <= 0 || T > 65535 || H >= (1 << 30) || W >= (1 << 30)) return fail(LSPIV_ESHAPE, "bad shape");
+  for (int k : {k1, k2})
+    if (k != 0 && (k < 1 || k > 31 || k % 2 == 0)) return fail(LSPIV_EINVAL, "kernel size %d must be odd, 1..31", k);
+  if (k1 == 0) return fail(LSPIV_EINVAL, "kernel size missing");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  hipError_t e = lspiv::launch_blur(d_frames, dtype, (int)T, (int)H, (int)W, k1, k2, d_out, stream ? (hipStream_t)stream : c->stream);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return LSPIV_OK;
+}
+
+static int blur_common_host(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, int k1, int k2, float* out) {
+  if (!frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
+  if (dtype < 0 || dtype > 2 || T < 1 || H <= 0 || W <= 0) return fail(LSPIV_EINVAL, "bad argument");
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  const size_t ib = (size_t)T * H * W * elem_size(dtype), ob = (size_t)T * H * W * sizeof(float);
+  rc = ensure(&c->d_frames, &c->frames_cap, ib);
+  if (rc) return rc;
+  rc = ensure(&c->d_planes, &c->planes_cap, ob);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_frames, frames, ib, hipMemcpyHostToDevice, c->stream));
+  rc = blur_common_dev(c->d_frames, dtype, T, H, W, k1, k2, c->d_planes, c->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out, c->d_planes, ob, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
+
+int lspiv_gaussian_blur(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, int ksize, float* out) {
+  return blur_common_host(frames, dtype, T, H, W, ksize, 0, out);
+}
+int lspiv_gaussian_blur_dev(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, int ksize, float* d_out,
+                            void* stream) {
+  return blur_common_dev(d_frames, dtype, T, H, W, ksize, 0, d_out, stream);
+}
+int lspiv_edge_detect(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, int ksize_1, int ksize_2, float* out) {
+  if (ksize_2 < ksize_1) return fail(LSPIV_EINVAL, "edge_detect expects ksize_2 >= ksize_1");
+  return blur_common_host(frames, dtype, T, H, W, ksize_1, ksize_2, out);
+}
+int lspiv_edge_detect_dev(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, int ksize_1, int ksize_2,
+                          float* d_out, void* stream) {
+  if (ksize_2 < ksize_1) return fail(LSPIV_EINVAL, "edge_detect expects ksize_2 >= ksize_1");
+  return blur_common_dev(d_frames, dtype, T, H, W, ksize_1, ksize_2, d_out, stream);
+}
+
 // ---- device-resident helpers ------------------------------------------------------------------
 int lspiv_dev_malloc(void** d_ptr, size_t bytes) {
   if (!d_ptr) return fail(LSPIV_EINVAL, "d_ptr is NULL");

@@ -1,8 +1,10 @@
 """Mirror of the element-wise ``Frames`` filters of pyorc on the MI355X.
 
 ``normalize`` (pyorc/api/frames.py:279-306), ``minmax`` (:344-362) and ``time_diff`` (:409-436) are plain
-numpy/xarray arithmetic in the reference and are reproduced bit for bit; ``edge_detect`` / ``smooth`` are
-``cv2.GaussianBlur`` calls (pyorc/cv.py:142-183) and are not covered (cv2 cannot be installed here to pin them).
+numpy/xarray arithmetic in the reference and are reproduced bit for bit.  ``smooth`` (:438-467) and ``edge_detect``
+(:308-342) are ``cv2.GaussianBlur`` calls (pyorc/cv.py:142-183): OpenCV cannot be installed here, so its published
+algorithm is restated (coefficient tables, separable float32 filter, BORDER_REFLECT_101) -- expect ~1e-6 agreement
+with a real cv2, not bit identity.
 """
 
 from __future__ import annotations
@@ -43,3 +45,28 @@ def normalize(frames, samples: int = 15) -> np.ndarray:
     out = np.empty_like(a)
     _lib.check(_lib.load().lspiv_normalize(_lib.ptr(a), a.shape[0], a.shape[1], a.shape[2], int(samples), _lib.ptr(out)))
     return out
+
+
+def _blur(frames, k1: int, k2: int) -> np.ndarray:
+    a = np.asarray(frames)
+    single = a.ndim == 2
+    a = _lib.as_frames(a[None] if single else a)
+    _lib.require_device()
+    out = np.empty(a.shape, dtype=np.float32)
+    lib = _lib.load()
+    if k2:
+        rc = lib.lspiv_edge_detect(_lib.ptr(a), _lib.DTYPE_CODES[a.dtype], a.shape[0], a.shape[1], a.shape[2], k1, k2, _lib.ptr(out))
+    else:
+        rc = lib.lspiv_gaussian_blur(_lib.ptr(a), _lib.DTYPE_CODES[a.dtype], a.shape[0], a.shape[1], a.shape[2], k1, _lib.ptr(out))
+    _lib.check(rc)
+    return out[0] if single else out
+
+
+def smooth(frames, wdw: int = 1) -> np.ndarray:
+    """``Frames.smooth``: Gaussian blur with a (2 wdw + 1)^2 kernel, float32."""
+    return _blur(frames, 2 * int(wdw) + 1, 0)
+
+
+def edge_detect(frames, wdw_1: int = 1, wdw_2: int = 2) -> np.ndarray:
+    """``Frames.edge_detect``: blur(2 wdw_2 + 1) - blur(2 wdw_1 + 1), float32."""
+    return _blur(frames, 2 * int(wdw_1) + 1, 2 * int(wdw_2) + 1)

@@ -6,12 +6,14 @@ x4..x8 the bytes of the camera stack) -> ``get_piv()`` (window stack x3.9, corre
 ``to_netcdf`` (int16).  ``CameraToVelocity`` keeps everything between the raw uint8 camera frames and the result
 block in HBM and calls only ``*_dev`` entry points of the C ABI:
 
-    H2D uint8 frames -> lspiv_normalize_dev (optional) -> lspiv_project_frames_dev -> lspiv_piv_pairs_dev
+    H2D uint8 frames -> lspiv_normalize_dev -> lspiv_edge_detect_dev -> lspiv_minmax_dev   (each optional)
+                     -> lspiv_project_frames_dev -> lspiv_piv_pairs_dev
                      -> lspiv_pack_int16_dev (optional) -> D2H (16 B or 8 B per vector)
 
 Every stage is the same kernel the stand-alone mirrors (``filters``, ``project``, ``piv``) call, so the chain is
 bit-identical to running them one by one (tested).  The camera-geometry index maps are pyorc's
-(``CameraConfig.map_idx_img_ortho`` / ``map_mean_idx_img_ortho``); cv2-based filters are not part of the chain.
+(``CameraConfig.map_idx_img_ortho`` / ``map_mean_idx_img_ortho``).  With ``normalize_samples=15, edge_detect=(1, 2),
+minmax=(-5, 5)`` the chain is the whole ``frames:`` + ``get_piv`` part of the Ngwerere recipe.
 """
 
 from __future__ import annotations
@@ -50,18 +52,22 @@ class CameraToVelocity:
 
     def __init__(self, cam_shape, ortho_shape, idx_img, idx_ortho, src_idx=None, uidx=None, norm_idx=None,
                  window_size=(32, 32), overlap=(16, 16), normalize_samples: Optional[int] = None,
-                 signal_threshold: Optional[float] = None):
+                 signal_threshold: Optional[float] = None, edge_detect: Optional[tuple] = None,
+                 minmax: Optional[tuple] = None):
         _lib.require_device()
         self.cam_shape = (int(cam_shape[0]), int(cam_shape[1]))
         self.ortho_shape = (int(ortho_shape[0]), int(ortho_shape[1]))
         self.window_size, self.overlap = tuple(window_size), tuple(overlap)
         self.normalize_samples = normalize_samples
         self.signal_threshold = -1.0 if signal_threshold is None else float(signal_threshold)
+        self.edge_detect = None if edge_detect is None else (2 * int(edge_detect[0]) + 1, 2 * int(edge_detect[1]) + 1)
+        self.minmax = None if minmax is None else (float("-inf") if minmax[0] is None else float(minmax[0]),
+                                                   float("inf") if minmax[1] is None else float(minmax[1]))
         self.n_rows, self.n_cols = window.get_array_shape(self.ortho_shape, self.window_size, self.overlap)
         if self.n_rows < 1 or self.n_cols < 1:
             raise ValueError("ortho frame smaller than the interrogation window")
         self.projection = Projection(self.cam_shape, self.ortho_shape, idx_img, idx_ortho, src_idx, uidx, norm_idx)
-        self._cam, self._norm, self._ortho, self._out, self._packed = (_DevBuf() for _ in range(5))
+        self._cam, self._norm, self._edge, self._ortho, self._out, self._packed = (_DevBuf() for _ in range(6))
 
     def run(self, frames, packed: bool = False):
         """Returns (u, v, corr_max, s2n) float32, or their int16 packing (scale 0.01, fill -9999) when ``packed``.
@@ -87,8 +93,18 @@ class CameraToVelocity:
                 raise AssertionError(f"Amount of frames is too small to provide {self.normalize_samples} samples")
             src = self._norm.ensure(T * n_cam)
             _lib.check(lib.lspiv_normalize_dev(d_cam, T, self.cam_shape[0], self.cam_shape[1], self.normalize_samples, src, None))
+        src_dtype = np.uint8
+        if self.edge_detect:
+            d_edge = self._edge.ensure(T * n_cam * 4)
+            _lib.check(lib.lspiv_edge_detect_dev(src, 0, T, self.cam_shape[0], self.cam_shape[1], self.edge_detect[0],
+                                                 self.edge_detect[1], d_edge, None))
+            src, src_dtype = d_edge, np.float32
+        if self.minmax:
+            if src_dtype is np.uint8:
+                raise ValueError("minmax in the chain follows edge_detect (float32 frames); uint8 frames are not thresholded")
+            _lib.check(lib.lspiv_minmax_dev(src, T * n_cam, self.minmax[0], self.minmax[1], src, None))   # in place
         d_ortho = self._ortho.ensure(T * n_ortho * 4)
-        self.projection.project_frames_dev(src.value, np.uint8, T, d_ortho.value)
+        self.projection.project_frames_dev(src.value, src_dtype, T, d_ortho.value)
         d_out = self._out.ensure(4 * n_vec * 4)
         _lib.check(lib.lspiv_piv_pairs_dev(d_ortho, 1, T, self.ortho_shape[0], self.ortho_shape[1], self.window_size[0],
                                            self.window_size[1], self.overlap[0], self.overlap[1], self.signal_threshold,
@@ -106,7 +122,7 @@ class CameraToVelocity:
 
     def close(self):
         self.projection.close()
-        for b in (self._cam, self._norm, self._ortho, self._out, self._packed):
+        for b in (self._cam, self._norm, self._edge, self._ortho, self._out, self._packed):
             b.free()
 
     def __enter__(self):

@@ -116,4 +116,44 @@ def test_gpu_camera_to_velocity_chain_equals_stage_by_stage(gpu):
             assert chain.run(cam[:9])[0].shape == (8, 7, 9)   # buffers are reused for a shorter chunk
             with pytest.raises(ValueError):
                 chain.run(cam.astype(np.float32))
+    # the Ngwerere frames recipe: normalize -> edge_detect(1, 2) -> minmax(-5, 5) -> project -> get_piv
+    staged = filters.minmax(filters.edge_detect(filters.normalize(cam, 15), 1, 2), -5, 5)
+    ref = pyorc_amd.piv_pairs(p.project_frames(staged), (32, 32), (16, 16))
+    with CameraToVelocity(src, dst, *maps, normalize_samples=15, edge_detect=(1, 2), minmax=(-5, 5)) as chain:
+        for a, b in zip(ref, chain.run(cam)):
+            assert np.array_equal(a, b, equal_nan=True)
     p.close()
+
+
+def test_oracle_gaussian_blur_matches_scipy_mirror_correlation():
+    from scipy.ndimage import correlate1d
+
+    img = np.random.default_rng(0).random((37, 53)).astype(np.float32)
+    for ks in (1, 3, 5, 7, 9, 15, 31):
+        k = fo.gaussian_kernel(ks).astype(np.float64)
+        assert abs(k.sum() - 1) < 1e-6 and len(k) == ks and np.allclose(k, k[::-1])
+        ref = correlate1d(correlate1d(img.astype(np.float64), k, axis=1, mode="mirror"), k, axis=0, mode="mirror")
+        assert np.abs(fo.gaussian_blur(img, ks) - ref).max() < 5e-7
+    assert fo.gaussian_kernel(5).tolist() == [0.0625, 0.25, 0.375, 0.25, 0.0625]      # OpenCV's fixed table
+    e = fo.edge_detect(img[None], 1, 2)
+    assert e.shape == (1, 37, 53) and e.dtype == np.float32 and abs(float(e.mean())) < 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32, np.float64])
+def test_gpu_smooth_and_edge_detect(gpu, dtype):
+    from pyorc_amd import filters
+
+    fr = particle_stack(3, 70, 131, seed=21, density=0.05)
+    fr = fr if dtype == np.uint8 else fr.astype(dtype) * 0.41 - 7.0
+    for wdw in (1, 2, 3, 5, 15):
+        got = filters.smooth(fr, wdw)
+        ref = fo.smooth(fr, wdw)
+        assert got.dtype == np.float32 and np.abs(got - ref).max() <= 2e-6 * max(1.0, float(np.abs(ref).max()))
+    for w1, w2 in ((1, 2), (1, 3), (2, 7)):
+        got = filters.edge_detect(fr, w1, w2)
+        ref = fo.edge_detect(fr, w1, w2)
+        assert np.abs(got - ref).max() <= 4e-6 * max(1.0, float(np.abs(fr).max()))
+    assert np.abs(filters.smooth(fr[0], 1) - fo.gaussian_blur(fr[0], 3)).max() < 1e-4
+    tiny = fr[:, :5, :3]                                                          # smaller than the halo: reflect101 wraps
+    assert np.abs(filters.smooth(tiny, 3) - fo.smooth(tiny, 3)).max() <= 2e-6 * max(1.0, float(np.abs(tiny).max()))

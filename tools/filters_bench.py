@@ -23,3 +23,10 @@ print(f"minmax     f32    : {t*1e3:.2f} ms, {b/t/1e9:.0f} GB/s = {b/t/8e12*100:.
 t = timed(lambda: _lib.check(lib.lspiv_normalize_dev(d_f, T, H, W, 15, d_n, None)), 3)
 b = T * n * (1 + 1 + 1)  # min/max pass read, normalise pass read + write (mean plane is L2-resident)
 print(f"normalize  u8->u8 : {t*1e3:.2f} ms / {T} frames, {b/t/1e9:.0f} GB/s algorithmic = {b/t/8e12*100:.1f}% of 8 TB/s (incl. 2 hipMalloc/hipFree + sync)")
+for name, fn, k in (("smooth k=3", lambda: lib.lspiv_gaussian_blur_dev(d_f, 0, T - 1, H, W, 3, d_o, None), 3),
+                    ("smooth k=7", lambda: lib.lspiv_gaussian_blur_dev(d_f, 0, T - 1, H, W, 7, d_o, None), 7),
+                    ("edge 3|5   ", lambda: lib.lspiv_edge_detect_dev(d_f, 0, T - 1, H, W, 3, 5, d_o, None), 5),
+                    ("edge 5|15  ", lambda: lib.lspiv_edge_detect_dev(d_f, 0, T - 1, H, W, 5, 15, d_o, None), 15)):
+    t = timed(lambda: _lib.check(fn()))
+    b = (T - 1) * n * (1 + 4)
+    print(f"{name} u8->f32: {t*1e3:.2f} ms / {T-1} frames = {(T-1)/t:.0f} frames/s, {b/t/1e9:.0f} GB/s algorithmic (1 u8 read + 1 f32 write per px) = {b/t/8e12*100:.1f}% of 8 TB/s")

@@ -11,9 +11,9 @@ maps = projection_maps(src, dst, tilt=0.3, seed=1)
 rng = np.random.default_rng(0)
 base = (rng.random(src) ** 6 * 255).astype(np.uint8)
 cam = np.stack([np.roll(base, (2 * t, -5 * t), (0, 1)) for t in range(T)])
-for samples, packed in ((None, False), (15, False), (15, True)):
-    with CameraToVelocity(src, dst, *maps, normalize_samples=samples) as chain:
+for samples, packed, edge in ((None, False, None), (15, False, None), (15, True, None), (15, True, (1, 2))):
+    with CameraToVelocity(src, dst, *maps, normalize_samples=samples, edge_detect=edge, minmax=(-5, 5) if edge else None) as chain:
         chain.run(cam[:31])
         best = min((lambda t0: (chain.run(cam, packed=packed), time.perf_counter() - t0)[1])(time.perf_counter()) for _ in range(3))
-    print(f"normalize={samples} packed={packed}: {T-1} pairs in {best*1e3:.1f} ms -> {(T-1)/best:.0f} pairs/s host-to-host "
+    print(f"normalize={samples} edge_detect={edge} packed={packed}: {T-1} pairs in {best*1e3:.1f} ms -> {(T-1)/best:.0f} pairs/s host-to-host "
           f"({cam.nbytes/best/1e9:.1f} GB/s of camera frames)")
