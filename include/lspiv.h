@@ -169,6 +169,54 @@ int lspiv_minmax_dev(const float* d_frames, int64_t n, float lo, float hi, float
 int lspiv_normalize(const uint8_t* frames, int64_t T, int64_t H, int64_t W, int samples, uint8_t* out);
 int lspiv_normalize_dev(const uint8_t* d_frames, int64_t T, int64_t H, int64_t W, int samples, uint8_t* d_out, void* stream);
 
+/* N3 -- post-PIV masks, ds.velocimetry.mask.* (pyorc/api/mask.py:147-403), on the result block
+ * fields = [v_x | v_y | corr | s2n], each (T, R, C) float32 (lspiv_piv_pairs_dev's d_out after
+ * lspiv_scale_velocity_dev).  mask: uint8, 1 = keep; (T, R, C), or (R, C) for the time-reducing kinds.
+ * xarray's expressions are restated through the numpy calls they dispatch to (oracle/mask_oracle.py; unpinned
+ * against a real xarray).  Reference quirks kept: stack_window's y range excludes +wdw (helpers.py:672-679),
+ * variance's np.maximum(mean, 1e30), rolling's NaN edges.
+ *   kind                     params (doubles)                                         mask shape
+ *   LSPIV_MASK_MINMAX      0 s_min, s_max                                 :147-160    (T,R,C)
+ *   LSPIV_MASK_ANGLE       1 angle_expected, angle_tolerance              :162-185    (T,R,C)
+ *   LSPIV_MASK_COUNT       2 tolerance                                    :187-201    (R,C)
+ *   LSPIV_MASK_CORR        3 tolerance                                    :203-213    (T,R,C)
+ *   LSPIV_MASK_S2N         4 tolerance                                    :215-225    (T,R,C)
+ *   LSPIV_MASK_OUTLIERS    5 tolerance, mode (0 "or", 1 "and")            :227-252    (T,R,C)
+ *   LSPIV_MASK_VARIANCE    6 tolerance, mode                              :254-284    (R,C)
+ *   LSPIV_MASK_ROLLING     7 wdw, tolerance                               :286-303    (T,R,C)
+ *   LSPIV_MASK_WINDOW_NAN  8 tolerance, x_min, x_max, y_min, y_max        :305-340    (T,R,C)
+ *   LSPIV_MASK_WINDOW_MEAN 9 tolerance, mode, x_min, x_max, y_min, y_max  :342-383    (T,R,C)
+ * lspiv_mask_apply    ds[var].where(mask) on all four variables (:132-145); mask_has_time 0 for an (R,C) mask.
+ * lspiv_time_mean     ds.mean(dim="time") -- the reduce_time=True pre-step (:51-52); out (4, R, C).
+ * lspiv_window_replace  fillna with the neighbourhood nanmean, iter times (:385-403), in place.
+ * lspiv_scale_velocity_dev  px/frame -> m/s in place on the first two planes: (u * res / dt).astype(float32),
+ *                     pyorc/velocimetry/ffpiv.py:418-419; dt: HOST array, one entry per time step. */
+#define LSPIV_MASK_MINMAX 0
+#define LSPIV_MASK_ANGLE 1
+#define LSPIV_MASK_COUNT 2
+#define LSPIV_MASK_CORR 3
+#define LSPIV_MASK_S2N 4
+#define LSPIV_MASK_OUTLIERS 5
+#define LSPIV_MASK_VARIANCE 6
+#define LSPIV_MASK_ROLLING 7
+#define LSPIV_MASK_WINDOW_NAN 8
+#define LSPIV_MASK_WINDOW_MEAN 9
+int lspiv_mask(const float* fields, int64_t T, int64_t R, int64_t C, int kind, const double* params, int n_params,
+               uint8_t* mask);
+int lspiv_mask_dev(const float* d_fields, int64_t T, int64_t R, int64_t C, int kind, const double* params, int n_params,
+                   uint8_t* d_mask, void* stream);
+int lspiv_mask_apply(float* fields, int64_t T, int64_t R, int64_t C, const uint8_t* mask, int mask_has_time);
+int lspiv_mask_apply_dev(float* d_fields, int64_t T, int64_t R, int64_t C, const uint8_t* d_mask, int mask_has_time,
+                         void* stream);
+int lspiv_time_mean(const float* fields, int64_t T, int64_t R, int64_t C, float* out);
+int lspiv_time_mean_dev(const float* d_fields, int64_t T, int64_t R, int64_t C, float* d_out, void* stream);
+int lspiv_window_replace(float* fields, int64_t T, int64_t R, int64_t C, int x_min, int x_max, int y_min, int y_max,
+                         int iter);
+int lspiv_window_replace_dev(float* d_fields, int64_t T, int64_t R, int64_t C, int x_min, int x_max, int y_min,
+                             int y_max, int iter, void* stream);
+int lspiv_scale_velocity_dev(float* d_fields, int64_t T, int64_t n_vec, double res_x, double res_y, const double* dt,
+                             void* stream);
+
 /* N4 -- on-disk packing of the result variables (pyorc/const.py:80-83: int16, scale_factor 0.01,
  * _FillValue -9999; arithmetic of xarray's encoder: float32 x / float32 scale, NaN -> fill, round half even). */
 int lspiv_pack_int16(const float* values, int64_t n, float scale, int fill, int16_t* packed);

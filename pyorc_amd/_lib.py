@@ -80,6 +80,15 @@ SIGNATURES = {
     "lspiv_gaussian_blur_dev": (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _vp, _vp]),
     "lspiv_edge_detect": (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp]),
     "lspiv_edge_detect_dev": (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp, _vp]),
+    "lspiv_mask": (_i32, [_vp, _i64, _i64, _i64, _i32, _vp, _i32, _vp]),
+    "lspiv_mask_dev": (_i32, [_vp, _i64, _i64, _i64, _i32, _vp, _i32, _vp, _vp]),
+    "lspiv_mask_apply": (_i32, [_vp, _i64, _i64, _i64, _vp, _i32]),
+    "lspiv_mask_apply_dev": (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _vp]),
+    "lspiv_time_mean": (_i32, [_vp, _i64, _i64, _i64, _vp]),
+    "lspiv_time_mean_dev": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "lspiv_window_replace": (_i32, [_vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32]),
+    "lspiv_window_replace_dev": (_i32, [_vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "lspiv_scale_velocity_dev": (_i32, [_vp, _i64, _i64, C.c_double, C.c_double, _vp, _vp]),
     "lspiv_pack_int16": (_i32, [_vp, _i64, _f32, _i32, _vp]),
     "lspiv_pack_int16_dev": (_i32, [_vp, _i64, _f32, _i32, _vp, _vp]),
     "lspiv_dev_malloc": (_i32, [C.POINTER(_vp), _sz]),

@@ -190,6 +190,13 @@ hipError_t launch_normalize(const uint8_t* frames, int64_t frame_elems, int n_fr
 // Gaussian blur (ksize_b == 0) or band filter blur(ksize_b) - blur(ksize_a); odd sizes 1..31
 hipError_t launch_blur(const void* frames, int dtype, int n_frames, int H, int W, int ksize_a, int ksize_b, float* out,
                        hipStream_t s);
+// post-PIV masks on the [v_x | v_y | corr | s2n] block (masks.hip); kinds / params as in include/lspiv.h
+hipError_t launch_mask(const float* f, int64_t T, int R, int C, int kind, const double* p, uint8_t* mask, hipStream_t s);
+hipError_t launch_mask_apply(float* f, int64_t T, int64_t n, const uint8_t* mask, int mask_has_time, hipStream_t s);
+hipError_t launch_time_mean(const float* f, int64_t T, int64_t n, float* out, hipStream_t s);
+hipError_t launch_window_replace(const float* in, int64_t planes, int R, int C, int x_min, int x_max, int y_min, int y_max,
+                                 float* out, hipStream_t s);
+hipError_t launch_scale_velocity(float* f, int64_t T, int64_t n, float res_x, float res_y, const double* d_dt, hipStream_t s);
 // synthetic particle-image stack (bench / test utility)
 hipError_t launch_synth_particles(uint8_t* d_frames, int64_t T, int H, int W, uint64_t seed, float density,
                                   hipStream_t s);

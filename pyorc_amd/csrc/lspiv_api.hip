@@ -668,6 +668,193 @@ int lspiv_pack_int16(const float* values, int64_t n, float scale, int fill, int1
   return LSPIV_OK;
 }
 
+// ---- post-PIV masks (N3) ------------------------------------------------------------------------------
+namespace {
+const int kMaskParams[10] = {2, 2, 1, 1, 1, 2, 2, 2, 5, 6};
+bool mask_is_2d(int kind) { return kind == LSPIV_MASK_COUNT || kind == LSPIV_MASK_VARIANCE; }
+
+int check_fields(const void* f, int64_t T, int64_t R, int64_t C) {
+  if (!f) return fail(LSPIV_EINVAL, "NULL argument");
+  if (T < 1 || R < 1 || C < 1 || R >= (1 << 30) || C >= (1 << 30) || T * R * C >= ((int64_t)1 << 40))
+    return fail(LSPIV_ESHAPE, "bad field shape (%lld, %lld, %lld)", (long long)T, (long long)R, (long long)C);
+  return LSPIV_OK;
+}
+}  // namespace
+
+int lspiv_mask_dev(const float* d_fields, int64_t T, int64_t R, int64_t C, int kind, const double* params, int n_params,
+                   uint8_t* d_mask, void* stream) {
+  int rc = check_fields(d_fields, T, R, C);
+  if (rc) return rc;
+  if (!d_mask || !params) return fail(LSPIV_EINVAL, "NULL argument");
+  if (kind < 0 || kind > 9) return fail(LSPIV_EINVAL, "unknown mask kind %d", kind);
+  if (n_params != kMaskParams[kind]) return fail(LSPIV_EINVAL, "mask kind %d takes %d parameters, got %d", kind, kMaskParams[kind], n_params);
+  if (kind == LSPIV_MASK_ROLLING && (params[0] < 1 || params[0] > 1e6)) return fail(LSPIV_EINVAL, "rolling window must be >= 1");
+  if (kind >= LSPIV_MASK_WINDOW_NAN) {
+    const double* w = params + (kind == LSPIV_MASK_WINDOW_NAN ? 1 : 2);
+    for (int i = 0; i < 4; ++i)
+      if (!(std::fabs(w[i]) <= 1024)) return fail(LSPIV_EINVAL, "window stride %g out of range", w[i]);
+  }
+  DeviceCtx* c;
+  rc = get_ctx(&c);
+  if (rc) return rc;
+  hipError_t e = lspiv::launch_mask(d_fields, T, (int)R, (int)C, kind, params, d_mask, stream ? (hipStream_t)stream : c->stream);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return LSPIV_OK;
+}
+
+int lspiv_mask(const float* fields, int64_t T, int64_t R, int64_t C, int kind, const double* params, int n_params,
+               uint8_t* mask) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  int rc = check_fields(fields, T, R, C);
+  if (rc) return rc;
+  if (!mask) return fail(LSPIV_EINVAL, "NULL argument");
+  DeviceCtx* c;
+  rc = get_ctx(&c);
+  if (rc) return rc;
+  const size_t fb = (size_t)4 * T * R * C * sizeof(float), mb = (size_t)(mask_is_2d(kind) ? 1 : T) * R * C;
+  rc = ensure(&c->d_frames, &c->frames_cap, fb);
+  if (rc) return rc;
+  rc = ensure(&c->d_planes, &c->planes_cap, mb);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_frames, fields, fb, hipMemcpyHostToDevice, c->stream));
+  rc = lspiv_mask_dev((const float*)c->d_frames, T, R, C, kind, params, n_params, (uint8_t*)c->d_planes, c->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(mask, c->d_planes, mb, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
+
+int lspiv_mask_apply_dev(float* d_fields, int64_t T, int64_t R, int64_t C, const uint8_t* d_mask, int mask_has_time,
+                         void* stream) {
+  int rc = check_fields(d_fields, T, R, C);
+  if (rc) return rc;
+  if (!d_mask) return fail(LSPIV_EINVAL, "NULL argument");
+  DeviceCtx* c;
+  rc = get_ctx(&c);
+  if (rc) return rc;
+  hipError_t e = lspiv::launch_mask_apply(d_fields, T, R * C, d_mask, mask_has_time != 0, stream ? (hipStream_t)stream : c->stream);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return LSPIV_OK;
+}
+
+int lspiv_mask_apply(float* fields, int64_t T, int64_t R, int64_t C, const uint8_t* mask, int mask_has_time) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  int rc = check_fields(fields, T, R, C);
+  if (rc) return rc;
+  if (!mask) return fail(LSPIV_EINVAL, "NULL argument");
+  DeviceCtx* c;
+  rc = get_ctx(&c);
+  if (rc) return rc;
+  const size_t fb = (size_t)4 * T * R * C * sizeof(float), mb = (size_t)(mask_has_time ? T : 1) * R * C;
+  rc = ensure(&c->d_frames, &c->frames_cap, fb);
+  if (rc) return rc;
+  rc = ensure(&c->d_planes, &c->planes_cap, mb);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_frames, fields, fb, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->d_planes, mask, mb, hipMemcpyHostToDevice, c->stream));
+  rc = lspiv_mask_apply_dev((float*)c->d_frames, T, R, C, (const uint8_t*)c->d_planes, mask_has_time, c->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(fields, c->d_frames, fb, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
+
+int lspiv_time_mean_dev(const float* d_fields, int64_t T, int64_t R, int64_t C, float* d_out, void* stream) {
+  int rc = check_fields(d_fields, T, R, C);
+  if (rc) return rc;
+  if (!d_out) return fail(LSPIV_EINVAL, "NULL argument");
+  DeviceCtx* c;
+  rc = get_ctx(&c);
+  if (rc) return rc;
+  hipError_t e = lspiv::launch_time_mean(d_fields, T, R * C, d_out, stream ? (hipStream_t)stream : c->stream);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return LSPIV_OK;
+}
+
+int lspiv_time_mean(const float* fields, int64_t T, int64_t R, int64_t C, float* out) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  int rc = check_fields(fields, T, R, C);
+  if (rc) return rc;
+  if (!out) return fail(LSPIV_EINVAL, "NULL argument");
+  DeviceCtx* c;
+  rc = get_ctx(&c);
+  if (rc) return rc;
+  const size_t fb = (size_t)4 * T * R * C * sizeof(float), ob = (size_t)4 * R * C * sizeof(float);
+  rc = ensure(&c->d_frames, &c->frames_cap, fb);
+  if (rc) return rc;
+  rc = ensure(&c->d_planes, &c->planes_cap, ob);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_frames, fields, fb, hipMemcpyHostToDevice, c->stream));
+  rc = lspiv_time_mean_dev((const float*)c->d_frames, T, R, C, c->d_planes, c->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out, c->d_planes, ob, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
+
+int lspiv_window_replace_dev(float* d_fields, int64_t T, int64_t R, int64_t C, int x_min, int x_max, int y_min,
+                             int y_max, int iter, void* stream) {
+  int rc = check_fields(d_fields, T, R, C);
+  if (rc) return rc;
+  if (iter < 0 || std::abs(x_min) > 1024 || std::abs(x_max) > 1024 || std::abs(y_min) > 1024 || std::abs(y_max) > 1024)
+    return fail(LSPIV_EINVAL, "bad window / iteration count");
+  DeviceCtx* c;
+  rc = get_ctx(&c);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  const size_t fb = (size_t)4 * T * R * C * sizeof(float);
+  float* d_tmp = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_tmp, fb));
+  hipError_t e = hipSuccess;
+  float *src = d_fields, *dst = d_tmp;
+  for (int i = 0; i < iter && e == hipSuccess; ++i) {
+    e = lspiv::launch_window_replace(src, 4 * T, (int)R, (int)C, x_min, x_max, y_min, y_max, dst, s);
+    std::swap(src, dst);
+  }
+  if (e == hipSuccess && src != d_fields) e = hipMemcpyAsync(d_fields, src, fb, hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);  // the temporary is freed below
+  hipFree(d_tmp);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "window_replace failed: %s", hipGetErrorString(e));
+  return LSPIV_OK;
+}
+
+int lspiv_window_replace(float* fields, int64_t T, int64_t R, int64_t C, int x_min, int x_max, int y_min, int y_max,
+                         int iter) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  int rc = check_fields(fields, T, R, C);
+  if (rc) return rc;
+  DeviceCtx* c;
+  rc = get_ctx(&c);
+  if (rc) return rc;
+  const size_t fb = (size_t)4 * T * R * C * sizeof(float);
+  rc = ensure(&c->d_frames, &c->frames_cap, fb);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_frames, fields, fb, hipMemcpyHostToDevice, c->stream));
+  rc = lspiv_window_replace_dev((float*)c->d_frames, T, R, C, x_min, x_max, y_min, y_max, iter, c->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(fields, c->d_frames, fb, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
+
+int lspiv_scale_velocity_dev(float* d_fields, int64_t T, int64_t n_vec, double res_x, double res_y, const double* dt,
+                             void* stream) {
+  if (!d_fields || !dt) return fail(LSPIV_EINVAL, "NULL argument");
+  if (T < 1 || n_vec < 1) return fail(LSPIV_ESHAPE, "bad shape");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  double* d_dt = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_dt, (size_t)T * sizeof(double)));
+  hipError_t e = hipMemcpyAsync(d_dt, dt, (size_t)T * sizeof(double), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = lspiv::launch_scale_velocity(d_fields, T, n_vec, (float)res_x, (float)res_y, d_dt, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);  // dt is a host array and the temporary is freed below
+  hipFree(d_dt);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "scale_velocity failed: %s", hipGetErrorString(e));
+  return LSPIV_OK;
+}
+
 // ---- element-wise filters (N2) ---------------------------------------------------------------------
 int lspiv_time_diff_dev(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, float thres, int use_abs,
                         float* d_out, void* stream) {
