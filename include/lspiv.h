@@ -114,6 +114,11 @@ int lspiv_ensemble_begin(int64_t H, int64_t W, int wy, int wx, int oy, int ox, l
 int lspiv_ensemble_accumulate(lspiv_ensemble* handle, const void* frames, int dtype, int64_t T,
                               float corr_min, float s2n_min, float signal_threshold,
                               float* corr_max /* (T-1)*n_win */, float* s2n /* (T-1)*n_win */);
+/* same on a device-resident chunk: d_corr_s2n = [corr_max | s2n], 2*(T-1)*n_win float32 in HBM; asynchronous on
+ * `stream` (NULL = the library's stream). */
+int lspiv_ensemble_accumulate_dev(lspiv_ensemble* handle, const void* d_frames, int dtype, int64_t T,
+                                  float corr_min, float s2n_min, float signal_threshold,
+                                  float* d_corr_s2n, void* stream);
 /* count filter (count < count_min * n_frames -> NaN), mean plane, sub-pixel peak.
  * u, v (n_win) in pixels; corr_count (n_win) float32; corr_mean NULL or n_win*wy*wx float32.  */
 int lspiv_ensemble_finish(lspiv_ensemble* handle, float count_min, float n_frames,

@@ -62,6 +62,7 @@ SIGNATURES = {
     "lspiv_u_v_displacement": (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _vp]),
     "lspiv_ensemble_begin": (_i32, [_i64, _i64, _i32, _i32, _i32, _i32, C.POINTER(_vp)]),
     "lspiv_ensemble_accumulate": (_i32, [_vp, _vp, _i32, _i64, _f32, _f32, _f32, _vp, _vp]),
+    "lspiv_ensemble_accumulate_dev": (_i32, [_vp, _vp, _i32, _i64, _f32, _f32, _f32, _vp, _vp]),
     "lspiv_ensemble_finish": (_i32, [_vp, _f32, _f32, _vp, _vp, _vp, _vp]),
     "lspiv_ensemble_export": (_i32, [_vp, _vp, _vp]),
     "lspiv_ensemble_import": (_i32, [_vp, _vp, _vp, _i32]),

@@ -434,6 +434,25 @@ int lspiv_ensemble_begin(int64_t H, int64_t W, int wy, int wx, int oy, int ox, l
   return LSPIV_OK;
 }
 
+int lspiv_ensemble_accumulate_dev(lspiv_ensemble* h, const void* d_frames, int dtype, int64_t T, float corr_min,
+                                  float s2n_min, float signal_threshold, float* d_corr_s2n, void* stream) {
+  if (!h || !d_frames || !d_corr_s2n) return fail(LSPIV_EINVAL, "NULL argument");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  lspiv::PivParams p;
+  rc = fill_params(&p, d_frames, dtype, T, h->H, h->W, h->wy, h->wx, h->oy, h->ox, signal_threshold, h->g);
+  if (rc) return rc;
+  const size_t n_tiles = (size_t)(T - 1) * h->g.n_rows * h->g.n_cols;
+  p.cmax = d_corr_s2n;
+  p.s2n = d_corr_s2n + n_tiles;
+  p.corr_min = corr_min;
+  p.s2n_min = s2n_min;
+  p.corr_sum = h->d_sum;
+  p.corr_count = h->d_count;
+  return dispatch(p, dtype, true, stream ? (hipStream_t)stream : c->stream);
+}
+
 int lspiv_ensemble_accumulate(lspiv_ensemble* h, const void* frames, int dtype, int64_t T, float corr_min,
                               float s2n_min, float signal_threshold, float* corr_max, float* s2n) {
   std::lock_guard<std::mutex> host_lock(g_host_mu);
@@ -450,16 +469,7 @@ int lspiv_ensemble_accumulate(lspiv_ensemble* h, const void* frames, int dtype, 
   rc = ensure(&c->d_out, &c->out_cap, 4 * n_tiles * sizeof(float));
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(c->d_frames, frames, fbytes, hipMemcpyHostToDevice, c->stream));
-  lspiv::PivParams p;
-  rc = fill_params(&p, c->d_frames, dtype, T, h->H, h->W, h->wy, h->wx, h->oy, h->ox, signal_threshold, h->g);
-  if (rc) return rc;
-  p.cmax = c->d_out;
-  p.s2n = c->d_out + n_tiles;
-  p.corr_min = corr_min;
-  p.s2n_min = s2n_min;
-  p.corr_sum = h->d_sum;
-  p.corr_count = h->d_count;
-  rc = dispatch(p, dtype, true, c->stream);
+  rc = lspiv_ensemble_accumulate_dev(h, c->d_frames, dtype, T, corr_min, s2n_min, signal_threshold, c->d_out, c->stream);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(corr_max, c->d_out, n_tiles * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(s2n, c->d_out + n_tiles, n_tiles * sizeof(float), hipMemcpyDeviceToHost, c->stream));

@@ -528,27 +528,34 @@ __global__ __launch_bounds__(BLOCK, (kWavesPerSimd<T, N>)) void piv_fft_kernel(P
   }
 }
 
-// ---- ensemble kernel: a job owns two windows and walks all pairs of the chunk in order ---------
+// ---- ensemble kernel: a job owns ONE window and walks the pairs of the chunk in order, two at a time ---------
 // (pyorc/velocimetry/ffpiv.py:222-241,361-363): planes failing corr_min / s2n_min / finite are
-// zeroed, corr_sum += plane, corr_count += (corr_max > 1e-6).  The accumulation order is the
-// pair order, one owner per window => bit-reproducible, no atomics.  The running sums live in HBM
-// (L2-resident read-modify-write by their single owner) so the kernel keeps the register budget of the
-// per-timestep kernel.
+// zeroed, corr_sum += plane, corr_count += (corr_max > 1e-6).  The two planes that share an inverse FFT are the
+// SAME window of two consecutive frame pairs (2k, 2k+1), not two windows of one pair: that gives n_win jobs instead of
+// n_win / 2 (a 1080p grid then fills all 8192 half-wave slots of the chip instead of 48 % of them) and one
+// read-modify-write of the running sum per two pairs.  The accumulation order is still the pair order, one owner per
+// window => bit-reproducible, no atomics.  The running sums live in HBM (MALL-resident read-modify-write by their
+// single owner) so the kernel keeps the register budget of the per-timestep kernel.
 template <int N>
-__device__ __forceinline__ void accumulate_plane(float* dst, int lg, const float (&c)[N], bool first) {
+__device__ __forceinline__ void accumulate_planes(float* dst, int lg, const float (&c0)[N], bool keep0,
+                                                  const float (&c1)[N], bool keep1) {
   // corr_sum is kept in fft-shifted layout (what u_v_displacement expects)
   float* row = dst + ((lg + N / 2) & (N - 1)) * N;
 #pragma unroll
   for (int qd = 0; qd < N / 4; ++qd) {
     f32x4 acc = *reinterpret_cast<f32x4*>(row + 4 * qd);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] += c[(4 * qd + e + N / 2) & (N - 1)];
+    for (int e = 0; e < 4; ++e) {
+      const int j = (4 * qd + e + N / 2) & (N - 1);
+      acc[e] += keep0 ? c0[j] : 0.0f;   // pair 2k first, then 2k+1: the reference's summation order
+      acc[e] += keep1 ? c1[j] : 0.0f;
+    }
     *reinterpret_cast<f32x4*>(row + 4 * qd) = acc;
   }
 }
 
 template <typename T, int N, bool WANT_NZ>
-__global__ __launch_bounds__(BLOCK, 2) void piv_fft_ensemble_kernel(PivParams p) {
+__global__ __launch_bounds__(BLOCK, (kWavesPerSimd<T, N>)) void piv_fft_ensemble_kernel(PivParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using G = Geo<N>;
   const int lane = threadIdx.x & 63;
@@ -558,52 +565,32 @@ __global__ __launch_bounds__(BLOCK, 2) void piv_fft_ensemble_kernel(PivParams p)
   float* buf = smem + (wave * G::GROUPS + grp) * G::LDS_JOB;
   const int partner_byte = ((lane & ~(N - 1)) | ((N - lg) & (N - 1))) << 2;
   const uint32_t job = (blockIdx.x * WAVES_PER_BLOCK + wave) * G::GROUPS + grp;
-  uint32_t w[2];
-  bool valid[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    w[k] = job * 2 + k;
-    valid[k] = w[k] < p.n_win;
-    w[k] = valid[k] ? w[k] : p.n_win - 1;
-  }
-  float cnt0 = 0.0f, cnt1 = 0.0f;
-  for (uint32_t pair = 0; pair < p.n_pairs; ++pair) {
-    TileRef t[2] = {{pair, w[0], valid[0]}, {pair, w[1], valid[1]}};
+  const bool valid = job < p.n_win;
+  const uint32_t w = valid ? job : p.n_win - 1;
+  float cnt = 0.0f;
+  for (uint32_t pair = 0; pair < p.n_pairs; pair += 2) {
+    const bool two = pair + 1 < p.n_pairs;   // an odd chunk ends with a lone pair (its partner recomputes it, unused)
+    TileRef t[2] = {{pair, w, valid}, {two ? pair + 1 : pair, w, valid && two}};
     float xr[N], xi[N], mean[2];
-    bool skip[2];
+    bool skip[2], keep[2];
     correlate_job<T, N, WANT_NZ>(p, t, buf, lg, partner_byte, xr, xi, skip, mean);
-    float vmax, row_max;
-    vmax = plane_max<N>(xr, row_max);
-    {
-      float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean[0]);
-      const bool keep = !skip[0] && (cm >= p.corr_min) && (sn >= p.s2n_min);  // NaN s2n compares false
-      cm = keep ? cm : 0.0f;
-      sn = keep ? sn : 0.0f;
-      cnt0 += (cm > 1e-6f) ? 1.0f : 0.0f;
-      if (valid[0] && lg == 0) {
-        p.cmax[(size_t)pair * p.n_win + w[0]] = cm;
-        p.s2n[(size_t)pair * p.n_win + w[0]] = sn;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      float row_max;
+      const float vmax = plane_max<N>(k == 0 ? xr : xi, row_max);
+      float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean[k]);
+      keep[k] = t[k].valid && !skip[k] && (cm >= p.corr_min) && (sn >= p.s2n_min);  // NaN s2n compares false
+      cm = keep[k] ? cm : 0.0f;
+      sn = keep[k] ? sn : 0.0f;
+      cnt += (cm > 1e-6f) ? 1.0f : 0.0f;
+      if (t[k].valid && lg == 0) {
+        p.cmax[(size_t)t[k].pair * p.n_win + w] = cm;
+        p.s2n[(size_t)t[k].pair * p.n_win + w] = sn;
       }
-      if (valid[0] && keep) accumulate_plane<N>(p.corr_sum + (size_t)w[0] * G::NN, lg, xr, pair == 0);
     }
-    vmax = plane_max<N>(xi, row_max);
-    {
-      float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean[1]);
-      const bool keep = !skip[1] && (cm >= p.corr_min) && (sn >= p.s2n_min);
-      cm = keep ? cm : 0.0f;
-      sn = keep ? sn : 0.0f;
-      cnt1 += (cm > 1e-6f) ? 1.0f : 0.0f;
-      if (valid[1] && lg == 0) {
-        p.cmax[(size_t)pair * p.n_win + w[1]] = cm;
-        p.s2n[(size_t)pair * p.n_win + w[1]] = sn;
-      }
-      if (valid[1] && keep) accumulate_plane<N>(p.corr_sum + (size_t)w[1] * G::NN, lg, xi, pair == 0);
-    }
+    if (keep[0] || keep[1]) accumulate_planes<N>(p.corr_sum + (size_t)w * G::NN, lg, xr, keep[0], xi, keep[1]);
   }
-  if (lg == 0) {
-    if (valid[0]) p.corr_count[w[0]] += cnt0;
-    if (valid[1]) p.corr_count[w[1]] += cnt1;
-  }
+  if (valid && lg == 0) p.corr_count[w] += cnt;
 }
 
 template <typename T, int N, bool WANT_NZ>
@@ -611,7 +598,7 @@ static hipError_t launch_t(const PivParams& p, bool ensemble, hipStream_t s) {
   using G = Geo<N>;
   constexpr uint32_t jobs_per_block = WAVES_PER_BLOCK * G::GROUPS;
   if (ensemble) {
-    const uint32_t jobs = (p.n_win + 1) / 2;
+    const uint32_t jobs = p.n_win;
     const uint32_t blocks = (jobs + jobs_per_block - 1) / jobs_per_block;
     hipLaunchKernelGGL((piv_fft_ensemble_kernel<T, N, WANT_NZ>), dim3(blocks), dim3(BLOCK), G::LDS_BYTES, s, p);
     return hipGetLastError();

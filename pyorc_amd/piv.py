@@ -120,6 +120,13 @@ class Ensemble:
                                                          _lib.ptr(cm), _lib.ptr(sn)))
         return cm, sn
 
+    def accumulate_dev(self, d_frames: int, dtype, n_frames: int, corr_min: float, s2n_min: float,
+                       d_corr_s2n: int, signal_threshold: Optional[float] = None, stream: Optional[int] = None) -> None:
+        """Same on a chunk that already sits in HBM; d_corr_s2n receives [corr_max | s2n], 2*(T-1)*n_win float32."""
+        _lib.check(_lib.load().lspiv_ensemble_accumulate_dev(
+            self._h, C.c_void_p(d_frames), _lib.DTYPE_CODES[np.dtype(dtype)], n_frames, float(corr_min), float(s2n_min),
+            _sig(signal_threshold), C.c_void_p(d_corr_s2n), C.c_void_p(stream) if stream else None))
+
     def finish(self, count_min: float, n_frames: float, return_mean: bool = False):
         """Count filter + mean plane + sub-pixel peak: u, v (1, n_rows, n_cols) px, corr_count (n_win,)."""
         n_win = self.n_rows * self.n_cols
