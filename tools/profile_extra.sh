@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel-trace stats for the other kernels (64x64 FFT, projection, filters) -> gpurun_out/prof_extra_<tag>/
+# kernel-trace stats for the other kernels (64x64 FFT, projection, filters, masks, ensemble) -> gpurun_out/prof_extra_<tag>/
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r1}
 OUT=$R/gpurun_out/prof_extra_$TAG
@@ -11,4 +11,6 @@ run fft64 python $R/bench.py --steps 3 --warmup 1 --cpu-pairs 0 --window 64 --ov
 run project python $R/tools/project_bench.py 201
 run filters python $R/tools/filters_bench.py 201
 run dtypes python $R/tools/dtype_bench.py 100
+run masks python $R/tools/mask_bench.py 1000
+run ensemble python $R/tools/ensemble_bench.py 301
 for f in $OUT/*kernel_stats.csv; do echo == $f; grep -v "synth_" $f | cut -c1-170; done
