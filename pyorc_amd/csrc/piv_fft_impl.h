@@ -323,19 +323,22 @@ __device__ __forceinline__ void correlate_job(const PivParams& p, const TileRef 
   constexpr bool want_nz = WANT_NZ;  // compile-time: a run-time branch here splits the pipeline into basic
                                      // blocks and the register allocator spills across them
   RowRaw<T, N> raw[2][2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
+  auto fetch_rows = [&](int k) {
     const uint32_t wrow = p.div_ncols.div(t[k].win);
     const uint32_t wcol = t[k].win - wrow * (uint32_t)p.n_cols;
     const int64_t off = ((int64_t)t[k].pair * p.H + (int64_t)(wrow * p.sy + lg)) * p.W + (int64_t)wcol * p.sx;
     raw[k][0].fetch(frames + off);
     raw[k][1].fetch(frames + off + p.frame_elems);
-  }
+  };
+  // uint8 rows (8 VGPRs each) are all fetched up front; wider samples are addressed only when their window's turn
+  // comes -- four live 64-bit row pointers were exactly the 8 VGPRs that kept the float kernel above 128
+  if constexpr (sizeof(T) == 1) { fetch_rows(0); fetch_rows(1); }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     // keep the two windows' register-hungry phases apart: the scheduler otherwise interleaves window 1's
     // conversion with window 0's column FFT and spills
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (sizeof(T) != 1) fetch_rows(k);
     float scale;
     prepare_pair(raw[k][0], raw[k][1], xr, xi, want_nz, p.signal_threshold, scale, hi[k], skip[k]);
     fft_n<false>(xr, xi);              // along x
@@ -453,11 +456,14 @@ __device__ __forceinline__ void store_plane_rows(float* dst, int lg, const float
 // one box: 111.0 k pairs/s at 4 waves vs 103-104 k at the 129 VGPRs = 3 waves of an otherwise identical build);
 // 32x32 float rows are loaded where they are consumed and need a few more; 64x64 holds 128 + 66 + temporaries
 // (two waves, 254 VGPRs)
+#ifndef LSPIV_WAVES_32F
+#define LSPIV_WAVES_32F 4
+#endif
 #ifndef LSPIV_WAVES_32U8
 #define LSPIV_WAVES_32U8 4
 #endif
 template <typename T, int N>
-constexpr int kWavesPerSimd = (N == 32 && sizeof(T) == 1) ? LSPIV_WAVES_32U8 : 2;
+constexpr int kWavesPerSimd = (N == 32 && sizeof(T) == 1) ? LSPIV_WAVES_32U8 : (N == 32 && sizeof(T) == 4) ? LSPIV_WAVES_32F : 2;
 
 // ---- per-timestep kernel: one job (two neighbouring windows of one pair) per lane group ---------
 template <typename T, int N, bool PLANES, bool WANT_NZ>
