@@ -10,55 +10,96 @@
 // in their original order), then every frame is one gather kernel: HBM -> HBM, bit-identical to the reference
 // loop because each group's float32 sum is accumulated in the same order.  Output is float32 (the reference
 // returns the same float32 values widened to float64), laid out (T, Ho, Wo) -- exactly what the PIV kernels read.
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace lspiv {
 
-template <typename T>
+template <typename T, int FPT>
 __global__ __launch_bounds__(256) void project_kernel(const T* __restrict__ frames, int64_t src_elems, int n_frames,
                                                       const int* __restrict__ nn_src, const int* __restrict__ grp_of,
                                                       const int* __restrict__ grp_off, const int* __restrict__ grp_src,
                                                       float* __restrict__ out, int n_out) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= n_out) return;
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += gridDim.x * blockDim.x) {
   const int nn = nn_src[o];
   const int g = grp_of[o];
   int k0 = 0, k1 = 0;
   if (g >= 0) { k0 = grp_off[g]; k1 = grp_off[g + 1]; }
   const float cnt = (float)(k1 - k0);
-  const int t0 = blockIdx.y * 8;
-  const int t1 = min(n_frames, t0 + 8);
-  for (int t = t0; t < t1; ++t) {
-    const T* img = frames + (int64_t)t * src_elems;
+  const int t0 = blockIdx.y * FPT;
+  const T* img = frames + (int64_t)t0 * src_elems;
+  float* dst = out + (int64_t)t0 * n_out + o;
+  if (g < 0 && t0 + FPT <= n_frames) {
+    // the common cell: one nearest-neighbour sample per frame -- all FPT loads are issued before the first store
+    float val[FPT];
+#pragma unroll
+    for (int t = 0; t < FPT; ++t) val[t] = nn >= 0 ? to_f32(img[(int64_t)t * src_elems + nn]) : 0.0f;
+#pragma unroll
+    for (int t = 0; t < FPT; ++t) dst[(int64_t)t * n_out] = (val[t] != val[t]) ? 0.0f : val[t];   // fillna(0.0)
+    continue;
+  }
+  if (g >= 0 && t0 + FPT <= n_frames) {
+    // group mean: samples outer, frames inner -- each sample index is read once and its FPT gathers are independent;
+    // every frame still adds its samples in sample order (the numba loop's rounding)
+    float acc[FPT];
+#pragma unroll
+    for (int t = 0; t < FPT; ++t) acc[t] = 0.0f;
+    for (int k = k0; k < k1; ++k) {
+      const int64_t si = grp_src[k];
+#pragma unroll
+      for (int t = 0; t < FPT; ++t) acc[t] += to_f32(img[(int64_t)t * src_elems + si]);
+    }
+#pragma unroll
+    for (int t = 0; t < FPT; ++t) {
+      const float val = acc[t] / cnt;                                  // IEEE division == float64 division rounded once
+      dst[(int64_t)t * n_out] = (val != val) ? 0.0f : val;            // fillna(0.0)
+    }
+    continue;
+  }
+  const int nt = min(n_frames - t0, FPT);                              // ragged last block of frames
+  for (int t = 0; t < nt; ++t, img += src_elems) {
     float val = 0.0f;
     if (nn >= 0) val = to_f32(img[nn]);
     if (g >= 0) {
       float s = 0.0f;
-      for (int k = k0; k < k1; ++k) s += to_f32(img[grp_src[k]]);  // sample order: same rounding as the numba loop
-      val = s / cnt;                                                 // IEEE division == float64 division rounded once
+      for (int k = k0; k < k1; ++k) s += to_f32(img[grp_src[k]]);
+      val = s / cnt;
     }
-    out[(int64_t)t * n_out + o] = (val != val) ? 0.0f : val;         // fillna(0.0)
+    dst[(int64_t)t * n_out] = (val != val) ? 0.0f : val;
   }
+  }
+}
+
+template <typename T>
+static void launch_project_t(const T* frames, int64_t src_elems, int n_frames, const int* nn_src, const int* grp_of,
+                             const int* grp_off, const int* grp_src, float* out, int n_out, hipStream_t s) {
+  static const int fpt = getenv("LSPIV_PROJECT_FPT") ? atoi(getenv("LSPIV_PROJECT_FPT")) : 8;
+  static const int gx = getenv("LSPIV_PROJECT_GX") ? atoi(getenv("LSPIV_PROJECT_GX")) : 4096;   // x-persistent blocks
+  const unsigned bx = gx > 0 ? (unsigned)std::min((n_out + 255) / 256, gx) : (unsigned)((n_out + 255) / 256);
+#define LSPIV_PROJ(F)                                                                                              \
+  hipLaunchKernelGGL((project_kernel<T, F>), dim3(bx, (n_frames + F - 1) / F), dim3(256), 0, s, frames, \
+                     src_elems, n_frames, nn_src, grp_of, grp_off, grp_src, out, n_out)
+  switch (fpt) {
+    case 1: LSPIV_PROJ(1); break;
+    case 2: LSPIV_PROJ(2); break;
+    case 4: LSPIV_PROJ(4); break;
+    case 16: LSPIV_PROJ(16); break;
+    case 32: LSPIV_PROJ(32); break;
+    default: LSPIV_PROJ(8); break;
+  }
+#undef LSPIV_PROJ
 }
 
 hipError_t launch_project(const void* frames, int dtype, int64_t src_elems, int n_frames, const int* nn_src,
                           const int* grp_of, const int* grp_off, const int* grp_src, float* out, int n_out,
                           hipStream_t s) {
   if (n_frames <= 0 || n_out <= 0) return hipSuccess;
-  const dim3 grid((n_out + 255) / 256, (n_frames + 7) / 8);
   switch (dtype) {
-    case 0:
-      hipLaunchKernelGGL(project_kernel<uint8_t>, grid, dim3(256), 0, s, (const uint8_t*)frames, src_elems, n_frames,
-                         nn_src, grp_of, grp_off, grp_src, out, n_out);
-      break;
-    case 1:
-      hipLaunchKernelGGL(project_kernel<float>, grid, dim3(256), 0, s, (const float*)frames, src_elems, n_frames, nn_src,
-                         grp_of, grp_off, grp_src, out, n_out);
-      break;
-    case 2:
-      hipLaunchKernelGGL(project_kernel<double>, grid, dim3(256), 0, s, (const double*)frames, src_elems, n_frames,
-                         nn_src, grp_of, grp_off, grp_src, out, n_out);
-      break;
+    case 0: launch_project_t((const uint8_t*)frames, src_elems, n_frames, nn_src, grp_of, grp_off, grp_src, out, n_out, s); break;
+    case 1: launch_project_t((const float*)frames, src_elems, n_frames, nn_src, grp_of, grp_off, grp_src, out, n_out, s); break;
+    case 2: launch_project_t((const double*)frames, src_elems, n_frames, nn_src, grp_of, grp_off, grp_src, out, n_out, s); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -12,7 +12,9 @@ lib = _lib.load(); _lib.require_device()
 src = (2160, 3840) if os.environ.get("PROJ_4K") else (1080, 1920)
 dst, T = (1080, 1920), int(sys.argv[1]) if len(sys.argv) > 1 else 401
 idx_img, mask, src_idx, uidx, norm_idx = projection_maps(src, dst, tilt=0.3, seed=1)
-print(f"maps: nn {len(idx_img)} cells, groups {len(uidx)} with {len(src_idx)} samples (max {np.bincount(norm_idx).max()})")
+if os.environ.get("PROJ_IDENTITY"):   # upper bound of the kernel structure: a gather that is a straight copy
+    idx_img = mask = np.arange(dst[0] * dst[1], dtype=np.int64); src_idx = uidx = norm_idx = np.zeros(0, np.int64)
+print(f"maps: nn {len(idx_img)} cells, groups {len(uidx)} with {len(src_idx)} samples (max {np.bincount(norm_idx).max() if len(norm_idx) else 0})")
 p = Projection(src, dst, idx_img, mask, src_idx, uidx, norm_idx)
 d_cam, d_ortho, d_out = C.c_void_p(), C.c_void_p(), C.c_void_p()
 n_src, n_dst = src[0] * src[1], dst[0] * dst[1]
