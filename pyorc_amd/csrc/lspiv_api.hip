@@ -182,9 +182,12 @@ int fill_params(lspiv::PivParams* p, const void* d_frames, int dtype, int64_t T,
 }
 
 int dispatch(const lspiv::PivParams& p, int dtype, bool ensemble, hipStream_t s) {
-  const int kind = lspiv_kernel_kind(p.wy, p.wx);
+  int kind = lspiv_kernel_kind(p.wy, p.wx);
+  if (ensemble && kind > 3) kind = 3;   // the embedded kernels have no ensemble variant yet
   hipError_t e;
   switch (kind) {
+    case 4: e = lspiv::launch_piv_embed32(p, dtype, s); break;
+    case 5: e = lspiv::launch_piv_embed64(p, dtype, s); break;
     case 1: e = lspiv::launch_piv_fft32(p, dtype, ensemble, s); break;
     case 2: e = lspiv::launch_piv_fft64(p, dtype, ensemble, s); break;
     case 3: e = lspiv::launch_piv_direct(p, dtype, ensemble, s); break;
@@ -243,7 +246,9 @@ int lspiv_kernel_kind(int wy, int wx) {
   if (wy < 2 || wx < 2 || wy > LSPIV_MAX_WINDOW || wx > LSPIV_MAX_WINDOW) return LSPIV_EUNSUPPORTED;
   if (wy == 32 && wx == 32) return 1;
   if (wy == 64 && wx == 64) return 2;
-
+  static const bool no_embed = getenv("LSPIV_NO_EMBED") != nullptr;   // A/B switch: direct kernel for every other size
+  if (!no_embed && wy == wx && wy >= 4 && wy <= 16) return 4;
+  if (!no_embed && wy == wx && wy > 16 && wy < 32) return 5;
   return 3;
 }
 

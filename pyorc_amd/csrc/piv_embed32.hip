@@ -1,0 +1,6 @@
+// Square windows 4..16 embedded in the 32-point transforms (piv_fft_impl.h, "embedded mode").
+#include "piv_fft_impl.h"
+
+namespace lspiv {
+hipError_t launch_piv_embed32(const PivParams& p, int dtype, hipStream_t s) { return launch_embed<32>(p, dtype, s); }
+}  // namespace lspiv

@@ -255,6 +255,107 @@ __device__ __forceinline__ void prepare_pair(const RowRaw<T, N>& ra, const RowRa
   skip = !finite || (want_nz && below_threshold<N>(nza, nzb, thr));
 }
 
+struct TileRef {
+  uint32_t pair;   // frame pair index inside the chunk
+  uint32_t win;    // window index k * n_cols + m
+  bool valid;
+};
+
+__device__ __forceinline__ float bperm_f(int addr, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
+}
+
+// ---- embedded mode: a square n x n window, 4 <= n <= N/2, through the N-point transforms ------------------------
+// pyorc accepts any even window (the Ngwerere recipe asks for 25 -> 24, pyorc's tests use 10..20): those sizes have no
+// power-of-two FFT of their own, but their CIRCULAR correlation is exact inside a larger transform: a' zero-padded to
+// N x N, b' extended periodically (b'[y mod n][x mod n]); then for lags 0 <= k < n
+//     sum_{m < n} a'[m] b'_per[m + k] = sum_m a'[m] b'[(m + k) mod n]        (m + k <= 2n - 2 < N: no wrap of the big FFT)
+// in both axes, i.e. the top-left n x n corner of the N x N plane IS the n-point circular correlation; the other lags
+// are never looked at.  Statistics (mean, std, non-zero fraction) are those of the n x n windows; the mean is taken as
+// x0 + mean(x - x0), x0 the first sample, so a constant window has exactly zero variance for any n (the power-of-two
+// kernels get that from pairwise sums).  All sample types take the float path here.
+//
+// One window of the pair: load (zero-padded rows for a, periodic rows for b), statistics over the n x n samples,
+// x <- max(x - mean, 0); returns 1/std (0 for a zero-variance window).  The n x n samples are columns j < n (a uniform
+// test: scalar branches, no per-element lane masks) of rows < n (one lane mask, applied to the row totals).
+template <typename T, int N, bool WANT_NZ, bool PERIODIC>
+__device__ __forceinline__ float load_center_embed(const T* row, int n, bool row_in, int lane0_byte, float (&x)[N],
+                                                   int& nonzero, bool& finite) {
+  const float inv_nn = 1.0f / (float)(n * n);
+  int jm = 0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    if (PERIODIC) {
+      x[j] = to_f32(row[jm]);
+      jm = (jm + 1 == n) ? 0 : jm + 1;
+    } else {
+      x[j] = (j < n && row_in) ? to_f32(row[j]) : 0.0f;   // j < n is uniform: the padding costs no load
+    }
+    if (sizeof(T) == 8 && (j & 15) == 15) __builtin_amdgcn_sched_barrier(0);   // 8-byte samples: consume in chunks
+  }
+  const float x0 = bperm_f(lane0_byte, x[0]);
+  float s = 0.0f;
+  int nz = 0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    if (j < n) {
+      s += x[j] - x0;
+      if (WANT_NZ) nz += (x[j] != 0.0f) ? 1 : 0;
+    }
+  }
+  if (WANT_NZ) nonzero = group_sum_i<N>(row_in ? nz : 0);
+  const float mean = x0 + group_sum<N>(row_in ? s : 0.0f) * inv_nn;
+  float q = 0.0f;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    if (PERIODIC || j < n) {
+      const float d = x[j] - mean;
+      if (j < n) q += d * d;
+      x[j] = fmaxf(d, 0.0f);
+    }
+  }
+  if (!PERIODIC) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) x[j] = row_in ? x[j] : 0.0f;
+  }
+  q = group_sum<N>(row_in ? q : 0.0f);
+  finite = finite && (fabsf(mean) <= 3.0e38f) && (q <= 3.0e38f);
+  const float var = q * inv_nn;
+  return var > 0.0f ? __builtin_amdgcn_rsqf(var) : 0.0f;
+}
+
+template <typename T, int N, bool WANT_NZ>
+__device__ __forceinline__ void prepare_pair_embed(const PivParams& p, const TileRef& t, int lg, float (&xr)[N],
+                                                   float (&xi)[N], float& scale, float& hi, bool& skip) {
+  const int n = p.wy;
+  const float inv_nn = 1.0f / (float)(n * n);
+  const T* frames = static_cast<const T*>(p.frames);
+  const uint32_t wrow = p.div_ncols.div(t.win);
+  const uint32_t wcol = t.win - wrow * (uint32_t)p.n_cols;
+  const int64_t base = ((int64_t)t.pair * p.H + (int64_t)wrow * p.sy) * p.W + (int64_t)wcol * p.sx;
+  const bool row_in = lg < n;
+  const int lane0_byte = (int)((threadIdx.x & 63u) & ~(unsigned)(N - 1)) << 2;
+  bool finite = true;
+  int nza = 0, nzb = 0;
+  const float inv_a = load_center_embed<T, N, WANT_NZ, false>(frames + base + (int64_t)(row_in ? lg : 0) * p.W, n, row_in,
+                                                               lane0_byte, xr, nza, finite);
+  __builtin_amdgcn_sched_barrier(0);   // one window after the other: only one raw row in flight next to the finished one
+  const float inv_b = load_center_embed<T, N, WANT_NZ, true>(frames + base + p.frame_elems + (int64_t)(lg % n) * p.W, n,
+                                                              row_in, lane0_byte, xi, nzb, finite);
+  const bool dead = (inv_a == 0.0f) || (inv_b == 0.0f);
+  const float rho = dead ? 0.0f : inv_b * __builtin_amdgcn_rcpf(inv_a);
+  // plane = (unnormalised inverse N x N transform) / N^2 / n^2, and the cross-spectrum formula carries a factor 4
+  scale = dead ? 0.0f : inv_a * inv_a * inv_nn * (1.0f / (4.0f * (float)Geo<N>::NN));
+  hi = dead ? 0.0f : 1.0f;
+#pragma unroll
+  for (int j = 0; j < N; ++j) xi[j] *= rho;
+  skip = !finite;
+  if (WANT_NZ) {
+    const float fa = (float)nza * inv_nn, fb = (float)nzb * inv_nn;
+    skip = skip || !(fa >= p.signal_threshold && fb >= p.signal_threshold);
+  }
+}
+
 // LDS transpose of one real N x N plane held as lane = row: lane r scatters its row down column r of
 // the buffer (ds_write_b32, the lanes of a group hit consecutive banks), then reads buffer row r =
 // tile column r with ds_read_b128 (row stride N+4 dwords: 16-byte aligned, and the 16 lanes of a b128
@@ -283,9 +384,6 @@ __device__ __forceinline__ void transpose2(float* buf, int lg, float (&xr)[N], f
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[32], float (&xi)[32]) { fft32<INV>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[64], float (&xi)[64]) { fft64<INV>(xr, xi); }
 
-__device__ __forceinline__ float bperm_f(int addr, float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
-}
 
 // lane = kx, registers = ky hold Z = FFT2(a + i b).  Writes s * 4 conj(A) B for ky = 0..N/2 into
 // (rr, ri); Z[-k] = mirrored lane's Z[N - ky].
@@ -303,16 +401,10 @@ __device__ __forceinline__ void cross_spectrum_half(int partner_byte, const floa
   }
 }
 
-struct TileRef {
-  uint32_t pair;   // frame pair index inside the chunk
-  uint32_t win;    // window index k * n_cols + m
-  bool valid;
-};
-
 // Everything between "two window pairs" and "two clipped correlation planes in registers".
 // On return xr = plane of tile 0, xi = plane of tile 1, natural (un-shifted) order: lane = row y,
 // register = column x;  skip[k] = plane k is NaN (signal pre-mask / non-finite input).
-template <typename T, int N, bool WANT_NZ>
+template <typename T, int N, bool WANT_NZ, bool EMBED = false>
 __device__ __forceinline__ void correlate_job(const PivParams& p, const TileRef (&t)[2], float* buf, int lg,
                                               int partner_byte, float (&xr)[N], float (&xi)[N], bool (&skip)[2],
                                               float (&mean)[2]) {
@@ -332,15 +424,19 @@ __device__ __forceinline__ void correlate_job(const PivParams& p, const TileRef 
   };
   // uint8 rows (8 VGPRs each) are all fetched up front; wider samples are addressed only when their window's turn
   // comes -- four live 64-bit row pointers were exactly the 8 VGPRs that kept the float kernel above 128
-  if constexpr (sizeof(T) == 1) { fetch_rows(0); fetch_rows(1); }
+  if constexpr (sizeof(T) == 1 && !EMBED) { fetch_rows(0); fetch_rows(1); }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     // keep the two windows' register-hungry phases apart: the scheduler otherwise interleaves window 1's
     // conversion with window 0's column FFT and spills
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (sizeof(T) != 1) fetch_rows(k);
     float scale;
-    prepare_pair(raw[k][0], raw[k][1], xr, xi, want_nz, p.signal_threshold, scale, hi[k], skip[k]);
+    if constexpr (EMBED) {
+      prepare_pair_embed<T, N, WANT_NZ>(p, t[k], lg, xr, xi, scale, hi[k], skip[k]);
+    } else {
+      if constexpr (sizeof(T) != 1) fetch_rows(k);
+      prepare_pair(raw[k][0], raw[k][1], xr, xi, want_nz, p.signal_threshold, scale, hi[k], skip[k]);
+    }
     fft_n<false>(xr, xi);              // along x
     transpose2<N>(buf, lg, xr, xi);    // lane = kx, regs = y
     fft_n<false>(xr, xi);              // along y -> Z[ky][kx]
@@ -531,6 +627,137 @@ __global__ __launch_bounds__(BLOCK, (kWavesPerSimd<T, N>)) void piv_fft_kernel(P
   if constexpr (PLANES) {
     if (t[0].valid) store_plane_rows<N>(p.planes + ((size_t)t[0].pair * p.n_win + t[0].win) * G::NN, lg, xr, skip[0]);
     if (t[1].valid) store_plane_rows<N>(p.planes + ((size_t)t[1].pair * p.n_win + t[1].win) * G::NN, lg, xi, skip[1]);
+  }
+}
+
+// ---- embedded mode epilogue: corr_max, mean, np.argmax and the sub-pixel fit over the n x n corner ----------------
+// The plane is parked in LDS un-shifted (row ky at buf[ky * LDS_ROW + kx]); the reference's plane is its fftshift,
+// shifted index = (k + n/2) mod n.  Same first-maximum rule and arithmetic as find_peak, with run-time n.
+template <int N>
+__device__ __forceinline__ void find_peak_embed(float* buf, int lg, const float (&c)[N], int n, float& vmax, float& mean,
+                                                float& u, float& v) {
+  constexpr int LR = Geo<N>::LDS_ROW;
+  constexpr int NONE = 1 << 12;
+  f32x4* wrow = reinterpret_cast<f32x4*>(buf + lg * LR);
+#pragma unroll
+  for (int q = 0; q < N / 4; ++q) {
+    const f32x4 w = {c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
+    wrow[q] = w;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const bool row_in = lg < n;
+  float rmax = -1.0f, rsum = 0.0f;
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+    if (j < n) { rmax = fmaxf(rmax, c[j]); rsum += c[j]; }
+  rmax = row_in ? rmax : -1.0f;
+  rsum = row_in ? rsum : 0.0f;
+  vmax = group_max<N>(rmax);
+  mean = group_sum<N>(rsum) / (float)(n * n);
+  const int C = n / 2, M = n - 1;
+  const int sh = lg + C >= n ? lg + C - n : lg + C;                       // this lane's shifted row AND column
+  const int ip = group_min_i<N>((row_in && rmax == vmax) ? sh : NONE);    // first shifted row with the maximum
+  const int y = ip - C < 0 ? ip - C + n : ip - C;
+  const int jp = group_min_i<N>((row_in && buf[y * LR + lg] == vmax) ? sh : NONE);   // first shifted column in that row
+  const bool border = (ip == 0 || ip == M || jp == 0 || jp == M);
+  const int x = jp - C < 0 ? jp - C + n : jp - C;
+  const int ym = y == 0 ? M : y - 1, yp = y == M ? 0 : y + 1;
+  const int xm = x == 0 ? M : x - 1, xp = x == M ? 0 : x + 1;
+  const float c0 = vmax + kEpsPeak;
+  const float cl = buf[ym * LR + x] + kEpsPeak;
+  const float cr = buf[yp * LR + x] + kEpsPeak;
+  const float cd = buf[y * LR + xm] + kEpsPeak;
+  const float cu = buf[y * LR + xp] + kEpsPeak;
+  const float l0 = __builtin_amdgcn_logf(c0);
+  v = (float)ip + gauss_offset_fast(__builtin_amdgcn_logf(cl), l0, __builtin_amdgcn_logf(cr)) - (float)C;
+  u = (float)jp + gauss_offset_fast(__builtin_amdgcn_logf(cd), l0, __builtin_amdgcn_logf(cu)) - (float)C;
+  if (border) u = v = __builtin_nanf("");
+}
+
+// fft-shifted n x n plane out of the parked LDS copy (cross_corr's volume); call before the buffer is reused
+template <int N>
+__device__ __forceinline__ void store_plane_embed(float* dst, const float* buf, int lg, int n, bool nan_plane) {
+  constexpr int LR = Geo<N>::LDS_ROW;
+  if (lg < n) {
+    const int C = n / 2;
+    const int sh = lg + C >= n ? lg + C - n : lg + C;
+    for (int jp = 0; jp < n; ++jp) {
+      const int x = jp - C < 0 ? jp - C + n : jp - C;
+      dst[sh * n + jp] = nan_plane ? __builtin_nanf("") : buf[lg * LR + x];
+    }
+  }
+}
+
+template <typename T, int N, bool PLANES, bool WANT_NZ>
+__global__ __launch_bounds__(BLOCK, 2) void piv_fft_embed_kernel(PivParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using G = Geo<N>;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int grp = lane / N;
+  const int lg = lane & (N - 1);
+  float* buf = smem + (wave * G::GROUPS + grp) * G::LDS_JOB;
+  const int partner_byte = ((lane & ~(N - 1)) | ((N - lg) & (N - 1))) << 2;
+  const uint32_t nb = gridDim.x;                                   // XCD-aware block order, as piv_fft_kernel
+  const uint32_t q = nb >> 3, r = nb & 7u;
+  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const uint32_t blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  const uint32_t jobs_per_pair = (p.n_win + 1) >> 1;
+  uint32_t job = (blk * WAVES_PER_BLOCK + wave) * G::GROUPS + grp;
+  const bool job_valid = job < p.n_pairs * jobs_per_pair;
+  job = job_valid ? job : p.n_pairs * jobs_per_pair - 1;
+  const uint32_t pair = p.div_jobs.div(job);
+  const uint32_t w0 = (job - pair * jobs_per_pair) * 2;
+  TileRef t[2];
+  t[0].pair = t[1].pair = pair;
+  t[0].win = w0;
+  t[0].valid = job_valid;
+  t[1].valid = job_valid && (w0 + 1 < p.n_win);
+  t[1].win = (w0 + 1 < p.n_win) ? w0 + 1 : w0;
+
+  float xr[N], xi[N], dc[2];
+  bool skip[2];
+  correlate_job<T, N, WANT_NZ, true>(p, t, buf, lg, partner_byte, xr, xi, skip, dc);
+  const int n = p.wy;
+  const float nanv = __builtin_nanf("");
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    float vmax, mean, u, v;
+    find_peak_embed<N>(buf, lg, k == 0 ? xr : xi, n, vmax, mean, u, v);
+    float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean);
+    if (skip[k]) u = v = cm = sn = nanv;
+    if (t[k].valid && lg == 0) {
+      const uint32_t g = t[k].pair * p.n_win + t[k].win;
+      p.u[g] = u; p.v[g] = v; p.cmax[g] = cm; p.s2n[g] = sn;
+    }
+    if constexpr (PLANES) {
+      if (t[k].valid) store_plane_embed<N>(p.planes + ((size_t)t[k].pair * p.n_win + t[k].win) * n * n, buf, lg, n, skip[k]);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <typename T, int N, bool WANT_NZ>
+static hipError_t launch_embed_t(const PivParams& p, hipStream_t s) {
+  using G = Geo<N>;
+  constexpr uint32_t jobs_per_block = WAVES_PER_BLOCK * G::GROUPS;
+  const uint32_t jobs = p.n_pairs * ((p.n_win + 1) / 2);
+  const uint32_t blocks = (jobs + jobs_per_block - 1) / jobs_per_block;
+  if (p.planes)
+    hipLaunchKernelGGL((piv_fft_embed_kernel<T, N, true, WANT_NZ>), dim3(blocks), dim3(BLOCK), G::LDS_BYTES, s, p);
+  else
+    hipLaunchKernelGGL((piv_fft_embed_kernel<T, N, false, WANT_NZ>), dim3(blocks), dim3(BLOCK), G::LDS_BYTES, s, p);
+  return hipGetLastError();
+}
+
+template <int N>
+static hipError_t launch_embed(const PivParams& p, int dtype, hipStream_t s) {
+  const bool nz = p.signal_threshold >= 0.0f;
+  switch (dtype) {
+    case 0: return nz ? launch_embed_t<uint8_t, N, true>(p, s) : launch_embed_t<uint8_t, N, false>(p, s);
+    case 1: return nz ? launch_embed_t<float, N, true>(p, s) : launch_embed_t<float, N, false>(p, s);
+    case 2: return nz ? launch_embed_t<double, N, true>(p, s) : launch_embed_t<double, N, false>(p, s);
+    default: return hipErrorInvalidValue;
   }
 }
 

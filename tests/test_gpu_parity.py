@@ -393,3 +393,43 @@ def test_ensemble_accumulate_dev_equals_host_variant(gpu):
     for a, b in zip(host.finish(0.2, 5), dev.finish(0.2, 5)):
         assert np.array_equal(a, b, equal_nan=True)
     host.close(); dev.close(); lib.lspiv_dev_free(d_f); lib.lspiv_dev_free(d_o)
+
+
+@pytest.mark.parametrize("n", [4, 6, 8, 9, 12, 14, 16, 18, 20, 22, 25, 28, 30, 31])
+def test_embedded_windows_every_size(gpu, n):
+    """Square windows 4..31 run inside the 32- / 64-point FFT kernels (zero-padded a, periodic b: exact circular
+    correlation in the top-left corner).  Every size, three dtypes, threshold, constant / empty regions, planes."""
+    from pyorc_amd import _lib
+
+    assert _lib.load().lspiv_kernel_kind(n, n) == (4 if n <= 16 else 5)
+    fr = particle_stack(4, 3 * n + 5, 4 * n + 3, seed=100 + n, density=0.06)
+    ov = (n // 2, n // 3)
+    small = dict(min_ok=0.2, min_neighbour=0.05 if n >= 16 else 0.2)
+    check_against_oracle(fr, (n, n), ov, **small)
+    check_against_oracle(fr.astype(np.float32) * 0.37 - 11.0, (n, n), ov, thr=0.3, **small)
+    f64 = fr.astype(np.float64) * 2.1 - 40.0
+    f64[1] = 0.0                                       # an empty frame: two dead pairs, exact zeros
+    f64[:, : n + 2, : n + 2] = -2.5                    # a constant corner: zero variance for any n
+    check_against_oracle(f64, (n, n), ov, min_ok=0.0, min_neighbour=small["min_neighbour"])
+
+
+def test_embedded_and_direct_kernels_agree(gpu):
+    """LSPIV_NO_EMBED=1 sends every non-power-of-two window to the direct spatial kernel: same answers."""
+    import subprocess
+    import sys
+
+    code = ("import numpy as np, pyorc_amd; from pyorc_amd.synth import particle_stack; "
+            "fr = particle_stack(3, 90, 120, seed=8, density=0.05); "
+            "np.save(sys.argv[1], np.stack(pyorc_amd.piv_pairs(fr, (24, 24), (12, 12)) + pyorc_amd.piv_pairs(fr, (10, 10), (5, 5))[:0]))")
+    outs = []
+    for env_extra in ({}, {"LSPIV_NO_EMBED": "1"}):
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"embed_ab_{len(outs)}.npy")
+        subprocess.run([sys.executable, "-c", "import sys; " + code, path], check=True, env={**os.environ, **env_extra},
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        outs.append(np.load(path))
+    a, b = outs
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    assert rel_err(a[2:], b[2:].astype(np.float64)) <= 1e-5          # corr_max, s2n
+    cond = c_oracle.piv_pairs(particle_stack(3, 90, 120, seed=8, density=0.05), (24, 24), (12, 12), return_cond=True)[-1]
+    ok = c_oracle.well_posed(cond, min_neighbour=0.05)
+    assert ok.mean() > 0.5 and rel_err(a[0][ok], b[0][ok].astype(np.float64)) <= TOL and rel_err(a[1][ok], b[1][ok].astype(np.float64)) <= TOL

@@ -38,6 +38,10 @@ for case in range(n_cases):
     e_c, e_s, e_u, e_v = err(cm, cmo), err(sn, sno), err(u, uo, ok), err(v, vo, ok)
     fail = nan_bad > 0 or max(e_c, e_s, e_u, e_v) > 1e-4
     bad += fail
+    if fail and os.environ.get("FUZZ_DUMP"):
+        os.makedirs(os.environ["FUZZ_DUMP"], exist_ok=True)
+        np.savez_compressed(os.path.join(os.environ["FUZZ_DUMP"], f"case{case}.npz"), fr=fr, ws=(wsy, ws), ov=ov, thr=-1 if thr is None else thr,
+                            u=u, v=v, cm=cm, sn=sn, uo=uo, vo=vo, cmo=cmo, sno=sno)
     print(f"{'FAIL' if fail else 'ok  '} {case:3d} win ({wsy},{ws}) ov {ov} frame ({T},{H},{W}) {np.dtype(dtype).name:7s} thr {thr} "
           f"well-posed {ok.mean():.2f} errs c {e_c:.1e} s {e_s:.1e} u {e_u:.1e} v {e_v:.1e} nan {nan_bad}", flush=True)
 print(f"{n_cases} cases, {bad} failures, {time.time()-t_start:.1f} s")
