@@ -65,6 +65,7 @@ struct PivParams {
   uint32_t n_pairs;        // T-1
   FastDiv div_ncols;       // window index -> (row, col)
   FastDiv div_jobs;        // fft kernels: job index -> (pair, job in pair), divisor (n_win + 1) / 2
+  FastDiv div_nwin;        // one-window-per-job kernels: job index -> (pair, window), divisor n_win
 };
 
 // ---- wave64 cross-lane helpers -----------------------------------------------------------------

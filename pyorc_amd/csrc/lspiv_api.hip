@@ -178,6 +178,7 @@ int fill_params(lspiv::PivParams* p, const void* d_frames, int dtype, int64_t T,
   p->signal_threshold = signal_threshold;
   p->div_ncols = lspiv::FastDiv::make((uint32_t)g.n_cols);
   p->div_jobs = lspiv::FastDiv::make((uint32_t)((n_win + 1) / 2));
+  p->div_nwin = lspiv::FastDiv::make((uint32_t)n_win);
   return LSPIV_OK;
 }
 

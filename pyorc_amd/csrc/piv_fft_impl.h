@@ -425,12 +425,31 @@ __device__ __forceinline__ void correlate_job(const PivParams& p, const TileRef 
   // uint8 rows (8 VGPRs each) are all fetched up front; wider samples are addressed only when their window's turn
   // comes -- four live 64-bit row pointers were exactly the 8 VGPRs that kept the float kernel above 128
   if constexpr (sizeof(T) == 1 && !EMBED) { fetch_rows(0); fetch_rows(1); }
+  // 64-point embedding: ONE window per job.  Holding window 0's half spectrum (66 VGPRs) through window 1's scalar
+  // loads and masked statistics does not fit 256 VGPRs (200-900 B/lane of scratch, and slower than doing without the
+  // shared inverse), so the second slot of the inverse transform stays empty there: 2 instead of 1.5 transforms per
+  // window, no spills.
+  constexpr bool SINGLE = EMBED && N == 64;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     // keep the two windows' register-hungry phases apart: the scheduler otherwise interleaves window 1's
     // conversion with window 0's column FFT and spills
     __builtin_amdgcn_sched_barrier(0);
     float scale;
+    if constexpr (SINGLE) {
+      if (k == 1) {   // Q = R1 for ky <= N/2, conj of the mirrored lane above: the imaginary plane comes out ~0
+        hi[1] = 0.0f;
+        skip[1] = true;
+#pragma unroll
+        for (int ky = 0; ky <= H; ++ky) { xr[ky] = R1r[ky]; xi[ky] = R1i[ky]; }
+#pragma unroll
+        for (int ky = 1; ky < H; ++ky) {
+          xr[N - ky] = bperm_f(partner_byte, R1r[ky]);
+          xi[N - ky] = -bperm_f(partner_byte, R1i[ky]);
+        }
+        break;
+      }
+    }
     if constexpr (EMBED) {
       prepare_pair_embed<T, N, WANT_NZ>(p, t[k], lg, xr, xi, scale, hi[k], skip[k]);
     } else {
@@ -702,18 +721,19 @@ __global__ __launch_bounds__(BLOCK, 2) void piv_fft_embed_kernel(PivParams p) {
   const uint32_t q = nb >> 3, r = nb & 7u;
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const uint32_t blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  const uint32_t jobs_per_pair = (p.n_win + 1) >> 1;
+  constexpr bool SINGLE = N == 64;                                 // one window per job (see correlate_job)
+  const uint32_t jobs_per_pair = SINGLE ? p.n_win : (p.n_win + 1) >> 1;
   uint32_t job = (blk * WAVES_PER_BLOCK + wave) * G::GROUPS + grp;
   const bool job_valid = job < p.n_pairs * jobs_per_pair;
   job = job_valid ? job : p.n_pairs * jobs_per_pair - 1;
-  const uint32_t pair = p.div_jobs.div(job);
-  const uint32_t w0 = (job - pair * jobs_per_pair) * 2;
+  const uint32_t pair = SINGLE ? p.div_nwin.div(job) : p.div_jobs.div(job);
+  const uint32_t w0 = (job - pair * jobs_per_pair) * (SINGLE ? 1 : 2);
   TileRef t[2];
   t[0].pair = t[1].pair = pair;
   t[0].win = w0;
   t[0].valid = job_valid;
-  t[1].valid = job_valid && (w0 + 1 < p.n_win);
-  t[1].win = (w0 + 1 < p.n_win) ? w0 + 1 : w0;
+  t[1].valid = !SINGLE && job_valid && (w0 + 1 < p.n_win);
+  t[1].win = (!SINGLE && w0 + 1 < p.n_win) ? w0 + 1 : w0;
 
   float xr[N], xi[N], dc[2];
   bool skip[2];
@@ -721,7 +741,7 @@ __global__ __launch_bounds__(BLOCK, 2) void piv_fft_embed_kernel(PivParams p) {
   const int n = p.wy;
   const float nanv = __builtin_nanf("");
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < (SINGLE ? 1 : 2); ++k) {
     float vmax, mean, u, v;
     find_peak_embed<N>(buf, lg, k == 0 ? xr : xi, n, vmax, mean, u, v);
     float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean);
@@ -741,7 +761,7 @@ template <typename T, int N, bool WANT_NZ>
 static hipError_t launch_embed_t(const PivParams& p, hipStream_t s) {
   using G = Geo<N>;
   constexpr uint32_t jobs_per_block = WAVES_PER_BLOCK * G::GROUPS;
-  const uint32_t jobs = p.n_pairs * ((p.n_win + 1) / 2);
+  const uint32_t jobs = p.n_pairs * (N == 64 ? p.n_win : (p.n_win + 1) / 2);
   const uint32_t blocks = (jobs + jobs_per_block - 1) / jobs_per_block;
   if (p.planes)
     hipLaunchKernelGGL((piv_fft_embed_kernel<T, N, true, WANT_NZ>), dim3(blocks), dim3(BLOCK), G::LDS_BYTES, s, p);

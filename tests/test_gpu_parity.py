@@ -28,7 +28,7 @@ def rel_err(got, ref, floor=0.05):
     return float(np.nanmax(e)) if np.isfinite(e).any() else 0.0
 
 
-def check_against_oracle(frames, ws, ov, thr=None, min_ok=0.5, min_neighbour=0.02):
+def check_against_oracle(frames, ws, ov, thr=None, min_ok=0.5, min_neighbour=0.02, plane_tol=2e-6):
     import pyorc_amd
 
     u, v, cm, sn, planes = pyorc_amd.piv_pairs(frames, ws, ov, thr, return_planes=True)
@@ -46,7 +46,7 @@ def check_against_oracle(frames, ws, ov, thr=None, min_ok=0.5, min_neighbour=0.0
     assert rel_err(cm, cmo.astype(np.float64)) <= TOL
     assert rel_err(sn, sno.astype(np.float64)) <= TOL
     assert np.array_equal(np.isnan(planes), np.isnan(po_planes))
-    assert np.nanmax(np.abs(planes - po_planes), initial=0.0) < 2e-6
+    assert np.nanmax(np.abs(planes - po_planes), initial=0.0) < plane_tol
     if ok.any():
         assert rel_err(u[ok], uo[ok].astype(np.float64)) <= TOL
         assert rel_err(v[ok], vo[ok].astype(np.float64)) <= TOL
@@ -404,13 +404,15 @@ def test_embedded_windows_every_size(gpu, n):
     assert _lib.load().lspiv_kernel_kind(n, n) == (4 if n <= 16 else 5)
     fr = particle_stack(4, 3 * n + 5, 4 * n + 3, seed=100 + n, density=0.06)
     ov = (n // 2, n // 3)
-    small = dict(min_ok=0.2, min_neighbour=0.05 if n >= 16 else 0.2)
+    # 16-sample windows inside a 1024-point transform: the periodic copy of b carries 64x the window's energy, which
+    # costs the smallest sizes half a digit of float32 headroom on the planes (gate on corr / u / v unchanged: 1e-4)
+    small = dict(min_ok=0.2, min_neighbour=0.05 if n >= 16 else 0.2, plane_tol=2e-6 if n >= 8 else 5e-6)
     check_against_oracle(fr, (n, n), ov, **small)
     check_against_oracle(fr.astype(np.float32) * 0.37 - 11.0, (n, n), ov, thr=0.3, **small)
     f64 = fr.astype(np.float64) * 2.1 - 40.0
     f64[1] = 0.0                                       # an empty frame: two dead pairs, exact zeros
     f64[:, : n + 2, : n + 2] = -2.5                    # a constant corner: zero variance for any n
-    check_against_oracle(f64, (n, n), ov, min_ok=0.0, min_neighbour=small["min_neighbour"])
+    check_against_oracle(f64, (n, n), ov, min_ok=0.0, min_neighbour=small["min_neighbour"], plane_tol=small["plane_tol"])
 
 
 def test_embedded_and_direct_kernels_agree(gpu):
