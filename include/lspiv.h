@@ -62,8 +62,8 @@ int         lspiv_get_device(int* device);
 int         lspiv_device_name(int device, char* buf, size_t len);
 int         lspiv_synchronize(void);                    /* hipDeviceSynchronize             */
 /* which kernel a window size dispatches to: 1 = FFT 32x32, 2 = FFT 64x64, 4 / 5 = square windows 4..16 /
- * 17..31 embedded in the 32- / 64-point FFT kernels, 3 = direct spatial correlation (everything else, and the
- * ensemble mode of kinds 4 / 5); <0 = unsupported.  Host-only. */
+ * 17..31 embedded in the 32- / 64-point FFT kernels, 3 = direct spatial correlation (everything else);
+ * <0 = unsupported.  Host-only. */
 int         lspiv_kernel_kind(int wy, int wx);
 
 /* ---------------------------------------------------------------- window grid (host) ----- */

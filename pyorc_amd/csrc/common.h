@@ -172,9 +172,9 @@ __device__ __forceinline__ float to_f32(double x) { return (float)x; }
 hipError_t launch_piv_fft32(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 hipError_t launch_piv_fft64(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 hipError_t launch_piv_direct(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
-// square windows 4..16 / 17..31 through the 32- / 64-point transforms (per-timestep mode only)
-hipError_t launch_piv_embed32(const PivParams& p, int dtype, hipStream_t s);
-hipError_t launch_piv_embed64(const PivParams& p, int dtype, hipStream_t s);
+// square windows 4..16 / 17..31 through the 32- / 64-point transforms
+hipError_t launch_piv_embed32(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
+hipError_t launch_piv_embed64(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 hipError_t launch_peaks_from_planes(const float* planes, uint32_t n_planes, int wy, int wx,
                                     float* u, float* v, hipStream_t s);
 // mean[w][o] = count[w] < min_count ? NaN : sum[w][o] / count[w]   (pyorc/velocimetry/ffpiv.py:280-282)

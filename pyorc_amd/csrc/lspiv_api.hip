@@ -183,12 +183,11 @@ int fill_params(lspiv::PivParams* p, const void* d_frames, int dtype, int64_t T,
 }
 
 int dispatch(const lspiv::PivParams& p, int dtype, bool ensemble, hipStream_t s) {
-  int kind = lspiv_kernel_kind(p.wy, p.wx);
-  if (ensemble && kind > 3) kind = 3;   // the embedded kernels have no ensemble variant yet
+  const int kind = lspiv_kernel_kind(p.wy, p.wx);
   hipError_t e;
   switch (kind) {
-    case 4: e = lspiv::launch_piv_embed32(p, dtype, s); break;
-    case 5: e = lspiv::launch_piv_embed64(p, dtype, s); break;
+    case 4: e = lspiv::launch_piv_embed32(p, dtype, ensemble, s); break;
+    case 5: e = lspiv::launch_piv_embed64(p, dtype, ensemble, s); break;
     case 1: e = lspiv::launch_piv_fft32(p, dtype, ensemble, s); break;
     case 2: e = lspiv::launch_piv_fft64(p, dtype, ensemble, s); break;
     case 3: e = lspiv::launch_piv_direct(p, dtype, ensemble, s); break;

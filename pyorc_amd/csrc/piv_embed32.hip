@@ -2,5 +2,7 @@
 #include "piv_fft_impl.h"
 
 namespace lspiv {
-hipError_t launch_piv_embed32(const PivParams& p, int dtype, hipStream_t s) { return launch_embed<32>(p, dtype, s); }
+hipError_t launch_piv_embed32(const PivParams& p, int dtype, bool ensemble, hipStream_t s) {
+  return launch_embed<32>(p, dtype, ensemble, s);
+}
 }  // namespace lspiv

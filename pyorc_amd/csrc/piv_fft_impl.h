@@ -757,10 +757,84 @@ __global__ __launch_bounds__(BLOCK, 2) void piv_fft_embed_kernel(PivParams p) {
   }
 }
 
+// Ensemble correlation for the embedded sizes: a job owns one window and walks the chunk's pairs in order (two per
+// iteration in the 32-point variant, sharing the inverse transform like piv_fft_ensemble_kernel; one in the 64-point
+// variant), adding every kept plane to its n x n slice of corr_sum (fft-shifted layout) through the parked LDS copy:
+// row by row, lane = column, so the read-modify-write is coalesced.
 template <typename T, int N, bool WANT_NZ>
-static hipError_t launch_embed_t(const PivParams& p, hipStream_t s) {
+__global__ __launch_bounds__(BLOCK, 2) void piv_fft_embed_ensemble_kernel(PivParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using G = Geo<N>;
+  constexpr int LR = G::LDS_ROW;
+  constexpr bool SINGLE = N == 64;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int grp = lane / N;
+  const int lg = lane & (N - 1);
+  float* buf = smem + (wave * G::GROUPS + grp) * G::LDS_JOB;
+  const int partner_byte = ((lane & ~(N - 1)) | ((N - lg) & (N - 1))) << 2;
+  const uint32_t job = (blockIdx.x * WAVES_PER_BLOCK + wave) * G::GROUPS + grp;
+  const bool valid = job < p.n_win;
+  const uint32_t w = valid ? job : p.n_win - 1;
+  const int n = p.wy, C = n / 2;
+  const bool row_in = lg < n;
+  const int xs = lg - C < 0 ? lg - C + n : lg - C;       // un-shifted column of this lane's shifted column
+  float* sum = p.corr_sum + (size_t)w * n * n;
+  float cnt = 0.0f;
+  for (uint32_t pair = 0; pair < p.n_pairs; pair += SINGLE ? 1 : 2) {
+    const bool two = !SINGLE && pair + 1 < p.n_pairs;
+    TileRef t[2] = {{pair, w, valid}, {two ? pair + 1 : pair, w, valid && two}};
+    float xr[N], xi[N], dc[2];
+    bool skip[2];
+    correlate_job<T, N, WANT_NZ, true>(p, t, buf, lg, partner_byte, xr, xi, skip, dc);
+#pragma unroll
+    for (int k = 0; k < (SINGLE ? 1 : 2); ++k) {
+      const float (&c)[N] = k == 0 ? xr : xi;
+      float rmax = -1.0f, rsum = 0.0f;
+#pragma unroll
+      for (int j = 0; j < N; ++j)
+        if (j < n) { rmax = fmaxf(rmax, c[j]); rsum += c[j]; }
+      const float vmax = group_max<N>(row_in ? rmax : -1.0f);
+      const float mean = group_sum<N>(row_in ? rsum : 0.0f) / (float)(n * n);
+      float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean);
+      const bool keep = t[k].valid && !skip[k] && (cm >= p.corr_min) && (sn >= p.s2n_min);  // NaN s2n compares false
+      cm = keep ? cm : 0.0f;
+      sn = keep ? sn : 0.0f;
+      cnt += (cm > 1e-6f) ? 1.0f : 0.0f;
+      if (t[k].valid && lg == 0) {
+        p.cmax[(size_t)t[k].pair * p.n_win + w] = cm;
+        p.s2n[(size_t)t[k].pair * p.n_win + w] = sn;
+      }
+      if (keep) {
+        f32x4* wrow = reinterpret_cast<f32x4*>(buf + lg * LR);
+#pragma unroll
+        for (int q = 0; q < N / 4; ++q) {
+          const f32x4 v = {c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
+          wrow[q] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (row_in) {
+          for (int ip = 0; ip < n; ++ip) {
+            const int y = ip - C < 0 ? ip - C + n : ip - C;
+            sum[ip * n + lg] += buf[y * LR + xs];
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  if (valid && lg == 0) p.corr_count[w] += cnt;
+}
+
+template <typename T, int N, bool WANT_NZ>
+static hipError_t launch_embed_t(const PivParams& p, bool ensemble, hipStream_t s) {
   using G = Geo<N>;
   constexpr uint32_t jobs_per_block = WAVES_PER_BLOCK * G::GROUPS;
+  if (ensemble) {
+    hipLaunchKernelGGL((piv_fft_embed_ensemble_kernel<T, N, WANT_NZ>), dim3((p.n_win + jobs_per_block - 1) / jobs_per_block),
+                       dim3(BLOCK), G::LDS_BYTES, s, p);
+    return hipGetLastError();
+  }
   const uint32_t jobs = p.n_pairs * (N == 64 ? p.n_win : (p.n_win + 1) / 2);
   const uint32_t blocks = (jobs + jobs_per_block - 1) / jobs_per_block;
   if (p.planes)
@@ -771,12 +845,12 @@ static hipError_t launch_embed_t(const PivParams& p, hipStream_t s) {
 }
 
 template <int N>
-static hipError_t launch_embed(const PivParams& p, int dtype, hipStream_t s) {
+static hipError_t launch_embed(const PivParams& p, int dtype, bool ensemble, hipStream_t s) {
   const bool nz = p.signal_threshold >= 0.0f;
   switch (dtype) {
-    case 0: return nz ? launch_embed_t<uint8_t, N, true>(p, s) : launch_embed_t<uint8_t, N, false>(p, s);
-    case 1: return nz ? launch_embed_t<float, N, true>(p, s) : launch_embed_t<float, N, false>(p, s);
-    case 2: return nz ? launch_embed_t<double, N, true>(p, s) : launch_embed_t<double, N, false>(p, s);
+    case 0: return nz ? launch_embed_t<uint8_t, N, true>(p, ensemble, s) : launch_embed_t<uint8_t, N, false>(p, ensemble, s);
+    case 1: return nz ? launch_embed_t<float, N, true>(p, ensemble, s) : launch_embed_t<float, N, false>(p, ensemble, s);
+    case 2: return nz ? launch_embed_t<double, N, true>(p, ensemble, s) : launch_embed_t<double, N, false>(p, ensemble, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -288,15 +288,19 @@ def test_get_ffpiv_ensemble_vs_oracle(gpu, kw):
         assert np.array_equal(got.coords["time"], t[ref["pair_index"]])
 
 
-def test_ensemble_other_window_size(gpu):
+@pytest.mark.parametrize("n,T", [(24, 6), (10, 7), (16, 5), (26, 4), (48, 4)])
+def test_ensemble_other_window_size(gpu, n, T):
+    """Ensemble mode of the embedded sizes (24, 26: 64-point variant; 10, 16: 32-point variant, two pairs per
+    iteration incl. an odd pair count) and of the direct kernel (48)."""
     from pyorc_amd import frames as F
 
-    fr = particle_stack(6, 96, 96, seed=35, density=0.05)
-    got = F.get_piv(fr, 24, ensemble_corr=True, corr_min=0.1, s2n_min=1.5)
-    ref = po.get_ffpiv(fr, np.ones(5), (24, 24), (12, 12), 1.0, 1.0, ensemble_corr=True, corr_min=0.1, s2n_min=1.5)
+    fr = particle_stack(T, 4 * n, 4 * n, seed=35 + n, density=0.05)
+    got = F.get_piv(fr, n, ensemble_corr=True, corr_min=0.1, s2n_min=1.5)
+    ref = po.get_ffpiv(fr, np.ones(T - 1), (n, n), (n // 2, n // 2), 1.0, 1.0, ensemble_corr=True, corr_min=0.1, s2n_min=1.5)
     for k in ("v_x", "v_y", "corr", "s2n"):
         assert np.array_equal(np.isnan(got[k]), np.isnan(ref[k])), k
-    assert rel_err(got["v_x"], ref["v_x"].astype(np.float64)) <= 2e-4
+    assert rel_err(got["corr"], ref["corr"].astype(np.float64)) <= TOL and rel_err(got["s2n"], ref["s2n"].astype(np.float64)) <= TOL
+    assert rel_err(got["v_x"], ref["v_x"].astype(np.float64)) <= 2e-4 and rel_err(got["v_y"], ref["v_y"].astype(np.float64)) <= 2e-4
 
 
 def test_pipelined_upload_equals_single_batch(gpu, monkeypatch):
