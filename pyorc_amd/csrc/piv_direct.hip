@@ -7,15 +7,14 @@
 // evaluates the same circular cross-correlation directly in the spatial domain,
 //     plane[i'][j'] = clip( (1/N) sum_{y,x} a'[y][x] b'[(y+i'-cy) % wy][(x+j'-cx) % wx], 0, 1 )
 // which is what clip(fftshift(irfft2(conj(rfft2 a') rfft2 b'))/N, 0, 1) computes (ffpiv ncc, A4),
-// with a', b' the mean-offset, std-normalised, zero-clipped windows (A3).  One wavefront per
-// window pair, both windows staged in LDS as float32; O(N^2) work per output instead of O(log N)
-// -- a correctness path, ~10x slower than the FFT kernel at 32x32.
+// with a', b' the mean-offset, std-normalised, zero-clipped windows (A3).  One 4-wave block per window pair, both
+// windows staged in LDS as float32 (b with periodically doubled rows), every thread accumulating 8 neighbouring lags
+// in registers: O(N^2) multiply-adds per output instead of O(log N).  Square windows up to 31 do NOT come here any
+// more (they run embedded in the FFT kernels, piv_fft_impl.h); this is the path for non-square windows and 33..63.
 #include "common.h"
 
 namespace lspiv {
 
-constexpr int MAXW = 64;
-constexpr int MAXN = MAXW * MAXW;
 
 struct WaveArg {
   float v;
@@ -29,79 +28,132 @@ __device__ __forceinline__ void wave_argmax(float& v, int& idx) {
   argmax_merge(v, idx, pv, pi);
 }
 
-// stage one window into LDS as float, return the sum of (x - x0), x0 = its first sample (deterministic
-// lane-strided order).  Summing offsets from x0 makes a constant window come out with an exactly-zero sum, hence
-// mean == x0 and zero variance, for ANY window size -- the FFT kernels get the same from pairwise sums of 2^k terms.
+// ---- block-level pieces: 256 threads (4 waves) work on one window pair -----------------------------------------
+constexpr int DBLOCK = 256;
+constexpr int DXB = 8;            // lags per thread: one a-sample and one new b-sample feed 8 FMAs
+
+struct DirectGeo {
+  int n, bpitch, strips_per_row;  // samples per window; padded length of a doubled b row; ceil(wx / DXB)
+  __device__ DirectGeo(int wy, int wx) : n(wy * wx), bpitch(wx + ((wx + DXB - 1) / DXB) * DXB), strips_per_row((wx + DXB - 1) / DXB) {}
+};
+
+// sum over the block in a fixed order (wave reductions, then the four partials left to right): deterministic
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return ((red[0] + red[1]) + red[2]) + red[3];
+}
+__device__ __forceinline__ int block_sum_i(int v, int* red) {
+  v = half_sum_i(v);
+  v += __shfl_xor(v, 32, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// Stage one window into LDS (row pitch `pitch`; with `periodic` every row is continued periodically up to the pitch,
+// which turns the circular column shift into a plain offset), mean-offset / variance / clip in place.  The mean is
+// x0 + mean(x - x0), x0 the first sample: a constant window has exactly zero variance for any size.
+// Returns 1/std (0 if std == 0).
 template <typename T>
-__device__ __forceinline__ float stage_window(const T* src, int W, int wy, int wx, float* dst, int lane, int& nonzero,
-                                              float& x0) {
+__device__ __forceinline__ float stage_window(const T* src, int W, int wy, int wx, float* dst, int pitch, bool periodic,
+                                              float* red, int& nonzero, bool& finite) {
   const int n = wy * wx;
-  x0 = to_f32(src[0]);
+  const float x0 = to_f32(src[0]);
   float s = 0.0f;
   int nz = 0;
-  for (int o = lane; o < n; o += 64) {
+  for (int o = threadIdx.x; o < n; o += DBLOCK) {
     const int y = o / wx, x = o - y * wx;
     const float v = to_f32(src[(int64_t)y * W + x]);
-    dst[o] = v;
+    dst[y * pitch + x] = v;
     s += v - x0;
     nz += (v != 0.0f) ? 1 : 0;
   }
-  nonzero = half_sum_i(nz);
-  nonzero += __shfl_xor(nonzero, 32, 64);
-  return wave_sum(s);
-}
-
-// mean-offset / variance / clip in LDS; returns 1/std (0 if std == 0)
-__device__ __forceinline__ float normalize_window(float* w, int n, float sum_off, float x0, int lane, bool& finite) {
-  const float mean = x0 + sum_off / (float)n;
+  nonzero = block_sum_i(nz, reinterpret_cast<int*>(red));
+  const float mean = x0 + block_sum(s, red) / (float)n;
   float ssq = 0.0f;
-  for (int o = lane; o < n; o += 64) {
-    const float d = w[o] - mean;
+  for (int o = threadIdx.x; o < n; o += DBLOCK) {
+    const int y = o / wx, x = o - y * wx;
+    const float d = dst[y * pitch + x] - mean;
     ssq += d * d;
-    w[o] = fmaxf(d, 0.0f);
+    dst[y * pitch + x] = fmaxf(d, 0.0f);
   }
-  ssq = wave_sum(ssq);
+  ssq = block_sum(ssq, red);
   finite = finite && (fabsf(mean) <= 3.0e38f) && (ssq <= 3.0e38f);
+  if (periodic) {
+    const int ext = pitch - wx;
+    for (int o = threadIdx.x; o < wy * ext; o += DBLOCK) {
+      const int y = o / ext, x = o - y * ext;
+      dst[y * pitch + wx + x] = dst[y * pitch + x % wx];
+    }
+  }
   const float var = ssq / (float)n;
   return var > 0.0f ? 1.0f / sqrtf(var) : 0.0f;
 }
 
-// correlation plane of the staged pair into plane[] (shifted layout), clipped to [0, 1]
-__device__ __forceinline__ void correlate_direct(const float* a, const float* b, float* plane, int wy, int wx,
-                                                 float scale, int lane) {
-  const int n = wy * wx;
+// plane[i'][j'] (fft-shifted) = clip(scale * sum_{y,x} a[y][x] b[(y + dy) % wy][(x + dx) % wx], 0, 1), dy = i' - cy, dx = j' - cx.
+// A thread owns DXB consecutive un-shifted lags dx of one dy: per (y, x) one broadcast read of a, one new b sample,
+// DXB FMAs -- the doubled b rows make the window of b samples slide without a modulo.
+__device__ __forceinline__ void correlate_direct(const float* a, const float* b2, float* plane, int wy, int wx,
+                                                 const DirectGeo& g, float scale) {
   const int cy = wy / 2, cx = wx / 2;
-  for (int o = lane; o < n; o += 64) {
-    const int ip = o / wx, jp = o - ip * wx;
-    int dy = ip - cy; dy += dy < 0 ? wy : 0;
-    int dx = jp - cx; dx += dx < 0 ? wx : 0;
-    float tot = 0.0f;
+  const int strips = wy * g.strips_per_row;
+  for (int sidx = threadIdx.x; sidx < strips; sidx += DBLOCK) {
+    const int dy = sidx / g.strips_per_row, dx0 = (sidx - dy * g.strips_per_row) * DXB;
+    float acc[DXB];
+#pragma unroll
+    for (int e = 0; e < DXB; ++e) acc[e] = 0.0f;
+    int yb = dy;
     for (int y = 0; y < wy; ++y) {
-      int yb = y + dy; yb -= yb >= wy ? wy : 0;
       const float* ar = a + y * wx;
-      const float* br = b + yb * wx;
-      float rs = 0.0f;
-      int x = 0;
-      for (; x < wx - dx; ++x) rs = fmaf(ar[x], br[x + dx], rs);
-      for (; x < wx; ++x) rs = fmaf(ar[x], br[x + dx - wx], rs);
-      tot += rs;
+      const float* br = b2 + yb * g.bpitch + dx0;
+      float w[DXB];
+#pragma unroll
+      for (int e = 0; e < DXB - 1; ++e) w[e] = br[e];
+      for (int x = 0; x < wx; ++x) {
+        w[DXB - 1] = br[x + DXB - 1];
+        const float av = ar[x];
+#pragma unroll
+        for (int e = 0; e < DXB; ++e) acc[e] = fmaf(av, w[e], acc[e]);
+#pragma unroll
+        for (int e = 0; e < DXB - 1; ++e) w[e] = w[e + 1];
+      }
+      yb = (yb + 1 == wy) ? 0 : yb + 1;
     }
-    plane[o] = fminf(fmaxf(tot * scale, 0.0f), 1.0f);
+    const int ip = dy + cy >= wy ? dy + cy - wy : dy + cy;
+#pragma unroll
+    for (int e = 0; e < DXB; ++e) {
+      const int dx = dx0 + e;
+      if (dx < wx) {
+        const int jp = dx + cx >= wx ? dx + cx - wx : dx + cx;
+        plane[ip * wx + jp] = fminf(fmaxf(acc[e] * scale, 0.0f), 1.0f);
+      }
+    }
   }
 }
 
-__device__ __forceinline__ void plane_reduce(const float* plane, int n, int lane, float& vmax, int& imax, float& sum) {
+// max / first arg-max (row-major) / sum of the LDS plane over the block
+__device__ __forceinline__ void plane_reduce(const float* plane, int n, float* red, float& vmax, int& imax, float& sum) {
   float best = -1.0f;
   int bi = 0x7fffffff;
   float s = 0.0f;
-  for (int o = lane; o < n; o += 64) {
+  for (int o = threadIdx.x; o < n; o += DBLOCK) {
     const float v = plane[o];
     s += v;
     if (v > best) { best = v; bi = o; }
   }
-  vmax = best; imax = bi;
-  wave_argmax(vmax, imax);
-  sum = wave_sum(s);
+  wave_argmax(best, bi);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { red[8 + (threadIdx.x >> 6)] = best; reinterpret_cast<int*>(red)[12 + (threadIdx.x >> 6)] = bi; }
+  __syncthreads();
+  vmax = red[8];
+  imax = reinterpret_cast<int*>(red)[12];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) argmax_merge(vmax, imax, red[8 + k], reinterpret_cast<int*>(red)[12 + k]);
+  sum = block_sum(s, red);
 }
 
 // sub-pixel peak of a plane addressed through `ld` (LDS or global), flat argmax index imax
@@ -125,94 +177,100 @@ __device__ __forceinline__ void subpixel_generic(F ld, int wy, int wx, int imax,
       (float)(wx / 2);
 }
 
-// one window pair -> plane in LDS + (corr_max, sum).  Returns false when the plane is NaN.
+// one window pair -> plane in LDS.  Returns false when the plane is NaN (non-finite input / signal threshold).
 template <typename T>
-__device__ __forceinline__ bool direct_pair(const PivParams& p, uint32_t pair, uint32_t win, float* a, float* b,
-                                            float* plane, int lane) {
+__device__ __forceinline__ bool direct_pair(const PivParams& p, uint32_t pair, uint32_t win, float* a, float* b2,
+                                            float* plane, float* red, const DirectGeo& g) {
   const T* frames = static_cast<const T*>(p.frames);
   const uint32_t wrow = win / (uint32_t)p.n_cols, wcol = win - wrow * (uint32_t)p.n_cols;
   const int64_t off = ((int64_t)pair * p.H + (int64_t)wrow * p.sy) * p.W + (int64_t)wcol * p.sx;
-  const int n = p.wy * p.wx;
   int nza, nzb;
-  float a0, b0;
-  const float sa = stage_window(frames + off, p.W, p.wy, p.wx, a, lane, nza, a0);
-  const float sb = stage_window(frames + off + p.frame_elems, p.W, p.wy, p.wx, b, lane, nzb, b0);
-  __builtin_amdgcn_wave_barrier();
   bool finite = true;
-  const float inv_a = normalize_window(a, n, sa, a0, lane, finite);
-  const float inv_b = normalize_window(b, n, sb, b0, lane, finite);
-  __builtin_amdgcn_wave_barrier();
+  const float inv_a = stage_window(frames + off, p.W, p.wy, p.wx, a, p.wx, false, red, nza, finite);
+  const float inv_b = stage_window(frames + off + p.frame_elems, p.W, p.wy, p.wx, b2, g.bpitch, true, red, nzb, finite);
+  __syncthreads();
   bool ok = finite;
   if (p.signal_threshold >= 0.0f) {
-    const float fa = (float)nza / (float)n, fb = (float)nzb / (float)n;
+    const float fa = (float)nza / (float)g.n, fb = (float)nzb / (float)g.n;
     ok = ok && (fa >= p.signal_threshold) && (fb >= p.signal_threshold);
   }
-  correlate_direct(a, b, plane, p.wy, p.wx, inv_a * inv_b / (float)n, lane);
-  __builtin_amdgcn_wave_barrier();
+  correlate_direct(a, b2, plane, p.wy, p.wx, g, inv_a * inv_b / (float)g.n);
+  __syncthreads();
   return ok;
 }
 
+// LDS: a (n) | doubled b (wy * bpitch) | plane (n) | 16 dwords of reduction scratch
+__device__ __forceinline__ void carve(float* smem, const DirectGeo& g, int wy, float*& a, float*& b2, float*& plane, float*& red) {
+  a = smem; b2 = a + g.n; plane = b2 + wy * g.bpitch; red = plane + g.n;
+}
+static size_t direct_lds_bytes(int wy, int wx) {
+  const int bpitch = wx + ((wx + DXB - 1) / DXB) * DXB;
+  return ((size_t)2 * wy * wx + (size_t)wy * bpitch + 16) * sizeof(float);
+}
+
 template <typename T>
-__global__ __launch_bounds__(64) void piv_direct_kernel(PivParams p) {
-  __shared__ float a[MAXN], b[MAXN], plane[MAXN];
-  const int lane = threadIdx.x;
-  const uint32_t g = blockIdx.x;
-  const uint32_t pair = g / p.n_win, win = g - pair * p.n_win;
-  const int n = p.wy * p.wx;
-  const bool ok = direct_pair<T>(p, pair, win, a, b, plane, lane);
+__global__ __launch_bounds__(DBLOCK) void piv_direct_kernel(PivParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const DirectGeo g(p.wy, p.wx);
+  float *a, *b2, *plane, *red;
+  carve(smem, g, p.wy, a, b2, plane, red);
+  const uint32_t t = blockIdx.x;
+  const uint32_t pair = t / p.n_win, win = t - pair * p.n_win;
+  const bool ok = direct_pair<T>(p, pair, win, a, b2, plane, red, g);
   float vmax, sum, u, v;
   int imax;
-  plane_reduce(plane, n, lane, vmax, imax, sum);
+  plane_reduce(plane, g.n, red, vmax, imax, sum);
   subpixel_generic([&](int o) { return plane[o]; }, p.wy, p.wx, imax, u, v);
-  float cm = vmax, sn = vmax / (sum / (float)n);
+  float cm = vmax, sn = vmax / (sum / (float)g.n);
   if (!ok) u = v = cm = sn = __builtin_nanf("");
-  if (lane == 0) {
-    p.u[g] = u; p.v[g] = v; p.cmax[g] = cm; p.s2n[g] = sn;
+  if (threadIdx.x == 0) {
+    p.u[t] = u; p.v[t] = v; p.cmax[t] = cm; p.s2n[t] = sn;
   }
   if (p.planes) {
-    float* dst = p.planes + (size_t)g * n;
-    for (int o = lane; o < n; o += 64) dst[o] = ok ? plane[o] : __builtin_nanf("");
+    float* dst = p.planes + (size_t)t * g.n;
+    for (int o = threadIdx.x; o < g.n; o += DBLOCK) dst[o] = ok ? plane[o] : __builtin_nanf("");
   }
 }
 
-// ensemble: one wave owns one window and walks the chunk's pairs in order (see piv_fft32.hip)
+// ensemble: one block owns one window and walks the chunk's pairs in order (see piv_fft_impl.h); the running sum
+// of the chunk lives in HBM (corr_sum), one coalesced read-modify-write per kept pair
 template <typename T>
-__global__ __launch_bounds__(64) void piv_direct_ensemble_kernel(PivParams p) {
-  __shared__ float a[MAXN], b[MAXN], plane[MAXN], acc[MAXN];
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(DBLOCK) void piv_direct_ensemble_kernel(PivParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const DirectGeo g(p.wy, p.wx);
+  float *a, *b2, *plane, *red;
+  carve(smem, g, p.wy, a, b2, plane, red);
   const uint32_t win = blockIdx.x;
-  const int n = p.wy * p.wx;
-  for (int o = lane; o < n; o += 64) acc[o] = 0.0f;
+  float* dst = p.corr_sum + (size_t)win * g.n;
   float cnt = 0.0f;
   for (uint32_t pair = 0; pair < p.n_pairs; ++pair) {
-    const bool ok = direct_pair<T>(p, pair, win, a, b, plane, lane);
+    const bool ok = direct_pair<T>(p, pair, win, a, b2, plane, red, g);
     float vmax, sum;
     int imax;
-    plane_reduce(plane, n, lane, vmax, imax, sum);
-    float cm = vmax, sn = vmax / (sum / (float)n);
+    plane_reduce(plane, g.n, red, vmax, imax, sum);
+    float cm = vmax, sn = vmax / (sum / (float)g.n);
     const bool keep = ok && (cm >= p.corr_min) && (sn >= p.s2n_min);
     cm = keep ? cm : 0.0f;
     sn = keep ? sn : 0.0f;
     cnt += (cm > 1e-6f) ? 1.0f : 0.0f;
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
       p.cmax[(size_t)pair * p.n_win + win] = cm;
       p.s2n[(size_t)pair * p.n_win + win] = sn;
     }
     if (keep)
-      for (int o = lane; o < n; o += 64) acc[o] += plane[o];
-    __builtin_amdgcn_wave_barrier();
+      for (int o = threadIdx.x; o < g.n; o += DBLOCK) dst[o] += plane[o];
+    __syncthreads();
   }
-  float* dst = p.corr_sum + (size_t)win * n;
-  for (int o = lane; o < n; o += 64) dst[o] += acc[o];
-  if (lane == 0) p.corr_count[win] += cnt;
+  if (threadIdx.x == 0) p.corr_count[win] += cnt;
 }
 
 template <typename T>
 static hipError_t launch_t(const PivParams& p, bool ensemble, hipStream_t s) {
+  const size_t lds = direct_lds_bytes(p.wy, p.wx);
   if (ensemble)
-    hipLaunchKernelGGL(piv_direct_ensemble_kernel<T>, dim3(p.n_win), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(piv_direct_ensemble_kernel<T>, dim3(p.n_win), dim3(DBLOCK), lds, s, p);
   else
-    hipLaunchKernelGGL(piv_direct_kernel<T>, dim3(p.n_tiles), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(piv_direct_kernel<T>, dim3(p.n_tiles), dim3(DBLOCK), lds, s, p);
   return hipGetLastError();
 }
 
