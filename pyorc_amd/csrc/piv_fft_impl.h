@@ -28,6 +28,7 @@
 //     9 KB of LDS per wave); N = 64 needs 254 VGPRs and runs two.
 // MFMA is deliberately unused: this is FFT + pointwise work (BASELINE.json north_star).
 #pragma once
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -571,6 +572,9 @@ __device__ __forceinline__ void store_plane_rows(float* dst, int lg, const float
 // one box: 111.0 k pairs/s at 4 waves vs 103-104 k at the 129 VGPRs = 3 waves of an otherwise identical build);
 // 32x32 float rows are loaded where they are consumed and need a few more; 64x64 holds 128 + 66 + temporaries
 // (two waves, 254 VGPRs)
+#ifndef LSPIV_WALK_WAVES
+#define LSPIV_WALK_WAVES 3
+#endif
 #ifndef LSPIV_WAVES_32F
 #define LSPIV_WAVES_32F 4
 #endif
@@ -646,6 +650,158 @@ __global__ __launch_bounds__(BLOCK, (kWavesPerSimd<T, N>)) void piv_fft_kernel(P
   if constexpr (PLANES) {
     if (t[0].valid) store_plane_rows<N>(p.planes + ((size_t)t[0].pair * p.n_win + t[0].win) * G::NN, lg, xr, skip[0]);
     if (t[1].valid) store_plane_rows<N>(p.planes + ((size_t)t[1].pair * p.n_win + t[1].win) * G::NN, lg, xi, skip[1]);
+  }
+}
+
+// ---- time-walking kernel: a job owns ONE window and walks a run of consecutive frame pairs ---------------------------
+// The normalised window of frame t is the "b" of pair (t-1, t) and the "a" of pair (t, t+1), and its normalisation
+// (own mean / std / clip) is the same in both roles, so its spectrum F_t can be computed once.  An iteration takes TWO
+// new frames of the window, packs them z = x_f + i x_{f+1} (both already unit-variance, so they are balanced), and
+//   one forward 2-D FFT        -> Z;  P = Z[k] + conj Z[-k] = 2 F_f,  Q = (Z[k] - conj Z[-k]) / i = 2 F_{f+1}
+//   R_a = conj(F_prev) P  (pair f-1),  R_b = conj(P) Q  (pair f),  both scaled by 1 / (4 N^4)
+//   one inverse 2-D FFT of R_a + i R_b -> the two correlation planes;  F_prev <- Q
+// i.e. 2 complex transforms and 2 window conversions per two pairs, where the per-pair kernel above needs 3 and 4.
+// The only state carried between iterations is the Hermitian half of F_prev (N/2 + 1 complex values per lane), the
+// same 34 registers (N = 32) the per-pair kernel spends on R1, so the budget of 128 VGPRs / 4 waves per SIMD holds.
+// The time axis of a chunk is cut into segments of `seg_len` pairs (odd: seg_len + 1 frames = whole iterations) to
+// have enough jobs; a segment's first iteration has no F_prev and yields one plane.  Which frame a window shares its
+// transforms with depends on where the segment starts, so results are bit-reproducible for a given chunk but differ
+// in the last float32 bit between different chunkings (the per-pair kernel does not; LSPIV_WALK=0 selects it).
+template <typename T, int N, bool WANT_NZ>
+__device__ __forceinline__ void prepare_one(const RowRaw<T, N>& raw, float (&x)[N], int& nonzero, bool& finite,
+                                            bool& dead) {
+  if constexpr (sizeof(T) == 1) {
+    const RowStats st = stats_u8<N>(raw, WANT_NZ, nonzero);
+    center_u8<N>(raw, st.mean, st.inv_std, x);   // max((byte - mean) / std, 0); all zero for a constant window
+    dead = st.inv_std == 0.0f;
+  } else {
+    const float inv = load_center<N>(raw, x, WANT_NZ, nonzero, finite);
+#pragma unroll
+    for (int j = 0; j < N; ++j) x[j] *= inv;
+    dead = inv == 0.0f;
+  }
+}
+
+template <typename T, int N, bool PLANES, bool WANT_NZ>
+__global__ __launch_bounds__(BLOCK, LSPIV_WALK_WAVES) void piv_fft_walk_kernel(PivParams p, uint32_t seg_len,
+                                                                                    uint32_t n_seg) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using G = Geo<N>;
+  constexpr int H = N / 2;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int grp = lane / N;
+  const int lg = lane & (N - 1);
+  float* buf = smem + (wave * G::GROUPS + grp) * G::LDS_JOB;
+  const int partner_byte = ((lane & ~(N - 1)) | ((N - lg) & (N - 1))) << 2;
+  const int lane0_byte = (lane & ~(N - 1)) << 2;
+
+  // XCD-aware block order (block b runs on XCD b % 8): every XCD gets one contiguous range of jobs = whole segments,
+  // so a frame is pulled into one L2 only
+  const uint32_t nb = gridDim.x;
+  const uint32_t q = nb >> 3, r = nb & 7u;
+  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const uint32_t blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  uint32_t job = (blk * WAVES_PER_BLOCK + wave) * G::GROUPS + grp;   // job = segment * n_win + window
+  const bool job_valid = job < n_seg * p.n_win;
+  job = job_valid ? job : n_seg * p.n_win - 1;
+  const uint32_t seg = p.div_nwin.div(job);
+  const uint32_t win = job - seg * p.n_win;
+  const uint32_t p0 = seg * seg_len;
+  const uint32_t p1 = min(p0 + seg_len, p.n_pairs);                  // pairs [p0, p1) = frames p0 .. p1
+  const uint32_t wrow = p.div_ncols.div(win);
+  const uint32_t wcol = win - wrow * (uint32_t)p.n_cols;
+  const T* row = static_cast<const T*>(p.frames) + ((int64_t)p0 * p.H + (int64_t)(wrow * p.sy + lg)) * p.W +
+                 (int64_t)wcol * p.sx;
+  constexpr float kScale = 1.0f / (4.0f * (float)G::NN * (float)G::NN);
+  const float nanv = __builtin_nanf("");
+
+  float fpr[H + 1], fpi[H + 1];      // 2 F_prev, ky = 0 .. N/2
+#pragma unroll
+  for (int ky = 0; ky <= H; ++ky) fpr[ky] = fpi[ky] = 0.0f;
+  bool prev_dead = true, prev_finite = true;
+  int prev_nz = G::NN;
+
+  for (uint32_t f = p0; f <= p1; f += 2, row += 2 * p.frame_elems) {
+    const bool has2 = f + 1 <= p1;
+    float xr[N], xi[N];
+    bool dead0, dead1, fin0 = true, fin1 = true;
+    int nz0 = G::NN, nz1 = G::NN;
+    {
+      RowRaw<T, N> raw0, raw1;
+      raw0.fetch(row);
+      raw1.fetch(has2 ? row + p.frame_elems : row);
+      prepare_one<T, N, WANT_NZ>(raw0, xr, nz0, fin0, dead0);
+      prepare_one<T, N, WANT_NZ>(raw1, xi, nz1, fin1, dead1);
+    }
+    fft_n<false>(xr, xi);              // along x
+    transpose2<N>(buf, lg, xr, xi);    // lane = kx, regs = y
+    fft_n<false>(xr, xi);              // along y -> Z[ky][kx]
+    // un-pack the two spectra, form both cross spectra and pack them for the shared inverse, one ky at a time (a
+    // step only touches registers ky and N - ky of this lane and of the mirrored lane, so it can run in place)
+#pragma unroll
+    for (int ky = 0; ky <= H; ++ky) {
+      const int kn = (N - ky) & (N - 1);
+      const float mr = bperm_f(partner_byte, xr[kn]);
+      const float mi = bperm_f(partner_byte, xi[kn]);
+      const float pr = (xr[ky] + mr) * kScale, pi = (xi[ky] - mi) * kScale;   // 2 F_f / (4 N^4)
+      const float qr = xi[ky] + mi, qi = mr - xr[ky];                         // 2 F_{f+1}
+      const float ar = fpr[ky] * pr + fpi[ky] * pi, ai = fpr[ky] * pi - fpi[ky] * pr;   // conj(F_prev) P
+      const float br = pr * qr + pi * qi, bi = pr * qi - pi * qr;                       // conj(P) Q
+      fpr[ky] = qr;
+      fpi[ky] = qi;
+      xr[ky] = ar - bi;                // (R_a + i R_b)[ky][kx]
+      xi[ky] = ai + br;
+      if (ky >= 1 && ky < H) {         // rows above N/2: conj of (R_a - i R_b) at the mirrored lane
+        xr[kn] = bperm_f(partner_byte, ar + bi);
+        xi[kn] = -bperm_f(partner_byte, ai - br);
+      }
+    }
+    const float mean_a = bperm_f(lane0_byte, xr[0]), mean_b = bperm_f(lane0_byte, xi[0]);   // plane means = DC bins
+    __builtin_amdgcn_sched_barrier(0);
+    fft_n<true>(xr, xi);                 // along ky
+    transpose2<N>(buf, lg, xr, xi);      // lane = y, regs = kx
+    fft_n<true>(xr, xi);                 // along kx -> c_a + i c_b
+    const bool dead_a = prev_dead || dead0, dead_b = dead0 || dead1;
+    const float hi_a = dead_a ? 0.0f : 1.0f, hi_b = dead_b ? 0.0f : 1.0f;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      xr[j] = __builtin_amdgcn_fmed3f(xr[j], 0.0f, hi_a);
+      xi[j] = __builtin_amdgcn_fmed3f(xi[j], 0.0f, hi_b);
+    }
+    bool skip_a = !(prev_finite && fin0), skip_b = !(fin0 && fin1);
+    if (WANT_NZ) {
+      skip_a = skip_a || below_threshold<N>(prev_nz, nz0, p.signal_threshold);
+      skip_b = skip_b || below_threshold<N>(nz0, nz1, p.signal_threshold);
+    }
+    const bool valid_a = job_valid && f > p0, valid_b = job_valid && has2;
+    {
+      float row_max, u, v;
+      const float vmax = plane_max<N>(xr, row_max);
+      find_peak<N>(buf, lg, xr, vmax, row_max, u, v);
+      float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean_a);
+      if (skip_a) u = v = cm = sn = nanv;
+      if (valid_a && lg == 0) {
+        const uint32_t g = (f - 1) * p.n_win + win;
+        p.u[g] = u; p.v[g] = v; p.cmax[g] = cm; p.s2n[g] = sn;
+      }
+    }
+    {
+      float row_max, u, v;
+      const float vmax = plane_max<N>(xi, row_max);
+      find_peak<N>(buf, lg, xi, vmax, row_max, u, v);
+      float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean_b);
+      if (skip_b) u = v = cm = sn = nanv;
+      if (valid_b && lg == 0) {
+        const uint32_t g = f * p.n_win + win;
+        p.u[g] = u; p.v[g] = v; p.cmax[g] = cm; p.s2n[g] = sn;
+      }
+    }
+    if constexpr (PLANES) {
+      if (valid_a) store_plane_rows<N>(p.planes + ((size_t)(f - 1) * p.n_win + win) * G::NN, lg, xr, skip_a);
+      if (valid_b) store_plane_rows<N>(p.planes + ((size_t)f * p.n_win + win) * G::NN, lg, xi, skip_b);
+    }
+    prev_dead = dead1; prev_finite = fin1; prev_nz = nz1;
   }
 }
 
@@ -928,6 +1084,26 @@ static hipError_t launch_t(const PivParams& p, bool ensemble, hipStream_t s) {
     const uint32_t jobs = p.n_win;
     const uint32_t blocks = (jobs + jobs_per_block - 1) / jobs_per_block;
     hipLaunchKernelGGL((piv_fft_ensemble_kernel<T, N, WANT_NZ>), dim3(blocks), dim3(BLOCK), G::LDS_BYTES, s, p);
+    return hipGetLastError();
+  }
+  // LSPIV_WALK: 0 = per-pair kernel; unset / 1 = time-walking kernel for 32 x 32 windows with segments sized to keep
+  // >= ~4 jobs per half-wave slot of the chip; n > 1 = segments of n pairs (odd values waste no half iteration)
+  const char* walk_env = getenv("LSPIV_WALK");   // read per launch: tests switch kernels inside one process
+  const int walk = walk_env ? atoi(walk_env) : 1;
+  if (N == 32 && walk != 0 && p.n_pairs >= 3) {
+    uint32_t seg_len = walk > 1 ? (uint32_t)walk : 31;
+    if (walk == 1) {
+      const uint64_t want_jobs = 4ull * 8192ull;
+      while (seg_len > 3 && (uint64_t)p.n_win * ((p.n_pairs + seg_len - 1) / seg_len) < want_jobs) seg_len -= 2;
+    }
+    seg_len = std::min(seg_len, p.n_pairs);
+    const uint32_t n_seg = (p.n_pairs + seg_len - 1) / seg_len;
+    const uint64_t wjobs = (uint64_t)n_seg * p.n_win;
+    const uint32_t wblocks = (uint32_t)((wjobs + jobs_per_block - 1) / jobs_per_block);
+    if (p.planes)
+      hipLaunchKernelGGL((piv_fft_walk_kernel<T, N, true, WANT_NZ>), dim3(wblocks), dim3(BLOCK), G::LDS_BYTES, s, p, seg_len, n_seg);
+    else
+      hipLaunchKernelGGL((piv_fft_walk_kernel<T, N, false, WANT_NZ>), dim3(wblocks), dim3(BLOCK), G::LDS_BYTES, s, p, seg_len, n_seg);
     return hipGetLastError();
   }
   const uint32_t jobs = p.n_pairs * ((p.n_win + 1) / 2);

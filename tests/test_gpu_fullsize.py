@@ -13,6 +13,7 @@ import pytest
 
 from oracle import c_oracle
 from pyorc_amd import _lib, window
+from tests.conftest import assert_chunk_close
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -82,7 +83,7 @@ def test_config2_1080p_1000_pairs(gpu):
         check_sample(st, out, ws, ov, starts=[0, 499, 998])                     # oracle on a spread sample
         for first, n in ((0, 334), (333, 334), (666, 335)):                     # time chunks with a 1-frame halo
             part = st.run(ws, ov, first=first, n_frames=n)
-            assert np.array_equal(part, out[:, first:first + n - 1], equal_nan=True)
+            assert_chunk_close(part, out[:, first:first + n - 1])
         u = out[0]
         assert 2.5 < np.nanmedian(u) < 3.5 and np.isnan(u).mean() < 0.05       # flow 3 + 2 sin(.) px/frame
     finally:
@@ -108,7 +109,7 @@ def test_config4_4k(gpu):
         out = st.run(ws, ov)
         assert out.shape == (4, 100, 134, 239)
         check_sample(st, out, ws, ov, starts=[0, 98])
-        assert np.array_equal(out[:, 50:75], st.run(ws, ov, first=50, n_frames=26), equal_nan=True)
+        assert_chunk_close(st.run(ws, ov, first=50, n_frames=26), out[:, 50:75])
     finally:
         st.free()
 
@@ -141,8 +142,9 @@ def test_config1_ngwerere_geometry(gpu):
     assert ds["v_x"].shape == (20, 48, 53) and np.array_equal(ds.coords["time"], t[1:])
     assert np.array_equal(ds.coords["x"], np.arange(875)[16::16][:53])
     whole = F.get_piv(fr, 32, time=t, resolution=0.01)
-    for k in ds:
-        assert np.array_equal(ds[k], whole[k], equal_nan=True)
+    scale = 0.01 * 30.0                                                           # px/frame -> m/s
+    assert_chunk_close([ds["v_x"] / scale, ds["v_y"] / scale, ds["corr"], ds["s2n"]],
+                       [whole["v_x"] / scale, whole["v_y"] / scale, whole["corr"], whole["s2n"]])
     uo, vo, cmo, sno, cond = c_oracle.piv_pairs(fr, (32, 32), (16, 16), return_cond=True)
     ok = c_oracle.well_posed(cond)
     assert ok.mean() > 0.9

@@ -9,6 +9,8 @@ north star prescribes; the oracle is float64.
 import ctypes as C
 import os
 
+import warnings
+
 import numpy as np
 import pytest
 
@@ -136,7 +138,7 @@ def test_extreme_overlaps(gpu, ws, ov, shape):
     check_against_oracle(fr, ws, ov, min_ok=0.2)
 
 
-def test_input_layouts_and_dtypes(gpu):
+def test_input_layouts_and_dtypes(gpu, per_pair_kernel):
     """Whatever numpy hands over: non-contiguous views, Fortran order, small integer types, bool, T = 2."""
     import pyorc_amd
 
@@ -246,7 +248,7 @@ def test_fused_results_equal_two_step_results(gpu):
 
 
 # ------------------------------------------------------------------ get_ffpiv / get_piv -------------
-def test_get_ffpiv_timestep_chunking_is_bit_identical(gpu):
+def test_get_ffpiv_timestep_chunking_is_bit_identical(gpu, per_pair_kernel):
     from pyorc_amd import frames as F
 
     fr = particle_stack(9, 128, 160, seed=31)
@@ -266,6 +268,30 @@ def test_get_ffpiv_timestep_chunking_is_bit_identical(gpu):
     floor = 0.05 * 0.01 * 30  # 0.05 px in m/s
     for k in ("v_x", "v_y"):
         assert rel_err(whole[k], ref[k].astype(np.float64), floor=floor) <= TOL
+
+
+def test_get_ffpiv_timestep_chunking_default_kernel(gpu):
+    """Same as above with the default time-walking kernel: chunkings agree to float32 rounding, every chunking agrees
+    with the oracle, and a rerun of the same chunking is bit-identical."""
+    from pyorc_amd import frames as F
+    from tests.conftest import assert_chunk_close
+
+    fr = particle_stack(24, 128, 160, seed=32)
+    t = np.arange(24) / 30.0
+    whole = F.get_piv(fr, 32, time=t, resolution=0.01)
+    again = F.get_piv(fr, 32, time=t, resolution=0.01)
+    ref = po.get_ffpiv(fr, np.diff(t), (32, 32), (16, 16), 0.01, 0.01)
+    sc = 0.01 * 30.0
+    as4 = lambda d: [np.asarray(d["v_x"]) / sc, np.asarray(d["v_y"]) / sc, d["corr"], d["s2n"]]
+    for k in whole:
+        assert np.array_equal(whole[k], again[k], equal_nan=True)
+        assert np.array_equal(np.isnan(whole[k]), np.isnan(ref[k]))
+    assert rel_err(whole["corr"], ref["corr"].astype(np.float64)) <= TOL and rel_err(whole["s2n"], ref["s2n"].astype(np.float64)) <= TOL
+    for cs in (2, 3, 5, 8, 13):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            part = F.get_piv(fr, 32, time=t, resolution=0.01, chunksize=cs)
+        assert_chunk_close(as4(part), as4(whole))
 
 
 @pytest.mark.parametrize("kw", [dict(corr_min=0.0, s2n_min=0.0, count_min=0.0), dict(), dict(corr_min=0.5, s2n_min=4.0),
@@ -303,7 +329,7 @@ def test_ensemble_other_window_size(gpu, n, T):
     assert rel_err(got["v_x"], ref["v_x"].astype(np.float64)) <= 2e-4 and rel_err(got["v_y"], ref["v_y"].astype(np.float64)) <= 2e-4
 
 
-def test_pipelined_upload_equals_single_batch(gpu, monkeypatch):
+def test_pipelined_upload_equals_single_batch(gpu, monkeypatch, per_pair_kernel):
     """Host entry point: staging the stack in sub-batches of frames (two pinned slots, compute overlapped with
     the next DMA) must equal one batch bit for bit, for every batch geometry including 1 frame per batch."""
     import pyorc_amd
