@@ -683,7 +683,7 @@ __device__ __forceinline__ void prepare_one(const RowRaw<T, N>& raw, float (&x)[
 }
 
 template <typename T, int N, bool PLANES, bool WANT_NZ>
-__global__ __launch_bounds__(BLOCK, LSPIV_WALK_WAVES) void piv_fft_walk_kernel(PivParams p, uint32_t seg_len,
+__global__ __launch_bounds__(BLOCK, (N == 32 && sizeof(T) < 8 ? LSPIV_WALK_WAVES : 2)) void piv_fft_walk_kernel(PivParams p, uint32_t seg_len,
                                                                                     uint32_t n_seg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using G = Geo<N>;
@@ -1090,8 +1090,8 @@ static hipError_t launch_t(const PivParams& p, bool ensemble, hipStream_t s) {
   // >= ~4 jobs per half-wave slot of the chip; n > 1 = segments of n pairs (odd values waste no half iteration)
   const char* walk_env = getenv("LSPIV_WALK");   // read per launch: tests switch kernels inside one process
   const int walk = walk_env ? atoi(walk_env) : 1;
-  if (N == 32 && walk != 0 && p.n_pairs >= 3) {
-    uint32_t seg_len = walk > 1 ? (uint32_t)walk : 31;
+  if (walk != 0 && p.n_pairs >= 3) {
+    uint32_t seg_len = walk > 1 ? (uint32_t)walk : 63;
     if (walk == 1) {
       const uint64_t want_jobs = 4ull * 8192ull;
       while (seg_len > 3 && (uint64_t)p.n_win * ((p.n_pairs + seg_len - 1) / seg_len) < want_jobs) seg_len -= 2;
