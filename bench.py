@@ -47,24 +47,26 @@ def parse():
     return ap.parse_args()
 
 
-def measured_traffic(kernel_substr: str, pairs: int, H: int, W: int):
+def measured_traffic(kernel_substr: str, pairs: int, H: int, W: int, window_size: int, overlap: int):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_summary.json,
     written by tools/summarize_profile.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this very
-    command).  Only returned when the profiled launch had the same shape; otherwise null."""
+    command).  Only returned when the profiled launch had the same shape and kernel (latest summary wins); otherwise
+    null."""
     import glob
 
     best = None
+    want = {"pairs": pairs, "H": H, "W": W, "window": window_size, "overlap": overlap}
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
+        launch = d.get("launch", {"pairs": 1000, "H": 1080, "W": 1920, "window": 32, "overlap": 16})
+        if launch != want:
+            continue
         for name, k in d.get("kernels", {}).items():
             if kernel_substr in name and "hbm_traffic_bytes" in k:
-                # WRITE_SIZE is exactly the result block: use it to check the profiled shape matches this run
-                nr, nc = window.get_array_shape((H, W), (32, 32), (16, 16))
-                if abs(k["hbm_write_bytes"] - 16.0 * pairs * nr * nc) < 0.01 * k["hbm_write_bytes"]:
-                    best = {"bytes": round(k["hbm_traffic_bytes"]), "source": os.path.basename(f)}
+                best = {"bytes": round(k["hbm_traffic_bytes"]), "source": os.path.basename(f)}
     return best
 
 
@@ -225,6 +227,9 @@ def main():
         return
 
     b_alg_pair = 2 * H * W * 1 + 16 * n_win  # both frames read once + 4 f32 per window
+    # the kernel the library dispatches this shape to (pyorc_amd/csrc/piv_fft_impl.h, launch_t): time-walking by default
+    walking = os.environ.get("LSPIV_WALK", "1") != "0" and a.window in (32, 64) and a.pairs >= 3
+    kernel_name = f"piv_fft_{'walk_' if walking else ''}kernel<unsigned char, {a.window}, false, false>"
     achieved = b_alg_pair * a.pairs / (kernel_ms * 1e-3) / 1e9
     pairs_per_s = world * a.pairs * a.steps / dt
     out = {
@@ -252,7 +257,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": f"piv_fft_kernel<unsigned char, {a.window}, false, false>",
+            "kernel": kernel_name,
             "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -266,7 +271,7 @@ def main():
                           "achieved_tflops": round(0.66e9 * a.pairs / (kernel_ms * 1e-3) / 1e12, 2), "peak_tflops": 157.3},
         },
     }
-    tr = measured_traffic("piv_fft_kernel<unsigned char, 32", a.pairs, H, W) if (a.window, a.overlap) == (32, 16) else None
+    tr = measured_traffic(kernel_name.split(",")[0] + ",", a.pairs, H, W, a.window, a.overlap)
     if tr:
         out["roofline"]["traffic"] = tr["bytes"]
         out["roofline"]["traffic_source"] = f"profiles/{tr['source']} (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"

@@ -14,6 +14,8 @@ import os
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
+# optional: the launch shape the profile was taken on (bench.py defaults), so bench.py can match it: pairs H W window overlap
+shape = [int(x) for x in sys.argv[3:8]] if len(sys.argv) >= 8 else [1000, 1080, 1920, 32, 16]
 acc = collections.defaultdict(list)
 for f in glob.glob(os.path.join(src, "pmc_*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
@@ -24,7 +26,7 @@ stats = {}
 for r in csv.DictReader(open(os.path.join(src, "trace_kernel_stats.csv"))):
     if "piv_" in r["Name"]:
         stats[r["Name"]] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"])}
-out = {"tag": tag, "source": src, "kernels": {}}
+out = {"tag": tag, "source": src, "launch": dict(zip(("pairs", "H", "W", "window", "overlap"), shape)), "kernels": {}}
 for k in kernels:
     c = {n: sum(v) / len(v) for (kk, n), v in acc.items() if kk == k}
     d = {"counters_mean_per_launch": c, "trace": stats.get(k)}
