@@ -682,6 +682,9 @@ __device__ __forceinline__ void prepare_one(const RowRaw<T, N>& raw, float (&x)[
   }
 }
 
+#ifndef LSPIV_WALK_SB
+#define LSPIV_WALK_SB do { if constexpr (N == 32) __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
 template <typename T, int N, bool PLANES, bool WANT_NZ>
 __global__ __launch_bounds__(BLOCK, (N == 32 && sizeof(T) < 8 ? LSPIV_WALK_WAVES : 2)) void piv_fft_walk_kernel(PivParams p, uint32_t seg_len,
                                                                                     uint32_t n_seg) {
@@ -732,11 +735,16 @@ __global__ __launch_bounds__(BLOCK, (N == 32 && sizeof(T) < 8 ? LSPIV_WALK_WAVES
       raw0.fetch(row);
       raw1.fetch(has2 ? row + p.frame_elems : row);
       prepare_one<T, N, WANT_NZ>(raw0, xr, nz0, fin0, dead0);
+      LSPIV_WALK_SB;
       prepare_one<T, N, WANT_NZ>(raw1, xi, nz1, fin1, dead1);
     }
+    LSPIV_WALK_SB;
     fft_n<false>(xr, xi);              // along x
+    LSPIV_WALK_SB;
     transpose2<N>(buf, lg, xr, xi);    // lane = kx, regs = y
+    LSPIV_WALK_SB;
     fft_n<false>(xr, xi);              // along y -> Z[ky][kx]
+    LSPIV_WALK_SB;
     // un-pack the two spectra, form both cross spectra and pack them for the shared inverse, one ky at a time (a
     // step only touches registers ky and N - ky of this lane and of the mirrored lane, so it can run in place)
 #pragma unroll
@@ -760,8 +768,11 @@ __global__ __launch_bounds__(BLOCK, (N == 32 && sizeof(T) < 8 ? LSPIV_WALK_WAVES
     const float mean_a = bperm_f(lane0_byte, xr[0]), mean_b = bperm_f(lane0_byte, xi[0]);   // plane means = DC bins
     __builtin_amdgcn_sched_barrier(0);
     fft_n<true>(xr, xi);                 // along ky
+    LSPIV_WALK_SB;
     transpose2<N>(buf, lg, xr, xi);      // lane = y, regs = kx
+    LSPIV_WALK_SB;
     fft_n<true>(xr, xi);                 // along kx -> c_a + i c_b
+    LSPIV_WALK_SB;
     const bool dead_a = prev_dead || dead0, dead_b = dead0 || dead1;
     const float hi_a = dead_a ? 0.0f : 1.0f, hi_b = dead_b ? 0.0f : 1.0f;
 #pragma unroll
