@@ -465,3 +465,27 @@ def test_embedded_and_direct_kernels_agree(gpu):
     cond = c_oracle.piv_pairs(particle_stack(3, 90, 120, seed=8, density=0.05), (24, 24), (12, 12), return_cond=True)[-1]
     ok = c_oracle.well_posed(cond, min_neighbour=0.05)
     assert ok.mean() > 0.5 and rel_err(a[0][ok], b[0][ok].astype(np.float64)) <= TOL and rel_err(a[1][ok], b[1][ok].astype(np.float64)) <= TOL
+
+
+@pytest.mark.parametrize("seg,P,ws", [("1", 3, 32), ("1", 4, 32), ("3", 10, 32), ("5", 11, 32), ("7", 23, 32), ("31", 40, 32),
+                                      ("2", 9, 32), ("4", 9, 32), ("3", 7, 64), ("1", 5, 64)])
+def test_walking_kernel_segments_vs_oracle(gpu, monkeypatch, seg, P, ws):
+    """The time-walking kernel under every segment geometry (odd / even segment lengths, a last segment of one pair,
+    an odd frame count) against the oracle: planes, thresholds, an empty frame and a constant corner in the stack."""
+    monkeypatch.setenv("LSPIV_WALK", seg)
+    fr = particle_stack(P + 1, 2 * ws + 9, 3 * ws + 5, seed=7 * P + ws, density=0.05)
+    ov = (ws // 2, ws // 2)
+    check_against_oracle(fr, (ws, ws), ov, min_ok=0.3)
+    f32 = fr.astype(np.float32) * 0.7 - 20.0
+    f32[P // 2] = 3.0                                    # a constant frame: both pairs that touch it are dead
+    f32[:, : ws + 4, : ws + 4] = -1.25                   # a constant corner in every frame
+    check_against_oracle(f32, (ws, ws), ov, thr=0.25, min_ok=0.0)
+    if ws == 32:
+        check_against_oracle(fr.astype(np.float64) - 3.0, (ws, ws), (20, 7), min_ok=0.2)
+    monkeypatch.setenv("LSPIV_WALK", "0")                # and the per-pair kernel agrees to rounding
+    import pyorc_amd
+    from tests.conftest import assert_chunk_close
+
+    ref = pyorc_amd.piv_pairs(fr, (ws, ws), ov)
+    monkeypatch.setenv("LSPIV_WALK", seg)
+    assert_chunk_close(pyorc_amd.piv_pairs(fr, (ws, ws), ov), ref)

@@ -15,7 +15,7 @@ for case in range(n_cases):
     ws = int(rng.choice([32, 32, 32, 64, 64, 16, 24, 10, 48]))
     wsy = ws if rng.random() < 0.8 else int(rng.choice([8, 16, 20, 32]))
     ov = (int(rng.integers(0, wsy)), int(rng.integers(0, ws)))
-    H = int(rng.integers(wsy, wsy * 4 + 7)); W = int(rng.integers(ws, ws * 5 + 9)); T = int(rng.integers(2, 6))
+    H = int(rng.integers(wsy, wsy * 4 + 7)); W = int(rng.integers(ws, ws * 5 + 9)); T = int(rng.integers(2, 6)) if rng.random() < 0.6 else int(rng.integers(6, 14))
     dtype = rng.choice([np.uint8, np.float32, np.float64])
     thr = None if rng.random() < 0.6 else float(rng.uniform(0, 0.6))
     fr = particle_stack(T, H, W, seed=int(rng.integers(1 << 30)), density=float(rng.uniform(0.01, 0.08)))
