@@ -121,3 +121,34 @@ def make_projection_golden():
 
 if __name__ == "__main__":
     make_projection_golden()
+
+
+def make_rows_golden():
+    """rows_golden.npz: small inputs + the oracles' outputs for the section-8(f) rows N2 (filters) and N3 (masks)."""
+    from oracle import filters_oracle as fo
+    from oracle import mask_oracle as mo
+
+    rng = np.random.default_rng(21)
+    fr = rng.integers(0, 256, (5, 18, 23)).astype(np.uint8)
+    out = {"frames": fr,
+           "normalize_2": fo.normalize(fr, 2), "time_diff": fo.time_diff(fr, thres=3.0, abs=True),
+           "minmax": fo.minmax(fo.time_diff(fr), -20.0, 35.0),
+           "smooth_1": fo.smooth(fr, 1), "smooth_4": fo.smooth(fr, 4), "edge_1_2": fo.edge_detect(fr, 1, 2),
+           "edge_2_6": fo.edge_detect(fr.astype(np.float32) * 0.5 - 30.0, 2, 6)}
+    f = np.empty((4, 9, 7, 8), np.float32)
+    f[0] = rng.normal(0.6, 0.5, f.shape[1:]); f[1] = rng.normal(-0.1, 0.3, f.shape[1:])
+    f[2] = rng.random(f.shape[1:]); f[3] = rng.random(f.shape[1:]) * 30
+    f[:, rng.random(f.shape[1:]) < 0.15] = np.nan
+    f[:, :, 0, 0] = np.nan
+    out["fields"] = f
+    for name, kw in (("minmax", {}), ("angle", {}), ("count", {}), ("corr", dict(tolerance=0.3)), ("s2n", {}),
+                     ("outliers", dict(tolerance=0.8, mode="and")), ("variance", {}), ("rolling", dict(wdw=4, tolerance=0.6)),
+                     ("window_nan", dict(wdw=1)), ("window_mean", dict(wdw=2, tolerance=0.5, mode="and"))):
+        out["mask_" + name] = getattr(mo, name)(f, **kw)
+    out["window_replace"] = mo.window_replace(f, wdw=1, iter=2)
+    out["time_mean"] = mo.time_mean(f)
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "rows_golden.npz"), **out)
+
+
+if __name__ == "__main__":
+    make_rows_golden()

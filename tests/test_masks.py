@@ -170,3 +170,26 @@ def test_gpu_device_chain_scale_mask_apply_pack(gpu):
     for d in (d_f, d_m, d_p):
         lib.lspiv_dev_free(d)
     assert np.array_equal(pk, po.encode_int16(g)) and (pk != -9999).any()
+
+
+@pytest.mark.gpu
+def test_gpu_rows_golden_filters_and_masks(gpu):
+    """HIP results against the committed fixture tests/golden/rows_golden.npz (inputs + oracle outputs of N2 / N3)."""
+    import os
+
+    from pyorc_amd import filters
+    from pyorc_amd import mask as pm
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rows_golden.npz"))
+    fr, f = g["frames"], g["fields"]
+    eq = lambda a, b: np.array_equal(a, b, equal_nan=True)
+    assert eq(filters.normalize(fr, 2), g["normalize_2"]) and eq(filters.time_diff(fr, thres=3.0, abs=True), g["time_diff"])
+    assert eq(filters.minmax(filters.time_diff(fr), -20.0, 35.0), g["minmax"])
+    for got, key in ((filters.smooth(fr, 1), "smooth_1"), (filters.smooth(fr, 4), "smooth_4"),
+                     (filters.edge_detect(fr, 1, 2), "edge_1_2"), (filters.edge_detect(fr.astype(np.float32) * 0.5 - 30.0, 2, 6), "edge_2_6")):
+        assert np.abs(got - g[key]).max() <= 4e-6 * 255
+    for name, params in (("minmax", [0.1, 5.0]), ("count", [0.33]), ("corr", [0.3]), ("s2n", [10]), ("outliers", [0.8, 1]),
+                         ("variance", [5, 1]), ("rolling", [4, 0.6]), ("window_nan", [0.7, -1, 1, -1, 1]),
+                         ("window_mean", [0.5, 1, -2, 2, -2, 2])):
+        assert eq(pm.run_mask(f, name, params), g["mask_" + name]), name
+    assert eq(pm.time_mean(f), g["time_mean"])

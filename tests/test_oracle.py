@@ -200,3 +200,22 @@ def test_config1_ngwerere_geometry_cpu_plumbing():
     assert ok.mean() > 0.95 and np.abs(ref["v_x"][ok] - vx[ok]).max() < 1e-4
     ut, _ = flow_field(785, 875, (np.arange(48)[:, None] * 16 + 16.0), (np.arange(53)[None, :] * 16 + 16.0))
     assert np.nanmedian(np.abs(u[0] - ut)) < 0.15
+
+
+def test_rows_golden_pins_filter_and_mask_oracles():
+    """tests/golden/rows_golden.npz freezes the N2 / N3 oracles (regenerate with tests/golden/make_golden.py)."""
+    from oracle import filters_oracle as fo
+    from oracle import mask_oracle as mo
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rows_golden.npz"))
+    fr, f = g["frames"], g["fields"]
+    eq = lambda a, b: np.array_equal(a, b, equal_nan=True)
+    assert eq(fo.normalize(fr, 2), g["normalize_2"]) and eq(fo.time_diff(fr, thres=3.0, abs=True), g["time_diff"])
+    assert eq(fo.minmax(fo.time_diff(fr), -20.0, 35.0), g["minmax"])
+    assert eq(fo.smooth(fr, 1), g["smooth_1"]) and eq(fo.smooth(fr, 4), g["smooth_4"])
+    assert eq(fo.edge_detect(fr, 1, 2), g["edge_1_2"]) and eq(fo.edge_detect(fr.astype(np.float32) * 0.5 - 30.0, 2, 6), g["edge_2_6"])
+    for name, kw in (("minmax", {}), ("angle", {}), ("count", {}), ("corr", dict(tolerance=0.3)), ("s2n", {}),
+                     ("outliers", dict(tolerance=0.8, mode="and")), ("variance", {}), ("rolling", dict(wdw=4, tolerance=0.6)),
+                     ("window_nan", dict(wdw=1)), ("window_mean", dict(wdw=2, tolerance=0.5, mode="and"))):
+        assert eq(getattr(mo, name)(f, **kw), g["mask_" + name]), name
+    assert eq(mo.window_replace(f, wdw=1, iter=2), g["window_replace"]) and eq(mo.time_mean(f), g["time_mean"])
