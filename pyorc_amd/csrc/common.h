@@ -62,6 +62,10 @@ struct PivParams {
   float corr_min, s2n_min;
   float* corr_sum;         // n_win * wy * wx
   float* corr_count;       // n_win
+  // walking ensemble kernels: per-segment partial sums / counts (zeroed by the caller), merged in segment order
+  float* part_sum;         // n_seg * n_win * wy * wx, or nullptr: the single-owner kernels
+  float* part_cnt;         // n_seg * n_win
+  uint32_t seg_len, n_seg; // pairs per segment (odd), number of segments
   uint32_t n_pairs;        // T-1
   FastDiv div_ncols;       // window index -> (row, col)
   FastDiv div_jobs;        // fft kernels: job index -> (pair, job in pair), divisor (n_win + 1) / 2
@@ -178,6 +182,20 @@ hipError_t launch_piv_embed64(const PivParams& p, int dtype, bool ensemble, hipS
 hipError_t launch_peaks_from_planes(const float* planes, uint32_t n_planes, int wy, int wx,
                                     float* u, float* v, hipStream_t s);
 // mean[w][o] = count[w] < min_count ? NaN : sum[w][o] / count[w]   (pyorc/velocimetry/ffpiv.py:280-282)
+// segments of the walking ENSEMBLE kernels: enough jobs for ~3 rounds of the chip, segments of an odd number of pairs
+inline void ensemble_segments(uint32_t n_win, uint32_t n_pairs, int window, uint32_t* seg_len, uint32_t* n_seg) {
+  const uint32_t slots = window == 32 ? 6144u : 2048u;   // half-wave jobs at 3 waves/SIMD; wave jobs at 2
+  uint32_t want = (3u * slots + n_win - 1) / n_win;
+  if (want < 1) want = 1;
+  uint32_t len = (n_pairs + want - 1) / want;
+  if (len < 3) len = 3;
+  len |= 1u;
+  if (len > n_pairs) len = n_pairs;
+  *seg_len = len;
+  *n_seg = (n_pairs + len - 1) / len;
+}
+hipError_t launch_ensemble_merge(const float* part_sum, const float* part_cnt, uint32_t n_seg, uint32_t n_win, int plane_elems,
+                                 float* corr_sum, float* corr_count, hipStream_t s);
 hipError_t launch_ensemble_mean(const float* sum, const float* count, float min_count, uint32_t n_win,
                                 int plane_elems, float* mean, hipStream_t s);
 // orthoprojection gather (project.hip) and int16 result packing

@@ -212,6 +212,8 @@ struct lspiv_ensemble {
   int device;
   float* d_sum;    // n_win * wy * wx
   float* d_count;  // n_win
+  float* d_part;   // walking kernels: per-segment partial sums + counts (grow-only workspace)
+  size_t part_cap;
 };
 
 extern "C" {
@@ -455,7 +457,20 @@ int lspiv_ensemble_accumulate_dev(lspiv_ensemble* h, const void* d_frames, int d
   p.s2n_min = s2n_min;
   p.corr_sum = h->d_sum;
   p.corr_count = h->d_count;
-  return dispatch(p, dtype, true, stream ? (hipStream_t)stream : c->stream);
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  const int kind = lspiv_kernel_kind(h->wy, h->wx);
+  const char* walk_env = getenv("LSPIV_WALK");
+  if ((kind == 1 || kind == 2) && !(walk_env && atoi(walk_env) == 0) && p.n_pairs >= 3) {
+    lspiv::ensemble_segments(p.n_win, p.n_pairs, h->wy, &p.seg_len, &p.n_seg);
+    const size_t plane = (size_t)h->wy * h->wx;
+    const size_t need = (size_t)p.n_seg * p.n_win * (plane + 1) * sizeof(float);
+    rc = ensure(&h->d_part, &h->part_cap, need);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(h->d_part, 0, need, s));
+    p.part_sum = h->d_part;
+    p.part_cnt = h->d_part + (size_t)p.n_seg * p.n_win * plane;
+  }
+  return dispatch(p, dtype, true, s);
 }
 
 int lspiv_ensemble_accumulate(lspiv_ensemble* h, const void* frames, int dtype, int64_t T, float corr_min,
@@ -545,6 +560,7 @@ int lspiv_ensemble_destroy(lspiv_ensemble* h) {
   if (!h) return LSPIV_OK;
   if (h->d_sum) hipFree(h->d_sum);
   if (h->d_count) hipFree(h->d_count);
+  if (h->d_part) hipFree(h->d_part);
   delete h;
   return LSPIV_OK;
 }

@@ -685,12 +685,96 @@ __device__ __forceinline__ void prepare_one(const RowRaw<T, N>& raw, float (&x)[
 #ifndef LSPIV_WALK_SB
 #define LSPIV_WALK_SB do { if constexpr (N == 32) __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif
+
+// what a walking job carries from one iteration to the next
+template <int N>
+struct WalkCarry {
+  float fpr[N / 2 + 1], fpi[N / 2 + 1];   // 2 F_prev, ky = 0 .. N/2
+  bool prev_dead, prev_finite;
+  int prev_nz;
+  __device__ __forceinline__ void reset() {
+#pragma unroll
+    for (int ky = 0; ky <= N / 2; ++ky) fpr[ky] = fpi[ky] = 0.0f;
+    prev_dead = true; prev_finite = true; prev_nz = N * N;
+  }
+};
+
+// One iteration: rows of frames f (and f + 1 when `has2`) of the job's window -> clipped planes xr (pair f-1) and xi
+// (pair f), their means (DC bins) and NaN flags; the carry moves on to frame f + 1.
+template <typename T, int N, bool WANT_NZ>
+__device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row, bool has2, float* buf, int lg,
+                                               int partner_byte, int lane0_byte, WalkCarry<N>& c, float (&xr)[N],
+                                               float (&xi)[N], float& mean_a, float& mean_b, bool& skip_a, bool& skip_b) {
+  using G = Geo<N>;
+  constexpr int H = N / 2;
+  constexpr float kScale = 1.0f / (4.0f * (float)G::NN * (float)G::NN);
+  bool dead0, dead1, fin0 = true, fin1 = true;
+  int nz0 = G::NN, nz1 = G::NN;
+  {
+    RowRaw<T, N> raw0, raw1;
+    raw0.fetch(row);
+    raw1.fetch(has2 ? row + p.frame_elems : row);
+    prepare_one<T, N, WANT_NZ>(raw0, xr, nz0, fin0, dead0);
+    LSPIV_WALK_SB;
+    prepare_one<T, N, WANT_NZ>(raw1, xi, nz1, fin1, dead1);
+  }
+  LSPIV_WALK_SB;
+  fft_n<false>(xr, xi);              // along x
+  LSPIV_WALK_SB;
+  transpose2<N>(buf, lg, xr, xi);    // lane = kx, regs = y
+  LSPIV_WALK_SB;
+  fft_n<false>(xr, xi);              // along y -> Z[ky][kx]
+  LSPIV_WALK_SB;
+  // un-pack the two spectra, form both cross spectra and pack them for the shared inverse, one ky at a time (a
+  // step only touches registers ky and N - ky of this lane and of the mirrored lane, so it can run in place)
+#pragma unroll
+  for (int ky = 0; ky <= H; ++ky) {
+    const int kn = (N - ky) & (N - 1);
+    const float mr = bperm_f(partner_byte, xr[kn]);
+    const float mi = bperm_f(partner_byte, xi[kn]);
+    const float pr = (xr[ky] + mr) * kScale, pi = (xi[ky] - mi) * kScale;   // 2 F_f / (4 N^4)
+    const float qr = xi[ky] + mi, qi = mr - xr[ky];                         // 2 F_{f+1}
+    const float ar = c.fpr[ky] * pr + c.fpi[ky] * pi, ai = c.fpr[ky] * pi - c.fpi[ky] * pr;   // conj(F_prev) P
+    const float br = pr * qr + pi * qi, bi = pr * qi - pi * qr;                               // conj(P) Q
+    c.fpr[ky] = qr;
+    c.fpi[ky] = qi;
+    xr[ky] = ar - bi;                // (R_a + i R_b)[ky][kx]
+    xi[ky] = ai + br;
+    if (ky >= 1 && ky < H) {         // rows above N/2: conj of (R_a - i R_b) at the mirrored lane
+      xr[kn] = bperm_f(partner_byte, ar + bi);
+      xi[kn] = -bperm_f(partner_byte, ai - br);
+    }
+  }
+  mean_a = bperm_f(lane0_byte, xr[0]);   // plane means = DC bins
+  mean_b = bperm_f(lane0_byte, xi[0]);
+  __builtin_amdgcn_sched_barrier(0);
+  fft_n<true>(xr, xi);                 // along ky
+  LSPIV_WALK_SB;
+  transpose2<N>(buf, lg, xr, xi);      // lane = y, regs = kx
+  LSPIV_WALK_SB;
+  fft_n<true>(xr, xi);                 // along kx -> c_a + i c_b
+  LSPIV_WALK_SB;
+  const bool dead_a = c.prev_dead || dead0, dead_b = dead0 || dead1;
+  const float hi_a = dead_a ? 0.0f : 1.0f, hi_b = dead_b ? 0.0f : 1.0f;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    xr[j] = __builtin_amdgcn_fmed3f(xr[j], 0.0f, hi_a);
+    xi[j] = __builtin_amdgcn_fmed3f(xi[j], 0.0f, hi_b);
+  }
+  skip_a = !(c.prev_finite && fin0);
+  skip_b = !(fin0 && fin1);
+  if (WANT_NZ) {
+    skip_a = skip_a || below_threshold<N>(c.prev_nz, nz0, p.signal_threshold);
+    skip_b = skip_b || below_threshold<N>(nz0, nz1, p.signal_threshold);
+  }
+  c.prev_dead = dead1; c.prev_finite = fin1; c.prev_nz = nz1;
+}
+
 template <typename T, int N, bool PLANES, bool WANT_NZ>
 __global__ __launch_bounds__(BLOCK, (N == 32 && sizeof(T) < 8 ? LSPIV_WALK_WAVES : 2)) void piv_fft_walk_kernel(PivParams p, uint32_t seg_len,
                                                                                     uint32_t n_seg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using G = Geo<N>;
-  constexpr int H = N / 2;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int grp = lane / N;
@@ -716,75 +800,15 @@ __global__ __launch_bounds__(BLOCK, (N == 32 && sizeof(T) < 8 ? LSPIV_WALK_WAVES
   const uint32_t wcol = win - wrow * (uint32_t)p.n_cols;
   const T* row = static_cast<const T*>(p.frames) + ((int64_t)p0 * p.H + (int64_t)(wrow * p.sy + lg)) * p.W +
                  (int64_t)wcol * p.sx;
-  constexpr float kScale = 1.0f / (4.0f * (float)G::NN * (float)G::NN);
   const float nanv = __builtin_nanf("");
 
-  float fpr[H + 1], fpi[H + 1];      // 2 F_prev, ky = 0 .. N/2
-#pragma unroll
-  for (int ky = 0; ky <= H; ++ky) fpr[ky] = fpi[ky] = 0.0f;
-  bool prev_dead = true, prev_finite = true;
-  int prev_nz = G::NN;
-
+  WalkCarry<N> carry;
+  carry.reset();
   for (uint32_t f = p0; f <= p1; f += 2, row += 2 * p.frame_elems) {
     const bool has2 = f + 1 <= p1;
-    float xr[N], xi[N];
-    bool dead0, dead1, fin0 = true, fin1 = true;
-    int nz0 = G::NN, nz1 = G::NN;
-    {
-      RowRaw<T, N> raw0, raw1;
-      raw0.fetch(row);
-      raw1.fetch(has2 ? row + p.frame_elems : row);
-      prepare_one<T, N, WANT_NZ>(raw0, xr, nz0, fin0, dead0);
-      LSPIV_WALK_SB;
-      prepare_one<T, N, WANT_NZ>(raw1, xi, nz1, fin1, dead1);
-    }
-    LSPIV_WALK_SB;
-    fft_n<false>(xr, xi);              // along x
-    LSPIV_WALK_SB;
-    transpose2<N>(buf, lg, xr, xi);    // lane = kx, regs = y
-    LSPIV_WALK_SB;
-    fft_n<false>(xr, xi);              // along y -> Z[ky][kx]
-    LSPIV_WALK_SB;
-    // un-pack the two spectra, form both cross spectra and pack them for the shared inverse, one ky at a time (a
-    // step only touches registers ky and N - ky of this lane and of the mirrored lane, so it can run in place)
-#pragma unroll
-    for (int ky = 0; ky <= H; ++ky) {
-      const int kn = (N - ky) & (N - 1);
-      const float mr = bperm_f(partner_byte, xr[kn]);
-      const float mi = bperm_f(partner_byte, xi[kn]);
-      const float pr = (xr[ky] + mr) * kScale, pi = (xi[ky] - mi) * kScale;   // 2 F_f / (4 N^4)
-      const float qr = xi[ky] + mi, qi = mr - xr[ky];                         // 2 F_{f+1}
-      const float ar = fpr[ky] * pr + fpi[ky] * pi, ai = fpr[ky] * pi - fpi[ky] * pr;   // conj(F_prev) P
-      const float br = pr * qr + pi * qi, bi = pr * qi - pi * qr;                       // conj(P) Q
-      fpr[ky] = qr;
-      fpi[ky] = qi;
-      xr[ky] = ar - bi;                // (R_a + i R_b)[ky][kx]
-      xi[ky] = ai + br;
-      if (ky >= 1 && ky < H) {         // rows above N/2: conj of (R_a - i R_b) at the mirrored lane
-        xr[kn] = bperm_f(partner_byte, ar + bi);
-        xi[kn] = -bperm_f(partner_byte, ai - br);
-      }
-    }
-    const float mean_a = bperm_f(lane0_byte, xr[0]), mean_b = bperm_f(lane0_byte, xi[0]);   // plane means = DC bins
-    __builtin_amdgcn_sched_barrier(0);
-    fft_n<true>(xr, xi);                 // along ky
-    LSPIV_WALK_SB;
-    transpose2<N>(buf, lg, xr, xi);      // lane = y, regs = kx
-    LSPIV_WALK_SB;
-    fft_n<true>(xr, xi);                 // along kx -> c_a + i c_b
-    LSPIV_WALK_SB;
-    const bool dead_a = prev_dead || dead0, dead_b = dead0 || dead1;
-    const float hi_a = dead_a ? 0.0f : 1.0f, hi_b = dead_b ? 0.0f : 1.0f;
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-      xr[j] = __builtin_amdgcn_fmed3f(xr[j], 0.0f, hi_a);
-      xi[j] = __builtin_amdgcn_fmed3f(xi[j], 0.0f, hi_b);
-    }
-    bool skip_a = !(prev_finite && fin0), skip_b = !(fin0 && fin1);
-    if (WANT_NZ) {
-      skip_a = skip_a || below_threshold<N>(prev_nz, nz0, p.signal_threshold);
-      skip_b = skip_b || below_threshold<N>(nz0, nz1, p.signal_threshold);
-    }
+    float xr[N], xi[N], mean_a, mean_b;
+    bool skip_a, skip_b;
+    walk_iteration<T, N, WANT_NZ>(p, row, has2, buf, lg, partner_byte, lane0_byte, carry, xr, xi, mean_a, mean_b, skip_a, skip_b);
     const bool valid_a = job_valid && f > p0, valid_b = job_valid && has2;
     {
       float row_max, u, v;
@@ -812,7 +836,6 @@ __global__ __launch_bounds__(BLOCK, (N == 32 && sizeof(T) < 8 ? LSPIV_WALK_WAVES
       if (valid_a) store_plane_rows<N>(p.planes + ((size_t)(f - 1) * p.n_win + win) * G::NN, lg, xr, skip_a);
       if (valid_b) store_plane_rows<N>(p.planes + ((size_t)f * p.n_win + win) * G::NN, lg, xi, skip_b);
     }
-    prev_dead = dead1; prev_finite = fin1; prev_nz = nz1;
   }
 }
 
@@ -1087,10 +1110,78 @@ __global__ __launch_bounds__(BLOCK, (kWavesPerSimd<T, N>)) void piv_fft_ensemble
   if (valid && lg == 0) p.corr_count[w] += cnt;
 }
 
+// Walking ENSEMBLE kernel: the same iteration, but the planes are masked (corr_min, s2n_min, finite) and added to the
+// job's partial sum instead of being searched for a peak.  A job = (time segment, window); each segment has its own
+// partial sum in HBM (zeroed by the caller), merged afterwards in segment order (ensemble_merge_kernel): fixed
+// summation order, no atomics, and ~3 rounds of jobs on the chip where one job per window would leave it 2/3 idle.
+template <typename T, int N, bool WANT_NZ>
+__global__ __launch_bounds__(BLOCK, (N == 32 && sizeof(T) < 8 ? LSPIV_WALK_WAVES : 2)) void piv_fft_walk_ensemble_kernel(PivParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using G = Geo<N>;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int grp = lane / N;
+  const int lg = lane & (N - 1);
+  float* buf = smem + (wave * G::GROUPS + grp) * G::LDS_JOB;
+  const int partner_byte = ((lane & ~(N - 1)) | ((N - lg) & (N - 1))) << 2;
+  const int lane0_byte = (lane & ~(N - 1)) << 2;
+  const uint32_t nb = gridDim.x;                                   // XCD-aware block order, as piv_fft_walk_kernel
+  const uint32_t q = nb >> 3, r = nb & 7u;
+  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const uint32_t blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  uint32_t job = (blk * WAVES_PER_BLOCK + wave) * G::GROUPS + grp;   // job = segment * n_win + window
+  const bool job_valid = job < p.n_seg * p.n_win;
+  job = job_valid ? job : p.n_seg * p.n_win - 1;
+  const uint32_t seg = p.div_nwin.div(job);
+  const uint32_t win = job - seg * p.n_win;
+  const uint32_t p0 = seg * p.seg_len;
+  const uint32_t p1 = min(p0 + p.seg_len, p.n_pairs);
+  const uint32_t wrow = p.div_ncols.div(win);
+  const uint32_t wcol = win - wrow * (uint32_t)p.n_cols;
+  const T* row = static_cast<const T*>(p.frames) + ((int64_t)p0 * p.H + (int64_t)(wrow * p.sy + lg)) * p.W +
+                 (int64_t)wcol * p.sx;
+  float* part = p.part_sum + (size_t)job * G::NN;
+  float cnt = 0.0f;
+  WalkCarry<N> carry;
+  carry.reset();
+  for (uint32_t f = p0; f <= p1; f += 2, row += 2 * p.frame_elems) {
+    const bool has2 = f + 1 <= p1;
+    float xr[N], xi[N], mean[2];
+    bool skip[2], keep[2];
+    walk_iteration<T, N, WANT_NZ>(p, row, has2, buf, lg, partner_byte, lane0_byte, carry, xr, xi, mean[0], mean[1], skip[0], skip[1]);
+    const bool valid[2] = {job_valid && f > p0, job_valid && has2};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      float row_max;
+      const float vmax = plane_max<N>(k == 0 ? xr : xi, row_max);
+      float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean[k]);
+      keep[k] = valid[k] && !skip[k] && (cm >= p.corr_min) && (sn >= p.s2n_min);  // NaN s2n compares false
+      cm = keep[k] ? cm : 0.0f;
+      sn = keep[k] ? sn : 0.0f;
+      cnt += (cm > 1e-6f) ? 1.0f : 0.0f;
+      if (valid[k] && lg == 0) {
+        const size_t g = (size_t)(f - 1 + k) * p.n_win + win;
+        p.cmax[g] = cm;
+        p.s2n[g] = sn;
+      }
+    }
+    if (keep[0] || keep[1]) accumulate_planes<N>(part, lg, xr, keep[0], xi, keep[1]);
+  }
+  if (job_valid && lg == 0) p.part_cnt[job] = cnt;
+}
+
 template <typename T, int N, bool WANT_NZ>
 static hipError_t launch_t(const PivParams& p, bool ensemble, hipStream_t s) {
   using G = Geo<N>;
   constexpr uint32_t jobs_per_block = WAVES_PER_BLOCK * G::GROUPS;
+  if (ensemble && p.part_sum) {   // walking ensemble kernel + ordered merge of the per-segment partial sums
+    const uint64_t wjobs = (uint64_t)p.n_seg * p.n_win;
+    hipLaunchKernelGGL((piv_fft_walk_ensemble_kernel<T, N, WANT_NZ>), dim3((uint32_t)((wjobs + jobs_per_block - 1) / jobs_per_block)),
+                       dim3(BLOCK), G::LDS_BYTES, s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_ensemble_merge(p.part_sum, p.part_cnt, p.n_seg, p.n_win, G::NN, p.corr_sum, p.corr_count, s);
+  }
   if (ensemble) {
     const uint32_t jobs = p.n_win;
     const uint32_t blocks = (jobs + jobs_per_block - 1) / jobs_per_block;

@@ -17,6 +17,32 @@ __global__ void ensemble_mean_kernel(const float* sum, const float* count, float
   }
 }
 
+// walking ensemble kernels: corr_sum += part[0] + part[1] + ... in segment (= time) order, counts likewise
+__global__ __launch_bounds__(256) void ensemble_merge_kernel(const float* __restrict__ part_sum, const float* __restrict__ part_cnt,
+                                                             uint32_t n_seg, int64_t n_elems, uint32_t n_win,
+                                                             float* __restrict__ corr_sum, float* __restrict__ corr_count) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n_elems) {
+    float acc = corr_sum[i];
+    for (uint32_t sg = 0; sg < n_seg; ++sg) acc += part_sum[(int64_t)sg * n_elems + i];
+    corr_sum[i] = acc;
+  }
+  if (i < n_win) {
+    float c = corr_count[i];
+    for (uint32_t sg = 0; sg < n_seg; ++sg) c += part_cnt[(int64_t)sg * n_win + i];
+    corr_count[i] = c;
+  }
+}
+
+hipError_t launch_ensemble_merge(const float* part_sum, const float* part_cnt, uint32_t n_seg, uint32_t n_win, int plane_elems,
+                                 float* corr_sum, float* corr_count, hipStream_t s) {
+  const int64_t n_elems = (int64_t)n_win * plane_elems;
+  if (n_elems == 0) return hipSuccess;
+  hipLaunchKernelGGL(ensemble_merge_kernel, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, s, part_sum, part_cnt, n_seg,
+                     n_elems, n_win, corr_sum, corr_count);
+  return hipGetLastError();
+}
+
 hipError_t launch_ensemble_mean(const float* sum, const float* count, float min_count, uint32_t n_win,
                                 int plane_elems, float* mean, hipStream_t s) {
   if (n_win == 0) return hipSuccess;
