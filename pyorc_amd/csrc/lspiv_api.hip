@@ -79,6 +79,7 @@ struct DeviceCtx {
   void* d_frames = nullptr;  size_t frames_cap = 0;
   float* d_out = nullptr;    size_t out_cap = 0;
   float* d_planes = nullptr; size_t planes_cap = 0;
+  void* d_scratch = nullptr; size_t scratch_cap = 0;   // temporaries of *_dev entry points (normalize)
   void* pinned[2] = {nullptr, nullptr}; size_t pinned_cap = 0;  // H2D staging ring
   hipEvent_t staged[2] = {nullptr, nullptr};
   bool arch_ok = false;
@@ -610,7 +611,11 @@ int lspiv_projection_create(int64_t src_h, int64_t src_w, int64_t dst_h, int64_t
     const size_t b = std::max<size_t>(v.size(), 1) * sizeof(int);
     hipError_t e = hipMalloc((void**)d, b);
     if (e != hipSuccess) return e;
-    return v.empty() ? hipSuccess : hipMemcpy(*d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice);
+    // on the library's stream, then waited for: a null-stream hipMemcpy from pageable memory may return before the
+    // DMA has landed, and the (non-blocking) stream the kernels run on does not synchronise with the null stream
+    if (v.empty()) return hipSuccess;
+    e = hipMemcpyAsync(*d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, c->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(c->stream);
   };
   hipError_t e = up(&h->d_nn, nn);
   if (e == hipSuccess) e = up(&h->d_grp_of, grp_of);
@@ -962,14 +967,15 @@ int lspiv_normalize_dev(const uint8_t* d_frames, int64_t T, int64_t H, int64_t W
   int rc = get_ctx(&c);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-  float* d_mean = nullptr;
-  int* d_mm = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_mean, (size_t)H * W * sizeof(float)));
-  hipError_t e = hipMalloc((void**)&d_mm, (size_t)2 * T * sizeof(int));
-  if (e == hipSuccess) e = lspiv::launch_normalize(d_frames, H * W, (int)T, (int)iv, d_mean, d_mm, d_mm + T, d_out, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);  // the temporaries are freed below
-  hipFree(d_mean);
-  if (d_mm) hipFree(d_mm);
+  // temporaries (mean plane + per-frame min / max) live in the context's grow-only scratch buffer: no allocation and
+  // no synchronisation per call.  (hipMallocAsync / hipFreeAsync on this stream gave run-to-run different outputs on
+  // ROCm 7.2 and were dropped.)  Calls that overlap in time must therefore be issued on one stream.
+  const size_t mean_bytes = ((size_t)H * W * sizeof(float) + 255) & ~(size_t)255;
+  rc = ensure(&c->d_scratch, &c->scratch_cap, mean_bytes + (size_t)2 * T * sizeof(int));
+  if (rc) return rc;
+  float* d_mean = (float*)c->d_scratch;
+  int* d_mm = (int*)((char*)c->d_scratch + mean_bytes);
+  hipError_t e = lspiv::launch_normalize(d_frames, H * W, (int)T, (int)iv, d_mean, d_mm, d_mm + T, d_out, s);
   if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? LSPIV_ENOMEM : LSPIV_EHIP, "normalize failed: %s", hipGetErrorString(e));
   return LSPIV_OK;
 }
@@ -1057,17 +1063,33 @@ int lspiv_dev_malloc(void** d_ptr, size_t bytes) {
   return LSPIV_OK;
 }
 int lspiv_dev_free(void* d_ptr) { if (d_ptr) HIP_TRY(hipFree(d_ptr)); return LSPIV_OK; }
+// The three helpers below run on the library's stream and wait for it: the kernels are launched on a NON-BLOCKING
+// stream, which does not synchronise with the null stream, and a null-stream hipMemcpy from pageable memory / hipMemset
+// may return before the data has landed (seen as a flaky first launch reading a half-written stack).
 int lspiv_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes) {
-  HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice)); return LSPIV_OK;
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
 }
 int lspiv_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes) {
   DeviceCtx* c;
   int rc = get_ctx(&c);
   if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  HIP_TRY(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost)); return LSPIV_OK;
+  return LSPIV_OK;
 }
-int lspiv_memset_dev(void* d_ptr, int value, size_t bytes) { HIP_TRY(hipMemset(d_ptr, value, bytes)); return LSPIV_OK; }
+int lspiv_memset_dev(void* d_ptr, int value, size_t bytes) {
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(d_ptr, value, bytes, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
 
 int lspiv_event_create(void** ev) {
   if (!ev) return fail(LSPIV_EINVAL, "ev is NULL");
