@@ -127,6 +127,7 @@ def main():
         _lib.check(lib.lspiv_dev_malloc(C.byref(d_frames), T * H * W))
         _lib.check(lib.lspiv_dev_malloc(C.byref(d_out), 4 * n_tiles * 4))
     _lib.check(lib.lspiv_synth_particles_dev(d_frames, T, H, W, a.seed + rank, 0.02))
+    _lib.check(lib.lspiv_synchronize())  # the generator ran on the library's stream; the steps may use another one
 
     def launch_all():
         _lib.check(lib.lspiv_piv_pairs_dev(d_frames, 0, T, H, W, ws[0], ws[1], ov[0], ov[1], -1.0, d_out, None, None))
