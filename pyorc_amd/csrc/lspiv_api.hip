@@ -438,6 +438,7 @@ int lspiv_ensemble_begin(int64_t H, int64_t W, int wy, int wx, int oy, int ox, l
   h->d_count = (float*)p;
   HIP_TRY(hipMemsetAsync(h->d_sum, 0, n_win * wy * wx * sizeof(float), c->stream));
   HIP_TRY(hipMemsetAsync(h->d_count, 0, n_win * sizeof(float), c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // lspiv_ensemble_accumulate_dev may be given another stream
   *handle = h;
   return LSPIV_OK;
 }
