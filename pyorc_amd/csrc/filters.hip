@@ -299,6 +299,65 @@ __global__ __launch_bounds__(256) void blur_strip_kernel(const T* __restrict__ f
   }
 }
 
+// Run-time radii (> 3): the same streaming structure, with the last 2R+1 row-filtered values of every column kept
+// in a wave-private LDS ring instead of registers (the ring slot is wave-uniform, the column is the lane: no cross-lane
+// traffic besides the staged input row).  One row of loads is kept in flight ahead of the row being filtered.
+template <typename T, bool EDGE>
+__global__ __launch_bounds__(256) void blur_ring_kernel(const T* __restrict__ frames, int H, int W, BlurTaps ka, BlurTaps kb,
+                                                        float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int R = EDGE ? kb.r : ka.r, M = 2 * R + 1;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int per_wave = (BLUR_TW + 2 * R) + (EDGE ? 2 : 1) * M * 64;
+  float* buf = lds + wv * per_wave;              // staged input row, 64 + 2R samples
+  float* ring_a = buf + BLUR_TW + 2 * R;         // M rows of 64 row-filtered values (kernel A)
+  float* ring_b = ring_a + M * 64;               // (kernel B, EDGE only)
+  const int x0 = blockIdx.x * BLUR_TW, y0 = (blockIdx.y * 4 + wv) * BLUR_TS;
+  if (y0 >= H) return;
+  const T* img = frames + (int64_t)blockIdx.z * H * W;
+  const int x = x0 + lane;
+  float* dst = out + (int64_t)blockIdx.z * H * W + x;
+  const int cx0 = reflect101(x - R, W);
+  const int cx1 = lane < 2 * R ? reflect101(x + 64 - R, W) : 0;
+  const int n_rows = BLUR_TS + 2 * R;
+  const T* row = img + (int64_t)reflect101(y0 - R, H) * W;
+  T n0 = row[cx0], n1 = row[cx1];
+  int slot = 0;
+  for (int i = 0; i < n_rows; ++i) {
+    const float v0 = to_f32(n0), v1 = to_f32(n1);
+    if (i + 1 < n_rows) {                          // next row's loads go out before this row is filtered
+      row = img + (int64_t)reflect101(y0 - R + i + 1, H) * W;
+      n0 = row[cx0];
+      n1 = row[cx1];
+    }
+    __builtin_amdgcn_wave_barrier();
+    buf[lane] = v0;
+    if (lane < 2 * R) buf[lane + 64] = v1;
+    __builtin_amdgcn_wave_barrier();
+    ring_a[slot * 64 + lane] = taps<0, 1>(buf + lane + R, ka);
+    if (EDGE) ring_b[slot * 64 + lane] = taps<0, 1>(buf + lane + R, kb);
+    if (i >= 2 * R) {
+      const int y = y0 + i - 2 * R;
+      int c = slot - R;                            // ring slot of the centre row
+      c += c < 0 ? M : 0;
+      auto column = [&](const float* ring, const BlurTaps& k) {
+        float acc = ring[c * 64 + lane] * k.k[0];
+        int lo = c, hi = c;
+        for (int j = 1; j <= k.r; ++j) {
+          lo = lo == 0 ? M - 1 : lo - 1;
+          hi = hi == M - 1 ? 0 : hi + 1;
+          acc += k.k[j] * (ring[lo * 64 + lane] + ring[hi * 64 + lane]);
+        }
+        return acc;
+      };
+      float res = column(ring_a, ka);
+      if (EDGE) res = column(ring_b, kb) - res;
+      if (y < H && x < W) dst[(int64_t)y * W] = res;
+    }
+    slot = slot == M - 1 ? 0 : slot + 1;
+  }
+}
+
 // getGaussianKernel(ksize, sigma <= 0, CV_32F)
 static BlurTaps make_taps(int ksize) {
   BlurTaps t;
@@ -345,7 +404,22 @@ hipError_t launch_blur(const void* frames, int dtype, int n_frames, int H, int W
 #undef LSPIV_STRIP4
     return hipGetLastError();
   }
-  // run-time radii: block kernel, 16 x 64 tiles
+  // run-time radii: streaming ring kernel (LSPIV_BLUR_BLOCK=1: the tile-per-block kernel it replaced, for A/B)
+  static const bool use_block = getenv("LSPIV_BLUR_BLOCK") != nullptr;
+  if (!use_block) {
+    const int strips = (H + BLUR_TS - 1) / BLUR_TS;
+    const dim3 grid((W + BLUR_TW - 1) / BLUR_TW, (strips + 3) / 4, n_frames);
+    const size_t lds = (size_t)4 * ((BLUR_TW + 2 * R) + (edge ? 2 : 1) * (2 * R + 1) * 64) * sizeof(float);
+#define LSPIV_RING(T, E) hipLaunchKernelGGL((blur_ring_kernel<T, E>), grid, dim3(256), lds, s, (const T*)frames, H, W, ka, kb, out)
+    switch (dtype) {
+      case 0: if (edge) LSPIV_RING(uint8_t, true); else LSPIV_RING(uint8_t, false); break;
+      case 1: if (edge) LSPIV_RING(float, true); else LSPIV_RING(float, false); break;
+      case 2: if (edge) LSPIV_RING(double, true); else LSPIV_RING(double, false); break;
+      default: return hipErrorInvalidValue;
+    }
+#undef LSPIV_RING
+    return hipGetLastError();
+  }
   const int TH = 16;
   const size_t lds = ((size_t)(TH + 2 * R) * (BLUR_TW + 2 * R) + (size_t)(edge ? 2 : 1) * (TH + 2 * R) * BLUR_TW) * sizeof(float);
   const dim3 grid((W + BLUR_TW - 1) / BLUR_TW, (H + TH - 1) / TH, n_frames);

@@ -26,6 +26,9 @@ print(f"normalize  u8->u8 : {t*1e3:.2f} ms / {T} frames, {b/t/1e9:.0f} GB/s algo
 for name, fn, k in (("smooth k=3", lambda: lib.lspiv_gaussian_blur_dev(d_f, 0, T - 1, H, W, 3, d_o, None), 3),
                     ("smooth k=7", lambda: lib.lspiv_gaussian_blur_dev(d_f, 0, T - 1, H, W, 7, d_o, None), 7),
                     ("edge 3|5   ", lambda: lib.lspiv_edge_detect_dev(d_f, 0, T - 1, H, W, 3, 5, d_o, None), 5),
+                    ("edge 5|9 (wdw 2|4)  ", lambda: lib.lspiv_edge_detect_dev(d_f, 0, T - 1, H, W, 5, 9, d_o, None), 9),
+                    ("smooth k=11", lambda: lib.lspiv_gaussian_blur_dev(d_f, 0, T - 1, H, W, 11, d_o, None), 11),
+                    ("edge 13|21 (wdw 6|10)", lambda: lib.lspiv_edge_detect_dev(d_f, 0, T - 1, H, W, 13, 21, d_o, None), 21),
                     ("edge 5|15  ", lambda: lib.lspiv_edge_detect_dev(d_f, 0, T - 1, H, W, 5, 15, d_o, None), 15)):
     t = timed(lambda: _lib.check(fn()))
     b = (T - 1) * n * (1 + 4)
