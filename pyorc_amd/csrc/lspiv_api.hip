@@ -128,6 +128,23 @@ void staged_copy(void* dst, const void* src, size_t bytes) {
   for (auto& t : th) t.join();
 }
 
+// float64 frames (what pyorc's project_numpy hands over) are narrowed to float32 while they are staged:
+// the kernels convert every sample to float32 first thing anyway (same IEEE round-to-nearest conversion on both
+// sides, so the results are bit-identical), and the PCIe transfer -- the bound of the host entry points -- halves.
+void staged_narrow(float* dst, const double* src, size_t n) {
+  static const int nthreads = getenv("LSPIV_STAGE_THREADS") ? std::max(1, atoi(getenv("LSPIV_STAGE_THREADS"))) : 4;
+  auto work = [=](size_t a, size_t b) { for (size_t i = a; i < b; ++i) dst[i] = (float)src[i]; };
+  if (nthreads <= 1 || n < ((size_t)1 << 19)) { work(0, n); return; }
+  std::vector<std::thread> th;
+  const size_t part = ((n / nthreads) + 1023) & ~(size_t)1023;
+  for (int i = 1; i < nthreads; ++i) {
+    const size_t a = std::min(n, part * i), b = std::min(n, part * (i + 1));
+    if (b > a) th.emplace_back(work, a, b);
+  }
+  work(0, std::min(n, part));
+  for (auto& t : th) t.join();
+}
+
 // two pinned staging slots of >= one frame each (LSPIV_STAGE_BYTES per slot, default 32 MiB)
 int stage_ring(DeviceCtx* c, size_t frame_bytes) {
   const size_t want = getenv("LSPIV_STAGE_BYTES") ? (size_t)atoll(getenv("LSPIV_STAGE_BYTES")) : ((size_t)32 << 20);
@@ -332,7 +349,8 @@ int lspiv_piv_pairs(const void* frames, int dtype, int64_t T, int64_t H, int64_t
   DeviceCtx* c;
   rc = get_ctx(&c);
   if (rc) return rc;
-  const size_t fbytes = (size_t)T * H * W * elem_size(dtype);
+  const int dev_dtype = dtype == LSPIV_F64 ? LSPIV_F32 : dtype;   // float64 is narrowed while it is staged
+  const size_t fbytes = (size_t)T * H * W * elem_size(dev_dtype);
   const size_t n_tiles = (size_t)(T - 1) * g.n_rows * g.n_cols;
   rc = ensure(&c->d_frames, &c->frames_cap, fbytes);
   if (rc) return rc;
@@ -343,13 +361,15 @@ int lspiv_piv_pairs(const void* frames, int dtype, int64_t T, int64_t H, int64_t
     if (rc) return rc;
   }
   // Pipelined upload: the stack is copied through a two-slot pinned ring in sub-batches of whole frames; the
-  // kernel for the pairs of sub-batch k runs while sub-batch k+1 is staged and DMA'd.  Window pairing is
-  // chunk-invariant, so this equals one launch over the whole stack bit for bit.
+  // kernel for the pairs of sub-batch k runs while sub-batch k+1 is staged and DMA'd.  With the per-pair kernels
+  // (LSPIV_WALK=0) this equals one launch over the whole stack bit for bit; the walking kernels see every sub-batch
+  // as a chunk of its own.
   lspiv::PivParams base;
-  rc = fill_params(&base, c->d_frames, dtype, T, H, W, wy, wx, oy, ox, signal_threshold, g);
+  rc = fill_params(&base, c->d_frames, dev_dtype, T, H, W, wy, wx, oy, ox, signal_threshold, g);
   if (rc) return rc;
   const size_t n_win = (size_t)g.n_rows * g.n_cols;
-  const size_t frame_bytes = (size_t)H * W * elem_size(dtype);
+  const size_t frame_bytes = (size_t)H * W * elem_size(dev_dtype);
+  const size_t src_frame_bytes = (size_t)H * W * elem_size(dtype);
   rc = stage_ring(c, frame_bytes);
   if (rc) return rc;
   const int64_t fpb = std::max<int64_t>(1, (int64_t)(c->pinned_cap / frame_bytes));
@@ -359,7 +379,10 @@ int lspiv_piv_pairs(const void* frames, int dtype, int64_t T, int64_t H, int64_t
     const int slot = batch & 1;
     if (batch >= 2) HIP_TRY(hipEventSynchronize(c->staged[slot]));  // the slot's previous DMA has drained
     const size_t nb = (size_t)(f1 - f0) * frame_bytes;
-    staged_copy(c->pinned[slot], (const char*)frames + (size_t)f0 * frame_bytes, nb);
+    if (dtype == LSPIV_F64)
+      staged_narrow((float*)c->pinned[slot], (const double*)((const char*)frames + (size_t)f0 * src_frame_bytes), (size_t)(f1 - f0) * H * W);
+    else
+      staged_copy(c->pinned[slot], (const char*)frames + (size_t)f0 * src_frame_bytes, nb);
     HIP_TRY(hipMemcpyAsync((char*)c->d_frames + (size_t)f0 * frame_bytes, c->pinned[slot], nb, hipMemcpyHostToDevice,
                            c->copy_stream));
     HIP_TRY(hipEventRecord(c->staged[slot], c->copy_stream));
@@ -375,7 +398,7 @@ int lspiv_piv_pairs(const void* frames, int dtype, int64_t T, int64_t H, int64_t
       p.cmax = c->d_out + 2 * n_tiles + p0 * n_win;
       p.s2n = c->d_out + 3 * n_tiles + p0 * n_win;
       p.planes = corr_planes ? c->d_planes + (size_t)p0 * n_win * wy * wx : nullptr;
-      rc = dispatch(p, dtype, false, c->stream);
+      rc = dispatch(p, dev_dtype, false, c->stream);
       if (rc) return rc;
     }
     f0 = f1;
