@@ -174,6 +174,34 @@ int ensure(P** ptr, size_t* cap, size_t bytes) {
   return LSPIV_OK;
 }
 
+// Whole-stack upload through the pinned ring (staging threads + DMA overlapped, float64 narrowed to float32): the
+// consumer stream waits for every slot's DMA.  *dev_dtype is the sample type the device copy ends up with.
+int upload_stack(DeviceCtx* c, const void* frames, int dtype, int64_t T, int64_t frame_elems, int* dev_dtype) {
+  *dev_dtype = dtype == LSPIV_F64 ? LSPIV_F32 : dtype;
+  const size_t frame_bytes = (size_t)frame_elems * elem_size(*dev_dtype), src_frame_bytes = (size_t)frame_elems * elem_size(dtype);
+  int rc = ensure(&c->d_frames, &c->frames_cap, (size_t)T * frame_bytes);
+  if (rc) return rc;
+  rc = stage_ring(c, frame_bytes);
+  if (rc) return rc;
+  const int64_t fpb = std::max<int64_t>(1, (int64_t)(c->pinned_cap / frame_bytes));
+  int batch = 0;
+  for (int64_t f0 = 0; f0 < T; ++batch) {
+    const int64_t f1 = std::min<int64_t>(T, f0 + fpb);
+    const int slot = batch & 1;
+    if (batch >= 2) HIP_TRY(hipEventSynchronize(c->staged[slot]));  // the slot's previous DMA has drained
+    const size_t nb = (size_t)(f1 - f0) * frame_bytes;
+    if (dtype == LSPIV_F64)
+      staged_narrow((float*)c->pinned[slot], (const double*)((const char*)frames + (size_t)f0 * src_frame_bytes), (size_t)(f1 - f0) * frame_elems);
+    else
+      staged_copy(c->pinned[slot], (const char*)frames + (size_t)f0 * src_frame_bytes, nb);
+    HIP_TRY(hipMemcpyAsync((char*)c->d_frames + (size_t)f0 * frame_bytes, c->pinned[slot], nb, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(hipEventRecord(c->staged[slot], c->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->staged[slot], 0));
+    f0 = f1;
+  }
+  return LSPIV_OK;
+}
+
 int fill_params(lspiv::PivParams* p, const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, int wy, int wx,
                 int oy, int ox, float signal_threshold, const Grid& g) {
   if (dtype < 0 || dtype > 2) return fail(LSPIV_EINVAL, "dtype %d not in {0:u8, 1:f32, 2:f64}", dtype);
@@ -466,23 +494,17 @@ int lspiv_ensemble_begin(int64_t H, int64_t W, int wy, int wx, int oy, int ox, l
   return LSPIV_OK;
 }
 
-int lspiv_ensemble_accumulate_dev(lspiv_ensemble* h, const void* d_frames, int dtype, int64_t T, float corr_min,
-                                  float s2n_min, float signal_threshold, float* d_corr_s2n, void* stream) {
-  if (!h || !d_frames || !d_corr_s2n) return fail(LSPIV_EINVAL, "NULL argument");
-  DeviceCtx* c;
-  int rc = get_ctx(&c);
-  if (rc) return rc;
+static int ensemble_launch(lspiv_ensemble* h, DeviceCtx* c, const void* d_frames, int dtype, int64_t T, float corr_min,
+                           float s2n_min, float signal_threshold, float* d_cmax, float* d_s2n, hipStream_t s) {
   lspiv::PivParams p;
-  rc = fill_params(&p, d_frames, dtype, T, h->H, h->W, h->wy, h->wx, h->oy, h->ox, signal_threshold, h->g);
+  int rc = fill_params(&p, d_frames, dtype, T, h->H, h->W, h->wy, h->wx, h->oy, h->ox, signal_threshold, h->g);
   if (rc) return rc;
-  const size_t n_tiles = (size_t)(T - 1) * h->g.n_rows * h->g.n_cols;
-  p.cmax = d_corr_s2n;
-  p.s2n = d_corr_s2n + n_tiles;
+  p.cmax = d_cmax;
+  p.s2n = d_s2n;
   p.corr_min = corr_min;
   p.s2n_min = s2n_min;
   p.corr_sum = h->d_sum;
   p.corr_count = h->d_count;
-  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   const int kind = lspiv_kernel_kind(h->wy, h->wx);
   const char* walk_env = getenv("LSPIV_WALK");
   if ((kind == 1 || kind == 2) && !(walk_env && atoi(walk_env) == 0) && p.n_pairs >= 3) {
@@ -498,6 +520,18 @@ int lspiv_ensemble_accumulate_dev(lspiv_ensemble* h, const void* d_frames, int d
   return dispatch(p, dtype, true, s);
 }
 
+int lspiv_ensemble_accumulate_dev(lspiv_ensemble* h, const void* d_frames, int dtype, int64_t T, float corr_min,
+                                  float s2n_min, float signal_threshold, float* d_corr_s2n, void* stream) {
+  if (!h || !d_frames || !d_corr_s2n) return fail(LSPIV_EINVAL, "NULL argument");
+  if (T < 2) return fail(LSPIV_ESHAPE, "need at least 2 frames, got %lld", (long long)T);
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  const size_t n_tiles = (size_t)(T - 1) * h->g.n_rows * h->g.n_cols;
+  return ensemble_launch(h, c, d_frames, dtype, T, corr_min, s2n_min, signal_threshold, d_corr_s2n, d_corr_s2n + n_tiles,
+                         stream ? (hipStream_t)stream : c->stream);
+}
+
 int lspiv_ensemble_accumulate(lspiv_ensemble* h, const void* frames, int dtype, int64_t T, float corr_min,
                               float s2n_min, float signal_threshold, float* corr_max, float* s2n) {
   std::lock_guard<std::mutex> host_lock(g_host_mu);
@@ -507,15 +541,42 @@ int lspiv_ensemble_accumulate(lspiv_ensemble* h, const void* frames, int dtype, 
   if (rc) return rc;
   if (dtype < 0 || dtype > 2) return fail(LSPIV_EINVAL, "dtype %d not in {0:u8, 1:f32, 2:f64}", dtype);
   if (T < 2) return fail(LSPIV_ESHAPE, "need at least 2 frames, got %lld", (long long)T);
-  const size_t fbytes = (size_t)T * h->H * h->W * elem_size(dtype);
-  const size_t n_tiles = (size_t)(T - 1) * h->g.n_rows * h->g.n_cols;
-  rc = ensure(&c->d_frames, &c->frames_cap, fbytes);
+  const size_t n_win = (size_t)h->g.n_rows * h->g.n_cols, n_tiles = (size_t)(T - 1) * n_win;
+  rc = ensure(&c->d_out, &c->out_cap, 2 * n_tiles * sizeof(float));
   if (rc) return rc;
-  rc = ensure(&c->d_out, &c->out_cap, 4 * n_tiles * sizeof(float));
+  // Pipelined like lspiv_piv_pairs: the ensemble sums are additive over pairs, so the pairs of sub-batch k are
+  // accumulated (in order, on one stream) while sub-batch k+1 is staged and DMA'd.  float64 is narrowed while staged.
+  const int dev_dtype = dtype == LSPIV_F64 ? LSPIV_F32 : dtype;
+  const size_t frame_elems = (size_t)h->H * h->W;
+  const size_t frame_bytes = frame_elems * elem_size(dev_dtype), src_frame_bytes = frame_elems * elem_size(dtype);
+  rc = ensure(&c->d_frames, &c->frames_cap, (size_t)T * frame_bytes);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(c->d_frames, frames, fbytes, hipMemcpyHostToDevice, c->stream));
-  rc = lspiv_ensemble_accumulate_dev(h, c->d_frames, dtype, T, corr_min, s2n_min, signal_threshold, c->d_out, c->stream);
+  rc = stage_ring(c, frame_bytes);
   if (rc) return rc;
+  const int64_t fpb = std::max<int64_t>(1, (int64_t)(c->pinned_cap / frame_bytes));
+  {
+    int batch = 0;
+    for (int64_t f0 = 0; f0 < T; ++batch) {
+      const int64_t f1 = std::min<int64_t>(T, f0 + fpb);
+      const int slot = batch & 1;
+      if (batch >= 2) HIP_TRY(hipEventSynchronize(c->staged[slot]));
+      const size_t nb = (size_t)(f1 - f0) * frame_bytes;
+      if (dtype == LSPIV_F64)
+        staged_narrow((float*)c->pinned[slot], (const double*)((const char*)frames + (size_t)f0 * src_frame_bytes), (size_t)(f1 - f0) * frame_elems);
+      else
+        staged_copy(c->pinned[slot], (const char*)frames + (size_t)f0 * src_frame_bytes, nb);
+      HIP_TRY(hipMemcpyAsync((char*)c->d_frames + (size_t)f0 * frame_bytes, c->pinned[slot], nb, hipMemcpyHostToDevice, c->copy_stream));
+      HIP_TRY(hipEventRecord(c->staged[slot], c->copy_stream));
+      HIP_TRY(hipStreamWaitEvent(c->stream, c->staged[slot], 0));
+      const int64_t p0 = std::max<int64_t>(f0 - 1, 0), p1 = f1 - 1;  // pairs whose two frames are resident
+      if (p1 > p0) {
+        rc = ensemble_launch(h, c, (const char*)c->d_frames + (size_t)p0 * frame_bytes, dev_dtype, p1 - p0 + 1, corr_min, s2n_min,
+                             signal_threshold, c->d_out + p0 * n_win, c->d_out + n_tiles + p0 * n_win, c->stream);
+        if (rc) return rc;
+      }
+      f0 = f1;
+    }
+  }
   HIP_TRY(hipMemcpyAsync(corr_max, c->d_out, n_tiles * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(s2n, c->d_out + n_tiles, n_tiles * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
