@@ -279,8 +279,52 @@ __device__ __forceinline__ float bperm_f(int addr, float v) {
 // One window of the pair: load (zero-padded rows for a, periodic rows for b), statistics over the n x n samples,
 // x <- max(x - mean, 0); returns 1/std (0 for a zero-variance window).  The n x n samples are columns j < n (a uniform
 // test: scalar branches, no per-element lane masks) of rows < n (one lane mask, applied to the row totals).
+// Branch-free: "column j belongs to the window" is the uniform float m_j = (j < n) (a scalar select) and "this lane's
+// row belongs to it" the lane float r; masking is multiplication, so load + statistics are one basic block (the
+// per-column scalar branches of the other version cost more than the ~200 extra multiplies).  Used by the 64-point
+// variant; in the 32-point variant it needs 40 more VGPRs (2 waves instead of 3) and loses.
 template <typename T, int N, bool WANT_NZ, bool PERIODIC>
-__device__ __forceinline__ float load_center_embed(const T* row, int n, bool row_in, int lane0_byte, float (&x)[N],
+__device__ __forceinline__ float load_center_embed_bf(const T* row, int n, bool row_in, int lane0_byte, float (&x)[N],
+                                                   int& nonzero, bool& finite) {
+  const float inv_nn = 1.0f / (float)(n * n);
+  const float r = row_in ? 1.0f : 0.0f;
+  int jm = 0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    if (PERIODIC) {
+      x[j] = to_f32(row[jm]);
+      jm = (jm + 1 == n) ? 0 : jm + 1;
+    } else {
+      x[j] = to_f32(row[j < n ? j : n - 1]);   // always in bounds; columns >= n are masked below
+    }
+    if (sizeof(T) == 8 && (j & 15) == 15) __builtin_amdgcn_sched_barrier(0);   // 8-byte samples: consume in chunks
+  }
+  const float x0 = bperm_f(lane0_byte, x[0]);
+  float s = 0.0f, nz = 0.0f;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const float m = j < n ? 1.0f : 0.0f;
+    s = fmaf(x[j] - x0, m, s);
+    if (WANT_NZ) nz += (x[j] != 0.0f) ? m : 0.0f;
+  }
+  if (WANT_NZ) nonzero = group_sum_i<N>((int)(nz * r));
+  const float mean = x0 + group_sum<N>(s * r) * inv_nn;
+  float q = 0.0f;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const float m = j < n ? 1.0f : 0.0f;
+    const float d = x[j] - mean;
+    q = fmaf(d * m, d, q);
+    x[j] = PERIODIC ? fmaxf(d, 0.0f) : fmaxf(d, 0.0f) * (m * r);
+  }
+  q = group_sum<N>(q * r);
+  finite = finite && (fabsf(mean) <= 3.0e38f) && (q <= 3.0e38f);
+  const float var = q * inv_nn;
+  return var > 0.0f ? __builtin_amdgcn_rsqf(var) : 0.0f;
+}
+// uniform scalar branches on the column test (32-point variant)
+template <typename T, int N, bool WANT_NZ, bool PERIODIC>
+__device__ __forceinline__ float load_center_embed_br(const T* row, int n, bool row_in, int lane0_byte, float (&x)[N],
                                                    int& nonzero, bool& finite) {
   const float inv_nn = 1.0f / (float)(n * n);
   int jm = 0;
@@ -323,6 +367,13 @@ __device__ __forceinline__ float load_center_embed(const T* row, int n, bool row
   finite = finite && (fabsf(mean) <= 3.0e38f) && (q <= 3.0e38f);
   const float var = q * inv_nn;
   return var > 0.0f ? __builtin_amdgcn_rsqf(var) : 0.0f;
+}
+
+template <typename T, int N, bool WANT_NZ, bool PERIODIC>
+__device__ __forceinline__ float load_center_embed(const T* row, int n, bool row_in, int lane0_byte, float (&x)[N],
+                                                   int& nonzero, bool& finite) {
+  if constexpr (N == 64) return load_center_embed_bf<T, N, WANT_NZ, PERIODIC>(row, n, row_in, lane0_byte, x, nonzero, finite);
+  else return load_center_embed_br<T, N, WANT_NZ, PERIODIC>(row, n, row_in, lane0_byte, x, nonzero, finite);
 }
 
 template <typename T, int N, bool WANT_NZ>
