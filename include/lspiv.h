@@ -61,6 +61,10 @@ int         lspiv_set_device(int device);               /* per calling thread   
 int         lspiv_get_device(int* device);
 int         lspiv_device_name(int device, char* buf, size_t len);
 int         lspiv_synchronize(void);                    /* hipDeviceSynchronize             */
+/* run-time options: "walk" = 0 per-pair kernels (results independent of the time chunking, bit for bit), 1 the
+ * default time-walking kernels, n > 1 forced segment length, -1 back to the LSPIV_WALK environment variable. */
+int         lspiv_set_option(const char* name, int value);
+int         lspiv_get_option(const char* name, int* value);
 /* which kernel a window size dispatches to: 1 = FFT 32x32, 2 = FFT 64x64, 4 / 5 = square windows 4..16 /
  * 17..31 embedded in the 32- / 64-point FFT kernels, 3 = direct spatial correlation (everything else);
  * <0 = unsupported.  Host-only. */

@@ -52,6 +52,8 @@ SIGNATURES = {
     "lspiv_get_device": (_i32, [C.POINTER(_i32)]),
     "lspiv_device_name": (_i32, [_i32, C.c_char_p, _sz]),
     "lspiv_synchronize": (_i32, []),
+    "lspiv_set_option": (_i32, [C.c_char_p, _i32]),
+    "lspiv_get_option": (_i32, [C.c_char_p, C.POINTER(_i32)]),
     "lspiv_kernel_kind": (_i32, [_i32, _i32]),
     "lspiv_grid_shape": (_i32, [_i64, _i64, _i32, _i32, _i32, _i32, _pi64, _pi64]),
     "lspiv_grid_coords": (_i32, [_i64, _i64, _i32, _i32, _i32, _i32, _pi64, _pi64]),
@@ -141,6 +143,18 @@ def device_count() -> int:
 def require_device() -> None:
     if device_count() < 1:
         raise LspivError(LSPIV_ENODEV, "no gfx950 (MI355X) device visible; engine='hip' has no CPU fallback")
+
+
+def set_option(name: str, value: int) -> None:
+    """Run-time options of the library, e.g. ``set_option("walk", 0)``: per-pair kernels, whose results do not depend
+    on how the time axis is chunked (bit for bit); 1 = default time-walking kernels; -1 = follow ``LSPIV_WALK``."""
+    check(load().lspiv_set_option(name.encode(), int(value)))
+
+
+def get_option(name: str) -> int:
+    v = C.c_int(0)
+    check(load().lspiv_get_option(name.encode(), C.byref(v)))
+    return v.value
 
 
 def ptr(a: np.ndarray) -> C.c_void_p:

@@ -182,6 +182,9 @@ hipError_t launch_piv_embed64(const PivParams& p, int dtype, bool ensemble, hipS
 hipError_t launch_peaks_from_planes(const float* planes, uint32_t n_planes, int wy, int wx,
                                     float* u, float* v, hipStream_t s);
 // mean[w][o] = count[w] < min_count ? NaN : sum[w][o] / count[w]   (pyorc/velocimetry/ffpiv.py:280-282)
+// LSPIV_WALK as an integer (0 per-pair kernels, 1 default walking kernels, n > 1 forced segment length): the value set
+// through lspiv_set_option("walk", v) if any, else the environment variable read at every launch, else 1
+int walk_setting();
 // segments of the walking ENSEMBLE kernels: enough jobs for ~3 rounds of the chip, segments of an odd number of pairs
 inline void ensemble_segments(uint32_t n_win, uint32_t n_pairs, int window, uint32_t* seg_len, uint32_t* n_seg) {
   const uint32_t slots = window == 32 ? 6144u : 2048u;   // half-wave jobs at 3 waves/SIMD; wave jobs at 2

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -262,6 +263,14 @@ struct lspiv_ensemble {
   size_t part_cap;
 };
 
+static std::atomic<int> g_opt_walk{-1};   // lspiv_set_option("walk", v); -1: not set, fall back to the environment
+int lspiv::walk_setting() {
+  const int v = g_opt_walk.load();
+  if (v >= 0) return v;
+  const char* e = getenv("LSPIV_WALK");
+  return e ? atoi(e) : 1;
+}
+
 extern "C" {
 
 int lspiv_abi_version(void) { return LSPIV_ABI_VERSION; }
@@ -289,6 +298,21 @@ int lspiv_device_name(int device, char* buf, size_t len) {
   return LSPIV_OK;
 }
 int lspiv_synchronize(void) { HIP_TRY(hipDeviceSynchronize()); return LSPIV_OK; }
+
+int lspiv_set_option(const char* name, int value) {
+  if (!name) return fail(LSPIV_EINVAL, "option name is NULL");
+  if (strcmp(name, "walk") == 0) {
+    if (value < -1) return fail(LSPIV_EINVAL, "walk must be -1 (environment), 0, 1 or a segment length");
+    g_opt_walk.store(value);
+    return LSPIV_OK;
+  }
+  return fail(LSPIV_EINVAL, "unknown option '%s'", name);
+}
+int lspiv_get_option(const char* name, int* value) {
+  if (!name || !value) return fail(LSPIV_EINVAL, "NULL argument");
+  if (strcmp(name, "walk") == 0) { *value = lspiv::walk_setting(); return LSPIV_OK; }
+  return fail(LSPIV_EINVAL, "unknown option '%s'", name);
+}
 
 int lspiv_kernel_kind(int wy, int wx) {
   if (wy < 2 || wx < 2 || wy > LSPIV_MAX_WINDOW || wx > LSPIV_MAX_WINDOW) return LSPIV_EUNSUPPORTED;
@@ -506,8 +530,7 @@ static int ensemble_launch(lspiv_ensemble* h, DeviceCtx* c, const void* d_frames
   p.corr_sum = h->d_sum;
   p.corr_count = h->d_count;
   const int kind = lspiv_kernel_kind(h->wy, h->wx);
-  const char* walk_env = getenv("LSPIV_WALK");
-  if ((kind == 1 || kind == 2) && !(walk_env && atoi(walk_env) == 0) && p.n_pairs >= 3) {
+  if ((kind == 1 || kind == 2) && lspiv::walk_setting() != 0 && p.n_pairs >= 3) {
     lspiv::ensemble_segments(p.n_win, p.n_pairs, h->wy, &p.seg_len, &p.n_seg);
     const size_t plane = (size_t)h->wy * h->wx;
     const size_t need = (size_t)p.n_seg * p.n_win * (plane + 1) * sizeof(float);

@@ -1241,8 +1241,7 @@ static hipError_t launch_t(const PivParams& p, bool ensemble, hipStream_t s) {
   }
   // LSPIV_WALK: 0 = per-pair kernel; unset / 1 = time-walking kernel for 32 x 32 windows with segments sized to keep
   // >= ~4 jobs per half-wave slot of the chip; n > 1 = segments of n pairs (odd values waste no half iteration)
-  const char* walk_env = getenv("LSPIV_WALK");   // read per launch: tests switch kernels inside one process
-  const int walk = walk_env ? atoi(walk_env) : 1;
+  const int walk = walk_setting();   // option or environment, read per launch
   if (walk != 0 && p.n_pairs >= 3) {
     uint32_t seg_len = walk > 1 ? (uint32_t)walk : 63;
     if (walk == 1) {

@@ -171,3 +171,20 @@ def test_as_frames_dtype_rules():
     assert _lib.as_frames(np.zeros((4, 4, 2), np.uint8).transpose(2, 0, 1)).flags.c_contiguous
     with pytest.raises(ValueError):
         _lib.as_frames(np.zeros((4, 4)))
+
+
+def test_walk_option_overrides_the_environment(lib, monkeypatch):
+    """lspiv_set_option("walk", v) wins over LSPIV_WALK; -1 hands control back to the environment (no GPU needed)."""
+    import pyorc_amd
+
+    monkeypatch.delenv("LSPIV_WALK", raising=False)
+    pyorc_amd.set_option("walk", -1)
+    assert pyorc_amd.get_option("walk") == 1
+    monkeypatch.setenv("LSPIV_WALK", "0")
+    assert pyorc_amd.get_option("walk") == 0
+    pyorc_amd.set_option("walk", 31)
+    assert pyorc_amd.get_option("walk") == 31
+    pyorc_amd.set_option("walk", -1)
+    assert pyorc_amd.get_option("walk") == 0
+    with pytest.raises(_lib.LspivError):
+        pyorc_amd.set_option("no-such-option", 1)
