@@ -188,3 +188,47 @@ def test_walk_option_overrides_the_environment(lib, monkeypatch):
     assert pyorc_amd.get_option("walk") == 0
     with pytest.raises(_lib.LspivError):
         pyorc_amd.set_option("no-such-option", 1)
+
+
+def test_xarray_branches_of_the_mirrors(monkeypatch):
+    """get_piv / get_ffpiv / Mask on DataArray / Dataset inputs (a test double of xarray, tests/fake_xarray.py; the GPU
+    call is replaced by the oracle, so this runs on CPU): Dataset out, time = stamp of the 2nd frame, chunks loaded once."""
+    import importlib
+    import sys
+
+    from oracle import c_oracle
+    from pyorc_amd.synth import particle_stack
+    from tests import fake_xarray
+
+    monkeypatch.setitem(sys.modules, "xarray", fake_xarray)
+    import pyorc_amd.frames as F
+    import pyorc_amd.mask as M
+    import pyorc_amd.velocimetry as V
+
+    for mod in (V, F, M):
+        importlib.reload(mod)
+    try:
+        assert V.xr is fake_xarray
+        monkeypatch.setattr(V.piv, "piv_pairs", lambda fr, ws, ov, thr=None: tuple(a.astype(np.float32) for a in c_oracle.piv_pairs(np.asarray(fr), ws, ov, thr)))
+        monkeypatch.setattr(V.window, "available_memory", lambda: 1e12)
+        fr = particle_stack(7, 96, 128, seed=3)
+        t = np.arange(7) / 25.0
+        da = fake_xarray.DataArray(fr, ("time", "y", "x"), {"time": t, "y": np.arange(96)[::-1] * 0.02, "x": np.arange(128) * 0.02})
+        ds = F.get_piv(da, 32, resolution=0.02, chunksize=3)
+        assert isinstance(ds, fake_xarray.Dataset) and set(ds) == {"s2n", "corr", "v_x", "v_y"}
+        assert ds["v_x"].dims == ("time", "y", "x") and ds["v_x"].values.shape == (6, 5, 7) and ds["v_x"].values.dtype == np.float32
+        assert np.allclose(np.asarray(ds["time"].values, dtype=np.float64), t[1:])
+        ref = F.get_piv(fr, 32, time=t, resolution=0.02, chunksize=3)
+        for k in ref:
+            assert np.array_equal(ds[k].values, ref[k], equal_nan=True)
+        # masks on a Dataset: a DataArray comes back, in-place application keeps the Dataset type
+        monkeypatch.setattr(M, "run_mask", lambda block, kind, params: getattr(__import__("oracle.mask_oracle", fromlist=["x"]), kind)(block, *params[:1]) if kind in ("corr", "s2n") else None)
+        monkeypatch.setattr(M, "apply_mask", lambda block, mask: __import__("oracle.mask_oracle", fromlist=["x"]).apply(block, mask))
+        m = M.Mask(ds).corr(tolerance=0.3)
+        assert isinstance(m, fake_xarray.DataArray) and m.dims == ("time", "y", "x") and m.values.dtype == bool
+        M.Mask(ds).corr(tolerance=0.3, inplace=True)
+        assert isinstance(ds["v_x"], fake_xarray.DataArray) and np.isnan(ds["v_x"].values[~m.values]).all()
+    finally:
+        monkeypatch.undo()
+        for mod in (V, F, M):
+            importlib.reload(mod)
