@@ -34,7 +34,8 @@ constexpr int DXB = 8;            // lags per thread: one a-sample and one new b
 
 struct DirectGeo {
   int n, bpitch, strips_per_row;  // samples per window; padded length of a doubled b row; ceil(wx / DXB)
-  __device__ DirectGeo(int wy, int wx) : n(wy * wx), bpitch(wx + ((wx + DXB - 1) / DXB) * DXB), strips_per_row((wx + DXB - 1) / DXB) {}
+  // odd pitch: lanes of a wave read different rows of b (different dy), an even pitch folds them onto few LDS banks
+  __device__ DirectGeo(int wy, int wx) : n(wy * wx), bpitch((wx + ((wx + DXB - 1) / DXB) * DXB) | 1), strips_per_row((wx + DXB - 1) / DXB) {}
 };
 
 // sum over the block in a fixed order (wave reductions, then the four partials left to right): deterministic
@@ -204,7 +205,7 @@ __device__ __forceinline__ void carve(float* smem, const DirectGeo& g, int wy, f
   a = smem; b2 = a + g.n; plane = b2 + wy * g.bpitch; red = plane + g.n;
 }
 static size_t direct_lds_bytes(int wy, int wx) {
-  const int bpitch = wx + ((wx + DXB - 1) / DXB) * DXB;
+  const int bpitch = (wx + ((wx + DXB - 1) / DXB) * DXB) | 1;
   return ((size_t)2 * wy * wx + (size_t)wy * bpitch + 16) * sizeof(float);
 }
 
