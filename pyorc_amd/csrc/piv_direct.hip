@@ -11,6 +11,8 @@
 // windows staged in LDS as float32 (b with periodically doubled rows), every thread accumulating 8 neighbouring lags
 // in registers: O(N^2) multiply-adds per output instead of O(log N).  Square windows up to 31 do NOT come here any
 // more (they run embedded in the FFT kernels, piv_fft_impl.h); this is the path for non-square windows and 33..63.
+#include <algorithm>
+
 #include "common.h"
 
 namespace lspiv {
@@ -29,7 +31,7 @@ __device__ __forceinline__ void wave_argmax(float& v, int& idx) {
 }
 
 // ---- block-level pieces: 256 threads (4 waves) work on one window pair -----------------------------------------
-constexpr int DBLOCK = 256;
+constexpr int DBLOCK_MAX = 512;   // block = as many waves as the strips of one window pair need (2..8), one round of strips
 constexpr int DXB = 8;            // lags per thread: one a-sample and one new b-sample feed 8 FMAs
 
 struct DirectGeo {
@@ -44,7 +46,9 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  return ((red[0] + red[1]) + red[2]) + red[3];
+  float tot = red[0];
+  for (int k = 1; k < (int)(blockDim.x >> 6); ++k) tot += red[k];   // left to right: a fixed order
+  return tot;
 }
 __device__ __forceinline__ int block_sum_i(int v, int* red) {
   v = half_sum_i(v);
@@ -52,7 +56,9 @@ __device__ __forceinline__ int block_sum_i(int v, int* red) {
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  return red[0] + red[1] + red[2] + red[3];
+  int tot = red[0];
+  for (int k = 1; k < (int)(blockDim.x >> 6); ++k) tot += red[k];
+  return tot;
 }
 
 // Stage one window into LDS (row pitch `pitch`; with `periodic` every row is continued periodically up to the pitch,
@@ -66,7 +72,7 @@ __device__ __forceinline__ float stage_window(const T* src, int W, int wy, int w
   const float x0 = to_f32(src[0]);
   float s = 0.0f;
   int nz = 0;
-  for (int o = threadIdx.x; o < n; o += DBLOCK) {
+  for (int o = threadIdx.x; o < n; o += blockDim.x) {
     const int y = o / wx, x = o - y * wx;
     const float v = to_f32(src[(int64_t)y * W + x]);
     dst[y * pitch + x] = v;
@@ -76,7 +82,7 @@ __device__ __forceinline__ float stage_window(const T* src, int W, int wy, int w
   nonzero = block_sum_i(nz, reinterpret_cast<int*>(red));
   const float mean = x0 + block_sum(s, red) / (float)n;
   float ssq = 0.0f;
-  for (int o = threadIdx.x; o < n; o += DBLOCK) {
+  for (int o = threadIdx.x; o < n; o += blockDim.x) {
     const int y = o / wx, x = o - y * wx;
     const float d = dst[y * pitch + x] - mean;
     ssq += d * d;
@@ -86,7 +92,7 @@ __device__ __forceinline__ float stage_window(const T* src, int W, int wy, int w
   finite = finite && (fabsf(mean) <= 3.0e38f) && (ssq <= 3.0e38f);
   if (periodic) {
     const int ext = pitch - wx;
-    for (int o = threadIdx.x; o < wy * ext; o += DBLOCK) {
+    for (int o = threadIdx.x; o < wy * ext; o += blockDim.x) {
       const int y = o / ext, x = o - y * ext;
       dst[y * pitch + wx + x] = dst[y * pitch + x % wx];
     }
@@ -102,7 +108,7 @@ __device__ __forceinline__ void correlate_direct(const float* a, const float* b2
                                                  const DirectGeo& g, float scale) {
   const int cy = wy / 2, cx = wx / 2;
   const int strips = wy * g.strips_per_row;
-  for (int sidx = threadIdx.x; sidx < strips; sidx += DBLOCK) {
+  for (int sidx = threadIdx.x; sidx < strips; sidx += blockDim.x) {
     const int dy = sidx / g.strips_per_row, dx0 = (sidx - dy * g.strips_per_row) * DXB;
     float acc[DXB];
 #pragma unroll
@@ -141,19 +147,18 @@ __device__ __forceinline__ void plane_reduce(const float* plane, int n, float* r
   float best = -1.0f;
   int bi = 0x7fffffff;
   float s = 0.0f;
-  for (int o = threadIdx.x; o < n; o += DBLOCK) {
+  for (int o = threadIdx.x; o < n; o += blockDim.x) {
     const float v = plane[o];
     s += v;
     if (v > best) { best = v; bi = o; }
   }
   wave_argmax(best, bi);
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) { red[8 + (threadIdx.x >> 6)] = best; reinterpret_cast<int*>(red)[12 + (threadIdx.x >> 6)] = bi; }
+  if ((threadIdx.x & 63) == 0) { red[8 + (threadIdx.x >> 6)] = best; reinterpret_cast<int*>(red)[16 + (threadIdx.x >> 6)] = bi; }
   __syncthreads();
   vmax = red[8];
-  imax = reinterpret_cast<int*>(red)[12];
-#pragma unroll
-  for (int k = 1; k < 4; ++k) argmax_merge(vmax, imax, red[8 + k], reinterpret_cast<int*>(red)[12 + k]);
+  imax = reinterpret_cast<int*>(red)[16];
+  for (int k = 1; k < (int)(blockDim.x >> 6); ++k) argmax_merge(vmax, imax, red[8 + k], reinterpret_cast<int*>(red)[16 + k]);
   sum = block_sum(s, red);
 }
 
@@ -200,17 +205,17 @@ __device__ __forceinline__ bool direct_pair(const PivParams& p, uint32_t pair, u
   return ok;
 }
 
-// LDS: a (n) | doubled b (wy * bpitch) | plane (n) | 16 dwords of reduction scratch
+// LDS: a (n) | doubled b (wy * bpitch) | plane (n) | 24 dwords of reduction scratch (8 sums, 8 maxima, 8 indices)
 __device__ __forceinline__ void carve(float* smem, const DirectGeo& g, int wy, float*& a, float*& b2, float*& plane, float*& red) {
   a = smem; b2 = a + g.n; plane = b2 + wy * g.bpitch; red = plane + g.n;
 }
 static size_t direct_lds_bytes(int wy, int wx) {
   const int bpitch = (wx + ((wx + DXB - 1) / DXB) * DXB) | 1;
-  return ((size_t)2 * wy * wx + (size_t)wy * bpitch + 16) * sizeof(float);
+  return ((size_t)2 * wy * wx + (size_t)wy * bpitch + 24) * sizeof(float);
 }
 
 template <typename T>
-__global__ __launch_bounds__(DBLOCK) void piv_direct_kernel(PivParams p) {
+__global__ __launch_bounds__(DBLOCK_MAX) void piv_direct_kernel(PivParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const DirectGeo g(p.wy, p.wx);
   float *a, *b2, *plane, *red;
@@ -229,14 +234,14 @@ __global__ __launch_bounds__(DBLOCK) void piv_direct_kernel(PivParams p) {
   }
   if (p.planes) {
     float* dst = p.planes + (size_t)t * g.n;
-    for (int o = threadIdx.x; o < g.n; o += DBLOCK) dst[o] = ok ? plane[o] : __builtin_nanf("");
+    for (int o = threadIdx.x; o < g.n; o += blockDim.x) dst[o] = ok ? plane[o] : __builtin_nanf("");
   }
 }
 
 // ensemble: one block owns one window and walks the chunk's pairs in order (see piv_fft_impl.h); the running sum
 // of the chunk lives in HBM (corr_sum), one coalesced read-modify-write per kept pair
 template <typename T>
-__global__ __launch_bounds__(DBLOCK) void piv_direct_ensemble_kernel(PivParams p) {
+__global__ __launch_bounds__(DBLOCK_MAX) void piv_direct_ensemble_kernel(PivParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const DirectGeo g(p.wy, p.wx);
   float *a, *b2, *plane, *red;
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(DBLOCK) void piv_direct_ensemble_kernel(PivParams p
       p.s2n[(size_t)pair * p.n_win + win] = sn;
     }
     if (keep)
-      for (int o = threadIdx.x; o < g.n; o += DBLOCK) dst[o] += plane[o];
+      for (int o = threadIdx.x; o < g.n; o += blockDim.x) dst[o] += plane[o];
     __syncthreads();
   }
   if (threadIdx.x == 0) p.corr_count[win] += cnt;
@@ -268,10 +273,12 @@ __global__ __launch_bounds__(DBLOCK) void piv_direct_ensemble_kernel(PivParams p
 template <typename T>
 static hipError_t launch_t(const PivParams& p, bool ensemble, hipStream_t s) {
   const size_t lds = direct_lds_bytes(p.wy, p.wx);
+  const int strips = p.wy * ((p.wx + DXB - 1) / DXB);
+  const int threads = std::min(DBLOCK_MAX, std::max(128, ((strips + 63) / 64) * 64));
   if (ensemble)
-    hipLaunchKernelGGL(piv_direct_ensemble_kernel<T>, dim3(p.n_win), dim3(DBLOCK), lds, s, p);
+    hipLaunchKernelGGL(piv_direct_ensemble_kernel<T>, dim3(p.n_win), dim3(threads), lds, s, p);
   else
-    hipLaunchKernelGGL(piv_direct_kernel<T>, dim3(p.n_tiles), dim3(DBLOCK), lds, s, p);
+    hipLaunchKernelGGL(piv_direct_kernel<T>, dim3(p.n_tiles), dim3(threads), lds, s, p);
   return hipGetLastError();
 }
 
