@@ -18,7 +18,12 @@
  *     the thread-local message of the last failure on this thread;
  *   - "_dev" variants take DEVICE pointers (HBM-resident stacks, multi-GPU shards) and a
  *     stream handle (NULL = the library's own per-device stream); host variants stage
- *     through pinned buffers and synchronise before returning;
+ *     through pinned buffers and synchronise before returning.  The library's stream is
+ *     NON-BLOCKING (it does not synchronise with the NULL stream): device data handed to a
+ *     "_dev" call must already be complete, or the call must be given the stream that
+ *     produces it; lspiv_memcpy_h2d / _d2h / lspiv_memset_dev run on the library's stream and
+ *     wait for it.  "_dev" calls that need temporaries (normalize) share one scratch buffer
+ *     per device: calls that overlap in time must be issued on one stream;
  *   - NaN conventions follow the reference: skipped / invalid windows yield NaN, never an
  *     error (pyorc/velocimetry/ffpiv.py:93-97,465-466).
  */
