@@ -489,3 +489,29 @@ def test_walking_kernel_segments_vs_oracle(gpu, monkeypatch, seg, P, ws):
     ref = pyorc_amd.piv_pairs(fr, (ws, ws), ov)
     monkeypatch.setenv("LSPIV_WALK", seg)
     assert_chunk_close(pyorc_amd.piv_pairs(fr, (ws, ws), ov), ref)
+
+
+def test_float64_frames_are_narrowed_while_staged(gpu):
+    """Host entry points convert float64 stacks to float32 in the staging threads; the kernels would do the same
+    conversion on load, so results equal those of a float32 copy of the stack bit for bit (incl. non-representable
+    values and several staging sub-batches), per-timestep and ensemble mode."""
+    import pyorc_amd
+    import pyorc_amd.piv as P
+
+    rng = np.random.default_rng(3)
+    fr = particle_stack(9, 100, 140, seed=77).astype(np.float64) * 1.000000123 + rng.random((9, 100, 140)) * 1e-3 - 17.3
+    os.environ["LSPIV_STAGE_BYTES"] = str(100 * 140 * 4 * 2 + 7)       # two frames per staging slot
+    try:
+        a = pyorc_amd.piv_pairs(fr, (32, 32), (16, 16), 0.1)
+        b = pyorc_amd.piv_pairs(fr.astype(np.float32), (32, 32), (16, 16), 0.1)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y, equal_nan=True)
+        ea, eb = P.Ensemble(fr.shape[1:], (32, 32), (16, 16)), P.Ensemble(fr.shape[1:], (32, 32), (16, 16))
+        ca, sa = ea.accumulate(fr, 0.1, 1.5)
+        cb, sb = eb.accumulate(fr.astype(np.float32), 0.1, 1.5)
+        assert np.array_equal(ca, cb) and np.array_equal(sa, sb)
+        for x, y in zip(ea.finish(0.2, 1), eb.finish(0.2, 1)):
+            assert np.array_equal(x, y, equal_nan=True)
+        ea.close(); eb.close()
+    finally:
+        os.environ.pop("LSPIV_STAGE_BYTES", None)
