@@ -10,6 +10,11 @@ rank's packed (4, p_local, n_rows, n_cols) float32 result block (u | v | corr_ma
 sum all-reduce of corr_sum / corr_count, provided by ``allreduce_sum``.
 
 torch.distributed is plumbing here (rendezvous + collectives); the compute callable is injected.
+
+With the "nccl" backend import torch (and initialise the process group) BEFORE the first call into
+``liblspiv_hip.so``: the PyTorch wheel bundles its own ``libamdhip64``; loaded first, the dynamic loader hands the
+same copy to the library, loaded second the process ends up with two HIP runtimes and the second one finds no GPU
+(bench.py does it in this order).
 """
 
 from __future__ import annotations
