@@ -241,6 +241,9 @@ int lspiv_pack_int16_dev(const float* d_values, int64_t n, float scale, int fill
 /* For hosts that keep stacks in HBM (bench.py, one-process-per-GPU shards).                 */
 int lspiv_dev_malloc(void** d_ptr, size_t bytes);
 int lspiv_dev_free(void* d_ptr);
+/* pinned host memory: a uint8 / float32 stack that lives in it is DMA'd in place by lspiv_piv_pairs (no staging copy). */
+int lspiv_host_alloc(void** h_ptr, size_t bytes);
+int lspiv_host_free(void* h_ptr);
 int lspiv_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
 int lspiv_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
 int lspiv_memset_dev(void* d_ptr, int value, size_t bytes);

@@ -15,4 +15,4 @@ __version__ = "0.1.0"
 
 from . import window  # noqa: F401
 from .piv import cross_corr, piv_pairs, u_v_displacement  # noqa: F401
-from ._lib import get_option, set_option  # noqa: F401,E402
+from ._lib import get_option, pinned_empty, set_option  # noqa: F401,E402

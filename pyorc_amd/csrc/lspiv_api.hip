@@ -112,6 +112,13 @@ int get_ctx(DeviceCtx** out) {
   return LSPIV_OK;
 }
 
+// host memory registered with HIP (hipHostMalloc / lspiv_host_alloc / hipHostRegister) can be DMA'd in place
+static bool is_pinned(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeHost;
+}
+
 // pageable -> pinned copy on a few host threads (one core moves ~10 GB/s, PCIe Gen5 x16 takes ~55)
 void staged_copy(void* dst, const void* src, size_t bytes) {
   static const int nthreads = getenv("LSPIV_STAGE_THREADS") ? std::max(1, atoi(getenv("LSPIV_STAGE_THREADS"))) : 4;
@@ -427,17 +434,21 @@ int lspiv_piv_pairs(const void* frames, int dtype, int64_t T, int64_t H, int64_t
   rc = stage_ring(c, frame_bytes);
   if (rc) return rc;
   const int64_t fpb = std::max<int64_t>(1, (int64_t)(c->pinned_cap / frame_bytes));
+  const bool src_pinned = dtype != LSPIV_F64 && is_pinned(frames);
   int batch = 0;
   for (int64_t f0 = 0; f0 < T; ++batch) {
     const int64_t f1 = std::min<int64_t>(T, f0 + fpb);
     const int slot = batch & 1;
     if (batch >= 2) HIP_TRY(hipEventSynchronize(c->staged[slot]));  // the slot's previous DMA has drained
     const size_t nb = (size_t)(f1 - f0) * frame_bytes;
+    const void* dma_src = c->pinned[slot];
     if (dtype == LSPIV_F64)
       staged_narrow((float*)c->pinned[slot], (const double*)((const char*)frames + (size_t)f0 * src_frame_bytes), (size_t)(f1 - f0) * H * W);
+    else if (src_pinned)
+      dma_src = (const char*)frames + (size_t)f0 * src_frame_bytes;   // caller's stack is pinned: no staging copy
     else
       staged_copy(c->pinned[slot], (const char*)frames + (size_t)f0 * src_frame_bytes, nb);
-    HIP_TRY(hipMemcpyAsync((char*)c->d_frames + (size_t)f0 * frame_bytes, c->pinned[slot], nb, hipMemcpyHostToDevice,
+    HIP_TRY(hipMemcpyAsync((char*)c->d_frames + (size_t)f0 * frame_bytes, dma_src, nb, hipMemcpyHostToDevice,
                            c->copy_stream));
     HIP_TRY(hipEventRecord(c->staged[slot], c->copy_stream));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->staged[slot], 0));
@@ -1190,6 +1201,18 @@ int lspiv_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes) {
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
+int lspiv_host_alloc(void** h_ptr, size_t bytes) {
+  if (!h_ptr) return fail(LSPIV_EINVAL, "h_ptr is NULL");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  HIP_TRY(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+  return LSPIV_OK;
+}
+int lspiv_host_free(void* h_ptr) {
+  if (h_ptr) HIP_TRY(hipHostFree(h_ptr));
   return LSPIV_OK;
 }
 int lspiv_memset_dev(void* d_ptr, int value, size_t bytes) {

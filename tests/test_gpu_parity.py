@@ -515,3 +515,28 @@ def test_float64_frames_are_narrowed_while_staged(gpu):
         ea.close(); eb.close()
     finally:
         os.environ.pop("LSPIV_STAGE_BYTES", None)
+
+
+def test_pinned_host_stack_is_used_in_place(gpu):
+    """pyorc_amd.pinned_empty: a stack in page-locked host memory takes the no-staging path of lspiv_piv_pairs (same
+    sub-batches, same kernels) and must give the results of a pageable copy bit for bit."""
+    import pyorc_amd
+
+    fr = particle_stack(10, 96, 128, seed=9)
+    pin = pyorc_amd.pinned_empty(fr.shape, np.uint8)
+    pin[...] = fr
+    os.environ["LSPIV_STAGE_BYTES"] = str(96 * 128 * 3)
+    try:
+        a = pyorc_amd.piv_pairs(fr, (32, 32), (16, 16))
+        b = pyorc_amd.piv_pairs(pin, (32, 32), (16, 16))
+    finally:
+        os.environ.pop("LSPIV_STAGE_BYTES", None)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)
+    view = pin[2:7]                      # a view keeps the pinned allocation alive
+    del pin
+    assert np.array_equal(view, fr[2:7])
+    f32 = pyorc_amd.pinned_empty((4, 64, 64), np.float32)
+    f32[...] = particle_stack(4, 64, 64, seed=2)
+    for x, y in zip(pyorc_amd.piv_pairs(f32, (32, 32), (16, 16)), pyorc_amd.piv_pairs(np.array(f32), (32, 32), (16, 16))):
+        assert np.array_equal(x, y, equal_nan=True)

@@ -17,3 +17,8 @@ for dtype in (np.uint8, np.float32, np.float64):
         t0 = time.perf_counter(); pyorc_amd.piv_pairs(a); best = min(best, time.perf_counter() - t0)
     P = a.shape[0] - 1
     print(f"{np.dtype(dtype).name}: {P} pairs in {best*1e3:.1f} ms -> {P/best:.0f} pairs/s, {a.nbytes/best/1e9:.1f} GB/s of host frames")
+pin = pyorc_amd.pinned_empty(fr.shape, np.uint8); pin[...] = fr
+best = 1e9
+for _ in range(3):
+    t0 = time.perf_counter(); pyorc_amd.piv_pairs(pin); best = min(best, time.perf_counter() - t0)
+print(f"uint8, stack in pinned host memory: {T-1} pairs in {best*1e3:.1f} ms -> {(T-1)/best:.0f} pairs/s, {pin.nbytes/best/1e9:.1f} GB/s")
