@@ -151,3 +151,28 @@ def test_config1_ngwerere_geometry(gpu):
     assert rel_err(ds["corr"], cmo.astype(np.float64)) <= TOL and rel_err(ds["s2n"], sno.astype(np.float64)) <= TOL
     vx_ref = (uo.astype(np.float64) * 0.01 * 30.0)
     assert rel_err(ds["v_x"][ok], vx_ref[ok], floor=0.05 * 0.3) <= TOL
+
+
+def test_ngwerere_recipe_window_25(gpu):
+    """The window the Ngwerere recipe actually asks for (examples/ngwerere/ngwerere.yml: window_size 25 -> 24 after
+    round_to_even, overlap int(round(25) / 2) = 12, quirk Q6): 785 x 875 frames, 64 x 71 windows, the 64-point
+    embedded kernel, per-timestep and ensemble mode, against the C oracle."""
+    from pyorc_amd import frames as F
+    from pyorc_amd.synth import particle_stack
+
+    fr = particle_stack(7, 785, 875, seed=20260927 + 7)
+    t = np.arange(7) / 30.0
+    assert F.resolve_window(25, None) == ((24, 24), (24, 24), (12, 12))
+    assert _lib.load().lspiv_kernel_kind(24, 24) == 5
+    ds = F.get_piv(fr, 25, time=t, resolution=0.01)
+    assert ds["v_x"].shape == (6, 64, 71)
+    uo, vo, cmo, sno, cond = c_oracle.piv_pairs(fr, (24, 24), (12, 12), return_cond=True)
+    ok = c_oracle.well_posed(cond, min_neighbour=0.05)
+    assert ok.mean() > 0.8
+    assert np.array_equal(np.isnan(ds["corr"]), np.isnan(cmo))
+    assert rel_err(ds["corr"], cmo.astype(np.float64)) <= TOL and rel_err(ds["s2n"], sno.astype(np.float64)) <= TOL
+    assert rel_err(ds["v_x"][ok], (uo.astype(np.float64) * 0.3)[ok], floor=0.05 * 0.3) <= TOL
+    assert rel_err(ds["v_y"][ok], (vo.astype(np.float64) * 0.3)[ok], floor=0.05 * 0.3) <= TOL
+    ens = F.get_piv(fr, 25, time=t, resolution=0.01, ensemble_corr=True)
+    assert ens["v_x"].shape == (1, 64, 71) and np.isfinite(ens["v_x"]).mean() > 0.9
+    assert abs(float(np.nanmedian(ens["v_x"])) - float(np.nanmedian(ds["v_x"]))) < 0.05
