@@ -229,7 +229,7 @@ def main():
 
     b_alg_pair = 2 * H * W * 1 + 16 * n_win  # both frames read once + 4 f32 per window
     # the kernel the library dispatches this shape to (pyorc_amd/csrc/piv_fft_impl.h, launch_t): time-walking by default
-    walking = os.environ.get("LSPIV_WALK", "1") != "0" and a.window in (32, 64) and a.pairs >= 3
+    walking = os.environ.get("LSPIV_WALK", "1") != "0" and a.window in (16, 32, 64) and a.pairs >= 3
     kernel_name = f"piv_fft_{'walk_' if walking else ''}kernel<unsigned char, {a.window}, false, false>"
     achieved = b_alg_pair * a.pairs / (kernel_ms * 1e-3) / 1e9
     pairs_per_s = world * a.pairs * a.steps / dt

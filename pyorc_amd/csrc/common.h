@@ -113,6 +113,21 @@ __device__ __forceinline__ int half_sum_i(int x) {
   x += swz16_i(x);
   return x;
 }
+// the same over one DPP row of 16 lanes (16 x 16 windows: four jobs per wave)
+__device__ __forceinline__ float row_sum(float x) {
+  x += dpp_f<DPP_XOR1>(x);
+  x += dpp_f<DPP_XOR2>(x);
+  x += dpp_f<DPP_HALF_MIRROR>(x);
+  x += dpp_f<DPP_MIRROR>(x);
+  return x;
+}
+__device__ __forceinline__ int row_sum_i(int x) {
+  x += dpp_i<DPP_XOR1>(x);
+  x += dpp_i<DPP_XOR2>(x);
+  x += dpp_i<DPP_HALF_MIRROR>(x);
+  x += dpp_i<DPP_MIRROR>(x);
+  return x;
+}
 // sum over all 64 lanes (two halves joined by a cross-half permute)
 __device__ __forceinline__ float wave_sum(float x) {
   x = half_sum(x);
@@ -165,6 +180,21 @@ __device__ __forceinline__ float half_max(float x) {
   return x;
 }
 
+__device__ __forceinline__ int row_min_i(int x) {
+  x = min(x, dpp_i<DPP_XOR1>(x));
+  x = min(x, dpp_i<DPP_XOR2>(x));
+  x = min(x, dpp_i<DPP_HALF_MIRROR>(x));
+  x = min(x, dpp_i<DPP_MIRROR>(x));
+  return x;
+}
+__device__ __forceinline__ float row_max(float x) {
+  x = fmaxf(x, dpp_f<DPP_XOR1>(x));
+  x = fmaxf(x, dpp_f<DPP_XOR2>(x));
+  x = fmaxf(x, dpp_f<DPP_HALF_MIRROR>(x));
+  x = fmaxf(x, dpp_f<DPP_MIRROR>(x));
+  return x;
+}
+
 constexpr float kEpsPeak = 1e-7f;
 
 // element -> float conversion of the three frame dtypes
@@ -173,6 +203,7 @@ __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(double x) { return (float)x; }
 
 // launch entry points implemented by the kernel translation units
+hipError_t launch_piv_fft16(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 hipError_t launch_piv_fft32(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 hipError_t launch_piv_fft64(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 hipError_t launch_piv_direct(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
@@ -187,7 +218,7 @@ hipError_t launch_peaks_from_planes(const float* planes, uint32_t n_planes, int 
 int walk_setting();
 // segments of the walking ENSEMBLE kernels: enough jobs for ~3 rounds of the chip, segments of an odd number of pairs
 inline void ensemble_segments(uint32_t n_win, uint32_t n_pairs, int window, uint32_t* seg_len, uint32_t* n_seg) {
-  const uint32_t slots = window == 32 ? 6144u : 2048u;   // half-wave jobs at 3 waves/SIMD; wave jobs at 2
+  const uint32_t slots = window == 16 ? 16384u : window == 32 ? 6144u : 2048u;   // quarter- / half-wave jobs at 4 / 3 waves/SIMD; wave jobs at 2
   uint32_t want = (3u * slots + n_win - 1) / n_win;
   if (want < 1) want = 1;
   uint32_t len = (n_pairs + want - 1) / want;

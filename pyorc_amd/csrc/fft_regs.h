@@ -2,8 +2,8 @@
 //
 // A lane owns a whole row (or column) of an interrogation tile in VGPRs, so a length-N
 // transform is straight-line VALU code: no LDS, no cross-lane traffic, twiddles are
-// compile-time literals.  N = 32 is 8 radix-4 butterflies -> 21 twiddle multiplies ->
-// 4 radix-8 butterflies; N = 64 is 8 radix-8 -> 49 twiddles -> 8 radix-8.
+// compile-time literals.  N = 16 is 4 radix-4 -> 9 twiddles -> 4 radix-4; N = 32 is 8 radix-4 butterflies ->
+// 21 twiddle multiplies -> 4 radix-8 butterflies; N = 64 is 8 radix-8 -> 49 twiddles -> 8 radix-8.
 //
 // There is no reference kernel to mirror: pyorc delegates the FFT to rocket_fft/pocketfft on
 // the CPU.  Sign convention matches numpy: forward = exp(-2 pi i nk/N),
@@ -116,6 +116,28 @@ struct TwiddleRow {
     }
   }
 };
+
+// ---- length-16 transform: n = 4 n1 + n2, k = k1 + 4 k2 ------------------------------------------------
+//   X[k1 + 4 k2] = DFT4_{n2}( W16^{n2 k1} * DFT4_{n1} x[4 n1 + n2] ),  W16 = W64^4
+template <bool INV>
+__device__ __forceinline__ void fft16(float (&xr)[16], float (&xi)[16]) {
+#pragma unroll
+  for (int n2 = 0; n2 < 4; ++n2)
+    bfly4<INV>(xr[n2], xi[n2], xr[4 + n2], xi[4 + n2], xr[8 + n2], xi[8 + n2], xr[12 + n2], xi[12 + n2]);   // slot (k1, n2) = 4 k1 + n2
+  twiddle64<INV, 4 * 1 * 1>(xr[4 + 1], xi[4 + 1]);  twiddle64<INV, 4 * 2 * 1>(xr[4 + 2], xi[4 + 2]);  twiddle64<INV, 4 * 3 * 1>(xr[4 + 3], xi[4 + 3]);
+  twiddle64<INV, 4 * 1 * 2>(xr[8 + 1], xi[8 + 1]);  twiddle64<INV, 4 * 2 * 2>(xr[8 + 2], xi[8 + 2]);  twiddle64<INV, 4 * 3 * 2>(xr[8 + 3], xi[8 + 3]);
+  twiddle64<INV, 4 * 1 * 3>(xr[12 + 1], xi[12 + 1]); twiddle64<INV, 4 * 2 * 3>(xr[12 + 2], xi[12 + 2]); twiddle64<INV, 4 * 3 * 3>(xr[12 + 3], xi[12 + 3]);
+  float yr[16], yi[16];
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) {
+    float r0 = xr[4 * k1], i0 = xi[4 * k1], r1 = xr[4 * k1 + 1], i1 = xi[4 * k1 + 1];
+    float r2 = xr[4 * k1 + 2], i2 = xi[4 * k1 + 2], r3 = xr[4 * k1 + 3], i3 = xi[4 * k1 + 3];
+    bfly4<INV>(r0, i0, r1, i1, r2, i2, r3, i3);
+    yr[k1] = r0; yi[k1] = i0; yr[k1 + 4] = r1; yi[k1 + 4] = i1; yr[k1 + 8] = r2; yi[k1 + 8] = i2; yr[k1 + 12] = r3; yi[k1 + 12] = i3;
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { xr[k] = yr[k]; xi[k] = yi[k]; }
+}
 
 // ---- length-32 transform, in place, natural order in and out --------------------------------
 // n = 8 n1 + n2, k = k1 + 4 k2:  X[k1 + 4 k2] = DFT8_{n2}( W32^{n2 k1} * DFT4_{n1} x[8 n1 + n2] )

@@ -47,7 +47,7 @@ struct Geo {
   static constexpr int LDS_ROW = N + 4;             // dwords per padded row: 16-byte aligned, (N/4+1) l mod 16 slots
   static constexpr int LDS_JOB = N * LDS_ROW;       // dwords per group buffer
   static constexpr int LDS_BYTES = WAVES_PER_BLOCK * GROUPS * LDS_JOB * 4;
-  static constexpr int LOG2N = N == 32 ? 5 : 6;
+  static constexpr int LOG2N = N == 16 ? 4 : N == 32 ? 5 : 6;
 };
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -58,18 +58,21 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef f64x2 f64x2_u __attribute__((aligned(8)));
 
 // ---- reductions over the N lanes of a group ----------------------------------------------------
-template <int N> __device__ __forceinline__ float group_sum(float x) { return N == 32 ? half_sum(x) : wave_sum(x); }
+template <int N> __device__ __forceinline__ float group_sum(float x) { return N == 16 ? row_sum(x) : N == 32 ? half_sum(x) : wave_sum(x); }
 template <int N> __device__ __forceinline__ int group_sum_i(int x) {
+  if (N == 16) return row_sum_i(x);
   x = half_sum_i(x);
   if (N == 64) x += __shfl_xor(x, 32, 64);
   return x;
 }
 template <int N> __device__ __forceinline__ float group_max(float x) {
+  if (N == 16) return row_max(x);
   x = half_max(x);
   if (N == 64) x = fmaxf(x, __shfl_xor(x, 32, 64));
   return x;
 }
 template <int N> __device__ __forceinline__ int group_min_i(int x) {
+  if (N == 16) return row_min_i(x);
   x = half_min_i(x);
   if (N == 64) x = min(x, __shfl_xor(x, 32, 64));
   return x;
@@ -433,6 +436,7 @@ __device__ __forceinline__ void transpose2(float* buf, int lg, float (&xr)[N], f
   transpose_plane<N>(buf, lg, xi);
 }
 
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[16], float (&xi)[16]) { fft16<INV>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[32], float (&xi)[32]) { fft32<INV>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[64], float (&xi)[64]) { fft64<INV>(xr, xi); }
 
@@ -633,7 +637,7 @@ __device__ __forceinline__ void store_plane_rows(float* dst, int lg, const float
 #define LSPIV_WAVES_32U8 4
 #endif
 template <typename T, int N>
-constexpr int kWavesPerSimd = (N == 32 && sizeof(T) == 1) ? LSPIV_WAVES_32U8 : (N == 32 && sizeof(T) == 4) ? LSPIV_WAVES_32F : 2;
+constexpr int kWavesPerSimd = N == 16 ? 4 : (N == 32 && sizeof(T) == 1) ? LSPIV_WAVES_32U8 : (N == 32 && sizeof(T) == 4) ? LSPIV_WAVES_32F : 2;
 
 // ---- per-timestep kernel: one job (two neighbouring windows of one pair) per lane group ---------
 template <typename T, int N, bool PLANES, bool WANT_NZ>
@@ -822,7 +826,7 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
 }
 
 template <typename T, int N, bool PLANES, bool WANT_NZ>
-__global__ __launch_bounds__(BLOCK, (N == 32 && sizeof(T) < 8 ? LSPIV_WALK_WAVES : 2)) void piv_fft_walk_kernel(PivParams p, uint32_t seg_len,
+__global__ __launch_bounds__(BLOCK, (N == 16 ? 4 : N == 32 && sizeof(T) < 8 ? LSPIV_WALK_WAVES : 2)) void piv_fft_walk_kernel(PivParams p, uint32_t seg_len,
                                                                                     uint32_t n_seg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using G = Geo<N>;
@@ -1166,7 +1170,7 @@ __global__ __launch_bounds__(BLOCK, (kWavesPerSimd<T, N>)) void piv_fft_ensemble
 // partial sum in HBM (zeroed by the caller), merged afterwards in segment order (ensemble_merge_kernel): fixed
 // summation order, no atomics, and ~3 rounds of jobs on the chip where one job per window would leave it 2/3 idle.
 template <typename T, int N, bool WANT_NZ>
-__global__ __launch_bounds__(BLOCK, (N == 32 && sizeof(T) < 8 ? LSPIV_WALK_WAVES : 2)) void piv_fft_walk_ensemble_kernel(PivParams p) {
+__global__ __launch_bounds__(BLOCK, (N == 16 ? 4 : N == 32 && sizeof(T) < 8 ? LSPIV_WALK_WAVES : 2)) void piv_fft_walk_ensemble_kernel(PivParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using G = Geo<N>;
   const int lane = threadIdx.x & 63;

@@ -431,7 +431,7 @@ def test_embedded_windows_every_size(gpu, n):
     circular correlation in the top-left corner), 17..20 in the direct kernel.  Every size, three dtypes, threshold, constant / empty regions, planes."""
     from pyorc_amd import _lib
 
-    assert _lib.load().lspiv_kernel_kind(n, n) == (4 if n <= 16 else 3 if n <= 20 else 5)
+    assert _lib.load().lspiv_kernel_kind(n, n) == (6 if n == 16 else 4 if n < 16 else 3 if n <= 20 else 5)
     fr = particle_stack(4, 3 * n + 5, 4 * n + 3, seed=100 + n, density=0.06)
     ov = (n // 2, n // 3)
     # 16-sample windows inside a 1024-point transform: the periodic copy of b carries 64x the window's energy, which
@@ -468,7 +468,8 @@ def test_embedded_and_direct_kernels_agree(gpu):
 
 
 @pytest.mark.parametrize("seg,P,ws", [("1", 3, 32), ("1", 4, 32), ("3", 10, 32), ("5", 11, 32), ("7", 23, 32), ("31", 40, 32),
-                                      ("2", 9, 32), ("4", 9, 32), ("3", 7, 64), ("1", 5, 64)])
+                                      ("2", 9, 32), ("4", 9, 32), ("3", 7, 64), ("1", 5, 64), ("1", 6, 16), ("5", 12, 16),
+                                      ("0", 4, 16)])
 def test_walking_kernel_segments_vs_oracle(gpu, monkeypatch, seg, P, ws):
     """The time-walking kernel under every segment geometry (odd / even segment lengths, a last segment of one pair,
     an odd frame count) against the oracle: planes, thresholds, an empty frame and a constant corner in the stack."""
