@@ -328,7 +328,7 @@ int lspiv_kernel_kind(int wy, int wx) {
   if (wy == 64 && wx == 64) return 2;
   if (wy == 16 && wx == 16) return 6;
   static const bool no_embed = getenv("LSPIV_NO_EMBED") != nullptr;   // A/B switch: direct kernel for every other size
-  if (!no_embed && wy == wx && wy >= 4 && wy <= 16) return 4;
+  if (!no_embed && wy == wx && wy >= 4 && wy <= 15) return 4;
   // 17..20: the direct kernel's N^4 multiply-adds are still cheaper than two 64-point transforms per window (measured
   // crossover between 20 and 22, tools/direct_bench.py)
   if (!no_embed && wy == wx && wy > 20 && wy < 32) return 5;

@@ -427,7 +427,7 @@ def test_ensemble_accumulate_dev_equals_host_variant(gpu):
 
 @pytest.mark.parametrize("n", [4, 6, 8, 9, 12, 14, 16, 18, 20, 22, 25, 28, 30, 31])
 def test_embedded_windows_every_size(gpu, n):
-    """Square windows 4..16 and 21..31 run inside the 32- / 64-point FFT kernels (zero-padded a, periodic b: exact
+    """Square windows 4..15 and 21..31 run inside the 32- / 64-point FFT kernels (zero-padded a, periodic b: exact
     circular correlation in the top-left corner), 17..20 in the direct kernel.  Every size, three dtypes, threshold, constant / empty regions, planes."""
     from pyorc_amd import _lib
 
