@@ -208,6 +208,7 @@ hipError_t launch_piv_fft32(const PivParams& p, int dtype, bool ensemble, hipStr
 hipError_t launch_piv_fft64(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 hipError_t launch_piv_direct(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 // square windows 4..16 / 17..31 through the 32- / 64-point transforms
+hipError_t launch_piv_embed16(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 hipError_t launch_piv_embed32(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 hipError_t launch_piv_embed64(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 hipError_t launch_peaks_from_planes(const float* planes, uint32_t n_planes, int wy, int wx,

@@ -240,6 +240,7 @@ int dispatch(const lspiv::PivParams& p, int dtype, bool ensemble, hipStream_t s)
   const int kind = lspiv_kernel_kind(p.wy, p.wx);
   hipError_t e;
   switch (kind) {
+    case 7: e = lspiv::launch_piv_embed16(p, dtype, ensemble, s); break;
     case 4: e = lspiv::launch_piv_embed32(p, dtype, ensemble, s); break;
     case 5: e = lspiv::launch_piv_embed64(p, dtype, ensemble, s); break;
     case 6: e = lspiv::launch_piv_fft16(p, dtype, ensemble, s); break;
@@ -328,7 +329,8 @@ int lspiv_kernel_kind(int wy, int wx) {
   if (wy == 64 && wx == 64) return 2;
   if (wy == 16 && wx == 16) return 6;
   static const bool no_embed = getenv("LSPIV_NO_EMBED") != nullptr;   // A/B switch: direct kernel for every other size
-  if (!no_embed && wy == wx && wy >= 4 && wy <= 15) return 4;
+  if (!no_embed && wy == wx && wy >= 4 && wy <= 8) return 7;
+  if (!no_embed && wy == wx && wy >= 9 && wy <= 15) return 4;
   // 17..20: the direct kernel's N^4 multiply-adds are still cheaper than two 64-point transforms per window (measured
   // crossover between 20 and 22, tools/direct_bench.py)
   if (!no_embed && wy == wx && wy > 20 && wy < 32) return 5;

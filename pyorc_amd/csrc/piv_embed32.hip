@@ -1,4 +1,4 @@
-// Square windows 4..15 embedded in the 32-point transforms (16 x 16 has native kernels, piv_fft16.hip) (piv_fft_impl.h, "embedded mode").
+// Square windows 9..15 embedded in the 32-point transforms (4..8: piv_embed16.hip; 16 x 16 is native, piv_fft16.hip) (piv_fft_impl.h, "embedded mode").
 #include "piv_fft_impl.h"
 
 namespace lspiv {

@@ -425,13 +425,13 @@ def test_ensemble_accumulate_dev_equals_host_variant(gpu):
     host.close(); dev.close(); lib.lspiv_dev_free(d_f); lib.lspiv_dev_free(d_o)
 
 
-@pytest.mark.parametrize("n", [4, 6, 8, 9, 12, 14, 16, 18, 20, 22, 25, 28, 30, 31])
+@pytest.mark.parametrize("n", [4, 5, 6, 7, 8, 9, 12, 14, 16, 18, 20, 22, 25, 28, 30, 31])
 def test_embedded_windows_every_size(gpu, n):
-    """Square windows 4..15 and 21..31 run inside the 32- / 64-point FFT kernels (zero-padded a, periodic b: exact
+    """Square windows 4..8, 9..15 and 21..31 run inside the 16- / 32- / 64-point FFT kernels (zero-padded a, periodic b: exact
     circular correlation in the top-left corner), 17..20 in the direct kernel.  Every size, three dtypes, threshold, constant / empty regions, planes."""
     from pyorc_amd import _lib
 
-    assert _lib.load().lspiv_kernel_kind(n, n) == (6 if n == 16 else 4 if n < 16 else 3 if n <= 20 else 5)
+    assert _lib.load().lspiv_kernel_kind(n, n) == (7 if n <= 8 else 6 if n == 16 else 4 if n < 16 else 3 if n <= 20 else 5)
     fr = particle_stack(4, 3 * n + 5, 4 * n + 3, seed=100 + n, density=0.06)
     ov = (n // 2, n // 3)
     # 16-sample windows inside a 1024-point transform: the periodic copy of b carries 64x the window's energy, which
