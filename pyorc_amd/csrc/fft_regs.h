@@ -224,4 +224,57 @@ __device__ __forceinline__ void fft64(float (&xr)[64], float (&xi)[64]) {
   for (int k = 0; k < 64; ++k) { xr[k] = yr[k]; xi[k] = yi[k]; }
 }
 
+// ---- lengths 3 * 2^m (12, 24, 48): Good-Thomas prime-factor split, NO twiddles -------------------------------------
+// 3 and 2^m are coprime, so with the index maps  n = (N2 n1 + 3 n2) mod N  (input) and  k = (e1 k1 + e2 k2) mod N
+// (output; e1 = 1 mod 3, 0 mod N2;  e2 = 0 mod 3, 1 mod N2)  the length-N DFT is exactly a 3 x N2 two-dimensional
+// DFT:  W_N^{nk} = W_3^{n1 k1} W_N2^{n2 k2}.  All indices are compile-time, so the permutations cost nothing.
+template <bool INV>
+__device__ __forceinline__ void dft3(float& r0, float& i0, float& r1, float& i1, float& r2, float& i2) {
+  constexpr float s3 = 0.86602540378443865f;   // sin(2 pi / 3)
+  const float tr = r1 + r2, ti = i1 + i2;
+  const float ur = (r1 - r2) * s3, ui = (i1 - i2) * s3;
+  const float mr = fmaf(tr, -0.5f, r0), mi = fmaf(ti, -0.5f, i0);
+  r0 += tr; i0 += ti;
+  if constexpr (!INV) {   // X1 = m - i s3 (b - c),  X2 = m + i s3 (b - c)
+    r1 = mr + ui; i1 = mi - ur;
+    r2 = mr - ui; i2 = mi + ur;
+  } else {
+    r1 = mr - ui; i1 = mi + ur;
+    r2 = mr + ui; i2 = mi - ur;
+  }
+}
+template <bool INV> __device__ __forceinline__ void fft_pow2(float (&r)[4], float (&i)[4]) { bfly4<INV>(r[0], i[0], r[1], i[1], r[2], i[2], r[3], i[3]); }
+template <bool INV> __device__ __forceinline__ void fft_pow2(float (&r)[8], float (&i)[8]) { bfly8<INV>(r, i); }
+template <bool INV> __device__ __forceinline__ void fft_pow2(float (&r)[16], float (&i)[16]) { fft16<INV>(r, i); }
+
+constexpr int pfa_unit(int n_self, int n_other) {   // e = 1 mod n_self, 0 mod n_other
+  for (int e = n_other; e < n_self * n_other; e += n_other)
+    if (e % n_self == 1) return e;
+  return 0;
+}
+
+template <bool INV, int N2>
+__device__ __forceinline__ void fft_3x(float (&xr)[3 * N2], float (&xi)[3 * N2]) {
+  constexpr int N = 3 * N2;
+  constexpr int e1 = pfa_unit(3, N2), e2 = pfa_unit(N2, 3);
+  float yr[N], yi[N];   // slot (k1, n2) at N2 k1 + n2
+#pragma unroll
+  for (int n2 = 0; n2 < N2; ++n2) {
+    float r0 = xr[(3 * n2) % N], i0 = xi[(3 * n2) % N];
+    float r1 = xr[(N2 + 3 * n2) % N], i1 = xi[(N2 + 3 * n2) % N];
+    float r2 = xr[(2 * N2 + 3 * n2) % N], i2 = xi[(2 * N2 + 3 * n2) % N];
+    dft3<INV>(r0, i0, r1, i1, r2, i2);
+    yr[n2] = r0; yi[n2] = i0; yr[N2 + n2] = r1; yi[N2 + n2] = i1; yr[2 * N2 + n2] = r2; yi[2 * N2 + n2] = i2;
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 3; ++k1) {
+    float r[N2], i[N2];
+#pragma unroll
+    for (int n2 = 0; n2 < N2; ++n2) { r[n2] = yr[N2 * k1 + n2]; i[n2] = yi[N2 * k1 + n2]; }
+    fft_pow2<INV>(r, i);
+#pragma unroll
+    for (int k2 = 0; k2 < N2; ++k2) { xr[(e1 * k1 + e2 * k2) % N] = r[k2]; xi[(e1 * k1 + e2 * k2) % N] = i[k2]; }
+  }
+}
+
 }  // namespace lspiv

@@ -43,38 +43,71 @@ template <int N>
 struct Geo {
   static constexpr int NN = N * N;                  // samples per window
   static constexpr int HALF = N / 2;
-  static constexpr int GROUPS = 64 / N;             // jobs per wave
+  static constexpr bool POW2 = (N & (N - 1)) == 0;
+  static constexpr int LG = N <= 16 ? 16 : N <= 32 ? 32 : 64;   // lanes per job; lanes >= N idle along (N = 12, 24, 48)
+  static constexpr int GROUPS = 64 / LG;            // jobs per wave
   static constexpr int LDS_ROW = N + 4;             // dwords per padded row: 16-byte aligned, (N/4+1) l mod 16 slots
   static constexpr int LDS_JOB = N * LDS_ROW;       // dwords per group buffer
   static constexpr int LDS_BYTES = WAVES_PER_BLOCK * GROUPS * LDS_JOB * 4;
-  static constexpr int LOG2N = N == 16 ? 4 : N == 32 ? 5 : 6;
 };
 
+// index helpers valid for the non-power-of-two sizes too (3 * 2^m): i in [0, 2N)
+template <int N> __device__ __forceinline__ int wrap_n(int i) {
+  if constexpr (Geo<N>::POW2) return i & (N - 1);
+  else return i >= N ? i - N : i;
+}
+// lane -> the tile row it works on: lanes >= N of a group clone row N - 1 (they load, transform and reduce the same
+// values as lane N - 1 but never write LDS or HBM, and are masked out of sums / arg-min reductions)
+template <int N> __device__ __forceinline__ int row_of(int lg) {
+  if constexpr (Geo<N>::POW2) return lg;
+  else return lg < N ? lg : N - 1;
+}
+template <int N> __device__ __forceinline__ bool lane_active(int lg) {
+  if constexpr (Geo<N>::POW2) return true;
+  else return lg < N;
+}
+template <int N> __device__ __forceinline__ int partner_byte_of(int lane, int lg) {   // byte address of lane -kx
+  constexpr int LG = Geo<N>::LG;
+  if constexpr (Geo<N>::POW2) return ((lane & ~(LG - 1)) | ((N - lg) & (N - 1))) << 2;
+  else { const int r = row_of<N>(lg); return ((lane & ~(LG - 1)) | (r == 0 ? 0 : N - r)) << 2; }
+}
+
+template <int N> __device__ __forceinline__ int group_lane() { return (int)(threadIdx.x & (unsigned)(Geo<N>::LG - 1)); }
+template <int N> __device__ __forceinline__ int lane0_byte_of() {   // byte address of the group's lane 0 (ds_bpermute)
+  return (int)((threadIdx.x & 63u) & ~(unsigned)(Geo<N>::LG - 1)) << 2;
+}
+
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x2 u32x2_u __attribute__((aligned(1)));
 typedef u32x4 u32x4_u __attribute__((aligned(1)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef f32x4 f32x4_u __attribute__((aligned(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef f64x2 f64x2_u __attribute__((aligned(8)));
 
+__device__ __forceinline__ float bperm_f(int addr, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
+}
+
 // ---- reductions over the N lanes of a group ----------------------------------------------------
-template <int N> __device__ __forceinline__ float group_sum(float x) { return N == 16 ? row_sum(x) : N == 32 ? half_sum(x) : wave_sum(x); }
+template <int N> __device__ __forceinline__ float group_sum(float x) { return Geo<N>::LG == 16 ? row_sum(x) : Geo<N>::LG == 32 ? half_sum(x) : wave_sum(x); }
 template <int N> __device__ __forceinline__ int group_sum_i(int x) {
-  if (N == 16) return row_sum_i(x);
+  if (Geo<N>::LG == 16) return row_sum_i(x);
   x = half_sum_i(x);
-  if (N == 64) x += __shfl_xor(x, 32, 64);
+  if (Geo<N>::LG == 64) x += __shfl_xor(x, 32, 64);
   return x;
 }
 template <int N> __device__ __forceinline__ float group_max(float x) {
-  if (N == 16) return row_max(x);
+  if (Geo<N>::LG == 16) return row_max(x);
   x = half_max(x);
-  if (N == 64) x = fmaxf(x, __shfl_xor(x, 32, 64));
+  if (Geo<N>::LG == 64) x = fmaxf(x, __shfl_xor(x, 32, 64));
   return x;
 }
 template <int N> __device__ __forceinline__ int group_min_i(int x) {
-  if (N == 16) return row_min_i(x);
+  if (Geo<N>::LG == 16) return row_min_i(x);
   x = half_min_i(x);
-  if (N == 64) x = min(x, __shfl_xor(x, 32, 64));
+  if (Geo<N>::LG == 64) x = min(x, __shfl_xor(x, 32, 64));
   return x;
 }
 
@@ -84,10 +117,21 @@ __device__ __forceinline__ float tree_sum(const float (&x)[N]) {
   float s[N / 2];
 #pragma unroll
   for (int k = 0; k < N / 2; ++k) s[k] = x[2 * k] + x[2 * k + 1];
+  if constexpr (Geo<N>::POW2) {
 #pragma unroll
-  for (int w = N / 4; w >= 1; w >>= 1) {
+    for (int w = N / 4; w >= 1; w >>= 1) {
 #pragma unroll
-    for (int k = 0; k < w; ++k) s[k] = s[2 * k] + s[2 * k + 1];
+      for (int k = 0; k < w; ++k) s[k] = s[2 * k] + s[2 * k + 1];
+    }
+  } else {
+#pragma unroll
+    for (int cnt = N / 2; cnt > 1;) {
+      const int h = cnt / 2;
+#pragma unroll
+      for (int k = 0; k < h; ++k) s[k] = s[2 * k] + s[2 * k + 1];
+      if (cnt & 1) s[h] = s[cnt - 1];
+      cnt = h + (cnt & 1);
+    }
   }
   return s[0];
 }
@@ -100,6 +144,7 @@ template <typename T, int N>
 struct RowRaw {
   const T* p;
   __device__ __forceinline__ void fetch(const T* q) { p = q; }
+  __device__ __forceinline__ void mask(bool) {}
 };
 template <int N>
 struct RowRaw<uint8_t, N> {
@@ -110,6 +155,22 @@ struct RowRaw<uint8_t, N> {
       const u32x4 v = *reinterpret_cast<const u32x4_u*>(q + 16 * k);
       w[4 * k] = v[0]; w[4 * k + 1] = v[1]; w[4 * k + 2] = v[2]; w[4 * k + 3] = v[3];
     }
+    constexpr int done = N / 16 * 16;
+    if constexpr (N - done >= 8) {
+      const u32x2 v = *reinterpret_cast<const u32x2_u*>(q + done);
+      w[done / 4] = v[0]; w[done / 4 + 1] = v[1];
+    }
+    if constexpr ((N - done) % 8 == 4) {
+      uint32_t v;
+      __builtin_memcpy(&v, q + (N - 4), 4);
+      w[N / 4 - 1] = v;
+    }
+    if constexpr (!Geo<N>::POW2) mask(lane_active<N>(group_lane<N>()));
+  }
+  // idle lanes of a group (row_of): zero bytes count for nothing in the window sums
+  __device__ __forceinline__ void mask(bool active) {
+#pragma unroll
+    for (int k = 0; k < N / 4; ++k) w[k] = active ? w[k] : 0u;
   }
 };
 
@@ -167,13 +228,19 @@ __device__ __forceinline__ void center_u8(const RowRaw<uint8_t, N>& raw, float m
 template <int N>
 __device__ __forceinline__ float center_clip_f(float (&x)[N], bool want_nz, int& nonzero, bool& finite) {
   constexpr float inv_nn = 1.0f / Geo<N>::NN;
+  const bool active = lane_active<N>(group_lane<N>());   // constant true for the power-of-two sizes
   if (want_nz) {
     int c = 0;
 #pragma unroll
     for (int k = 0; k < N; ++k) c += (x[k] != 0.0f) ? 1 : 0;
-    nonzero = group_sum_i<N>(c);
+    nonzero = group_sum_i<N>(active ? c : 0);
   }
-  const float s = group_sum<N>(tree_sum<N>(x));
+  if constexpr (!Geo<N>::POW2) {   // N^2 is no power of two: shifted mean, so a constant window has exactly zero variance
+    const float x0 = bperm_f(lane0_byte_of<N>(), x[0]);
+#pragma unroll
+    for (int k = 0; k < N; ++k) x[k] -= x0;
+  }
+  const float s = group_sum<N>(active ? tree_sum<N>(x) : 0.0f);
   const float mean = s * inv_nn;
   float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -182,7 +249,7 @@ __device__ __forceinline__ float center_clip_f(float (&x)[N], bool want_nz, int&
     acc[k & 3] = fmaf(d, d, acc[k & 3]);
     x[k] = fmaxf(d, 0.0f);
   }
-  const float ssq = group_sum<N>((acc[0] + acc[1]) + (acc[2] + acc[3]));
+  const float ssq = group_sum<N>(active ? (acc[0] + acc[1]) + (acc[2] + acc[3]) : 0.0f);
   finite = finite && (fabsf(s) <= 3.0e38f) && (ssq <= 3.0e38f);
   const float var = ssq * inv_nn;
   return var > 0.0f ? __builtin_amdgcn_rsqf(var) : 0.0f;
@@ -265,9 +332,6 @@ struct TileRef {
   bool valid;
 };
 
-__device__ __forceinline__ float bperm_f(int addr, float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
-}
 
 // ---- embedded mode: a square n x n window, 4 <= n <= N/2, through the N-point transforms ------------------------
 // pyorc accepts any even window (the Ngwerere recipe asks for 25 -> 24, pyorc's tests use 10..20): those sizes have no
@@ -389,7 +453,7 @@ __device__ __forceinline__ void prepare_pair_embed(const PivParams& p, const Til
   const uint32_t wcol = t.win - wrow * (uint32_t)p.n_cols;
   const int64_t base = ((int64_t)t.pair * p.H + (int64_t)wrow * p.sy) * p.W + (int64_t)wcol * p.sx;
   const bool row_in = lg < n;
-  const int lane0_byte = (int)((threadIdx.x & 63u) & ~(unsigned)(N - 1)) << 2;
+  const int lane0_byte = lane0_byte_of<N>();
   bool finite = true;
   int nza = 0, nzb = 0;
   const float inv_a = load_center_embed<T, N, WANT_NZ, false>(frames + base + (int64_t)(row_in ? lg : 0) * p.W, n, row_in,
@@ -419,10 +483,12 @@ template <int N>
 __device__ __forceinline__ void transpose_plane(float* buf, int lg, float (&x)[N]) {
   constexpr int LR = Geo<N>::LDS_ROW;
   float* wcol = buf + lg;
+  if (lane_active<N>(lg)) {
 #pragma unroll
-  for (int j = 0; j < N; ++j) wcol[j * LR] = x[j];
+    for (int j = 0; j < N; ++j) wcol[j * LR] = x[j];
+  }
   __builtin_amdgcn_wave_barrier();  // same wave: LDS ops execute in order, this only pins the compiler
-  const f32x4* rrow = reinterpret_cast<const f32x4*>(buf + lg * LR);
+  const f32x4* rrow = reinterpret_cast<const f32x4*>(buf + row_of<N>(lg) * LR);
 #pragma unroll
   for (int q = 0; q < N / 4; ++q) {
     const f32x4 v = rrow[q];
@@ -439,6 +505,9 @@ __device__ __forceinline__ void transpose2(float* buf, int lg, float (&xr)[N], f
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[16], float (&xi)[16]) { fft16<INV>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[32], float (&xi)[32]) { fft32<INV>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[64], float (&xi)[64]) { fft64<INV>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[12], float (&xi)[12]) { fft_3x<INV, 4>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[24], float (&xi)[24]) { fft_3x<INV, 8>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[48], float (&xi)[48]) { fft_3x<INV, 16>(xr, xi); }
 
 
 // lane = kx, registers = ky hold Z = FFT2(a + i b).  Writes s * 4 conj(A) B for ky = 0..N/2 into
@@ -448,7 +517,7 @@ __device__ __forceinline__ void cross_spectrum_half(int partner_byte, const floa
                                                     float s, float (&rr)[N / 2 + 1], float (&ri)[N / 2 + 1]) {
 #pragma unroll
   for (int ky = 0; ky <= N / 2; ++ky) {
-    const int kn = (N - ky) & (N - 1);
+    const int kn = (N - ky) % N;
     const float wr = bperm_f(partner_byte, zr[kn]);
     const float wi = bperm_f(partner_byte, zi[kn]);
     const float ar = zr[ky], ai = zi[ky];
@@ -474,7 +543,7 @@ __device__ __forceinline__ void correlate_job(const PivParams& p, const TileRef 
   auto fetch_rows = [&](int k) {
     const uint32_t wrow = p.div_ncols.div(t[k].win);
     const uint32_t wcol = t[k].win - wrow * (uint32_t)p.n_cols;
-    const int64_t off = ((int64_t)t[k].pair * p.H + (int64_t)(wrow * p.sy + lg)) * p.W + (int64_t)wcol * p.sx;
+    const int64_t off = ((int64_t)t[k].pair * p.H + (int64_t)(wrow * p.sy + row_of<N>(lg))) * p.W + (int64_t)wcol * p.sx;
     raw[k][0].fetch(frames + off);
     raw[k][1].fetch(frames + off + p.frame_elems);
   };
@@ -539,7 +608,7 @@ __device__ __forceinline__ void correlate_job(const PivParams& p, const TileRef 
   // mean of a plane = its DC bin: sum_x IFFT(Q)[x] = N^2 Q[0][0], and Q[0][0] = s1 R1[0][0] + i s2 R2[0][0] sits
   // in lane kx = 0 of the group, register ky = 0.  (The reference averages the CLIPPED plane; the clip only
   // removes float rounding below zero -- a ~1e-8 relative difference, measured in the parity tests.)
-  const int lane0_byte = (int)((threadIdx.x & 63u) & ~(unsigned)(N - 1)) << 2;
+  const int lane0_byte = lane0_byte_of<N>();
   mean[0] = bperm_f(lane0_byte, xr[0]);
   mean[1] = bperm_f(lane0_byte, xi[0]);
   __builtin_amdgcn_sched_barrier(0);
@@ -581,21 +650,25 @@ __device__ __forceinline__ void find_peak(float* buf, int lg, const float (&c)[N
                                           float& u, float& v) {
   constexpr int LR = Geo<N>::LDS_ROW;
   constexpr int M = N - 1, C = N / 2, NONE = 1 << 12;
-  f32x4* wrow = reinterpret_cast<f32x4*>(buf + lg * LR);
+  const bool active = lane_active<N>(lg);
+  const int lr = row_of<N>(lg);
+  if (active) {
+    f32x4* wrow = reinterpret_cast<f32x4*>(buf + lg * LR);
 #pragma unroll
-  for (int q = 0; q < N / 4; ++q) {
-    const f32x4 w = {c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
-    wrow[q] = w;
+    for (int q = 0; q < N / 4; ++q) {
+      const f32x4 w = {c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
+      wrow[q] = w;
+    }
   }
   __builtin_amdgcn_wave_barrier();
-  const int sh = (lg + C) & M;                                           // this lane's shifted row AND column
-  const int ip = group_min_i<N>(row_max == vmax ? sh : NONE);            // first shifted row with the maximum
-  const int y = (ip + C) & M;
-  const int jp = group_min_i<N>(buf[y * LR + lg] == vmax ? sh : NONE);   // first shifted column in that row
+  const int sh = wrap_n<N>(lr + C);                                                  // this lane's shifted row AND column
+  const int ip = group_min_i<N>((active && row_max == vmax) ? sh : NONE);            // first shifted row with the maximum
+  const int y = wrap_n<N>(ip + C);
+  const int jp = group_min_i<N>((active && buf[y * LR + lr] == vmax) ? sh : NONE);   // first shifted column in that row
   const bool border = (ip == 0 || ip == M || jp == 0 || jp == M);
-  const int x = (jp + C) & M;
-  const int ym = (ip + C - 1) & M, yp = (ip + C + 1) & M;
-  const int xm = (jp + C - 1) & M, xp = (jp + C + 1) & M;
+  const int x = wrap_n<N>(jp + C);
+  const int ym = wrap_n<N>(ip + C - 1), yp = wrap_n<N>(ip + C + 1);
+  const int xm = wrap_n<N>(jp + C - 1), xp = wrap_n<N>(jp + C + 1);
   const float c0 = vmax + kEpsPeak;
   const float cl = buf[ym * LR + x] + kEpsPeak;
   const float cr = buf[yp * LR + x] + kEpsPeak;
@@ -612,13 +685,14 @@ __device__ __forceinline__ void find_peak(float* buf, int lg, const float (&c)[N
 template <int N>
 __device__ __forceinline__ void store_plane_rows(float* dst, int lg, const float (&c)[N], bool nan_plane) {
   // shifted row i' = (y + N/2) % N receives columns x = N/2..N-1, 0..N/2-1
-  float* row = dst + ((lg + N / 2) & (N - 1)) * N;
+  if (!lane_active<N>(lg)) return;
+  float* row = dst + wrap_n<N>(lg + N / 2) * N;
   const float nanv = __builtin_nanf("");
 #pragma unroll
   for (int q = 0; q < N / 4; ++q) {
     f32x4 v;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = nan_plane ? nanv : c[(4 * q + e + N / 2) & (N - 1)];
+    for (int e = 0; e < 4; ++e) v[e] = nan_plane ? nanv : c[(4 * q + e + N / 2) % N];
     *reinterpret_cast<f32x4*>(row + 4 * q) = v;
   }
 }
@@ -637,7 +711,7 @@ __device__ __forceinline__ void store_plane_rows(float* dst, int lg, const float
 #define LSPIV_WAVES_32U8 4
 #endif
 template <typename T, int N>
-constexpr int kWavesPerSimd = N == 16 ? 4 : (N == 32 && sizeof(T) == 1) ? LSPIV_WAVES_32U8 : (N == 32 && sizeof(T) == 4) ? LSPIV_WAVES_32F : 2;
+constexpr int kWavesPerSimd = N <= 24 ? 4 : (N == 32 && sizeof(T) == 1) ? LSPIV_WAVES_32U8 : (N == 32 && sizeof(T) == 4) ? LSPIV_WAVES_32F : 2;
 
 // ---- per-timestep kernel: one job (two neighbouring windows of one pair) per lane group ---------
 template <typename T, int N, bool PLANES, bool WANT_NZ>
@@ -646,10 +720,10 @@ __global__ __launch_bounds__(BLOCK, (kWavesPerSimd<T, N>)) void piv_fft_kernel(P
   using G = Geo<N>;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int grp = lane / N;
-  const int lg = lane & (N - 1);
+  const int grp = lane / G::LG;
+  const int lg = lane & (G::LG - 1);
   float* buf = smem + (wave * G::GROUPS + grp) * G::LDS_JOB;
-  const int partner_byte = ((lane & ~(N - 1)) | ((N - lg) & (N - 1))) << 2;
+  const int partner_byte = partner_byte_of<N>(lane, lg);
 
   // XCD-aware block order: block b runs on XCD b % 8; give every XCD one contiguous range of
   // jobs (= contiguous frame pairs) so a frame is pulled into one L2, not eight.
@@ -784,7 +858,7 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
   // step only touches registers ky and N - ky of this lane and of the mirrored lane, so it can run in place)
 #pragma unroll
   for (int ky = 0; ky <= H; ++ky) {
-    const int kn = (N - ky) & (N - 1);
+    const int kn = (N - ky) % N;
     const float mr = bperm_f(partner_byte, xr[kn]);
     const float mi = bperm_f(partner_byte, xi[kn]);
     const float pr = (xr[ky] + mr) * kScale, pi = (xi[ky] - mi) * kScale;   // 2 F_f / (4 N^4)
@@ -826,17 +900,17 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
 }
 
 template <typename T, int N, bool PLANES, bool WANT_NZ>
-__global__ __launch_bounds__(BLOCK, (N == 16 ? 4 : N == 32 && sizeof(T) < 8 ? LSPIV_WALK_WAVES : 2)) void piv_fft_walk_kernel(PivParams p, uint32_t seg_len,
+__global__ __launch_bounds__(BLOCK, (N <= 16 ? 4 : N <= 32 && sizeof(T) < 8 ? LSPIV_WALK_WAVES : 2)) void piv_fft_walk_kernel(PivParams p, uint32_t seg_len,
                                                                                     uint32_t n_seg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using G = Geo<N>;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int grp = lane / N;
-  const int lg = lane & (N - 1);
+  const int grp = lane / G::LG;
+  const int lg = lane & (G::LG - 1);
   float* buf = smem + (wave * G::GROUPS + grp) * G::LDS_JOB;
-  const int partner_byte = ((lane & ~(N - 1)) | ((N - lg) & (N - 1))) << 2;
-  const int lane0_byte = (lane & ~(N - 1)) << 2;
+  const int partner_byte = partner_byte_of<N>(lane, lg);
+  const int lane0_byte = lane0_byte_of<N>();
 
   // XCD-aware block order (block b runs on XCD b % 8): every XCD gets one contiguous range of jobs = whole segments,
   // so a frame is pulled into one L2 only
@@ -853,7 +927,7 @@ __global__ __launch_bounds__(BLOCK, (N == 16 ? 4 : N == 32 && sizeof(T) < 8 ? LS
   const uint32_t p1 = min(p0 + seg_len, p.n_pairs);                  // pairs [p0, p1) = frames p0 .. p1
   const uint32_t wrow = p.div_ncols.div(win);
   const uint32_t wcol = win - wrow * (uint32_t)p.n_cols;
-  const T* row = static_cast<const T*>(p.frames) + ((int64_t)p0 * p.H + (int64_t)(wrow * p.sy + lg)) * p.W +
+  const T* row = static_cast<const T*>(p.frames) + ((int64_t)p0 * p.H + (int64_t)(wrow * p.sy + row_of<N>(lg))) * p.W +
                  (int64_t)wcol * p.sx;
   const float nanv = __builtin_nanf("");
 
@@ -958,10 +1032,10 @@ __global__ __launch_bounds__(BLOCK, 2) void piv_fft_embed_kernel(PivParams p) {
   using G = Geo<N>;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int grp = lane / N;
-  const int lg = lane & (N - 1);
+  const int grp = lane / G::LG;
+  const int lg = lane & (G::LG - 1);
   float* buf = smem + (wave * G::GROUPS + grp) * G::LDS_JOB;
-  const int partner_byte = ((lane & ~(N - 1)) | ((N - lg) & (N - 1))) << 2;
+  const int partner_byte = partner_byte_of<N>(lane, lg);
   const uint32_t nb = gridDim.x;                                   // XCD-aware block order, as piv_fft_kernel
   const uint32_t q = nb >> 3, r = nb & 7u;
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
@@ -1014,10 +1088,10 @@ __global__ __launch_bounds__(BLOCK, 2) void piv_fft_embed_ensemble_kernel(PivPar
   constexpr bool SINGLE = N == 64;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int grp = lane / N;
-  const int lg = lane & (N - 1);
+  const int grp = lane / G::LG;
+  const int lg = lane & (G::LG - 1);
   float* buf = smem + (wave * G::GROUPS + grp) * G::LDS_JOB;
-  const int partner_byte = ((lane & ~(N - 1)) | ((N - lg) & (N - 1))) << 2;
+  const int partner_byte = partner_byte_of<N>(lane, lg);
   const uint32_t job = (blockIdx.x * WAVES_PER_BLOCK + wave) * G::GROUPS + grp;
   const bool valid = job < p.n_win;
   const uint32_t w = valid ? job : p.n_win - 1;
@@ -1112,13 +1186,14 @@ template <int N>
 __device__ __forceinline__ void accumulate_planes(float* dst, int lg, const float (&c0)[N], bool keep0,
                                                   const float (&c1)[N], bool keep1) {
   // corr_sum is kept in fft-shifted layout (what u_v_displacement expects)
-  float* row = dst + ((lg + N / 2) & (N - 1)) * N;
+  if (!lane_active<N>(lg)) return;
+  float* row = dst + wrap_n<N>(lg + N / 2) * N;
 #pragma unroll
   for (int qd = 0; qd < N / 4; ++qd) {
     f32x4 acc = *reinterpret_cast<f32x4*>(row + 4 * qd);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int j = (4 * qd + e + N / 2) & (N - 1);
+      const int j = (4 * qd + e + N / 2) % N;
       acc[e] += keep0 ? c0[j] : 0.0f;   // pair 2k first, then 2k+1: the reference's summation order
       acc[e] += keep1 ? c1[j] : 0.0f;
     }
@@ -1132,10 +1207,10 @@ __global__ __launch_bounds__(BLOCK, (kWavesPerSimd<T, N>)) void piv_fft_ensemble
   using G = Geo<N>;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int grp = lane / N;
-  const int lg = lane & (N - 1);
+  const int grp = lane / G::LG;
+  const int lg = lane & (G::LG - 1);
   float* buf = smem + (wave * G::GROUPS + grp) * G::LDS_JOB;
-  const int partner_byte = ((lane & ~(N - 1)) | ((N - lg) & (N - 1))) << 2;
+  const int partner_byte = partner_byte_of<N>(lane, lg);
   const uint32_t job = (blockIdx.x * WAVES_PER_BLOCK + wave) * G::GROUPS + grp;
   const bool valid = job < p.n_win;
   const uint32_t w = valid ? job : p.n_win - 1;
@@ -1170,16 +1245,16 @@ __global__ __launch_bounds__(BLOCK, (kWavesPerSimd<T, N>)) void piv_fft_ensemble
 // partial sum in HBM (zeroed by the caller), merged afterwards in segment order (ensemble_merge_kernel): fixed
 // summation order, no atomics, and ~3 rounds of jobs on the chip where one job per window would leave it 2/3 idle.
 template <typename T, int N, bool WANT_NZ>
-__global__ __launch_bounds__(BLOCK, (N == 16 ? 4 : N == 32 && sizeof(T) < 8 ? LSPIV_WALK_WAVES : 2)) void piv_fft_walk_ensemble_kernel(PivParams p) {
+__global__ __launch_bounds__(BLOCK, (N <= 16 ? 4 : N <= 32 && sizeof(T) < 8 ? LSPIV_WALK_WAVES : 2)) void piv_fft_walk_ensemble_kernel(PivParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using G = Geo<N>;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int grp = lane / N;
-  const int lg = lane & (N - 1);
+  const int grp = lane / G::LG;
+  const int lg = lane & (G::LG - 1);
   float* buf = smem + (wave * G::GROUPS + grp) * G::LDS_JOB;
-  const int partner_byte = ((lane & ~(N - 1)) | ((N - lg) & (N - 1))) << 2;
-  const int lane0_byte = (lane & ~(N - 1)) << 2;
+  const int partner_byte = partner_byte_of<N>(lane, lg);
+  const int lane0_byte = lane0_byte_of<N>();
   const uint32_t nb = gridDim.x;                                   // XCD-aware block order, as piv_fft_walk_kernel
   const uint32_t q = nb >> 3, r = nb & 7u;
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
@@ -1193,7 +1268,7 @@ __global__ __launch_bounds__(BLOCK, (N == 16 ? 4 : N == 32 && sizeof(T) < 8 ? LS
   const uint32_t p1 = min(p0 + p.seg_len, p.n_pairs);
   const uint32_t wrow = p.div_ncols.div(win);
   const uint32_t wcol = win - wrow * (uint32_t)p.n_cols;
-  const T* row = static_cast<const T*>(p.frames) + ((int64_t)p0 * p.H + (int64_t)(wrow * p.sy + lg)) * p.W +
+  const T* row = static_cast<const T*>(p.frames) + ((int64_t)p0 * p.H + (int64_t)(wrow * p.sy + row_of<N>(lg))) * p.W +
                  (int64_t)wcol * p.sx;
   float* part = p.part_sum + (size_t)job * G::NN;
   float cnt = 0.0f;

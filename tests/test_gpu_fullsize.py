@@ -155,15 +155,15 @@ def test_config1_ngwerere_geometry(gpu):
 
 def test_ngwerere_recipe_window_25(gpu):
     """The window the Ngwerere recipe actually asks for (examples/ngwerere/ngwerere.yml: window_size 25 -> 24 after
-    round_to_even, overlap int(round(25) / 2) = 12, quirk Q6): 785 x 875 frames, 64 x 71 windows, the 64-point
-    embedded kernel, per-timestep and ensemble mode, against the C oracle."""
+    round_to_even, overlap int(round(25) / 2) = 12, quirk Q6): 785 x 875 frames, 64 x 71 windows, the 24-point
+    FFT kernels, per-timestep and ensemble mode, against the C oracle."""
     from pyorc_amd import frames as F
     from pyorc_amd.synth import particle_stack
 
     fr = particle_stack(7, 785, 875, seed=20260927 + 7)
     t = np.arange(7) / 30.0
     assert F.resolve_window(25, None) == ((24, 24), (24, 24), (12, 12))
-    assert _lib.load().lspiv_kernel_kind(24, 24) == 5
+    assert _lib.load().lspiv_kernel_kind(24, 24) == 8
     ds = F.get_piv(fr, 25, time=t, resolution=0.01)
     assert ds["v_x"].shape == (6, 64, 71)
     uo, vo, cmo, sno, cond = c_oracle.piv_pairs(fr, (24, 24), (12, 12), return_cond=True)

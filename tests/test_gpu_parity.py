@@ -425,13 +425,14 @@ def test_ensemble_accumulate_dev_equals_host_variant(gpu):
     host.close(); dev.close(); lib.lspiv_dev_free(d_f); lib.lspiv_dev_free(d_o)
 
 
-@pytest.mark.parametrize("n", [4, 5, 6, 7, 8, 9, 12, 14, 16, 18, 20, 22, 25, 28, 30, 31])
+@pytest.mark.parametrize("n", [4, 5, 6, 7, 8, 9, 12, 14, 16, 18, 20, 22, 24, 25, 28, 30, 31, 48])
 def test_embedded_windows_every_size(gpu, n):
     """Square windows 4..8, 9..15 and 21..31 run inside the 16- / 32- / 64-point FFT kernels (zero-padded a, periodic b: exact
-    circular correlation in the top-left corner), 17..20 in the direct kernel.  Every size, three dtypes, threshold, constant / empty regions, planes."""
+    circular correlation in the top-left corner), 17..20 in the direct kernel; 12, 16, 24 and 48 have FFT kernels of their own.  Every size, three dtypes, threshold, constant / empty regions, planes."""
     from pyorc_amd import _lib
 
-    assert _lib.load().lspiv_kernel_kind(n, n) == (7 if n <= 8 else 6 if n == 16 else 4 if n < 16 else 3 if n <= 20 else 5)
+    native = {12: 9, 16: 6, 24: 8, 48: 10}    # own FFT kernels (12, 24, 48: prime-factor 3 x 2^m transforms)
+    assert _lib.load().lspiv_kernel_kind(n, n) == native.get(n, 7 if n <= 8 else 4 if n < 16 else 3 if n <= 20 else 5)
     fr = particle_stack(4, 3 * n + 5, 4 * n + 3, seed=100 + n, density=0.06)
     ov = (n // 2, n // 3)
     # 16-sample windows inside a 1024-point transform: the periodic copy of b carries 64x the window's energy, which
@@ -446,7 +447,8 @@ def test_embedded_windows_every_size(gpu, n):
 
 
 def test_embedded_and_direct_kernels_agree(gpu):
-    """LSPIV_NO_EMBED=1 sends every non-power-of-two window to the direct spatial kernel: same answers."""
+    """24 x 24 three ways: its own FFT kernel (default), embedded in the 64-point kernel (LSPIV_NO_PFA=1) and the direct
+    spatial kernel (LSPIV_NO_PFA=1 LSPIV_NO_EMBED=1): same answers."""
     import subprocess
     import sys
 
@@ -454,22 +456,24 @@ def test_embedded_and_direct_kernels_agree(gpu):
             "fr = particle_stack(3, 90, 120, seed=8, density=0.05); "
             "np.save(sys.argv[1], np.stack(pyorc_amd.piv_pairs(fr, (24, 24), (12, 12)) + pyorc_amd.piv_pairs(fr, (10, 10), (5, 5))[:0]))")
     outs = []
-    for env_extra in ({}, {"LSPIV_NO_EMBED": "1"}):
+    for env_extra in ({"LSPIV_NO_PFA": "1"}, {"LSPIV_NO_PFA": "1", "LSPIV_NO_EMBED": "1"}, {}):
         path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"embed_ab_{len(outs)}.npy")
         subprocess.run([sys.executable, "-c", "import sys; " + code, path], check=True, env={**os.environ, **env_extra},
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         outs.append(np.load(path))
-    a, b = outs
-    assert np.array_equal(np.isnan(a), np.isnan(b))
-    assert rel_err(a[2:], b[2:].astype(np.float64)) <= 1e-5          # corr_max, s2n
     cond = c_oracle.piv_pairs(particle_stack(3, 90, 120, seed=8, density=0.05), (24, 24), (12, 12), return_cond=True)[-1]
     ok = c_oracle.well_posed(cond, min_neighbour=0.05)
-    assert ok.mean() > 0.5 and rel_err(a[0][ok], b[0][ok].astype(np.float64)) <= TOL and rel_err(a[1][ok], b[1][ok].astype(np.float64)) <= TOL
+    a = outs[0]                                                        # 64-point embedded kernel
+    for b in outs[1:]:                                                 # direct kernel; the 24-point FFT kernel (default)
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        assert rel_err(a[2:], b[2:].astype(np.float64)) <= 1e-5          # corr_max, s2n
+        assert ok.mean() > 0.5 and rel_err(a[0][ok], b[0][ok].astype(np.float64)) <= TOL and rel_err(a[1][ok], b[1][ok].astype(np.float64)) <= TOL
 
 
 @pytest.mark.parametrize("seg,P,ws", [("1", 3, 32), ("1", 4, 32), ("3", 10, 32), ("5", 11, 32), ("7", 23, 32), ("31", 40, 32),
                                       ("2", 9, 32), ("4", 9, 32), ("3", 7, 64), ("1", 5, 64), ("1", 6, 16), ("5", 12, 16),
-                                      ("0", 4, 16)])
+                                      ("0", 4, 16), ("1", 6, 24), ("3", 8, 24), ("0", 4, 24), ("5", 11, 12), ("0", 3, 12),
+                                      ("1", 5, 48), ("0", 3, 48)])
 def test_walking_kernel_segments_vs_oracle(gpu, monkeypatch, seg, P, ws):
     """The time-walking kernel under every segment geometry (odd / even segment lengths, a last segment of one pair,
     an odd frame count) against the oracle: planes, thresholds, an empty frame and a constant corner in the stack."""
@@ -489,7 +493,8 @@ def test_walking_kernel_segments_vs_oracle(gpu, monkeypatch, seg, P, ws):
 
     ref = pyorc_amd.piv_pairs(fr, (ws, ws), ov)
     monkeypatch.setenv("LSPIV_WALK", seg)
-    assert_chunk_close(pyorc_amd.piv_pairs(fr, (ws, ws), ov), ref)
+    # 12 x 12 windows: ~200 vectors, so the 99.9th percentile is the single worst-conditioned sub-pixel fit
+    assert_chunk_close(pyorc_amd.piv_pairs(fr, (ws, ws), ov), ref, uv_tol=1e-4 if ws >= 16 else 1e-3)
 
 
 def test_float64_frames_are_narrowed_while_staged(gpu):
