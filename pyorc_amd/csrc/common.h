@@ -205,7 +205,9 @@ __device__ __forceinline__ float to_f32(double x) { return (float)x; }
 // launch entry points implemented by the kernel translation units
 hipError_t launch_piv_fft12(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 hipError_t launch_piv_fft16(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
+hipError_t launch_piv_fft20(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 hipError_t launch_piv_fft24(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
+hipError_t launch_piv_fft40(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 hipError_t launch_piv_fft48(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 hipError_t launch_piv_fft32(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 hipError_t launch_piv_fft64(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
@@ -223,7 +225,7 @@ int walk_setting();
 // segments of the walking ENSEMBLE kernels: enough jobs for ~3 rounds of the chip, segments of an odd number of pairs
 inline void ensemble_segments(uint32_t n_win, uint32_t n_pairs, int window, uint32_t* seg_len, uint32_t* n_seg) {
   // quarter- / half-wave jobs at 4 / 3 waves/SIMD; wave jobs at 2
-  const uint32_t slots = window <= 16 ? 16384u : window == 24 ? 8192u : window == 32 ? 6144u : 2048u;
+  const uint32_t slots = window <= 16 ? 16384u : window < 32 ? 8192u : window == 32 ? 6144u : 2048u;
   uint32_t want = (3u * slots + n_win - 1) / n_win;
   if (want < 1) want = 1;
   uint32_t len = (n_pairs + want - 1) / want;

@@ -224,23 +224,46 @@ __device__ __forceinline__ void fft64(float (&xr)[64], float (&xi)[64]) {
   for (int k = 0; k < 64; ++k) { xr[k] = yr[k]; xi[k] = yi[k]; }
 }
 
-// ---- lengths 3 * 2^m (12, 24, 48): Good-Thomas prime-factor split, NO twiddles -------------------------------------
-// 3 and 2^m are coprime, so with the index maps  n = (N2 n1 + 3 n2) mod N  (input) and  k = (e1 k1 + e2 k2) mod N
-// (output; e1 = 1 mod 3, 0 mod N2;  e2 = 0 mod 3, 1 mod N2)  the length-N DFT is exactly a 3 x N2 two-dimensional
-// DFT:  W_N^{nk} = W_3^{n1 k1} W_N2^{n2 k2}.  All indices are compile-time, so the permutations cost nothing.
+// ---- lengths P * 2^m, P = 3 or 5 (12, 20, 24, 40, 48): Good-Thomas prime-factor split, NO twiddles ----------------
+// P and 2^m are coprime, so with the index maps  n = (N2 n1 + P n2) mod N  (input) and  k = (e1 k1 + e2 k2) mod N
+// (output; e1 = 1 mod P, 0 mod N2;  e2 = 0 mod P, 1 mod N2)  the length-N DFT is exactly a P x N2 two-dimensional
+// DFT:  W_N^{nk} = W_P^{n1 k1} W_N2^{n2 k2}.  All indices are compile-time, so the permutations cost nothing.
 template <bool INV>
-__device__ __forceinline__ void dft3(float& r0, float& i0, float& r1, float& i1, float& r2, float& i2) {
+__device__ __forceinline__ void dft_small(float (&r)[3], float (&i)[3]) {
   constexpr float s3 = 0.86602540378443865f;   // sin(2 pi / 3)
-  const float tr = r1 + r2, ti = i1 + i2;
-  const float ur = (r1 - r2) * s3, ui = (i1 - i2) * s3;
-  const float mr = fmaf(tr, -0.5f, r0), mi = fmaf(ti, -0.5f, i0);
-  r0 += tr; i0 += ti;
+  const float tr = r[1] + r[2], ti = i[1] + i[2];
+  const float ur = (r[1] - r[2]) * s3, ui = (i[1] - i[2]) * s3;
+  const float mr = fmaf(tr, -0.5f, r[0]), mi = fmaf(ti, -0.5f, i[0]);
+  r[0] += tr; i[0] += ti;
   if constexpr (!INV) {   // X1 = m - i s3 (b - c),  X2 = m + i s3 (b - c)
-    r1 = mr + ui; i1 = mi - ur;
-    r2 = mr - ui; i2 = mi + ur;
+    r[1] = mr + ui; i[1] = mi - ur;
+    r[2] = mr - ui; i[2] = mi + ur;
   } else {
-    r1 = mr - ui; i1 = mi + ur;
-    r2 = mr + ui; i2 = mi - ur;
+    r[1] = mr - ui; i[1] = mi + ur;
+    r[2] = mr + ui; i[2] = mi - ur;
+  }
+}
+template <bool INV>
+__device__ __forceinline__ void dft_small(float (&r)[5], float (&i)[5]) {
+  constexpr float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;   // cos(2 pi / 5), cos(4 pi / 5)
+  constexpr float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;    // sin(2 pi / 5), sin(4 pi / 5)
+  const float t1r = r[1] + r[4], t1i = i[1] + i[4], t2r = r[2] + r[3], t2i = i[2] + i[3];
+  const float t3r = r[1] - r[4], t3i = i[1] - i[4], t4r = r[2] - r[3], t4i = i[2] - i[3];
+  const float m1r = fmaf(c2, t2r, fmaf(c1, t1r, r[0])), m1i = fmaf(c2, t2i, fmaf(c1, t1i, i[0]));
+  const float m2r = fmaf(c1, t2r, fmaf(c2, t1r, r[0])), m2i = fmaf(c1, t2i, fmaf(c2, t1i, i[0]));
+  const float u1r = fmaf(s2, t4r, s1 * t3r), u1i = fmaf(s2, t4i, s1 * t3i);
+  const float u2r = fmaf(-s1, t4r, s2 * t3r), u2i = fmaf(-s1, t4i, s2 * t3i);
+  r[0] += t1r + t2r; i[0] += t1i + t2i;
+  if constexpr (!INV) {   // X1 = m1 - i u1, X4 = m1 + i u1, X2 = m2 - i u2, X3 = m2 + i u2
+    r[1] = m1r + u1i; i[1] = m1i - u1r;
+    r[4] = m1r - u1i; i[4] = m1i + u1r;
+    r[2] = m2r + u2i; i[2] = m2i - u2r;
+    r[3] = m2r - u2i; i[3] = m2i + u2r;
+  } else {
+    r[1] = m1r - u1i; i[1] = m1i + u1r;
+    r[4] = m1r + u1i; i[4] = m1i - u1r;
+    r[2] = m2r - u2i; i[2] = m2i + u2r;
+    r[3] = m2r + u2i; i[3] = m2i - u2r;
   }
 }
 template <bool INV> __device__ __forceinline__ void fft_pow2(float (&r)[4], float (&i)[4]) { bfly4<INV>(r[0], i[0], r[1], i[1], r[2], i[2], r[3], i[3]); }
@@ -253,21 +276,22 @@ constexpr int pfa_unit(int n_self, int n_other) {   // e = 1 mod n_self, 0 mod n
   return 0;
 }
 
-template <bool INV, int N2>
-__device__ __forceinline__ void fft_3x(float (&xr)[3 * N2], float (&xi)[3 * N2]) {
-  constexpr int N = 3 * N2;
-  constexpr int e1 = pfa_unit(3, N2), e2 = pfa_unit(N2, 3);
+template <bool INV, int P, int N2>
+__device__ __forceinline__ void fft_pfa(float (&xr)[P * N2], float (&xi)[P * N2]) {
+  constexpr int N = P * N2;
+  constexpr int e1 = pfa_unit(P, N2), e2 = pfa_unit(N2, P);
   float yr[N], yi[N];   // slot (k1, n2) at N2 k1 + n2
 #pragma unroll
   for (int n2 = 0; n2 < N2; ++n2) {
-    float r0 = xr[(3 * n2) % N], i0 = xi[(3 * n2) % N];
-    float r1 = xr[(N2 + 3 * n2) % N], i1 = xi[(N2 + 3 * n2) % N];
-    float r2 = xr[(2 * N2 + 3 * n2) % N], i2 = xi[(2 * N2 + 3 * n2) % N];
-    dft3<INV>(r0, i0, r1, i1, r2, i2);
-    yr[n2] = r0; yi[n2] = i0; yr[N2 + n2] = r1; yi[N2 + n2] = i1; yr[2 * N2 + n2] = r2; yi[2 * N2 + n2] = i2;
+    float r[P], i[P];
+#pragma unroll
+    for (int n1 = 0; n1 < P; ++n1) { r[n1] = xr[(N2 * n1 + P * n2) % N]; i[n1] = xi[(N2 * n1 + P * n2) % N]; }
+    dft_small<INV>(r, i);
+#pragma unroll
+    for (int k1 = 0; k1 < P; ++k1) { yr[N2 * k1 + n2] = r[k1]; yi[N2 * k1 + n2] = i[k1]; }
   }
 #pragma unroll
-  for (int k1 = 0; k1 < 3; ++k1) {
+  for (int k1 = 0; k1 < P; ++k1) {
     float r[N2], i[N2];
 #pragma unroll
     for (int n2 = 0; n2 < N2; ++n2) { r[n2] = yr[N2 * k1 + n2]; i[n2] = yi[N2 * k1 + n2]; }

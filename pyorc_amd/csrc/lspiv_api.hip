@@ -247,6 +247,8 @@ int dispatch(const lspiv::PivParams& p, int dtype, bool ensemble, hipStream_t s)
     case 8: e = lspiv::launch_piv_fft24(p, dtype, ensemble, s); break;
     case 9: e = lspiv::launch_piv_fft12(p, dtype, ensemble, s); break;
     case 10: e = lspiv::launch_piv_fft48(p, dtype, ensemble, s); break;
+    case 11: e = lspiv::launch_piv_fft20(p, dtype, ensemble, s); break;
+    case 12: e = lspiv::launch_piv_fft40(p, dtype, ensemble, s); break;
     case 1: e = lspiv::launch_piv_fft32(p, dtype, ensemble, s); break;
     case 2: e = lspiv::launch_piv_fft64(p, dtype, ensemble, s); break;
     case 3: e = lspiv::launch_piv_direct(p, dtype, ensemble, s); break;
@@ -331,10 +333,12 @@ int lspiv_kernel_kind(int wy, int wx) {
   if (wy == 32 && wx == 32) return 1;
   if (wy == 64 && wx == 64) return 2;
   if (wy == 16 && wx == 16) return 6;
-  static const bool no_pfa = getenv("LSPIV_NO_PFA") != nullptr;       // A/B switch: 12 / 24 / 48 without their own FFT kernels
+  static const bool no_pfa = getenv("LSPIV_NO_PFA") != nullptr;       // A/B switch: 12 / 20 / 24 / 40 / 48 without their own FFT kernels
   if (!no_pfa && wy == 24 && wx == 24) return 8;
   if (!no_pfa && wy == 12 && wx == 12) return 9;
   if (!no_pfa && wy == 48 && wx == 48) return 10;
+  if (!no_pfa && wy == 20 && wx == 20) return 11;
+  if (!no_pfa && wy == 40 && wx == 40) return 12;
   static const bool no_embed = getenv("LSPIV_NO_EMBED") != nullptr;   // A/B switch: direct kernel for every other size
   if (!no_embed && wy == wx && wy >= 4 && wy <= 8) return 7;
   if (!no_embed && wy == wx && wy >= 9 && wy <= 15) return 4;

@@ -44,7 +44,7 @@ struct Geo {
   static constexpr int NN = N * N;                  // samples per window
   static constexpr int HALF = N / 2;
   static constexpr bool POW2 = (N & (N - 1)) == 0;
-  static constexpr int LG = N <= 16 ? 16 : N <= 32 ? 32 : 64;   // lanes per job; lanes >= N idle along (N = 12, 24, 48)
+  static constexpr int LG = N <= 16 ? 16 : N <= 32 ? 32 : 64;   // lanes per job; lanes >= N idle along (N = 12, 20, 24, 40, 48)
   static constexpr int GROUPS = 64 / LG;            // jobs per wave
   static constexpr int LDS_ROW = N + 4;             // dwords per padded row: 16-byte aligned, (N/4+1) l mod 16 slots
   static constexpr int LDS_JOB = N * LDS_ROW;       // dwords per group buffer
@@ -505,9 +505,11 @@ __device__ __forceinline__ void transpose2(float* buf, int lg, float (&xr)[N], f
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[16], float (&xi)[16]) { fft16<INV>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[32], float (&xi)[32]) { fft32<INV>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[64], float (&xi)[64]) { fft64<INV>(xr, xi); }
-template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[12], float (&xi)[12]) { fft_3x<INV, 4>(xr, xi); }
-template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[24], float (&xi)[24]) { fft_3x<INV, 8>(xr, xi); }
-template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[48], float (&xi)[48]) { fft_3x<INV, 16>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[12], float (&xi)[12]) { fft_pfa<INV, 3, 4>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[20], float (&xi)[20]) { fft_pfa<INV, 5, 4>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[24], float (&xi)[24]) { fft_pfa<INV, 3, 8>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[40], float (&xi)[40]) { fft_pfa<INV, 5, 8>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[48], float (&xi)[48]) { fft_pfa<INV, 3, 16>(xr, xi); }
 
 
 // lane = kx, registers = ky hold Z = FFT2(a + i b).  Writes s * 4 conj(A) B for ky = 0..N/2 into
