@@ -224,7 +224,7 @@ __device__ __forceinline__ void fft64(float (&xr)[64], float (&xi)[64]) {
   for (int k = 0; k < 64; ++k) { xr[k] = yr[k]; xi[k] = yi[k]; }
 }
 
-// ---- lengths P * 2^m, P = 3 or 5 (12, 20, 24, 40, 48): Good-Thomas prime-factor split, NO twiddles ----------------
+// ---- lengths P * 2^m, P odd (3, 5: hand-written butterflies; 7..15: dft_odd): Good-Thomas prime-factor split, NO twiddles --
 // P and 2^m are coprime, so with the index maps  n = (N2 n1 + P n2) mod N  (input) and  k = (e1 k1 + e2 k2) mod N
 // (output; e1 = 1 mod P, 0 mod N2;  e2 = 0 mod P, 1 mod N2)  the length-N DFT is exactly a P x N2 two-dimensional
 // DFT:  W_N^{nk} = W_P^{n1 k1} W_N2^{n2 k2}.  All indices are compile-time, so the permutations cost nothing.
@@ -265,6 +265,72 @@ __device__ __forceinline__ void dft_small(float (&r)[5], float (&i)[5]) {
     r[2] = m2r - u2i; i[2] = m2i + u2r;
     r[3] = m2r + u2i; i[3] = m2i - u2r;
   }
+}
+// cos / sin (2 pi j / P), rounded from double, for the odd factors without a hand-written butterfly
+template <int P> struct RootTab;
+template <> struct RootTab<7> {
+  static constexpr float c[7] = {1.0f, 0.6234897971153259f, -0.22252093255519867f, -0.9009688496589661f, -0.9009688496589661f, -0.22252093255519867f, 0.6234897971153259f};
+  static constexpr float s[7] = {0.0f, 0.7818315029144287f, 0.9749279022216797f, 0.4338837265968323f, -0.4338837265968323f, -0.9749279022216797f, -0.7818315029144287f};
+};
+template <> struct RootTab<9> {
+  static constexpr float c[9] = {1.0f, 0.7660444378852844f, 0.1736481785774231f, -0.5f, -0.9396926164627075f, -0.9396926164627075f, -0.5f, 0.1736481785774231f, 0.7660444378852844f};
+  static constexpr float s[9] = {0.0f, 0.6427876353263855f, 0.9848077297210693f, 0.8660253882408142f, 0.3420201539993286f, -0.3420201539993286f, -0.8660253882408142f, -0.9848077297210693f, -0.6427876353263855f};
+};
+template <> struct RootTab<11> {
+  static constexpr float c[11] = {1.0f, 0.8412535190582275f, 0.4154150187969208f, -0.1423148363828659f, -0.6548607349395752f, -0.9594929814338684f, -0.9594929814338684f, -0.6548607349395752f, -0.1423148363828659f, 0.4154150187969208f, 0.8412535190582275f};
+  static constexpr float s[11] = {0.0f, 0.5406408309936523f, 0.9096319675445557f, 0.9898214340209961f, 0.7557495832443237f, 0.28173255920410156f, -0.28173255920410156f, -0.7557495832443237f, -0.9898214340209961f, -0.9096319675445557f, -0.5406408309936523f};
+};
+template <> struct RootTab<13> {
+  static constexpr float c[13] = {1.0f, 0.8854560256004333f, 0.5680647492408752f, 0.1205366775393486f, -0.35460489988327026f, -0.7485107779502869f, -0.9709418416023254f, -0.9709418416023254f, -0.7485107779502869f, -0.35460489988327026f, 0.1205366775393486f, 0.5680647492408752f, 0.8854560256004333f};
+  static constexpr float s[13] = {0.0f, 0.4647231698036194f, 0.8229838609695435f, 0.9927088618278503f, 0.9350162148475647f, 0.6631226539611816f, 0.23931565880775452f, -0.23931565880775452f, -0.6631226539611816f, -0.9350162148475647f, -0.9927088618278503f, -0.8229838609695435f, -0.4647231698036194f};
+};
+template <> struct RootTab<15> {
+  static constexpr float c[15] = {1.0f, 0.9135454297065735f, 0.6691306233406067f, 0.30901700258255005f, -0.10452846437692642f, -0.5f, -0.80901700258255f, -0.9781476259231567f, -0.9781476259231567f, -0.80901700258255f, -0.5f, -0.10452846437692642f, 0.30901700258255005f, 0.6691306233406067f, 0.9135454297065735f};
+  static constexpr float s[15] = {0.0f, 0.4067366421222687f, 0.7431448101997375f, 0.9510565400123596f, 0.9945219159126282f, 0.8660253882408142f, 0.5877852439880371f, 0.2079116851091385f, -0.2079116851091385f, -0.5877852439880371f, -0.8660253882408142f, -0.9945219159126282f, -0.9510565400123596f, -0.7431448101997375f, -0.4067366421222687f};
+};
+// odd P: X_k = x0 + sum_j cos(2 pi jk/P) (x_j + x_{P-j}) -/+ i sum_j sin(2 pi jk/P) (x_j - x_{P-j}),  j = 1..(P-1)/2 --
+// (P-1)^2 real multiply-adds; k and P - k share both sums
+template <bool INV, int P>
+__device__ __forceinline__ void dft_odd(float (&r)[P], float (&i)[P]) {
+  constexpr int H = (P - 1) / 2;
+  float tr[H + 1], ti[H + 1], ur[H + 1], ui[H + 1];
+#pragma unroll
+  for (int j = 1; j <= H; ++j) {
+    tr[j] = r[j] + r[P - j]; ti[j] = i[j] + i[P - j];
+    ur[j] = r[j] - r[P - j]; ui[j] = i[j] - i[P - j];
+  }
+  const float x0r = r[0], x0i = i[0];
+  float sr = x0r, si = x0i;
+#pragma unroll
+  for (int j = 1; j <= H; ++j) { sr += tr[j]; si += ti[j]; }
+  r[0] = sr; i[0] = si;
+#pragma unroll
+  for (int k = 1; k <= H; ++k) {
+    float mr = x0r, mi = x0i, vr = 0.0f, vi = 0.0f;
+#pragma unroll
+    for (int j = 1; j <= H; ++j) {
+      const float c = RootTab<P>::c[(j * k) % P], sn = RootTab<P>::s[(j * k) % P];
+      mr = fmaf(c, tr[j], mr); mi = fmaf(c, ti[j], mi);
+      vr = fmaf(sn, ur[j], vr); vi = fmaf(sn, ui[j], vi);
+    }
+    if constexpr (!INV) {   // X_k = m - i v,  X_{P-k} = m + i v
+      r[k] = mr + vi; i[k] = mi - vr;
+      r[P - k] = mr - vi; i[P - k] = mi + vr;
+    } else {
+      r[k] = mr - vi; i[k] = mi + vr;
+      r[P - k] = mr + vi; i[P - k] = mi - vr;
+    }
+  }
+}
+template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[7], float (&i)[7]) { dft_odd<INV, 7>(r, i); }
+template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[9], float (&i)[9]) { dft_odd<INV, 9>(r, i); }
+template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[11], float (&i)[11]) { dft_odd<INV, 11>(r, i); }
+template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[13], float (&i)[13]) { dft_odd<INV, 13>(r, i); }
+template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[15], float (&i)[15]) { dft_odd<INV, 15>(r, i); }
+template <bool INV> __device__ __forceinline__ void fft_pow2(float (&r)[2], float (&i)[2]) {
+  const float ar = r[0] + r[1], ai = i[0] + i[1];
+  r[1] = r[0] - r[1]; i[1] = i[0] - i[1];
+  r[0] = ar; i[0] = ai;
 }
 template <bool INV> __device__ __forceinline__ void fft_pow2(float (&r)[4], float (&i)[4]) { bfly4<INV>(r[0], i[0], r[1], i[1], r[2], i[2], r[3], i[3]); }
 template <bool INV> __device__ __forceinline__ void fft_pow2(float (&r)[8], float (&i)[8]) { bfly8<INV>(r, i); }

@@ -244,11 +244,14 @@ int dispatch(const lspiv::PivParams& p, int dtype, bool ensemble, hipStream_t s)
     case 4: e = lspiv::launch_piv_embed32(p, dtype, ensemble, s); break;
     case 5: e = lspiv::launch_piv_embed64(p, dtype, ensemble, s); break;
     case 6: e = lspiv::launch_piv_fft16(p, dtype, ensemble, s); break;
-    case 8: e = lspiv::launch_piv_fft24(p, dtype, ensemble, s); break;
-    case 9: e = lspiv::launch_piv_fft12(p, dtype, ensemble, s); break;
-    case 10: e = lspiv::launch_piv_fft48(p, dtype, ensemble, s); break;
-    case 11: e = lspiv::launch_piv_fft20(p, dtype, ensemble, s); break;
-    case 12: e = lspiv::launch_piv_fft40(p, dtype, ensemble, s); break;
+    case 8:
+      switch (p.wy) {
+#define LSPIV_PFA_CASE(n) case n: e = lspiv::launch_piv_fft##n(p, dtype, ensemble, s); break;
+        LSPIV_PFA_SIZES(LSPIV_PFA_CASE)
+#undef LSPIV_PFA_CASE
+        default: return fail(LSPIV_EUNSUPPORTED, "no prime-factor kernel for window %d", p.wy);
+      }
+      break;
     case 1: e = lspiv::launch_piv_fft32(p, dtype, ensemble, s); break;
     case 2: e = lspiv::launch_piv_fft64(p, dtype, ensemble, s); break;
     case 3: e = lspiv::launch_piv_direct(p, dtype, ensemble, s); break;
@@ -333,12 +336,16 @@ int lspiv_kernel_kind(int wy, int wx) {
   if (wy == 32 && wx == 32) return 1;
   if (wy == 64 && wx == 64) return 2;
   if (wy == 16 && wx == 16) return 6;
-  static const bool no_pfa = getenv("LSPIV_NO_PFA") != nullptr;       // A/B switch: 12 / 20 / 24 / 40 / 48 without their own FFT kernels
-  if (!no_pfa && wy == 24 && wx == 24) return 8;
-  if (!no_pfa && wy == 12 && wx == 12) return 9;
-  if (!no_pfa && wy == 48 && wx == 48) return 10;
-  if (!no_pfa && wy == 20 && wx == 20) return 11;
-  if (!no_pfa && wy == 40 && wx == 40) return 12;
+  static const bool no_pfa = getenv("LSPIV_NO_PFA") != nullptr;       // A/B switch: the P * 2^m sizes without their own FFT kernels
+  if (!no_pfa && wy == wx) {
+    switch (wy) {
+#define LSPIV_PFA_CASE(n) case n:
+      LSPIV_PFA_SIZES(LSPIV_PFA_CASE)
+#undef LSPIV_PFA_CASE
+        return 8;
+      default: break;
+    }
+  }
   static const bool no_embed = getenv("LSPIV_NO_EMBED") != nullptr;   // A/B switch: direct kernel for every other size
   if (!no_embed && wy == wx && wy >= 4 && wy <= 8) return 7;
   if (!no_embed && wy == wx && wy >= 9 && wy <= 15) return 4;
@@ -558,7 +565,7 @@ static int ensemble_launch(lspiv_ensemble* h, DeviceCtx* c, const void* d_frames
   p.corr_sum = h->d_sum;
   p.corr_count = h->d_count;
   const int kind = lspiv_kernel_kind(h->wy, h->wx);
-  if ((kind == 1 || kind == 2 || kind == 6 || kind >= 8) && lspiv::walk_setting() != 0 && p.n_pairs >= 3) {
+  if ((kind == 1 || kind == 2 || kind == 6 || kind == 8) && lspiv::walk_setting() != 0 && p.n_pairs >= 3) {
     lspiv::ensemble_segments(p.n_win, p.n_pairs, h->wy, &p.seg_len, &p.n_seg);
     const size_t plane = (size_t)h->wy * h->wx;
     const size_t need = (size_t)p.n_seg * p.n_win * (plane + 1) * sizeof(float);

@@ -1,4 +1,4 @@
-// 12x12 interrogation windows (12 = 3 * 2^m: prime-factor FFT, fft_regs.h): instantiation of the fused FFT kernels
+// 12x12 interrogation windows (12 = 3 x 4: prime-factor FFT, fft_regs.h): instantiation of the fused FFT kernels
 // (piv_fft_impl.h); a job runs on the next power-of-two lane group, the surplus lanes idle along.
 #include "piv_fft_impl.h"
 

@@ -1,4 +1,4 @@
-// 20x20 interrogation windows (20 = 5 * 2^m: prime-factor FFT, fft_regs.h): instantiation of the fused FFT kernels
+// 20x20 interrogation windows (20 = 5 x 4: prime-factor FFT, fft_regs.h): instantiation of the fused FFT kernels
 // (piv_fft_impl.h); a job runs on the next power-of-two lane group, the surplus lanes idle along.
 #include "piv_fft_impl.h"
 

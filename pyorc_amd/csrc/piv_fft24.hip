@@ -1,4 +1,4 @@
-// 24x24 interrogation windows (24 = 3 * 2^m: prime-factor FFT, fft_regs.h): instantiation of the fused FFT kernels
+// 24x24 interrogation windows (24 = 3 x 8: prime-factor FFT, fft_regs.h): instantiation of the fused FFT kernels
 // (piv_fft_impl.h); a job runs on the next power-of-two lane group, the surplus lanes idle along.
 #include "piv_fft_impl.h"
 

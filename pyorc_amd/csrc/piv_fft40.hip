@@ -1,4 +1,4 @@
-// 40x40 interrogation windows (40 = 5 * 2^m: prime-factor FFT, fft_regs.h): instantiation of the fused FFT kernels
+// 40x40 interrogation windows (40 = 5 x 8: prime-factor FFT, fft_regs.h): instantiation of the fused FFT kernels
 // (piv_fft_impl.h); a job runs on the next power-of-two lane group, the surplus lanes idle along.
 #include "piv_fft_impl.h"
 

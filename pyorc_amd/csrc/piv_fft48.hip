@@ -1,4 +1,4 @@
-// 48x48 interrogation windows (48 = 3 * 2^m: prime-factor FFT, fft_regs.h): instantiation of the fused FFT kernels
+// 48x48 interrogation windows (48 = 3 x 16: prime-factor FFT, fft_regs.h): instantiation of the fused FFT kernels
 // (piv_fft_impl.h); a job runs on the next power-of-two lane group, the surplus lanes idle along.
 #include "piv_fft_impl.h"
 

@@ -44,7 +44,7 @@ struct Geo {
   static constexpr int NN = N * N;                  // samples per window
   static constexpr int HALF = N / 2;
   static constexpr bool POW2 = (N & (N - 1)) == 0;
-  static constexpr int LG = N <= 16 ? 16 : N <= 32 ? 32 : 64;   // lanes per job; lanes >= N idle along (N = 12, 20, 24, 40, 48)
+  static constexpr int LG = N <= 16 ? 16 : N <= 32 ? 32 : 64;   // lanes per job; lanes >= N idle along (N = 12, 20, 24, 28, 36 ...)
   static constexpr int GROUPS = 64 / LG;            // jobs per wave
   static constexpr int LDS_ROW = N + 4;             // dwords per padded row: 16-byte aligned, (N/4+1) l mod 16 slots
   static constexpr int LDS_JOB = N * LDS_ROW;       // dwords per group buffer
@@ -510,6 +510,12 @@ template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[20], float
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[24], float (&xi)[24]) { fft_pfa<INV, 3, 8>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[40], float (&xi)[40]) { fft_pfa<INV, 5, 8>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[48], float (&xi)[48]) { fft_pfa<INV, 3, 16>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[28], float (&xi)[28]) { fft_pfa<INV, 7, 4>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[36], float (&xi)[36]) { fft_pfa<INV, 9, 4>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[44], float (&xi)[44]) { fft_pfa<INV, 11, 4>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[52], float (&xi)[52]) { fft_pfa<INV, 13, 4>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[56], float (&xi)[56]) { fft_pfa<INV, 7, 8>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[60], float (&xi)[60]) { fft_pfa<INV, 15, 4>(xr, xi); }
 
 
 // lane = kx, registers = ky hold Z = FFT2(a + i b).  Writes s * 4 conj(A) B for ky = 0..N/2 into

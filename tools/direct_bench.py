@@ -8,7 +8,7 @@ H, W, P = 785, 875, int(sys.argv[1]) if len(sys.argv) > 1 else 40
 T = P + 1
 d_f = C.c_void_p(); _lib.check(lib.lspiv_dev_malloc(C.byref(d_f), T * H * W))
 _lib.check(lib.lspiv_synth_particles_dev(d_f, T, H, W, 5, 0.02))
-for ws in (8, 10, 12, 14, 16, 18, 20, 24, 26, 32, 36, 40, 48):
+for ws in (8, 10, 12, 14, 16, 18, 20, 24, 26, 28, 32, 36, 40, 44, 48, 52, 56, 60, 64):
     ov = ws // 2
     nr, nc = window.get_array_shape((H, W), (ws, ws), (ov, ov))
     d_o = C.c_void_p(); _lib.check(lib.lspiv_dev_malloc(C.byref(d_o), 16 * P * nr * nc))
@@ -17,7 +17,7 @@ for ws in (8, 10, 12, 14, 16, 18, 20, 24, 26, 32, 36, 40, 48):
     t0 = time.perf_counter()
     for _ in range(3): go()
     _lib.check(lib.lspiv_synchronize()); dt = (time.perf_counter() - t0) / 3
-    kind = {1: "fft32", 2: "fft64", 3: "direct", 4: "embed32", 5: "embed64", 6: "fft16", 7: "embed16", 8: "fft24", 9: "fft12", 10: "fft48", 11: "fft20", 12: "fft40"}[lib.lspiv_kernel_kind(ws, ws)]
+    kind = {1: "fft32", 2: "fft64", 3: "direct", 4: "embed32", 5: "embed64", 6: "fft16", 7: "embed16", 8: "pfa-fft"}[lib.lspiv_kernel_kind(ws, ws)]
     macs = P * nr * nc * float(ws) ** 4
     print(f"785x875 win {ws}/{ov} ({kind}): {nr*nc} windows/pair, {dt*1e3:.2f} ms / {P} pairs -> {P/dt:.0f} pairs/s, {P*nr*nc/dt/1e6:.1f} Mvec/s"
           + (f", {macs/dt/1e12:.2f} TMAC/s" if kind == "direct" else ""), flush=True)
