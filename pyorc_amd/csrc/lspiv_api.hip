@@ -336,7 +336,7 @@ int lspiv_kernel_kind(int wy, int wx) {
   if (wy == 32 && wx == 32) return 1;
   if (wy == 64 && wx == 64) return 2;
   if (wy == 16 && wx == 16) return 6;
-  static const bool no_pfa = getenv("LSPIV_NO_PFA") != nullptr;       // A/B switch: the P * 2^m sizes without their own FFT kernels
+  const bool no_pfa = getenv("LSPIV_NO_PFA") != nullptr;             // A/B switch: the P * 2^m sizes without their own FFT kernels
   if (!no_pfa && wy == wx) {
     switch (wy) {
 #define LSPIV_PFA_CASE(n) case n:
@@ -346,7 +346,7 @@ int lspiv_kernel_kind(int wy, int wx) {
       default: break;
     }
   }
-  static const bool no_embed = getenv("LSPIV_NO_EMBED") != nullptr;   // A/B switch: direct kernel for every other size
+  const bool no_embed = getenv("LSPIV_NO_EMBED") != nullptr;   // A/B switch: direct kernel for every other size
   if (!no_embed && wy == wx && wy >= 4 && wy <= 8) return 7;
   if (!no_embed && wy == wx && wy >= 9 && wy <= 15) return 4;
   // 17..20: the direct kernel's N^4 multiply-adds are still cheaper than two 64-point transforms per window (measured

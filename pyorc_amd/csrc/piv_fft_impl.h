@@ -46,7 +46,7 @@ struct Geo {
   static constexpr bool POW2 = (N & (N - 1)) == 0;
   static constexpr int LG = N <= 16 ? 16 : N <= 32 ? 32 : 64;   // lanes per job; lanes >= N idle along (N = 12, 20, 24, 28, 36 ...)
   static constexpr int GROUPS = 64 / LG;            // jobs per wave
-  static constexpr int LDS_ROW = N + 4;             // dwords per padded row: 16-byte aligned, (N/4+1) l mod 16 slots
+  static constexpr int LDS_ROW = N % 4 == 0 ? N + 4 : N + 2;   // dwords per padded row: 16-byte aligned, an odd number of 4-bank slots
   static constexpr int LDS_JOB = N * LDS_ROW;       // dwords per group buffer
   static constexpr int LDS_BYTES = WAVES_PER_BLOCK * GROUPS * LDS_JOB * 4;
 };
@@ -148,7 +148,8 @@ struct RowRaw {
 };
 template <int N>
 struct RowRaw<uint8_t, N> {
-  uint32_t w[N / 4];
+  static constexpr int W = (N + 3) / 4;   // N % 4 == 2: the last word holds two samples and two zero bytes
+  uint32_t w[W];
   __device__ __forceinline__ void fetch(const uint8_t* q) {
 #pragma unroll
     for (int k = 0; k < N / 16; ++k) {
@@ -160,17 +161,23 @@ struct RowRaw<uint8_t, N> {
       const u32x2 v = *reinterpret_cast<const u32x2_u*>(q + done);
       w[done / 4] = v[0]; w[done / 4 + 1] = v[1];
     }
-    if constexpr ((N - done) % 8 == 4) {
+    constexpr int done8 = N / 8 * 8;
+    if constexpr (N - done8 >= 4) {
       uint32_t v;
-      __builtin_memcpy(&v, q + (N - 4), 4);
-      w[N / 4 - 1] = v;
+      __builtin_memcpy(&v, q + done8, 4);
+      w[done8 / 4] = v;
+    }
+    if constexpr (N % 4 == 2) {
+      uint16_t v;
+      __builtin_memcpy(&v, q + (N - 2), 2);
+      w[W - 1] = v;
     }
     if constexpr (!Geo<N>::POW2) mask(lane_active<N>(group_lane<N>()));
   }
   // idle lanes of a group (row_of): zero bytes count for nothing in the window sums
   __device__ __forceinline__ void mask(bool active) {
 #pragma unroll
-    for (int k = 0; k < N / 4; ++k) w[k] = active ? w[k] : 0u;
+    for (int k = 0; k < W; ++k) w[k] = active ? w[k] : 0u;
   }
 };
 
@@ -187,14 +194,14 @@ __device__ __forceinline__ RowStats stats_u8(const RowRaw<uint8_t, N>& raw, bool
   constexpr int NN = Geo<N>::NN;
   uint32_t s = 0, q = 0;
 #pragma unroll
-  for (int k = 0; k < N / 4; ++k) {
+  for (int k = 0; k < (N + 3) / 4; ++k) {
     s = __builtin_amdgcn_udot4(raw.w[k], 0x01010101u, s, false);
     q = __builtin_amdgcn_udot4(raw.w[k], raw.w[k], q, false);
   }
   if (want_nz) {
     int nz = 0;
 #pragma unroll
-    for (int k = 0; k < N / 4; ++k) {  // 0x80 in every zero byte
+    for (int k = 0; k < (N + 3) / 4; ++k) {  // 0x80 in every zero byte (the padding bytes of a last half word are zero)
       const uint32_t t = ~(((raw.w[k] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | raw.w[k] | 0x7F7F7F7Fu);
       nz += 4 - __builtin_popcount(t);
     }
@@ -221,6 +228,11 @@ __device__ __forceinline__ void center_u8(const RowRaw<uint8_t, N>& raw, float m
     x[4 * k + 1] = fmaxf(fmaf((float)((w >> 8) & 0xffu), g, off), 0.0f);
     x[4 * k + 2] = fmaxf(fmaf((float)((w >> 16) & 0xffu), g, off), 0.0f);
     x[4 * k + 3] = fmaxf(fmaf((float)(w >> 24), g, off), 0.0f);
+  }
+  if constexpr (N % 4 == 2) {
+    const uint32_t w = raw.w[N / 4];
+    x[N - 2] = fmaxf(fmaf((float)(w & 0xffu), g, off), 0.0f);
+    x[N - 1] = fmaxf(fmaf((float)((w >> 8) & 0xffu), g, off), 0.0f);
   }
 }
 
@@ -262,6 +274,7 @@ __device__ __forceinline__ float load_center(const RowRaw<float, N>& raw, float 
     const f32x4 v = *reinterpret_cast<const f32x4_u*>(raw.p + 4 * k);
     x[4 * k + 0] = v[0]; x[4 * k + 1] = v[1]; x[4 * k + 2] = v[2]; x[4 * k + 3] = v[3];
   }
+  if constexpr (N % 4 == 2) { x[N - 2] = raw.p[N - 2]; x[N - 1] = raw.p[N - 1]; }
   return center_clip_f<N>(x, want_nz, nonzero, finite);
 }
 template <int N>
@@ -475,6 +488,35 @@ __device__ __forceinline__ void prepare_pair_embed(const PivParams& p, const Til
   }
 }
 
+// one row of a parked plane <-> registers: ds_read/write_b128, plus one b64 for the two last samples when N % 4 == 2
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int N>
+__device__ __forceinline__ void lds_row_read(const float* row, float (&x)[N]) {
+  const f32x4* r4 = reinterpret_cast<const f32x4*>(row);
+#pragma unroll
+  for (int q = 0; q < N / 4; ++q) {
+    const f32x4 v = r4[q];
+    x[4 * q] = v[0]; x[4 * q + 1] = v[1]; x[4 * q + 2] = v[2]; x[4 * q + 3] = v[3];
+  }
+  if constexpr (N % 4 == 2) {
+    const f32x2 v = *reinterpret_cast<const f32x2*>(row + (N - 2));
+    x[N - 2] = v[0]; x[N - 1] = v[1];
+  }
+}
+template <int N>
+__device__ __forceinline__ void lds_row_write(float* row, const float (&c)[N]) {
+  f32x4* w4 = reinterpret_cast<f32x4*>(row);
+#pragma unroll
+  for (int q = 0; q < N / 4; ++q) {
+    const f32x4 w = {c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
+    w4[q] = w;
+  }
+  if constexpr (N % 4 == 2) {
+    const f32x2 w = {c[N - 2], c[N - 1]};
+    *reinterpret_cast<f32x2*>(row + (N - 2)) = w;
+  }
+}
+
 // LDS transpose of one real N x N plane held as lane = row: lane r scatters its row down column r of
 // the buffer (ds_write_b32, the lanes of a group hit consecutive banks), then reads buffer row r =
 // tile column r with ds_read_b128 (row stride N+4 dwords: 16-byte aligned, and the 16 lanes of a b128
@@ -488,12 +530,7 @@ __device__ __forceinline__ void transpose_plane(float* buf, int lg, float (&x)[N
     for (int j = 0; j < N; ++j) wcol[j * LR] = x[j];
   }
   __builtin_amdgcn_wave_barrier();  // same wave: LDS ops execute in order, this only pins the compiler
-  const f32x4* rrow = reinterpret_cast<const f32x4*>(buf + row_of<N>(lg) * LR);
-#pragma unroll
-  for (int q = 0; q < N / 4; ++q) {
-    const f32x4 v = rrow[q];
-    x[4 * q] = v[0]; x[4 * q + 1] = v[1]; x[4 * q + 2] = v[2]; x[4 * q + 3] = v[3];
-  }
+  lds_row_read<N>(buf + row_of<N>(lg) * LR, x);
   __builtin_amdgcn_wave_barrier();
 }
 template <int N>
@@ -510,6 +547,13 @@ template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[20], float
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[24], float (&xi)[24]) { fft_pfa<INV, 3, 8>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[40], float (&xi)[40]) { fft_pfa<INV, 5, 8>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[48], float (&xi)[48]) { fft_pfa<INV, 3, 16>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[6], float (&xi)[6]) { fft_pfa<INV, 3, 2>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[10], float (&xi)[10]) { fft_pfa<INV, 5, 2>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[14], float (&xi)[14]) { fft_pfa<INV, 7, 2>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[18], float (&xi)[18]) { fft_pfa<INV, 9, 2>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[22], float (&xi)[22]) { fft_pfa<INV, 11, 2>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[26], float (&xi)[26]) { fft_pfa<INV, 13, 2>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[30], float (&xi)[30]) { fft_pfa<INV, 15, 2>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[28], float (&xi)[28]) { fft_pfa<INV, 7, 4>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[36], float (&xi)[36]) { fft_pfa<INV, 9, 4>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[44], float (&xi)[44]) { fft_pfa<INV, 11, 4>(xr, xi); }
@@ -660,14 +704,7 @@ __device__ __forceinline__ void find_peak(float* buf, int lg, const float (&c)[N
   constexpr int M = N - 1, C = N / 2, NONE = 1 << 12;
   const bool active = lane_active<N>(lg);
   const int lr = row_of<N>(lg);
-  if (active) {
-    f32x4* wrow = reinterpret_cast<f32x4*>(buf + lg * LR);
-#pragma unroll
-    for (int q = 0; q < N / 4; ++q) {
-      const f32x4 w = {c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
-      wrow[q] = w;
-    }
-  }
+  if (active) lds_row_write<N>(buf + lg * LR, c);
   __builtin_amdgcn_wave_barrier();
   const int sh = wrap_n<N>(lr + C);                                                  // this lane's shifted row AND column
   const int ip = group_min_i<N>((active && row_max == vmax) ? sh : NONE);            // first shifted row with the maximum
@@ -696,12 +733,22 @@ __device__ __forceinline__ void store_plane_rows(float* dst, int lg, const float
   if (!lane_active<N>(lg)) return;
   float* row = dst + wrap_n<N>(lg + N / 2) * N;
   const float nanv = __builtin_nanf("");
+  if constexpr (N % 4 == 0) {
 #pragma unroll
-  for (int q = 0; q < N / 4; ++q) {
-    f32x4 v;
+    for (int q = 0; q < N / 4; ++q) {
+      f32x4 v;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = nan_plane ? nanv : c[(4 * q + e + N / 2) % N];
-    *reinterpret_cast<f32x4*>(row + 4 * q) = v;
+      for (int e = 0; e < 4; ++e) v[e] = nan_plane ? nanv : c[(4 * q + e + N / 2) % N];
+      *reinterpret_cast<f32x4*>(row + 4 * q) = v;
+    }
+  } else {   // rows of N = 4 m + 2 floats are 8-byte aligned only
+#pragma unroll
+    for (int q = 0; q < N / 2; ++q) {
+      f32x2 v;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) v[e] = nan_plane ? nanv : c[(2 * q + e + N / 2) % N];
+      *reinterpret_cast<f32x2*>(row + 2 * q) = v;
+    }
   }
 }
 
@@ -1196,16 +1243,30 @@ __device__ __forceinline__ void accumulate_planes(float* dst, int lg, const floa
   // corr_sum is kept in fft-shifted layout (what u_v_displacement expects)
   if (!lane_active<N>(lg)) return;
   float* row = dst + wrap_n<N>(lg + N / 2) * N;
+  if constexpr (N % 4 == 0) {
 #pragma unroll
-  for (int qd = 0; qd < N / 4; ++qd) {
-    f32x4 acc = *reinterpret_cast<f32x4*>(row + 4 * qd);
+    for (int qd = 0; qd < N / 4; ++qd) {
+      f32x4 acc = *reinterpret_cast<f32x4*>(row + 4 * qd);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int j = (4 * qd + e + N / 2) % N;
-      acc[e] += keep0 ? c0[j] : 0.0f;   // pair 2k first, then 2k+1: the reference's summation order
-      acc[e] += keep1 ? c1[j] : 0.0f;
+      for (int e = 0; e < 4; ++e) {
+        const int j = (4 * qd + e + N / 2) % N;
+        acc[e] += keep0 ? c0[j] : 0.0f;   // pair 2k first, then 2k+1: the reference's summation order
+        acc[e] += keep1 ? c1[j] : 0.0f;
+      }
+      *reinterpret_cast<f32x4*>(row + 4 * qd) = acc;
     }
-    *reinterpret_cast<f32x4*>(row + 4 * qd) = acc;
+  } else {
+#pragma unroll
+    for (int qd = 0; qd < N / 2; ++qd) {
+      f32x2 acc = *reinterpret_cast<f32x2*>(row + 2 * qd);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int j = (2 * qd + e + N / 2) % N;
+        acc[e] += keep0 ? c0[j] : 0.0f;
+        acc[e] += keep1 ? c1[j] : 0.0f;
+      }
+      *reinterpret_cast<f32x2*>(row + 2 * qd) = acc;
+    }
   }
 }
 
