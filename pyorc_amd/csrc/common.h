@@ -203,10 +203,12 @@ __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(double x) { return (float)x; }
 
 // launch entry points implemented by the kernel translation units
+hipError_t launch_piv_fft8(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 hipError_t launch_piv_fft16(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
-// square windows P * 2^m (P odd <= 15) with prime-factor FFT kernels of their own, one translation unit each (piv_fftNN.hip;
+// square even windows that are no power of two (P * 2^m, P odd) with prime-factor FFT kernels of their own, one translation unit each (piv_fftNN.hip;
 // keep in step with PFA_SIZES in the Makefile)
-#define LSPIV_PFA_SIZES(X) X(6) X(10) X(12) X(14) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(36) X(40) X(44) X(48) X(52) X(56) X(60)
+#define LSPIV_PFA_SIZES(X) X(6) X(10) X(12) X(14) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(34) X(36) X(38) X(40) X(42) X(44) X(46) \
+  X(48) X(50) X(52) X(54) X(56) X(58) X(60) X(62)
 #define LSPIV_PFA_DECL(n) hipError_t launch_piv_fft##n(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 LSPIV_PFA_SIZES(LSPIV_PFA_DECL)
 #undef LSPIV_PFA_DECL

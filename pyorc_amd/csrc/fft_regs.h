@@ -224,7 +224,7 @@ __device__ __forceinline__ void fft64(float (&xr)[64], float (&xi)[64]) {
   for (int k = 0; k < 64; ++k) { xr[k] = yr[k]; xi[k] = yi[k]; }
 }
 
-// ---- lengths P * 2^m, P odd (3, 5: hand-written butterflies; 7..15: dft_odd): Good-Thomas prime-factor split, NO twiddles --
+// ---- lengths P * 2^m, P odd (3, 5: hand-written butterflies; 7..31: dft_odd): Good-Thomas prime-factor split, NO twiddles --
 // P and 2^m are coprime, so with the index maps  n = (N2 n1 + P n2) mod N  (input) and  k = (e1 k1 + e2 k2) mod N
 // (output; e1 = 1 mod P, 0 mod N2;  e2 = 0 mod P, 1 mod N2)  the length-N DFT is exactly a P x N2 two-dimensional
 // DFT:  W_N^{nk} = W_P^{n1 k1} W_N2^{n2 k2}.  All indices are compile-time, so the permutations cost nothing.
@@ -288,6 +288,38 @@ template <> struct RootTab<15> {
   static constexpr float c[15] = {1.0f, 0.9135454297065735f, 0.6691306233406067f, 0.30901700258255005f, -0.10452846437692642f, -0.5f, -0.80901700258255f, -0.9781476259231567f, -0.9781476259231567f, -0.80901700258255f, -0.5f, -0.10452846437692642f, 0.30901700258255005f, 0.6691306233406067f, 0.9135454297065735f};
   static constexpr float s[15] = {0.0f, 0.4067366421222687f, 0.7431448101997375f, 0.9510565400123596f, 0.9945219159126282f, 0.8660253882408142f, 0.5877852439880371f, 0.2079116851091385f, -0.2079116851091385f, -0.5877852439880371f, -0.8660253882408142f, -0.9945219159126282f, -0.9510565400123596f, -0.7431448101997375f, -0.4067366421222687f};
 };
+template <> struct RootTab<17> {
+  static constexpr float c[17] = {1.0f, 0.9324722290039062f, 0.739008903503418f, 0.4457383453845978f, 0.09226836264133453f, -0.2736629843711853f, -0.602634608745575f, -0.8502171635627747f, -0.9829730987548828f, -0.9829730987548828f, -0.8502171635627747f, -0.602634608745575f, -0.2736629843711853f, 0.09226836264133453f, 0.4457383453845978f, 0.739008903503418f, 0.9324722290039062f};
+  static constexpr float s[17] = {0.0f, 0.3612416684627533f, 0.6736956238746643f, 0.8951632976531982f, 0.9957341551780701f, 0.9618256688117981f, 0.7980172038078308f, 0.5264321565628052f, 0.1837495118379593f, -0.1837495118379593f, -0.5264321565628052f, -0.7980172038078308f, -0.9618256688117981f, -0.9957341551780701f, -0.8951632976531982f, -0.6736956238746643f, -0.3612416684627533f};
+};
+template <> struct RootTab<19> {
+  static constexpr float c[19] = {1.0f, 0.945817232131958f, 0.789140522480011f, 0.5469481348991394f, 0.24548548460006714f, -0.0825793445110321f, -0.4016954302787781f, -0.6772815585136414f, -0.8794737458229065f, -0.9863613247871399f, -0.9863613247871399f, -0.8794737458229065f, -0.6772815585136414f, -0.4016954302787781f, -0.0825793445110321f, 0.24548548460006714f, 0.5469481348991394f, 0.789140522480011f, 0.945817232131958f};
+  static constexpr float s[19] = {0.0f, 0.3246994614601135f, 0.614212691783905f, 0.8371664881706238f, 0.9694002866744995f, 0.9965844750404358f, 0.915773332118988f, 0.7357239127159119f, 0.47594738006591797f, 0.1645945906639099f, -0.1645945906639099f, -0.47594738006591797f, -0.7357239127159119f, -0.915773332118988f, -0.9965844750404358f, -0.9694002866744995f, -0.8371664881706238f, -0.614212691783905f, -0.3246994614601135f};
+};
+template <> struct RootTab<21> {
+  static constexpr float c[21] = {1.0f, 0.955572783946991f, 0.826238751411438f, 0.6234897971153259f, 0.36534103751182556f, 0.07473009079694748f, -0.22252093255519867f, -0.5f, -0.7330518960952759f, -0.9009688496589661f, -0.9888308048248291f, -0.9888308048248291f, -0.9009688496589661f, -0.7330518960952759f, -0.5f, -0.22252093255519867f, 0.07473009079694748f, 0.36534103751182556f, 0.6234897971153259f, 0.826238751411438f, 0.955572783946991f};
+  static constexpr float s[21] = {0.0f, 0.29475516080856323f, 0.5633200407028198f, 0.7818315029144287f, 0.9308737516403198f, 0.9972038269042969f, 0.9749279022216797f, 0.8660253882408142f, 0.6801727414131165f, 0.4338837265968323f, 0.1490422636270523f, -0.1490422636270523f, -0.4338837265968323f, -0.6801727414131165f, -0.8660253882408142f, -0.9749279022216797f, -0.9972038269042969f, -0.9308737516403198f, -0.7818315029144287f, -0.5633200407028198f, -0.29475516080856323f};
+};
+template <> struct RootTab<23> {
+  static constexpr float c[23] = {1.0f, 0.9629172682762146f, 0.8544194102287292f, 0.6825531721115112f, 0.4600650370121002f, 0.20345601439476013f, -0.06824241578578949f, -0.334879606962204f, -0.5766803026199341f, -0.7757112979888916f, -0.9172112941741943f, -0.9906859397888184f, -0.9906859397888184f, -0.9172112941741943f, -0.7757112979888916f, -0.5766803026199341f, -0.334879606962204f, -0.06824241578578949f, 0.20345601439476013f, 0.4600650370121002f, 0.6825531721115112f, 0.8544194102287292f, 0.9629172682762146f};
+  static constexpr float s[23] = {0.0f, 0.269796758890152f, 0.5195839405059814f, 0.7308359742164612f, 0.8878852128982544f, 0.9790840744972229f, 0.9976687431335449f, 0.9422609210014343f, 0.8169698715209961f, 0.6310879588127136f, 0.39840108156204224f, 0.13616664707660675f, -0.13616664707660675f, -0.39840108156204224f, -0.6310879588127136f, -0.8169698715209961f, -0.9422609210014343f, -0.9976687431335449f, -0.9790840744972229f, -0.8878852128982544f, -0.7308359742164612f, -0.5195839405059814f, -0.269796758890152f};
+};
+template <> struct RootTab<25> {
+  static constexpr float c[25] = {1.0f, 0.9685831665992737f, 0.8763066530227661f, 0.728968620300293f, 0.5358268022537231f, 0.30901700258255005f, 0.06279052048921585f, -0.187381312251091f, -0.4257792830467224f, -0.6374239921569824f, -0.80901700258255f, -0.9297764897346497f, -0.9921147227287292f, -0.9921147227287292f, -0.9297764897346497f, -0.80901700258255f, -0.6374239921569824f, -0.4257792830467224f, -0.187381312251091f, 0.06279052048921585f, 0.30901700258255005f, 0.5358268022537231f, 0.728968620300293f, 0.8763066530227661f, 0.9685831665992737f};
+  static constexpr float s[25] = {0.0f, 0.24868988990783691f, 0.4817536771297455f, 0.6845471262931824f, 0.8443279266357422f, 0.9510565400123596f, 0.9980267286300659f, 0.9822872281074524f, 0.9048270583152771f, 0.7705132365226746f, 0.5877852439880371f, 0.3681245446205139f, 0.12533323466777802f, -0.12533323466777802f, -0.3681245446205139f, -0.5877852439880371f, -0.7705132365226746f, -0.9048270583152771f, -0.9822872281074524f, -0.9980267286300659f, -0.9510565400123596f, -0.8443279266357422f, -0.6845471262931824f, -0.4817536771297455f, -0.24868988990783691f};
+};
+template <> struct RootTab<27> {
+  static constexpr float c[27] = {1.0f, 0.9730448722839355f, 0.8936326503753662f, 0.7660444378852844f, 0.5971586108207703f, 0.39607977867126465f, 0.1736481785774231f, -0.05814483016729355f, -0.2868032455444336f, -0.5f, -0.686241626739502f, -0.8354877829551697f, -0.9396926164627075f, -0.9932383298873901f, -0.9932383298873901f, -0.9396926164627075f, -0.8354877829551697f, -0.686241626739502f, -0.5f, -0.2868032455444336f, -0.05814483016729355f, 0.1736481785774231f, 0.39607977867126465f, 0.5971586108207703f, 0.7660444378852844f, 0.8936326503753662f, 0.9730448722839355f};
+  static constexpr float s[27] = {0.0f, 0.23061586916446686f, 0.448799192905426f, 0.6427876353263855f, 0.8021231889724731f, 0.9182161092758179f, 0.9848077297210693f, 0.9983081817626953f, 0.957989513874054f, 0.8660253882408142f, 0.7273736596107483f, 0.5495089888572693f, 0.3420201539993286f, 0.11609291285276413f, -0.11609291285276413f, -0.3420201539993286f, -0.5495089888572693f, -0.7273736596107483f, -0.8660253882408142f, -0.957989513874054f, -0.9983081817626953f, -0.9848077297210693f, -0.9182161092758179f, -0.8021231889724731f, -0.6427876353263855f, -0.448799192905426f, -0.23061586916446686f};
+};
+template <> struct RootTab<29> {
+  static constexpr float c[29] = {1.0f, 0.9766205549240112f, 0.9075754284858704f, 0.7960930466651917f, 0.6473863124847412f, 0.4684084355831146f, 0.26752832531929016f, 0.0541389100253582f, -0.16178199648857117f, -0.37013816833496094f, -0.5611870884895325f, -0.7259954810142517f, -0.856857180595398f, -0.9476531744003296f, -0.9941379427909851f, -0.9941379427909851f, -0.9476531744003296f, -0.856857180595398f, -0.7259954810142517f, -0.5611870884895325f, -0.37013816833496094f, -0.16178199648857117f, 0.0541389100253582f, 0.26752832531929016f, 0.4684084355831146f, 0.6473863124847412f, 0.7960930466651917f, 0.9075754284858704f, 0.9766205549240112f};
+  static constexpr float s[29] = {0.0f, 0.2149704396724701f, 0.41988909244537354f, 0.6051742434501648f, 0.7621620297431946f, 0.883512020111084f, 0.9635499715805054f, 0.9985334277153015f, 0.9868265390396118f, 0.9289767146110535f, 0.827688992023468f, 0.6876994371414185f, 0.5155538320541382f, 0.3193015158176422f, 0.10811901837587357f, -0.10811901837587357f, -0.3193015158176422f, -0.5155538320541382f, -0.6876994371414185f, -0.827688992023468f, -0.9289767146110535f, -0.9868265390396118f, -0.9985334277153015f, -0.9635499715805054f, -0.883512020111084f, -0.7621620297431946f, -0.6051742434501648f, -0.41988909244537354f, -0.2149704396724701f};
+};
+template <> struct RootTab<31> {
+  static constexpr float c[31] = {1.0f, 0.9795299172401428f, 0.9189578294754028f, 0.8207634687423706f, 0.6889669299125671f, 0.5289639830589294f, 0.3473052382469177f, 0.15142777562141418f, -0.05064916983246803f, -0.2506525218486786f, -0.44039416313171387f, -0.6121059656143188f, -0.7587581276893616f, -0.8743466138839722f, -0.954139232635498f, -0.9948693513870239f, -0.9948693513870239f, -0.954139232635498f, -0.8743466138839722f, -0.7587581276893616f, -0.6121059656143188f, -0.44039416313171387f, -0.2506525218486786f, -0.05064916983246803f, 0.15142777562141418f, 0.3473052382469177f, 0.5289639830589294f, 0.6889669299125671f, 0.8207634687423706f, 0.9189578294754028f, 0.9795299172401428f};
+  static constexpr float s[31] = {0.0f, 0.2012985199689865f, 0.3943558633327484f, 0.5712682008743286f, 0.7247927784919739f, 0.8486442565917969f, 0.9377521276473999f, 0.98846834897995f, 0.9987165331840515f, 0.9680771231651306f, 0.8978045582771301f, 0.790775716304779f, 0.651372492313385f, 0.4853019714355469f, 0.2993631362915039f, 0.10116831958293915f, -0.10116831958293915f, -0.2993631362915039f, -0.4853019714355469f, -0.651372492313385f, -0.790775716304779f, -0.8978045582771301f, -0.9680771231651306f, -0.9987165331840515f, -0.98846834897995f, -0.9377521276473999f, -0.8486442565917969f, -0.7247927784919739f, -0.5712682008743286f, -0.3943558633327484f, -0.2012985199689865f};
+};
 // odd P: X_k = x0 + sum_j cos(2 pi jk/P) (x_j + x_{P-j}) -/+ i sum_j sin(2 pi jk/P) (x_j - x_{P-j}),  j = 1..(P-1)/2 --
 // (P-1)^2 real multiply-adds; k and P - k share both sums
 template <bool INV, int P>
@@ -327,6 +359,14 @@ template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[9], flo
 template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[11], float (&i)[11]) { dft_odd<INV, 11>(r, i); }
 template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[13], float (&i)[13]) { dft_odd<INV, 13>(r, i); }
 template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[15], float (&i)[15]) { dft_odd<INV, 15>(r, i); }
+template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[17], float (&i)[17]) { dft_odd<INV, 17>(r, i); }
+template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[19], float (&i)[19]) { dft_odd<INV, 19>(r, i); }
+template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[21], float (&i)[21]) { dft_odd<INV, 21>(r, i); }
+template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[23], float (&i)[23]) { dft_odd<INV, 23>(r, i); }
+template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[25], float (&i)[25]) { dft_odd<INV, 25>(r, i); }
+template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[27], float (&i)[27]) { dft_odd<INV, 27>(r, i); }
+template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[29], float (&i)[29]) { dft_odd<INV, 29>(r, i); }
+template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[31], float (&i)[31]) { dft_odd<INV, 31>(r, i); }
 template <bool INV> __device__ __forceinline__ void fft_pow2(float (&r)[2], float (&i)[2]) {
   const float ar = r[0] + r[1], ai = i[0] + i[1];
   r[1] = r[0] - r[1]; i[1] = i[0] - i[1];

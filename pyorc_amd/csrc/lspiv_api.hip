@@ -243,7 +243,7 @@ int dispatch(const lspiv::PivParams& p, int dtype, bool ensemble, hipStream_t s)
     case 7: e = lspiv::launch_piv_embed16(p, dtype, ensemble, s); break;
     case 4: e = lspiv::launch_piv_embed32(p, dtype, ensemble, s); break;
     case 5: e = lspiv::launch_piv_embed64(p, dtype, ensemble, s); break;
-    case 6: e = lspiv::launch_piv_fft16(p, dtype, ensemble, s); break;
+    case 6: e = p.wy == 8 ? lspiv::launch_piv_fft8(p, dtype, ensemble, s) : lspiv::launch_piv_fft16(p, dtype, ensemble, s); break;
     case 8:
       switch (p.wy) {
 #define LSPIV_PFA_CASE(n) case n: e = lspiv::launch_piv_fft##n(p, dtype, ensemble, s); break;
@@ -336,6 +336,7 @@ int lspiv_kernel_kind(int wy, int wx) {
   if (wy == 32 && wx == 32) return 1;
   if (wy == 64 && wx == 64) return 2;
   if (wy == 16 && wx == 16) return 6;
+  if (wy == 8 && wx == 8 && getenv("LSPIV_NO_PFA") == nullptr) return 6;
   const bool no_pfa = getenv("LSPIV_NO_PFA") != nullptr;             // A/B switch: the P * 2^m sizes without their own FFT kernels
   if (!no_pfa && wy == wx) {
     switch (wy) {

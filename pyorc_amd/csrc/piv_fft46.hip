@@ -1,0 +1,9 @@
+// 46x46 interrogation windows (46 = 23 x 2: prime-factor FFT, fft_regs.h): instantiation of the fused FFT kernels
+// (piv_fft_impl.h); a job runs on the next power-of-two lane group, the surplus lanes idle along.
+#include "piv_fft_impl.h"
+
+namespace lspiv {
+hipError_t launch_piv_fft46(const PivParams& p, int dtype, bool ensemble, hipStream_t s) {
+  return launch_fft<46>(p, dtype, ensemble, s);
+}
+}  // namespace lspiv

@@ -45,6 +45,7 @@ struct Geo {
   static constexpr int HALF = N / 2;
   static constexpr bool POW2 = (N & (N - 1)) == 0;
   static constexpr int LG = N <= 16 ? 16 : N <= 32 ? 32 : 64;   // lanes per job; lanes >= N idle along (N = 12, 20, 24, 28, 36 ...)
+  static constexpr bool FULL = N == LG;             // every lane of the group owns a tile row (16, 32, 64)
   static constexpr int GROUPS = 64 / LG;            // jobs per wave
   static constexpr int LDS_ROW = N % 4 == 0 ? N + 4 : N + 2;   // dwords per padded row: 16-byte aligned, an odd number of 4-bank slots
   static constexpr int LDS_JOB = N * LDS_ROW;       // dwords per group buffer
@@ -59,16 +60,16 @@ template <int N> __device__ __forceinline__ int wrap_n(int i) {
 // lane -> the tile row it works on: lanes >= N of a group clone row N - 1 (they load, transform and reduce the same
 // values as lane N - 1 but never write LDS or HBM, and are masked out of sums / arg-min reductions)
 template <int N> __device__ __forceinline__ int row_of(int lg) {
-  if constexpr (Geo<N>::POW2) return lg;
+  if constexpr (Geo<N>::FULL) return lg;
   else return lg < N ? lg : N - 1;
 }
 template <int N> __device__ __forceinline__ bool lane_active(int lg) {
-  if constexpr (Geo<N>::POW2) return true;
+  if constexpr (Geo<N>::FULL) return true;
   else return lg < N;
 }
 template <int N> __device__ __forceinline__ int partner_byte_of(int lane, int lg) {   // byte address of lane -kx
   constexpr int LG = Geo<N>::LG;
-  if constexpr (Geo<N>::POW2) return ((lane & ~(LG - 1)) | ((N - lg) & (N - 1))) << 2;
+  if constexpr (Geo<N>::FULL) return ((lane & ~(LG - 1)) | ((N - lg) & (N - 1))) << 2;
   else { const int r = row_of<N>(lg); return ((lane & ~(LG - 1)) | (r == 0 ? 0 : N - r)) << 2; }
 }
 
@@ -172,7 +173,7 @@ struct RowRaw<uint8_t, N> {
       __builtin_memcpy(&v, q + (N - 2), 2);
       w[W - 1] = v;
     }
-    if constexpr (!Geo<N>::POW2) mask(lane_active<N>(group_lane<N>()));
+    if constexpr (!Geo<N>::FULL) mask(lane_active<N>(group_lane<N>()));
   }
   // idle lanes of a group (row_of): zero bytes count for nothing in the window sums
   __device__ __forceinline__ void mask(bool active) {
@@ -539,6 +540,7 @@ __device__ __forceinline__ void transpose2(float* buf, int lg, float (&xr)[N], f
   transpose_plane<N>(buf, lg, xi);
 }
 
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[8], float (&xi)[8]) { bfly8<INV>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[16], float (&xi)[16]) { fft16<INV>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[32], float (&xi)[32]) { fft32<INV>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[64], float (&xi)[64]) { fft64<INV>(xr, xi); }
@@ -554,6 +556,14 @@ template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[18], float
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[22], float (&xi)[22]) { fft_pfa<INV, 11, 2>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[26], float (&xi)[26]) { fft_pfa<INV, 13, 2>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[30], float (&xi)[30]) { fft_pfa<INV, 15, 2>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[34], float (&xi)[34]) { fft_pfa<INV, 17, 2>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[38], float (&xi)[38]) { fft_pfa<INV, 19, 2>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[42], float (&xi)[42]) { fft_pfa<INV, 21, 2>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[46], float (&xi)[46]) { fft_pfa<INV, 23, 2>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[50], float (&xi)[50]) { fft_pfa<INV, 25, 2>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[54], float (&xi)[54]) { fft_pfa<INV, 27, 2>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[58], float (&xi)[58]) { fft_pfa<INV, 29, 2>(xr, xi); }
+template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[62], float (&xi)[62]) { fft_pfa<INV, 31, 2>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[28], float (&xi)[28]) { fft_pfa<INV, 7, 4>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[36], float (&xi)[36]) { fft_pfa<INV, 9, 4>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[44], float (&xi)[44]) { fft_pfa<INV, 11, 4>(xr, xi); }

@@ -314,9 +314,9 @@ def test_get_ffpiv_ensemble_vs_oracle(gpu, kw):
         assert np.array_equal(got.coords["time"], t[ref["pair_index"]])
 
 
-@pytest.mark.parametrize("n,T", [(24, 6), (10, 7), (16, 5), (26, 4), (48, 4), (20, 5), (12, 6), (40, 4), (36, 3), (28, 5), (34, 3), (6, 5), (18, 4), (30, 3), (-10, 7), (-26, 4)])
+@pytest.mark.parametrize("n,T", [(24, 6), (10, 7), (16, 5), (26, 4), (48, 4), (20, 5), (12, 6), (40, 4), (36, 3), (28, 5), (34, 3), (6, 5), (18, 4), (30, 3), (-10, 7), (-26, 4), (-1034, 3), (62, 3), (42, 4), (8, 6)])
 def test_ensemble_other_window_size(gpu, monkeypatch, n, T):
-    """Ensemble mode of the 16-point and the prime-factor FFT kernels (6 ... 48), of the direct kernel (34) and, with
+    """Ensemble mode of the 16-point and the prime-factor FFT kernels (6 ... 48), of the direct kernel (34 with both switches) and, with
     LSPIV_NO_PFA=1 (negative n), of the embedded kernels (10: 32-point variant, two pairs per iteration incl. an odd pair
     count; 26: 64-point variant) that serve the odd sizes."""
     from pyorc_amd import _lib, frames as F
@@ -324,7 +324,10 @@ def test_ensemble_other_window_size(gpu, monkeypatch, n, T):
     if n < 0:
         n = -n
         monkeypatch.setenv("LSPIV_NO_PFA", "1")
-        assert _lib.load().lspiv_kernel_kind(n, n) in (4, 5)
+        if n > 1000:                                   # and past the embedded kernels: the direct spatial kernel
+            n -= 1000
+            monkeypatch.setenv("LSPIV_NO_EMBED", "1")
+        assert _lib.load().lspiv_kernel_kind(n, n) in ((4, 5) if n < 1000 and "LSPIV_NO_EMBED" not in os.environ else (3,))
 
     fr = particle_stack(T, 4 * n, 4 * n, seed=35 + n, density=0.05)
     got = F.get_piv(fr, n, ensemble_corr=True, corr_min=0.1, s2n_min=1.5)
@@ -431,14 +434,14 @@ def test_ensemble_accumulate_dev_equals_host_variant(gpu):
     host.close(); dev.close(); lib.lspiv_dev_free(d_f); lib.lspiv_dev_free(d_o)
 
 
-@pytest.mark.parametrize("n", [4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 18, 19, 20, 21, 22, 24, 25, 26, 27, 28, 30, 31, 36, 40, 44, 48, 52, 56, 60])
+@pytest.mark.parametrize("n", [4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 18, 19, 20, 21, 22, 24, 25, 26, 27, 28, 30, 31, 33, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62])
 def test_embedded_windows_every_size(gpu, n):
     """Square windows 4..8, 9..15 and 21..31 run inside the 16- / 32- / 64-point FFT kernels (zero-padded a, periodic b: exact
-    circular correlation in the top-left corner), 17..19 in the direct kernel; 16 and the sizes P x 2^m (P odd <= 15: 12, 20, 24, 28, 36 ... 60) have FFT kernels of their own.  Every size, three dtypes, threshold, constant / empty regions, planes."""
+    circular correlation in the top-left corner), 17..19 in the direct kernel; every even size has FFT kernels of its own (16 and the P x 2^m sizes).  Every size, three dtypes, threshold, constant / empty regions, planes."""
     from pyorc_amd import _lib
 
-    pfa = (6, 10, 12, 14, 18, 20, 22, 24, 26, 28, 30, 36, 40, 44, 48, 52, 56, 60)     # own FFT kernels (prime-factor P x 2^m transforms, P odd <= 15)
-    assert _lib.load().lspiv_kernel_kind(n, n) == (8 if n in pfa else 6 if n == 16 else 7 if n <= 8 else 4 if n < 16 else 3 if n <= 20 or n > 32 else 5)
+    pfa = [m for m in range(6, 64, 2) if m not in (8, 16, 32)]     # own FFT kernels (prime-factor P x 2^m transforms)
+    assert _lib.load().lspiv_kernel_kind(n, n) == (8 if n in pfa else 6 if n in (8, 16) else 7 if n <= 8 else 4 if n < 16 else 3 if n <= 20 or n > 32 else 5)
     fr = particle_stack(4, 3 * n + 5, 4 * n + 3, seed=100 + n, density=0.06)
     ov = (n // 2, n // 3)
     # 16-sample windows inside a 1024-point transform: the periodic copy of b carries 64x the window's energy, which
@@ -479,7 +482,7 @@ def test_embedded_and_direct_kernels_agree(gpu):
 @pytest.mark.parametrize("seg,P,ws", [("1", 3, 32), ("1", 4, 32), ("3", 10, 32), ("5", 11, 32), ("7", 23, 32), ("31", 40, 32),
                                       ("2", 9, 32), ("4", 9, 32), ("3", 7, 64), ("1", 5, 64), ("1", 6, 16), ("5", 12, 16),
                                       ("0", 4, 16), ("1", 6, 24), ("3", 8, 24), ("0", 4, 24), ("5", 11, 12), ("0", 3, 12),
-                                      ("1", 5, 48), ("0", 3, 48), ("1", 7, 20), ("3", 5, 20), ("0", 3, 20), ("1", 4, 40), ("0", 3, 40), ("1", 6, 28), ("3", 4, 56), ("1", 4, 60), ("0", 3, 36), ("1", 7, 10), ("3", 6, 18), ("0", 3, 22), ("1", 4, 30), ("5", 6, 6), ("0", 3, 14), ("1", 3, 26)])
+                                      ("1", 5, 48), ("0", 3, 48), ("1", 7, 20), ("3", 5, 20), ("0", 3, 20), ("1", 4, 40), ("0", 3, 40), ("1", 6, 28), ("3", 4, 56), ("1", 4, 60), ("0", 3, 36), ("1", 7, 10), ("3", 6, 18), ("0", 3, 22), ("1", 4, 30), ("5", 6, 6), ("0", 3, 14), ("1", 3, 26), ("1", 4, 34), ("3", 3, 50), ("0", 3, 62), ("1", 6, 8), ("0", 3, 8)])
 def test_walking_kernel_segments_vs_oracle(gpu, monkeypatch, seg, P, ws):
     """The time-walking kernel under every segment geometry (odd / even segment lengths, a last segment of one pair,
     an odd frame count) against the oracle: planes, thresholds, an empty frame and a constant corner in the stack."""

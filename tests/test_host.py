@@ -64,10 +64,11 @@ def test_kernel_dispatch_table(lib):
     assert lib.lspiv_kernel_kind(32, 32) == 1
     assert lib.lspiv_kernel_kind(9, 9) == 4 and lib.lspiv_kernel_kind(15, 15) == 4     # embedded in the 32-point FFT
     assert lib.lspiv_kernel_kind(16, 16) == 6                                            # native 16-point kernels
-    assert lib.lspiv_kernel_kind(4, 4) == 7 and lib.lspiv_kernel_kind(8, 8) == 7          # embedded in the 16-point FFT
+    assert lib.lspiv_kernel_kind(4, 4) == 7 and lib.lspiv_kernel_kind(7, 7) == 7          # embedded in the 16-point FFT
+    assert lib.lspiv_kernel_kind(8, 8) == 6                                              # native 8-point kernels
     assert lib.lspiv_kernel_kind(21, 21) == 5 and lib.lspiv_kernel_kind(25, 25) == 5   # embedded in the 64-point FFT
-    assert all(lib.lspiv_kernel_kind(n, n) == 8 for n in (6, 10, 12, 14, 18, 20, 22, 24, 26, 28, 30, 36, 40, 44, 48, 52, 56, 60))   # prime-factor FFT kernels
-    assert lib.lspiv_kernel_kind(24, 16) == 3 and lib.lspiv_kernel_kind(34, 34) == 3   # direct: non-square, 33..63
+    assert all(lib.lspiv_kernel_kind(n, n) == 8 for n in range(6, 64, 2) if n not in (8, 16, 32))   # prime-factor FFT kernels
+    assert lib.lspiv_kernel_kind(24, 16) == 3 and lib.lspiv_kernel_kind(35, 35) == 3   # direct: non-square, odd 33..63
     assert lib.lspiv_kernel_kind(17, 17) == 3 and lib.lspiv_kernel_kind(19, 19) == 3   # direct: cheaper than 2 x FFT64
     assert lib.lspiv_kernel_kind(64, 64) == 2
     assert lib.lspiv_kernel_kind(128, 128) == _lib.LSPIV_EUNSUPPORTED

@@ -8,7 +8,7 @@ H, W, P = 785, 875, int(sys.argv[1]) if len(sys.argv) > 1 else 40
 T = P + 1
 d_f = C.c_void_p(); _lib.check(lib.lspiv_dev_malloc(C.byref(d_f), T * H * W))
 _lib.check(lib.lspiv_synth_particles_dev(d_f, T, H, W, 5, 0.02))
-for ws in (8, 10, 12, 14, 16, 18, 20, 24, 26, 28, 32, 36, 40, 44, 48, 52, 56, 60, 64):
+for ws in (6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36, 40, 42, 44, 48, 50, 52, 56, 60, 62, 64):
     ov = ws // 2
     nr, nc = window.get_array_shape((H, W), (ws, ws), (ov, ov))
     d_o = C.c_void_p(); _lib.check(lib.lspiv_dev_malloc(C.byref(d_o), 16 * P * nr * nc))
