@@ -70,8 +70,9 @@ int         lspiv_synchronize(void);                    /* hipDeviceSynchronize 
  * default time-walking kernels, n > 1 forced segment length, -1 back to the LSPIV_WALK environment variable. */
 int         lspiv_set_option(const char* name, int value);
 int         lspiv_get_option(const char* name, int* value);
-/* which kernel a window size dispatches to: 6 = FFT 16x16, 1 = FFT 32x32, 2 = FFT 64x64, 7 / 4 / 5 = square windows
- * 4..8 / 9..15 / 21..31 embedded in the 16- / 32- / 64-point FFT kernels, 3 = direct spatial correlation (everything else);
+/* which kernel a window size dispatches to: 1 = FFT 32x32, 2 = FFT 64x64, 6 = FFT 8x8 / 16x16, 8 = prime-factor FFT
+ * kernels (every other even square window 6..62), 7 / 4 / 5 = odd square windows (and 4x4) 4..7 / 9..15 / 21..31
+ * embedded in the 16- / 32- / 64-point FFT kernels, 3 = direct spatial correlation (non-square, odd 17 / 19 / 33..63);
  * <0 = unsupported.  Host-only. */
 int         lspiv_kernel_kind(int wy, int wx);
 

@@ -1,4 +1,6 @@
-// Fused N x N interrogation-window kernels for gfx950 (CDNA4, wave64), N = 32 or 64.
+// Fused N x N interrogation-window kernels for gfx950 (CDNA4, wave64): N = 32 and 64 (the sizes the design is tuned for),
+// 8 and 16, and every other even N = P * 2^m up to 62 through prime-factor transforms (fft_regs.h); one instantiation
+// file per size (piv_fftNN.hip).
 //
 // Replaces, in ONE launch per frame chunk, what the reference does in three passes over a
 // (T-1, n_win, N, N) float volume (pyorc/velocimetry/ffpiv.py:446-474):
