@@ -259,6 +259,11 @@ int lspiv_event_destroy(void* ev);
  * advected by u = 3 + 2 sin(2 pi y/H), v = 1.5 cos(2 pi x/W) px/frame.  d_frames (T,H,W) uint8. */
 int lspiv_synth_particles_dev(void* d_frames, int64_t T, int64_t H, int64_t W, uint64_t seed, float density);
 
+/* Test hook: `count` independent length-n complex FFTs with the kernels' own register transforms (fft_regs.h), numpy
+ * conventions (forward exp(-2 pi i jk/n), inverse exp(+...), both unnormalised); in / out: host arrays of count*n
+ * interleaved (re, im) float pairs; n = 8, 16, 32, 64 or any even length 6..62 (the sizes lspiv_kernel_kind maps to 6 / 8). */
+int lspiv_debug_fft(int n, int inverse, const float* in, float* out, int64_t count);
+
 #ifdef __cplusplus
 }
 #endif

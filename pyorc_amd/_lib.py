@@ -106,6 +106,7 @@ SIGNATURES = {
     "lspiv_event_elapsed_ms": (_i32, [_vp, _vp, C.POINTER(_f32)]),
     "lspiv_event_destroy": (_i32, [_vp]),
     "lspiv_synth_particles_dev": (_i32, [_vp, _i64, _i64, _i64, C.c_uint64, _f32]),
+    "lspiv_debug_fft": (_i32, [_i32, _i32, _vp, _vp, _i64]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -263,6 +263,8 @@ hipError_t launch_time_mean(const float* f, int64_t T, int64_t n, float* out, hi
 hipError_t launch_window_replace(const float* in, int64_t planes, int R, int C, int x_min, int x_max, int y_min, int y_max,
                                  float* out, hipStream_t s);
 hipError_t launch_scale_velocity(float* f, int64_t T, int64_t n, float res_x, float res_y, const double* d_dt, hipStream_t s);
+// test hook: `count` independent length-n register FFTs (fft_debug.hip); interleaved re/im, n = 8, 16, 32, 64 or a prime-factor length
+hipError_t launch_fft_debug(int n, bool inverse, const float* in, float* out, int count, hipStream_t s);
 // synthetic particle-image stack (bench / test utility)
 hipError_t launch_synth_particles(uint8_t* d_frames, int64_t T, int H, int W, uint64_t seed, float density,
                                   hipStream_t s);

@@ -1280,4 +1280,23 @@ int lspiv_synth_particles_dev(void* d_frames, int64_t T, int64_t H, int64_t W, u
   return LSPIV_OK;
 }
 
+int lspiv_debug_fft(int n, int inverse, const float* in, float* out, int64_t count) {
+  if (!in || !out || count < 1 || count > (1 << 20)) return fail(LSPIV_EINVAL, "bad argument");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  const size_t bytes = (size_t)count * 2 * n * sizeof(float);
+  rc = ensure(&c->d_scratch, &c->scratch_cap, 2 * bytes);
+  if (rc) return rc;
+  float* d_in = (float*)c->d_scratch;
+  float* d_out = d_in + (size_t)count * 2 * n;
+  HIP_TRY(hipMemcpyAsync(d_in, in, bytes, hipMemcpyHostToDevice, c->stream));
+  hipError_t e = lspiv::launch_fft_debug(n, inverse != 0, d_in, d_out, (int)count, c->stream);
+  if (e == hipErrorInvalidValue) return fail(LSPIV_EUNSUPPORTED, "no register FFT of length %d", n);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  HIP_TRY(hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
+
 }  // extern "C"

@@ -777,6 +777,12 @@ __device__ __forceinline__ void store_plane_rows(float* dst, int lg, const float
 #ifndef LSPIV_WAVES_32U8
 #define LSPIV_WAVES_32U8 4
 #endif
+#ifndef LSPIV_WALK_WAVES_MID
+#define LSPIV_WALK_WAVES_MID 3
+#endif
+// walking kernels: the carried spectrum costs 32 x 32 one wave per SIMD
+template <typename T, int N>
+constexpr int kWalkWaves = N <= 16 ? 4 : (N < 32 && sizeof(T) < 8) ? LSPIV_WALK_WAVES_MID : (N == 32 && sizeof(T) < 8) ? LSPIV_WALK_WAVES : 2;
 template <typename T, int N>
 constexpr int kWavesPerSimd = N <= 24 ? 4 : (N == 32 && sizeof(T) == 1) ? LSPIV_WAVES_32U8 : (N == 32 && sizeof(T) == 4) ? LSPIV_WAVES_32F : 2;
 
@@ -879,7 +885,10 @@ __device__ __forceinline__ void prepare_one(const RowRaw<T, N>& raw, float (&x)[
 }
 
 #ifndef LSPIV_WALK_SB
-#define LSPIV_WALK_SB do { if constexpr (N == 32) __builtin_amdgcn_sched_barrier(0); } while (0)
+#ifndef LSPIV_WALK_SB_MIN
+#define LSPIV_WALK_SB_MIN 32
+#endif
+#define LSPIV_WALK_SB do { if constexpr (N >= LSPIV_WALK_SB_MIN && N <= 32) __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif
 
 // what a walking job carries from one iteration to the next
@@ -967,7 +976,7 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
 }
 
 template <typename T, int N, bool PLANES, bool WANT_NZ>
-__global__ __launch_bounds__(BLOCK, (N <= 16 ? 4 : N <= 32 && sizeof(T) < 8 ? LSPIV_WALK_WAVES : 2)) void piv_fft_walk_kernel(PivParams p, uint32_t seg_len,
+__global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_kernel(PivParams p, uint32_t seg_len,
                                                                                     uint32_t n_seg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using G = Geo<N>;
@@ -1326,7 +1335,7 @@ __global__ __launch_bounds__(BLOCK, (kWavesPerSimd<T, N>)) void piv_fft_ensemble
 // partial sum in HBM (zeroed by the caller), merged afterwards in segment order (ensemble_merge_kernel): fixed
 // summation order, no atomics, and ~3 rounds of jobs on the chip where one job per window would leave it 2/3 idle.
 template <typename T, int N, bool WANT_NZ>
-__global__ __launch_bounds__(BLOCK, (N <= 16 ? 4 : N <= 32 && sizeof(T) < 8 ? LSPIV_WALK_WAVES : 2)) void piv_fft_walk_ensemble_kernel(PivParams p) {
+__global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_ensemble_kernel(PivParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using G = Geo<N>;
   const int lane = threadIdx.x & 63;

@@ -556,3 +556,23 @@ def test_pinned_host_stack_is_used_in_place(gpu):
     f32[...] = particle_stack(4, 64, 64, seed=2)
     for x, y in zip(pyorc_amd.piv_pairs(f32, (32, 32), (16, 16)), pyorc_amd.piv_pairs(np.array(f32), (32, 32), (16, 16))):
         assert np.array_equal(x, y, equal_nan=True)
+
+
+@pytest.mark.parametrize("n", [8, 16, 32, 64] + [m for m in range(6, 64, 2) if m not in (8, 16, 32)])
+def test_register_ffts_match_numpy(gpu, n):
+    """The kernels' own register transforms (fft_regs.h: radix-4/8 for the powers of two, Good-Thomas prime-factor
+    splits with hand-written 3- / 5-point and generic odd-P butterflies for every other even length) against
+    numpy.fft, forward and inverse, through the lspiv_debug_fft test hook: 64 random transforms, a delta and a constant."""
+    from pyorc_amd import _lib
+
+    rng = np.random.default_rng(n)
+    z = (rng.standard_normal((66, n)) + 1j * rng.standard_normal((66, n))).astype(np.complex64)
+    z[64] = 0; z[64, 1] = 1.0                        # delta at 1: the twiddle row itself
+    z[65] = 2.5 - 1.0j                               # constant: only the DC bin
+    out = np.empty_like(z)
+    for inverse in (0, 1):
+        _lib.check(gpu.lspiv_debug_fft(n, inverse, _lib.ptr(z), _lib.ptr(out), z.shape[0]))
+        ref = np.fft.ifft(z.astype(np.complex128), axis=1) * n if inverse else np.fft.fft(z.astype(np.complex128), axis=1)
+        scale = np.abs(ref).max(axis=1, keepdims=True)
+        assert np.max(np.abs(out - ref) / scale) < 2e-6, (n, inverse)
+    assert gpu.lspiv_debug_fft(7, 0, _lib.ptr(z), _lib.ptr(out), 1) == _lib.LSPIV_EUNSUPPORTED
