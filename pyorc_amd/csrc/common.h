@@ -227,8 +227,8 @@ hipError_t launch_peaks_from_planes(const float* planes, uint32_t n_planes, int 
 int walk_setting();
 // segments of the walking ENSEMBLE kernels: enough jobs for ~3 rounds of the chip, segments of an odd number of pairs
 inline void ensemble_segments(uint32_t n_win, uint32_t n_pairs, int window, uint32_t* seg_len, uint32_t* n_seg) {
-  // quarter- / half-wave jobs at 4 / 3 waves/SIMD; wave jobs at 2
-  const uint32_t slots = window <= 16 ? 16384u : window < 32 ? 8192u : window == 32 ? 6144u : 2048u;
+  // quarter- / half-wave jobs at 4 / 3 waves/SIMD (32 x 32 with its partial sum in registers: 2); wave jobs at 2
+  const uint32_t slots = window <= 16 ? 16384u : window < 32 ? 8192u : window == 32 ? 4096u : 2048u;
   uint32_t want = (3u * slots + n_win - 1) / n_win;
   if (want < 1) want = 1;
   uint32_t len = (n_pairs + want - 1) / want;

@@ -1334,8 +1334,18 @@ __global__ __launch_bounds__(BLOCK, (kWavesPerSimd<T, N>)) void piv_fft_ensemble
 // job's partial sum instead of being searched for a peak.  A job = (time segment, window); each segment has its own
 // partial sum in HBM (zeroed by the caller), merged afterwards in segment order (ensemble_merge_kernel): fixed
 // summation order, no atomics, and ~3 rounds of jobs on the chip where one job per window would leave it 2/3 idle.
+// LSPIV_ENS_REGACC: the job's partial sum lives in N VGPRs per lane for the whole segment (lane = row y, register =
+// column x, the layout the planes come out of the inverse transform in) and is stored once at the end, instead of a
+// read-modify-write of its HBM slot every iteration.  Same sequence of float additions per element => same bits.
+#ifndef LSPIV_ENS_REGACC
+#define LSPIV_ENS_REGACC 1
+#endif
+template <int N> constexpr bool kEnsRegAcc = LSPIV_ENS_REGACC && N <= 32;
+template <typename T, int N>
+constexpr int kWalkEnsWaves = (kEnsRegAcc<N> && N == 32 && sizeof(T) < 8) ? 2 : kWalkWaves<T, N>;
+
 template <typename T, int N, bool WANT_NZ>
-__global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_ensemble_kernel(PivParams p) {
+__global__ __launch_bounds__(BLOCK, (kWalkEnsWaves<T, N>)) void piv_fft_walk_ensemble_kernel(PivParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using G = Geo<N>;
   const int lane = threadIdx.x & 63;
@@ -1362,6 +1372,11 @@ __global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_ensemb
                  (int64_t)wcol * p.sx;
   float* part = p.part_sum + (size_t)job * G::NN;
   float cnt = 0.0f;
+  float acc[kEnsRegAcc<N> ? N : 1];
+  if constexpr (kEnsRegAcc<N>) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc[j] = 0.0f;
+  }
   WalkCarry<N> carry;
   carry.reset();
   for (uint32_t f = p0; f <= p1; f += 2, row += 2 * p.frame_elems) {
@@ -1385,7 +1400,18 @@ __global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_ensemb
         p.s2n[g] = sn;
       }
     }
-    if (keep[0] || keep[1]) accumulate_planes<N>(part, lg, xr, keep[0], xi, keep[1]);
+    if constexpr (kEnsRegAcc<N>) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        acc[j] += keep[0] ? xr[j] : 0.0f;   // pair f-1 first, then f: the reference's summation order
+        acc[j] += keep[1] ? xi[j] : 0.0f;
+      }
+    } else {
+      if (keep[0] || keep[1]) accumulate_planes<N>(part, lg, xr, keep[0], xi, keep[1]);
+    }
+  }
+  if constexpr (kEnsRegAcc<N>) {
+    if (job_valid) store_plane_rows<N>(part, lg, acc, false);   // fft-shifted layout, like accumulate_planes
   }
   if (job_valid && lg == 0) p.part_cnt[job] = cnt;
 }
