@@ -358,10 +358,8 @@ template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[7], flo
 template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[9], float (&i)[9]) { dft_odd<INV, 9>(r, i); }
 template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[11], float (&i)[11]) { dft_odd<INV, 11>(r, i); }
 template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[13], float (&i)[13]) { dft_odd<INV, 13>(r, i); }
-template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[15], float (&i)[15]) { dft_odd<INV, 15>(r, i); }
 template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[17], float (&i)[17]) { dft_odd<INV, 17>(r, i); }
 template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[19], float (&i)[19]) { dft_odd<INV, 19>(r, i); }
-template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[21], float (&i)[21]) { dft_odd<INV, 21>(r, i); }
 template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[23], float (&i)[23]) { dft_odd<INV, 23>(r, i); }
 template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[25], float (&i)[25]) { dft_odd<INV, 25>(r, i); }
 template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[27], float (&i)[27]) { dft_odd<INV, 27>(r, i); }
@@ -376,6 +374,11 @@ template <bool INV> __device__ __forceinline__ void fft_pow2(float (&r)[4], floa
 template <bool INV> __device__ __forceinline__ void fft_pow2(float (&r)[8], float (&i)[8]) { bfly8<INV>(r, i); }
 template <bool INV> __device__ __forceinline__ void fft_pow2(float (&r)[16], float (&i)[16]) { fft16<INV>(r, i); }
 
+template <bool INV> __device__ __forceinline__ void fft_pow2(float (&r)[5], float (&i)[5]) { dft_small<INV>(r, i); }   // second factor of 15
+template <bool INV> __device__ __forceinline__ void fft_pow2(float (&r)[7], float (&i)[7]) { dft_small<INV>(r, i); }   // ... of 21
+
+template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[15], float (&i)[15]);   // nested splits, defined below
+template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[21], float (&i)[21]);
 constexpr int pfa_unit(int n_self, int n_other) {   // e = 1 mod n_self, 0 mod n_other
   for (int e = n_other; e < n_self * n_other; e += n_other)
     if (e % n_self == 1) return e;
@@ -406,5 +409,9 @@ __device__ __forceinline__ void fft_pfa(float (&xr)[P * N2], float (&xi)[P * N2]
     for (int k2 = 0; k2 < N2; ++k2) { xr[(e1 * k1 + e2 * k2) % N] = r[k2]; xi[(e1 * k1 + e2 * k2) % N] = i[k2]; }
   }
 }
+
+// 15 = 3 x 5 and 21 = 3 x 7 are coprime products themselves: the same split once more instead of the (P-1)^2 form
+template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[15], float (&i)[15]) { fft_pfa<INV, 3, 5>(r, i); }
+template <bool INV> __device__ __forceinline__ void dft_small(float (&r)[21], float (&i)[21]) { fft_pfa<INV, 3, 7>(r, i); }
 
 }  // namespace lspiv

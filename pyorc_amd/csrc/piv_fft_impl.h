@@ -771,6 +771,9 @@ __device__ __forceinline__ void store_plane_rows(float* dst, int lg, const float
 #ifndef LSPIV_WALK_WAVES
 #define LSPIV_WALK_WAVES 3
 #endif
+#ifndef LSPIV_WAVES_MID
+#define LSPIV_WAVES_MID 3
+#endif
 #ifndef LSPIV_WAVES_32F
 #define LSPIV_WAVES_32F 4
 #endif
@@ -784,7 +787,7 @@ __device__ __forceinline__ void store_plane_rows(float* dst, int lg, const float
 template <typename T, int N>
 constexpr int kWalkWaves = N <= 16 ? 4 : (N < 32 && sizeof(T) < 8) ? LSPIV_WALK_WAVES_MID : (N == 32 && sizeof(T) < 8) ? LSPIV_WALK_WAVES : 2;
 template <typename T, int N>
-constexpr int kWavesPerSimd = N <= 24 ? 4 : (N == 32 && sizeof(T) == 1) ? LSPIV_WAVES_32U8 : (N == 32 && sizeof(T) == 4) ? LSPIV_WAVES_32F : 2;
+constexpr int kWavesPerSimd = N <= 16 ? 4 : N <= 24 ? LSPIV_WAVES_MID : (N == 32 && sizeof(T) == 1) ? LSPIV_WAVES_32U8 : (N == 32 && sizeof(T) == 4) ? LSPIV_WAVES_32F : 2;
 
 // ---- per-timestep kernel: one job (two neighbouring windows of one pair) per lane group ---------
 template <typename T, int N, bool PLANES, bool WANT_NZ>
