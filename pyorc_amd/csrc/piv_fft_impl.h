@@ -875,14 +875,19 @@ __global__ __launch_bounds__(BLOCK, (kWavesPerSimd<T, N>)) void piv_fft_kernel(P
 template <typename T, int N, bool WANT_NZ>
 __device__ __forceinline__ void prepare_one(const RowRaw<T, N>& raw, float (&x)[N], int& nonzero, bool& finite,
                                             bool& dead) {
+  // every frame carries 1 / (2 N^2) on top of 1 / std, so each cross spectrum (a product of two frames' spectra)
+  // comes out scaled by the 1 / (4 N^4) the planes need -- no multiply in the un-packing loop; a power of two for
+  // N = 8 ... 64, i.e. the same bits as scaling the product
+  constexpr float kHalf = 1.0f / (2.0f * (float)Geo<N>::NN);
   if constexpr (sizeof(T) == 1) {
     const RowStats st = stats_u8<N>(raw, WANT_NZ, nonzero);
-    center_u8<N>(raw, st.mean, st.inv_std, x);   // max((byte - mean) / std, 0); all zero for a constant window
+    center_u8<N>(raw, st.mean, st.inv_std * kHalf, x);   // max((byte - mean) / std, 0) / (2 N^2); all zero for a constant window
     dead = st.inv_std == 0.0f;
   } else {
     const float inv = load_center<N>(raw, x, WANT_NZ, nonzero, finite);
+    const float g = inv * kHalf;
 #pragma unroll
-    for (int j = 0; j < N; ++j) x[j] *= inv;
+    for (int j = 0; j < N; ++j) x[j] *= g;
     dead = inv == 0.0f;
   }
 }
@@ -915,7 +920,6 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
                                                float (&xi)[N], float& mean_a, float& mean_b, bool& skip_a, bool& skip_b) {
   using G = Geo<N>;
   constexpr int H = N / 2;
-  constexpr float kScale = 1.0f / (4.0f * (float)G::NN * (float)G::NN);
   bool dead0, dead1, fin0 = true, fin1 = true;
   int nz0 = G::NN, nz1 = G::NN;
   {
@@ -940,8 +944,8 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
     const int kn = (N - ky) % N;
     const float mr = bperm_f(partner_byte, xr[kn]);
     const float mi = bperm_f(partner_byte, xi[kn]);
-    const float pr = (xr[ky] + mr) * kScale, pi = (xi[ky] - mi) * kScale;   // 2 F_f / (4 N^4)
-    const float qr = xi[ky] + mi, qi = mr - xr[ky];                         // 2 F_{f+1}
+    const float pr = xr[ky] + mr, pi = xi[ky] - mi;     // 2 F_f      (each with its frame's 1 / (2 N^2))
+    const float qr = xi[ky] + mi, qi = mr - xr[ky];     // 2 F_{f+1}
     const float ar = c.fpr[ky] * pr + c.fpi[ky] * pi, ai = c.fpr[ky] * pi - c.fpi[ky] * pr;   // conj(F_prev) P
     const float br = pr * qr + pi * qi, bi = pr * qi - pi * qr;                               // conj(P) Q
     c.fpr[ky] = qr;
