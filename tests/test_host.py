@@ -237,3 +237,21 @@ def test_xarray_branches_of_the_mirrors(monkeypatch):
         monkeypatch.undo()
         for mod in (V, F, M):
             importlib.reload(mod)
+
+
+def test_prime_factor_size_lists_agree(lib):
+    """The Makefile's PFA_SIZES (one translation unit per size), common.h's LSPIV_PFA_SIZES (declarations + dispatch) and the
+    instantiation files on disk name the same window sizes, and the dispatcher sends exactly those to kind 8."""
+    import re
+
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pyorc_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    sizes_mk = [int(x) for x in re.search(r"^PFA_SIZES\s*:=\s*(.*)$", mk, re.M).group(1).split()]
+    hdr = open(os.path.join(csrc, "common.h")).read()
+    block = re.search(r"#define LSPIV_PFA_SIZES\(X\)(.*?)\n#define", hdr, re.S).group(1)
+    sizes_h = [int(x) for x in re.findall(r"X\((\d+)\)", block)]
+    assert sizes_mk == sizes_h == sorted(sizes_h)
+    on_disk = sorted(int(m.group(1)) for f in os.listdir(csrc) if (m := re.fullmatch(r"piv_fft(\d+)\.hip", f)))
+    assert on_disk == sorted(sizes_h + [8, 16, 32, 64])
+    assert sizes_h == [n for n in range(2, 65) if lib.lspiv_kernel_kind(n, n) == 8]
+    assert all(n % 2 == 0 and n & (n - 1) for n in sizes_h)        # even, not a power of two
