@@ -8,7 +8,10 @@ to when bottleneck / numbagg are absent (they are not pyorc dependencies): ``mea
 ``skipna`` -> ``np.nanmean`` / ``np.nanstd`` (ddof 0) / ``count_nonzero(~isnan)``, ``shift`` -> NaN-filled shift,
 ``rolling(center=True).max()`` -> window ``[i - w//2, i + (w-1)//2]`` with NaN where it is incomplete, python-float
 thresholds compared in float32 (NEP 50 weak scalars; same result under numpy 1.x value-based casting).
-PARITY UNPINNED against a real xarray run; the reference's own mask tests (tests/test_mask.py) hold no numbers.
+PINNED for corr, minmax, rolling, outliers, variance, count, window_mean (+ reduce_time, apply): the chain of the reference's
+masking notebook applied to examples/ngwerere/ngwerere_piv.nc reproduces examples/ngwerere/ngwerere_masked.nc exactly
+(tests/test_masks.py::test_mask_oracle_reproduces_the_reference_masked_file, fixture tests/golden/ngwerere_masks.npz).
+angle, s2n, window_nan, window_replace: PARITY UNPINNED against a real xarray run (tests/test_mask.py holds no numbers).
 
 Quirks reproduced because they change results:
   * ``helpers.stack_window`` (pyorc/helpers.py:672-679) iterates ``range(wdw_y_min, wdw_y_max)`` -- the +wdw_y_max row

@@ -152,3 +152,41 @@ def make_rows_golden():
 
 if __name__ == "__main__":
     make_rows_golden()
+
+
+def make_ngwerere_masks():
+    """The one input -> output pair the reference ships for the post-PIV rows (N3 masks, N4 int16 encoding):
+    examples/ngwerere/ngwerere_piv.nc is what examples/03_Plotting_and_masking_velocimetry_results.ipynb opens, and
+    examples/ngwerere/ngwerere_masked.nc is what its last cell writes after
+        mask.corr, mask.minmax, mask.rolling, mask.outliers, mask.variance          (defaults, inplace=True)
+        mask.angle(angle_tolerance=0.5 * pi)                                        (NOT inplace: no effect)
+        mask.count(inplace=True), mask.window_mean(wdw=2, tolerance=0.5, reduce_time=True, inplace=True)
+        set_encoding(); to_netcdf()
+    Both are netCDF4 / HDF5 files; oracle/h5min.py reads them (no h5py here).  Stored as data only: the four int16
+    variables of the input as they sit on disk (scale_factor 0.01, _FillValue -9999, checked below) and the keep-mask of
+    the output (bit-packed) -- the output's kept values equal the input's, also checked below."""
+    import re
+    import struct
+
+    from oracle import h5min
+
+    src = "/root/reference/examples/ngwerere/"
+    names = ("v_x", "v_y", "corr", "s2n")
+    piv = h5min.read(src + "ngwerere_piv.nc", names + ("time", "x", "y"))
+    masked = h5min.read(src + "ngwerere_masked.nc", names)
+    for path in ("ngwerere_piv.nc", "ngwerere_masked.nc"):           # every scale_factor attribute is the double 0.01
+        buf = open(src + path, "rb").read()
+        hits = [m.start() for m in re.finditer(b"scale_factor", buf)]
+        assert len(hits) == 4 and all(buf[i + 53:i + 61] == struct.pack("<d", 0.01) for i in hits)
+        assert b"add_offset" not in buf
+    keep = masked["v_x"] != -9999
+    for k in names:
+        assert piv[k].dtype == np.int16 and piv[k].shape == (125, 59, 66)
+        assert np.array_equal(masked[k] != -9999, keep) and np.array_equal(masked[k][keep], piv[k][keep])
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ngwerere_masks.npz"),
+                        v_x=piv["v_x"], v_y=piv["v_y"], corr=piv["corr"], s2n=piv["s2n"], time=piv["time"], x=piv["x"], y=piv["y"],
+                        keep_bits=np.packbits(keep), scale_factor=np.float64(0.01), fill=np.int16(-9999))
+
+
+if __name__ == "__main__":
+    make_ngwerere_masks()

@@ -193,3 +193,66 @@ def test_gpu_rows_golden_filters_and_masks(gpu):
                          ("window_mean", [0.5, 1, -2, 2, -2, 2])):
         assert eq(pm.run_mask(f, name, params), g["mask_" + name]), name
     assert eq(pm.time_mean(f), g["time_mean"])
+
+
+# ---- pinned against the reference's own files ------------------------------------------------------------------------
+# examples/ngwerere/ngwerere_piv.nc -> examples/ngwerere/ngwerere_masked.nc, the input and the output of the reference's
+# masking notebook (tests/golden/make_golden.py::make_ngwerere_masks holds the recipe and how the fixture was made).
+
+def ngwerere_fixture():
+    import os
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ngwerere_masks.npz"))
+    raw = np.stack([z[k] for k in ("v_x", "v_y", "corr", "s2n")])                       # int16 as stored on disk
+    # CF decoding as xarray does it for int16 + scale_factor without add_offset: float32 data, scaled in float32
+    f = raw.astype(np.float32) * np.float32(z["scale_factor"])
+    f[raw == z["fill"]] = np.nan
+    keep = np.unpackbits(z["keep_bits"])[: raw[0].size].reshape(raw[0].shape).astype(bool)
+    return raw, f, keep
+
+
+NOTEBOOK_RECIPE = (("corr", {}), ("minmax", {}), ("rolling", {}), ("outliers", {}), ("variance", {}), ("count", {}))
+
+
+def test_mask_oracle_reproduces_the_reference_masked_file():
+    """PINS the mask oracle: the notebook's chain (corr, minmax, rolling, outliers, variance, count with their defaults,
+    then window_mean(wdw=2, tolerance=0.5, reduce_time=True)) applied to ngwerere_piv.nc keeps exactly the 93 824 of
+    486 750 vectors that the reference's ngwerere_masked.nc keeps -- no mismatch."""
+    raw, f, keep = ngwerere_fixture()
+    assert f.shape == (4, 125, 59, 66) and keep.sum() == 93824
+    kept_after = []
+    for name, kw in NOTEBOOK_RECIPE:
+        f = mo.apply(f, getattr(mo, name)(f, **kw))
+        kept_after.append(int((~np.isnan(f[0])).sum()))
+    f = mo.apply(f, mo.window_mean(mo.time_mean(f), wdw=2, tolerance=0.5)[0])
+    assert kept_after == [470651, 272982, 194997, 167523, 167523, 97677]                # every mask bites (variance: no-op)
+    for k in range(4):
+        assert np.array_equal(~np.isnan(f[k]), keep)
+    # N4: re-encoding what is left gives the bytes of ngwerere_masked.nc (kept values are the input's, the rest _FillValue)
+    from oracle import piv_oracle as po
+
+    assert np.array_equal(po.encode_int16(f), np.where(keep, raw, np.int16(-9999)))
+
+
+@pytest.mark.gpu
+def test_gpu_masks_reproduce_the_reference_masked_file(gpu):
+    """The HIP masks through the reference-shaped wrapper (`Mask`), then the int16 packing kernel: ngwerere_piv.nc in,
+    the bytes of ngwerere_masked.nc out."""
+    from pyorc_amd.mask import Mask
+    from pyorc_amd.velocimetry import PivResult
+
+    raw, f, keep = ngwerere_fixture()
+    ds = PivResult({k: f[i].copy() for i, k in enumerate(("v_x", "v_y", "corr", "s2n"))}, {})
+    m = Mask(ds)
+    for name, kw in NOTEBOOK_RECIPE:
+        getattr(m, name)(inplace=True, **kw)
+    m.angle(angle_tolerance=0.5 * np.pi)                                                # not in place in the notebook: no effect
+    m.window_mean(wdw=2, inplace=True, tolerance=0.5, reduce_time=True)
+    out = np.stack([np.asarray(ds[k]) for k in ("v_x", "v_y", "corr", "s2n")])
+    assert np.array_equal(~np.isnan(out[0]), keep)
+    from pyorc_amd import _lib
+
+    out = np.ascontiguousarray(out, dtype=np.float32)
+    packed = np.empty(out.shape, np.int16)
+    _lib.check(gpu.lspiv_pack_int16(_lib.ptr(out), out.size, 0.01, -9999, _lib.ptr(packed)))
+    assert np.array_equal(packed, np.where(keep, raw, np.int16(-9999)))
