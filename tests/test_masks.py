@@ -256,3 +256,22 @@ def test_gpu_masks_reproduce_the_reference_masked_file(gpu):
     packed = np.empty(out.shape, np.int16)
     _lib.check(gpu.lspiv_pack_int16(_lib.ptr(out), out.size, 0.01, -9999, _lib.ptr(packed)))
     assert np.array_equal(packed, np.where(keep, raw, np.int16(-9999)))
+
+
+REF_NC = "/root/reference/examples/ngwerere/"
+
+
+@pytest.mark.skipif(not __import__("os").path.exists(REF_NC + "ngwerere_piv.nc"), reason="reference checkout not present (GPU box)")
+def test_ngwerere_fixture_is_what_the_reference_files_hold():
+    """Provenance of tests/golden/ngwerere_masks.npz (build container only, where /root/reference is mounted): the
+    minimal HDF5 reader returns the same int16 variables from the reference's netCDF files as the fixture stores, and
+    ngwerere_masked.nc is ngwerere_piv.nc with _FillValue wherever the fixture's keep-mask is False."""
+    from oracle import h5min
+
+    raw, _, keep = ngwerere_fixture()
+    names = ("v_x", "v_y", "corr", "s2n")
+    piv = h5min.read(REF_NC + "ngwerere_piv.nc", names)
+    masked = h5min.read(REF_NC + "ngwerere_masked.nc", names)
+    for i, k in enumerate(names):
+        assert np.array_equal(piv[k], raw[i])
+        assert np.array_equal(masked[k], np.where(keep, raw[i], np.int16(-9999)))
