@@ -164,6 +164,8 @@ int lspiv_projection_destroy(lspiv_projection* handle);
  *   lspiv_time_diff   Frames.time_diff (pyorc/api/frames.py:409-436): out (T-1,H,W) float32 = f32(frame t+1) - f32(frame t),
  *                     values <= thres and NaN -> 0, |.| if use_abs
  *   lspiv_minmax      Frames.minmax (:344-362) on float32 frames: maximum(minimum(x, hi), lo), NaN propagates
+ *   lspiv_time_range  Frames.range (:364-379): out (H,W) in the frames' dtype = max over time - min over time (NaN skipped
+ *                     for float frames, an all-NaN pixel stays NaN)
  *   lspiv_normalize   Frames.normalize (:279-306) on uint8 frames: float32 mean of frames [::round(T/samples)] removed,
  *                     per-frame ((x - min) / (max - min) * 255) -> uint8
  *   lspiv_gaussian_blur / lspiv_edge_detect   Frames.smooth (:438-467) / Frames.edge_detect (:308-342): pyorc calls
@@ -180,6 +182,8 @@ int lspiv_edge_detect_dev(const void* d_frames, int dtype, int64_t T, int64_t H,
 int lspiv_time_diff(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, float thres, int use_abs, float* out);
 int lspiv_time_diff_dev(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, float thres, int use_abs,
                         float* d_out, void* stream);
+int lspiv_time_range(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, void* out);
+int lspiv_time_range_dev(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, void* d_out, void* stream);
 int lspiv_minmax(const float* frames, int64_t n, float lo, float hi, float* out);
 int lspiv_minmax_dev(const float* d_frames, int64_t n, float lo, float hi, float* d_out, void* stream);
 int lspiv_normalize(const uint8_t* frames, int64_t T, int64_t H, int64_t W, int samples, uint8_t* out);

@@ -11,6 +11,8 @@ installable here, so they are NOT restated -- see DESIGN.md section 8.  The refe
 
 from __future__ import annotations
 
+import warnings
+
 import numpy as np
 
 
@@ -32,6 +34,16 @@ def normalize(frames: np.ndarray, samples: int = 15) -> np.ndarray:
 def minmax(frames: np.ndarray, min=-np.inf, max=np.inf) -> np.ndarray:
     """frames.py:362 on float32 frames (the dtype edge_detect / time_diff hand over)."""
     return np.maximum(np.minimum(np.asarray(frames, dtype=np.float32), np.float32(max)), np.float32(min))
+
+
+def time_range(frames: np.ndarray) -> np.ndarray:
+    """frames.py:364-379: (max(dim="time") - min(dim="time")).astype(dtype); xarray skips NaN for float frames."""
+    a = np.asarray(frames)
+    if a.dtype.kind == "f":
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)                       # all-NaN pixels -> NaN
+            return (np.nanmax(a, axis=0) - np.nanmin(a, axis=0)).astype(a.dtype)
+    return (a.max(axis=0) - a.min(axis=0)).astype(a.dtype)
 
 
 def time_diff(frames: np.ndarray, thres: float = 0.0, abs: bool = False) -> np.ndarray:

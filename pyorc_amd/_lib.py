@@ -75,6 +75,8 @@ SIGNATURES = {
     "lspiv_projection_destroy": (_i32, [_vp]),
     "lspiv_time_diff": (_i32, [_vp, _i32, _i64, _i64, _i64, _f32, _i32, _vp]),
     "lspiv_time_diff_dev": (_i32, [_vp, _i32, _i64, _i64, _i64, _f32, _i32, _vp, _vp]),
+    "lspiv_time_range": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp]),
+    "lspiv_time_range_dev": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp]),
     "lspiv_minmax": (_i32, [_vp, _i64, _f32, _f32, _vp]),
     "lspiv_minmax_dev": (_i32, [_vp, _i64, _f32, _f32, _vp, _vp]),
     "lspiv_normalize": (_i32, [_vp, _i64, _i64, _i64, _i32, _vp]),

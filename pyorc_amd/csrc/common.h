@@ -251,6 +251,8 @@ hipError_t launch_pack_int16(const float* in, int64_t n, float scale, int fill, 
 hipError_t launch_time_diff(const void* frames, int dtype, int64_t frame_elems, int64_t n_frames, float thres, int use_abs,
                             float* out, hipStream_t s);
 hipError_t launch_minmax(const float* in, int64_t n, float lo, float hi, float* out, hipStream_t s);
+// Frames.range: (max - min over time) in the frames' own dtype, out (frame_elems) of that dtype
+hipError_t launch_time_range(const void* frames, int dtype, int64_t frame_elems, int64_t n_frames, void* out, hipStream_t s);
 hipError_t launch_normalize(const uint8_t* frames, int64_t frame_elems, int n_frames, int interval, float* d_mean,
                             int* d_mn, int* d_mx, uint8_t* out, hipStream_t s);
 // Gaussian blur (ksize_b == 0) or band filter blur(ksize_b) - blur(ksize_a); odd sizes 1..31

@@ -1,6 +1,6 @@
 // Element-wise pre-processing filters on frame stacks in HBM: the ones the reference
 // implements with plain numpy/xarray arithmetic, so they can be reproduced bit for bit --
-//   Frames.time_diff  pyorc/api/frames.py:409-436    Frames.minmax  :344-362    Frames.normalize  :279-306
+//   Frames.time_diff  pyorc/api/frames.py:409-436    Frames.minmax  :344-362    Frames.normalize  :279-306    Frames.range  :364-379
 // (edge_detect / smooth are cv2.GaussianBlur calls and are not covered).  All are HBM-bound streaming kernels:
 // 16-byte accesses per lane, grid-stride over the stack.
 #include <algorithm>
@@ -22,6 +22,61 @@ __global__ __launch_bounds__(256) void time_diff_kernel(const T* __restrict__ f,
     float d = to_f32(f[i + frame_elems]) - to_f32(f[i]);  // float32 difference of consecutive frames
     d = (d > thres) ? d : 0.0f;                           // .where(d > thres) then .fillna(0.0): NaN compares false
     out[i] = use_abs ? fabsf(d) : d;
+  }
+}
+
+// Frames.range (pyorc/api/frames.py:364-379): (max over time - min over time).astype(input dtype), one thread per pixel
+// column walking the frames; xarray's max / min skip NaN for float frames (nanmax / nanmin; an all-NaN pixel stays NaN).
+template <typename T>
+__global__ __launch_bounds__(256) void time_range_kernel(const T* __restrict__ f, int64_t frame_elems, int64_t n_frames,
+                                                         T* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < frame_elems; i += stride) {
+    T mx = f[i], mn = f[i];
+    bool any = mx == mx;
+    for (int64_t t = 1; t < n_frames; ++t) {
+      const T x = f[t * frame_elems + i];
+      if (x == x) {
+        mx = (!any || x > mx) ? x : mx;
+        mn = (!any || x < mn) ? x : mn;
+        any = true;
+      }
+    }
+    out[i] = any ? (T)(mx - mn) : mx;   // mx is the NaN of frame 0 when nothing else was seen
+  }
+}
+// uint8: 16 pixels per thread and frame (one 16-byte load), byte-wise max / min on the packed words
+typedef uint32_t u32x4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t bytes_max(uint32_t a, uint32_t b) {
+  uint32_t r = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const uint32_t x = (a >> (8 * k)) & 0xffu, y = (b >> (8 * k)) & 0xffu; r |= (x > y ? x : y) << (8 * k); }
+  return r;
+}
+__device__ __forceinline__ uint32_t bytes_min(uint32_t a, uint32_t b) {
+  uint32_t r = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const uint32_t x = (a >> (8 * k)) & 0xffu, y = (b >> (8 * k)) & 0xffu; r |= (x < y ? x : y) << (8 * k); }
+  return r;
+}
+__global__ __launch_bounds__(256) void time_range_u8x16_kernel(const uint8_t* __restrict__ f, int64_t frame_elems, int64_t n_frames,
+                                                               uint8_t* __restrict__ out) {
+  const int64_t n_vec = frame_elems / 16;   // the caller handles the tail with the scalar kernel
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+    u32x4f mx = *reinterpret_cast<const u32x4f*>(f + 16 * i), mn = mx;
+#pragma unroll 8
+    for (int64_t t = 1; t < n_frames; ++t) {   // 8 independent 16-byte loads in flight per lane (only ~8 waves per CU at 1080p)
+      const u32x4f x = *reinterpret_cast<const u32x4f*>(f + t * frame_elems + 16 * i);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { mx[k] = bytes_max(mx[k], x[k]); mn[k] = bytes_min(mn[k], x[k]); }
+    }
+    u32x4f r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {   // byte-wise mx - mn (never borrows: mx >= mn in every byte)
+      r[k] = mx[k] - mn[k];
+    }
+    *reinterpret_cast<u32x4f*>(out + 16 * i) = r;
   }
 }
 
@@ -128,6 +183,28 @@ hipError_t launch_time_diff(const void* frames, int dtype, int64_t frame_elems, 
     case 0: hipLaunchKernelGGL(time_diff_kernel<uint8_t>, dim3(blocks), dim3(256), 0, s, (const uint8_t*)frames, frame_elems, n_out, thres, use_abs, out); break;
     case 1: hipLaunchKernelGGL(time_diff_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)frames, frame_elems, n_out, thres, use_abs, out); break;
     case 2: hipLaunchKernelGGL(time_diff_kernel<double>, dim3(blocks), dim3(256), 0, s, (const double*)frames, frame_elems, n_out, thres, use_abs, out); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_time_range(const void* frames, int dtype, int64_t frame_elems, int64_t n_frames, void* out, hipStream_t s) {
+  if (frame_elems <= 0 || n_frames <= 0) return hipSuccess;
+  const unsigned blocks = (unsigned)std::min<int64_t>((frame_elems + 255) / 256, 256 * 32);
+  switch (dtype) {
+    case 0: {
+      const uint8_t* f = (const uint8_t*)frames;
+      const int64_t n_vec = (frame_elems % 16 == 0 && (reinterpret_cast<uintptr_t>(f) & 15) == 0) ? frame_elems / 16 : 0;
+      if (n_vec) {
+        const unsigned vb = (unsigned)std::min<int64_t>((n_vec + 255) / 256, 256 * 32);
+        hipLaunchKernelGGL(time_range_u8x16_kernel, dim3(vb), dim3(256), 0, s, f, frame_elems, n_frames, (uint8_t*)out);
+      } else {
+        hipLaunchKernelGGL(time_range_kernel<uint8_t>, dim3(blocks), dim3(256), 0, s, f, frame_elems, n_frames, (uint8_t*)out);
+      }
+      break;
+    }
+    case 1: hipLaunchKernelGGL(time_range_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)frames, frame_elems, n_frames, (float*)out); break;
+    case 2: hipLaunchKernelGGL(time_range_kernel<double>, dim3(blocks), dim3(256), 0, s, (const double*)frames, frame_elems, n_frames, (double*)out); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -1070,6 +1070,39 @@ int lspiv_time_diff(const void* frames, int dtype, int64_t T, int64_t H, int64_t
   return LSPIV_OK;
 }
 
+int lspiv_time_range_dev(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, void* d_out, void* stream) {
+  if (!d_frames || !d_out) return fail(LSPIV_EINVAL, "NULL argument");
+  if (dtype < 0 || dtype > 2) return fail(LSPIV_EINVAL, "dtype %d not in {0:u8, 1:f32, 2:f64}", dtype);
+  if (T < 1 || H <= 0 || W <= 0) return fail(LSPIV_ESHAPE, "need >= 1 frame of positive size");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  hipError_t e = lspiv::launch_time_range(d_frames, dtype, H * W, T, d_out, stream ? (hipStream_t)stream : c->stream);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return LSPIV_OK;
+}
+
+int lspiv_time_range(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, void* out) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  if (!frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
+  if (dtype < 0 || dtype > 2) return fail(LSPIV_EINVAL, "dtype %d not in {0:u8, 1:f32, 2:f64}", dtype);
+  if (T < 1 || H <= 0 || W <= 0) return fail(LSPIV_ESHAPE, "need >= 1 frame of positive size");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  const size_t ib = (size_t)T * H * W * elem_size(dtype), ob = (size_t)H * W * elem_size(dtype);
+  rc = ensure(&c->d_frames, &c->frames_cap, ib);
+  if (rc) return rc;
+  rc = ensure(&c->d_planes, &c->planes_cap, ob);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_frames, frames, ib, hipMemcpyHostToDevice, c->stream));
+  rc = lspiv_time_range_dev(c->d_frames, dtype, T, H, W, c->d_planes, c->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out, c->d_planes, ob, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
+
 int lspiv_minmax_dev(const float* d_frames, int64_t n, float lo, float hi, float* d_out, void* stream) {
   if (!d_frames || !d_out) return fail(LSPIV_EINVAL, "NULL argument");
   if (n < 0) return fail(LSPIV_EINVAL, "bad n");

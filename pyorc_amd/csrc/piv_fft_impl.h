@@ -896,7 +896,10 @@ __device__ __forceinline__ void prepare_one(const RowRaw<T, N>& raw, float (&x)[
 #ifndef LSPIV_WALK_SB_MIN
 #define LSPIV_WALK_SB_MIN 32
 #endif
-#define LSPIV_WALK_SB do { if constexpr (N >= LSPIV_WALK_SB_MIN && N <= 32) __builtin_amdgcn_sched_barrier(0); } while (0)
+#ifndef LSPIV_WALK_SB_MAX
+#define LSPIV_WALK_SB_MAX 32
+#endif
+#define LSPIV_WALK_SB do { if constexpr (N >= LSPIV_WALK_SB_MIN && N <= LSPIV_WALK_SB_MAX) __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif
 
 // what a walking job carries from one iteration to the next

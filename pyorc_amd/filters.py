@@ -24,6 +24,15 @@ def time_diff(frames, thres: float = 0.0, abs: bool = False) -> np.ndarray:
     return out
 
 
+def range(frames) -> np.ndarray:  # noqa: A001 -- the reference's method name
+    """``Frames.range``: (T, H, W) -> (H, W) in the frames' own dtype, maximum minus minimum through time (NaN skipped)."""
+    a = _lib.as_frames(frames)
+    _lib.require_device()
+    out = np.empty(a.shape[1:], dtype=a.dtype)
+    _lib.check(_lib.load().lspiv_time_range(_lib.ptr(a), _lib.DTYPE_CODES[a.dtype], a.shape[0], a.shape[1], a.shape[2], _lib.ptr(out)))
+    return out
+
+
 def minmax(frames, min=-np.inf, max=np.inf) -> np.ndarray:
     """``Frames.minmax`` on float32 frames: ``np.maximum(np.minimum(x, max), min)`` (NaN propagates)."""
     a = np.ascontiguousarray(frames, dtype=np.float32)

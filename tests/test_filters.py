@@ -26,6 +26,8 @@ def test_oracle_filters_follow_reference_arithmetic():
     assert np.isnan(m[0, 0, 0]) and np.nanmin(m) == -5 and np.nanmax(m) == 5
     with pytest.raises(AssertionError):
         fo.normalize(fr[:5], samples=15)
+    r = fo.time_range(np.array([[[3, 200]], [[9, 7]], [[4, 255]]], np.uint8))
+    assert r.dtype == np.uint8 and r.tolist() == [[6, 248]]                       # max - min through time, input dtype kept
 
 
 @pytest.mark.gpu
@@ -40,6 +42,26 @@ def test_gpu_time_diff_bit_exact(gpu, dtype):
     for thres, ab in ((0.0, False), (2.5, False), (-1.0, True)):
         got = filters.time_diff(fr, thres, ab)
         assert got.dtype == np.float32 and np.array_equal(got, fo.time_diff(fr, thres, ab))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,shape", [(np.uint8, (9, 130, 176)), (np.uint8, (5, 33, 41)), (np.float32, (9, 130, 171)),
+                                         (np.float64, (4, 50, 61)), (np.uint8, (1, 16, 16))])
+def test_gpu_range_bit_exact(gpu, dtype, shape):
+    """Frames.range (pyorc/api/frames.py:364-379): max - min through time in the frames' own dtype; the 16-pixel uint8
+    path (frame size a multiple of 16) and the scalar one, NaN skipped for float frames, an all-NaN pixel stays NaN."""
+    from pyorc_amd import filters
+
+    fr = particle_stack(*shape, seed=14)
+    if dtype != np.uint8:
+        fr = fr.astype(dtype) * 0.37 - 3.0
+        fr[shape[0] // 2, 5, 7] = np.nan
+        fr[:, 6, 8] = np.nan
+    got = filters.range(fr)
+    ref = fo.time_range(fr)
+    assert got.dtype == fr.dtype and got.shape == fr.shape[1:] and np.array_equal(got, ref, equal_nan=True)
+    if dtype != np.uint8:
+        assert np.isnan(got[6, 8]) and not np.isnan(got[5, 7])
 
 
 @pytest.mark.gpu
