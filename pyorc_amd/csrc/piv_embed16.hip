@@ -1,4 +1,5 @@
-// Square windows 4..8 embedded in the 16-point transforms (piv_fft_impl.h, "embedded mode"): four jobs per wave.
+// Square windows 4, 5, 7 (and 6, 8 under LSPIV_NO_PFA=1) embedded in the 16-point transforms (piv_fft_impl.h, "embedded
+// mode"): four jobs per wave.
 #include "piv_fft_impl.h"
 
 namespace lspiv {

@@ -1,4 +1,5 @@
-// Square windows 9..15 embedded in the 32-point transforms (4..8: piv_embed16.hip; 16 x 16 is native, piv_fft16.hip) (piv_fft_impl.h, "embedded mode").
+// Odd square windows 9..15 (and the even ones under LSPIV_NO_PFA=1) embedded in the 32-point transforms (piv_fft_impl.h,
+// "embedded mode"); the even sizes have FFT kernels of their own (piv_fftNN.hip).
 #include "piv_fft_impl.h"
 
 namespace lspiv {

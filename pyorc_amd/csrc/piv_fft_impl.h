@@ -350,8 +350,9 @@ struct TileRef {
 
 
 // ---- embedded mode: a square n x n window, 4 <= n <= N/2, through the N-point transforms ------------------------
-// pyorc accepts any even window (the Ngwerere recipe asks for 25 -> 24, pyorc's tests use 10..20): those sizes have no
-// power-of-two FFT of their own, but their CIRCULAR correlation is exact inside a larger transform: a' zero-padded to
+// Serves the ODD square windows (which only the C ABI can ask for: pyorc rounds window sizes to even, and every even size
+// has FFT kernels of its own) and the LSPIV_NO_PFA=1 cross-check path.  Such a size has no FFT of its own here, but its
+// CIRCULAR correlation is exact inside a larger transform: a' zero-padded to
 // N x N, b' extended periodically (b'[y mod n][x mod n]); then for lags 0 <= k < n
 //     sum_{m < n} a'[m] b'_per[m + k] = sum_m a'[m] b'[(m + k) mod n]        (m + k <= 2n - 2 < N: no wrap of the big FFT)
 // in both axes, i.e. the top-left n x n corner of the N x N plane IS the n-point circular correlation; the other lags
