@@ -253,8 +253,10 @@ hipError_t launch_time_diff(const void* frames, int dtype, int64_t frame_elems, 
 hipError_t launch_minmax(const float* in, int64_t n, float lo, float hi, float* out, hipStream_t s);
 // Frames.range: (max - min over time) in the frames' own dtype, out (frame_elems) of that dtype
 hipError_t launch_time_range(const void* frames, int dtype, int64_t frame_elems, int64_t n_frames, void* out, hipStream_t s);
+// d_part: normalize_part_bytes() of scratch for the per-wave (min, max) pairs of the space-major passes (nullptr: frame-major kernels)
+size_t normalize_part_bytes(int64_t frame_elems, int n_frames);
 hipError_t launch_normalize(const uint8_t* frames, int64_t frame_elems, int n_frames, int interval, float* d_mean,
-                            int* d_mn, int* d_mx, uint8_t* out, hipStream_t s);
+                            int* d_mn, int* d_mx, float* d_part, uint8_t* out, hipStream_t s);
 // Gaussian blur (ksize_b == 0) or band filter blur(ksize_b) - blur(ksize_a); odd sizes 1..31
 hipError_t launch_blur(const void* frames, int dtype, int n_frames, int H, int W, int ksize_a, int ksize_b, float* out,
                        hipStream_t s);

@@ -174,6 +174,115 @@ __global__ __launch_bounds__(256) void normalize_kernel(const uint8_t* __restric
   }
 }
 
+// ---- normalize, space-major passes 2 and 3 -------------------------------------------------------------------------
+// The frame-major kernels above re-read the float32 mean plane (4 B / pixel, 8 MB at 1080p: more than one XCD's L2) for
+// every frame in both passes -- 8 B / pixel of L2 / Infinity-Cache traffic next to the 3 B / pixel of HBM traffic.  Here a
+// block owns a SLICE of 8192 pixels and a run of frames: its part of the mean plane sits in registers (32 floats per
+// lane), every frame costs its 1 B / pixel (+ 1 B written in pass 3) and nothing else.  Pass 2 leaves one (min, max)
+// pair per wave and frame (plain stores, no atomics); a small kernel folds them per frame.  Same float32 arithmetic,
+// min / max are order-independent: bit-identical to the frame-major path.  Needs frame_elems % 16 == 0.
+constexpr int NORM_PX = 32;                 // pixels per lane: two 16-byte chunks
+constexpr int NORM_SLICE = 256 * NORM_PX;   // pixels per block
+typedef uint32_t u32x4n __attribute__((ext_vector_type(4)));
+
+struct NormLane {
+  int64_t c[2];      // first pixel of this lane's two chunks
+  bool v[2];         // chunk inside the frame
+  float m[2][16];    // the mean plane under them
+  __device__ __forceinline__ void init(const float* __restrict__ mean, int64_t frame_elems) {
+    const int64_t base = (int64_t)blockIdx.x * NORM_SLICE;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      c[k] = base + ((int64_t)k * 256 + threadIdx.x) * 16;
+      v[k] = c[k] < frame_elems;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 x = v[k] ? reinterpret_cast<const f32x4*>(mean + c[k])[q] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        m[k][4 * q] = x[0]; m[k][4 * q + 1] = x[1]; m[k][4 * q + 2] = x[2]; m[k][4 * q + 3] = x[3];
+      }
+    }
+  }
+};
+
+__global__ __launch_bounds__(256) void norm_minmax_space_kernel(const uint8_t* __restrict__ f, const float* __restrict__ mean,
+                                                                int64_t frame_elems, int n_frames, int seg_len,
+                                                                float* __restrict__ part, int n_ws) {
+  NormLane L;
+  L.init(mean, frame_elems);
+  const int t0 = blockIdx.y * seg_len, t1 = min(t0 + seg_len, n_frames);
+  const int ws = blockIdx.x * 4 + (threadIdx.x >> 6);
+#pragma unroll 4
+  for (int t = t0; t < t1; ++t) {   // frames are independent: four of them in flight per lane
+    const uint8_t* img = f + (int64_t)t * frame_elems;
+    float lo = 3.0e38f, hi = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (L.v[k]) {
+        const u32x4n w = *reinterpret_cast<const u32x4n*>(img + L.c[k]);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float d = (float)((w[e >> 2] >> (8 * (e & 3))) & 0xffu) - L.m[k][e];
+          lo = fminf(lo, d);
+          hi = fmaxf(hi, d);
+        }
+      }
+    }
+    lo = -half_max(-lo); hi = half_max(hi);
+    lo = fminf(lo, __shfl_xor(lo, 32, 64)); hi = fmaxf(hi, __shfl_xor(hi, 32, 64));
+    if ((threadIdx.x & 63) == 0) {
+      part[((int64_t)t * n_ws + ws) * 2] = lo;
+      part[((int64_t)t * n_ws + ws) * 2 + 1] = hi;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void norm_fold_kernel(const float* __restrict__ part, int n_ws, float* __restrict__ lo_out,
+                                                        float* __restrict__ hi_out) {
+  const int t = blockIdx.x;
+  float lo = 3.0e38f, hi = -3.0e38f;
+  for (int i = threadIdx.x; i < n_ws; i += 256) {
+    lo = fminf(lo, part[((int64_t)t * n_ws + i) * 2]);
+    hi = fmaxf(hi, part[((int64_t)t * n_ws + i) * 2 + 1]);
+  }
+  lo = -half_max(-lo); hi = half_max(hi);
+  lo = fminf(lo, __shfl_xor(lo, 32, 64)); hi = fmaxf(hi, __shfl_xor(hi, 32, 64));
+  __shared__ float red[2][4];
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = lo; red[1][threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    lo_out[t] = fminf(fminf(red[0][0], red[0][1]), fminf(red[0][2], red[0][3]));
+    hi_out[t] = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+  }
+}
+
+__global__ __launch_bounds__(256) void norm_stretch_space_kernel(const uint8_t* __restrict__ f, const float* __restrict__ mean,
+                                                                 int64_t frame_elems, int n_frames, int seg_len,
+                                                                 const float* __restrict__ lo_in, const float* __restrict__ hi_in,
+                                                                 uint8_t* __restrict__ out) {
+  NormLane L;
+  L.init(mean, frame_elems);
+  const int t0 = blockIdx.y * seg_len, t1 = min(t0 + seg_len, n_frames);
+#pragma unroll 4
+  for (int t = t0; t < t1; ++t) {
+    const float lo = lo_in[t], span = hi_in[t] - lo;
+    const uint8_t* img = f + (int64_t)t * frame_elems;
+    uint8_t* dst = out + (int64_t)t * frame_elems;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (L.v[k]) {
+        const u32x4n w = *reinterpret_cast<const u32x4n*>(img + L.c[k]);
+        u32x4n o = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float q = (((float)((w[e >> 2] >> (8 * (e & 3))) & 0xffu) - L.m[k][e]) - lo) / span * 255.0f;
+          o[e >> 2] |= (uint32_t)((q != q) ? (uint8_t)0 : (uint8_t)(int)q) << (8 * (e & 3));
+        }
+        *reinterpret_cast<u32x4n*>(dst + L.c[k]) = o;
+      }
+    }
+  }
+}
+
 hipError_t launch_time_diff(const void* frames, int dtype, int64_t frame_elems, int64_t n_frames, float thres, int use_abs,
                             float* out, hipStream_t s) {
   const int64_t n_out = (n_frames - 1) * frame_elems;
@@ -217,8 +326,13 @@ hipError_t launch_minmax(const float* in, int64_t n, float lo, float hi, float* 
   return hipGetLastError();
 }
 
+size_t normalize_part_bytes(int64_t frame_elems, int n_frames) {
+  const int64_t n_slices = (frame_elems + NORM_SLICE - 1) / NORM_SLICE;
+  return (size_t)n_frames * (size_t)(4 * n_slices) * 2 * sizeof(float);
+}
+
 hipError_t launch_normalize(const uint8_t* frames, int64_t frame_elems, int n_frames, int interval, float* d_mean,
-                            int* d_mn, int* d_mx, uint8_t* out, hipStream_t s) {
+                            int* d_mn, int* d_mx, float* d_part, uint8_t* out, hipStream_t s) {
   if (n_frames <= 0 || frame_elems <= 0) return hipSuccess;
   hipLaunchKernelGGL(sample_mean_kernel, dim3((unsigned)((frame_elems + 255) / 256)), dim3(256), 0, s, frames, frame_elems,
                      n_frames, interval, d_mean);
@@ -228,6 +342,21 @@ hipError_t launch_normalize(const uint8_t* frames, int64_t frame_elems, int n_fr
   if (e != hipSuccess) return e;
   // 64 blocks per frame: enough to stream, few enough that the per-block atomics stay cheap.  (Running the two passes
   // chunk by chunk so that the second one finds the frames in the Infinity Cache was tried: slower, 1.05 vs 0.83 ms.)
+  // space-major passes (mean plane in registers): LSPIV_NORM_FRAME_MAJOR=1 keeps the frame-major kernels for A/B
+  static const bool frame_major = getenv("LSPIV_NORM_FRAME_MAJOR") != nullptr;
+  if (!frame_major && d_part && frame_elems % 16 == 0 && (reinterpret_cast<uintptr_t>(frames) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    const int n_slices = (int)((frame_elems + NORM_SLICE - 1) / NORM_SLICE), n_ws = 4 * n_slices;
+    int n_seg = std::max(1, std::min(n_frames, (2048 + n_slices - 1) / n_slices));
+    const int seg_len = (n_frames + n_seg - 1) / n_seg;
+    n_seg = (n_frames + seg_len - 1) / seg_len;
+    float* lo = reinterpret_cast<float*>(d_mn);
+    float* hi = reinterpret_cast<float*>(d_mx);
+    hipLaunchKernelGGL(norm_minmax_space_kernel, dim3(n_slices, n_seg), dim3(256), 0, s, frames, d_mean, frame_elems, n_frames, seg_len, d_part, n_ws);
+    hipLaunchKernelGGL(norm_fold_kernel, dim3(n_frames), dim3(256), 0, s, d_part, n_ws, lo, hi);
+    hipLaunchKernelGGL(norm_stretch_space_kernel, dim3(n_slices, n_seg), dim3(256), 0, s, frames, d_mean, frame_elems, n_frames, seg_len, lo, hi, out);
+    return hipGetLastError();
+  }
   const bool vec = frame_elems % 4 == 0 && (reinterpret_cast<uintptr_t>(frames) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
   const int64_t per = vec ? frame_elems / 4 : frame_elems;
   const unsigned bx = (unsigned)std::min<int64_t>((per + 255) / 256, 64);

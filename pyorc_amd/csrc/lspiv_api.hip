@@ -1148,11 +1148,13 @@ int lspiv_normalize_dev(const uint8_t* d_frames, int64_t T, int64_t H, int64_t W
   // no synchronisation per call.  (hipMallocAsync / hipFreeAsync on this stream gave run-to-run different outputs on
   // ROCm 7.2 and were dropped.)  Calls that overlap in time must therefore be issued on one stream.
   const size_t mean_bytes = ((size_t)H * W * sizeof(float) + 255) & ~(size_t)255;
-  rc = ensure(&c->d_scratch, &c->scratch_cap, mean_bytes + (size_t)2 * T * sizeof(int));
+  const size_t mm_bytes = ((size_t)2 * T * sizeof(int) + 255) & ~(size_t)255;
+  rc = ensure(&c->d_scratch, &c->scratch_cap, mean_bytes + mm_bytes + lspiv::normalize_part_bytes(H * W, (int)T));
   if (rc) return rc;
   float* d_mean = (float*)c->d_scratch;
   int* d_mm = (int*)((char*)c->d_scratch + mean_bytes);
-  hipError_t e = lspiv::launch_normalize(d_frames, H * W, (int)T, (int)iv, d_mean, d_mm, d_mm + T, d_out, s);
+  float* d_part = (float*)((char*)c->d_scratch + mean_bytes + mm_bytes);
+  hipError_t e = lspiv::launch_normalize(d_frames, H * W, (int)T, (int)iv, d_mean, d_mm, d_mm + T, d_part, d_out, s);
   if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? LSPIV_ENOMEM : LSPIV_EHIP, "normalize failed: %s", hipGetErrorString(e));
   return LSPIV_OK;
 }
