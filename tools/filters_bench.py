@@ -21,8 +21,11 @@ t = timed(lambda: _lib.check(lib.lspiv_minmax_dev(d_o, (T - 1) * n, -5.0, 5.0, d
 b = (T - 1) * n * 8
 print(f"minmax     f32    : {t*1e3:.2f} ms, {b/t/1e9:.0f} GB/s = {b/t/8e12*100:.1f}% of 8 TB/s")
 t = timed(lambda: _lib.check(lib.lspiv_normalize_dev(d_f, T, H, W, 15, d_n, None)), 3)
-b = T * n * (1 + 1 + 1)  # min/max pass read, normalise pass read + write (mean plane is L2-resident)
+b = T * n * (1 + 1 + 1)  # min/max pass read, stretch pass read + write (the mean plane sits in registers)
 print(f"normalize  u8->u8 : {t*1e3:.2f} ms / {T} frames, {b/t/1e9:.0f} GB/s algorithmic = {b/t/8e12*100:.1f}% of 8 TB/s (3 passes: sampled mean, per-frame min/max, stretch)")
+t = timed(lambda: _lib.check(lib.lspiv_time_range_dev(d_f, 0, T, H, W, d_n, None)))
+b = T * n + n
+print(f"range      u8->u8 : {t*1e3:.2f} ms / {T} frames, {b/t/1e9:.0f} GB/s algorithmic (every frame read once) = {b/t/8e12*100:.1f}% of 8 TB/s")
 for name, fn, k in (("smooth k=3", lambda: lib.lspiv_gaussian_blur_dev(d_f, 0, T - 1, H, W, 3, d_o, None), 3),
                     ("smooth k=7", lambda: lib.lspiv_gaussian_blur_dev(d_f, 0, T - 1, H, W, 7, d_o, None), 7),
                     ("edge 3|5   ", lambda: lib.lspiv_edge_detect_dev(d_f, 0, T - 1, H, W, 3, 5, d_o, None), 5),
