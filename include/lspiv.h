@@ -164,6 +164,9 @@ int lspiv_projection_destroy(lspiv_projection* handle);
  *   lspiv_time_diff   Frames.time_diff (pyorc/api/frames.py:409-436): out (T-1,H,W) float32 = f32(frame t+1) - f32(frame t),
  *                     values <= thres and NaN -> 0, |.| if use_abs
  *   lspiv_minmax      Frames.minmax (:344-362) on float32 frames: maximum(minimum(x, hi), lo), NaN propagates
+ *   lspiv_reduce_rolling  Frames.reduce_rolling (:381-407) on uint8 frames, float64 arithmetic: trailing rolling mean over
+ *                     `samples` frames removed, clipped at 0, per-frame (x * 255 / max) -> uint8, 0 where the rolling mean is 0;
+ *                     frames without a complete window and frames whose maximum is 0 come out 0 (NaN.astype(uint8) on x86)
  *   lspiv_time_range  Frames.range (:364-379): out (H,W) in the frames' dtype = max over time - min over time (NaN skipped
  *                     for float frames, an all-NaN pixel stays NaN)
  *   lspiv_normalize   Frames.normalize (:279-306) on uint8 frames: float32 mean of frames [::round(T/samples)] removed,
@@ -188,6 +191,8 @@ int lspiv_minmax(const float* frames, int64_t n, float lo, float hi, float* out)
 int lspiv_minmax_dev(const float* d_frames, int64_t n, float lo, float hi, float* d_out, void* stream);
 int lspiv_normalize(const uint8_t* frames, int64_t T, int64_t H, int64_t W, int samples, uint8_t* out);
 int lspiv_normalize_dev(const uint8_t* d_frames, int64_t T, int64_t H, int64_t W, int samples, uint8_t* d_out, void* stream);
+int lspiv_reduce_rolling(const uint8_t* frames, int64_t T, int64_t H, int64_t W, int samples, uint8_t* out);
+int lspiv_reduce_rolling_dev(const uint8_t* d_frames, int64_t T, int64_t H, int64_t W, int samples, uint8_t* d_out, void* stream);
 
 /* N3 -- post-PIV masks, ds.velocimetry.mask.* (pyorc/api/mask.py:147-403), on the result block
  * fields = [v_x | v_y | corr | s2n], each (T, R, C) float32 (lspiv_piv_pairs_dev's d_out after

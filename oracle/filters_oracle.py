@@ -36,6 +36,30 @@ def minmax(frames: np.ndarray, min=-np.inf, max=np.inf) -> np.ndarray:
     return np.maximum(np.minimum(np.asarray(frames, dtype=np.float32), np.float32(max)), np.float32(min))
 
 
+def reduce_rolling(frames: np.ndarray, samples: int = 25) -> np.ndarray:
+    """frames.py:381-407 on uint8 frames, float64 like xarray: ``roll = rolling(time=samples).mean()`` (trailing window,
+    NaN until it is complete; the window sum of uint8 samples is an exact integer, so sum / samples has one rounding
+    whatever the summation order -- numpy's nanmean path; bottleneck's move_mean multiplies by 1 / samples instead and
+    may differ in the last bit), ``thres = maximum(frames - roll, 0)``, ``(thres * 255 / thres.max over the frame)
+    .astype(uint8).where(roll != 0, 0)``.  NaN -> uint8 (incomplete windows, 0 / 0 for a frame whose maximum is 0) is
+    undefined in C; numpy on x86-64 gives 0, which is what is restated here.  UNPINNED against a real xarray run."""
+    a = np.asarray(frames)
+    assert len(a) >= samples, f"Amount of frames is smaller than requested rolling of {samples} samples"
+    cs = np.cumsum(a.astype(np.int64), axis=0)
+    win = cs[samples - 1:].copy()
+    win[1:] -= cs[:-samples]
+    roll = win / float(samples)                                                  # (T - samples + 1, H, W) float64
+    x = a[samples - 1:].astype(np.float64)
+    thres = np.maximum(x - roll, 0.0)
+    fmax = thres.max(axis=-1).max(axis=-1)[:, None, None]
+    with np.errstate(all="ignore"):
+        q = thres * 255 / fmax
+    q = np.where(np.isnan(q) | (roll == 0), 0.0, q)
+    out = np.zeros(a.shape, np.uint8)
+    out[samples - 1:] = q.astype(np.uint8)
+    return out
+
+
 def time_range(frames: np.ndarray) -> np.ndarray:
     """frames.py:364-379: (max(dim="time") - min(dim="time")).astype(dtype); xarray skips NaN for float frames."""
     a = np.asarray(frames)

@@ -251,6 +251,11 @@ hipError_t launch_pack_int16(const float* in, int64_t n, float scale, int fill, 
 hipError_t launch_time_diff(const void* frames, int dtype, int64_t frame_elems, int64_t n_frames, float thres, int use_abs,
                             float* out, hipStream_t s);
 hipError_t launch_minmax(const float* in, int64_t n, float lo, float hi, float* out, hipStream_t s);
+// Frames.reduce_rolling on uint8 frames: trailing rolling mean removed, >= 0, per-frame
+// stretch to uint8; scratch of reduce_rolling_scratch_bytes()
+size_t reduce_rolling_scratch_bytes(int64_t frame_elems, int n_frames);
+hipError_t launch_reduce_rolling(const uint8_t* frames, int64_t frame_elems, int n_frames, int samples, double* scratch,
+                                 uint8_t* out, hipStream_t s);
 // Frames.range: (max - min over time) in the frames' own dtype, out (frame_elems) of that dtype
 hipError_t launch_time_range(const void* frames, int dtype, int64_t frame_elems, int64_t n_frames, void* out, hipStream_t s);
 // d_part: normalize_part_bytes() of scratch for the per-wave (min, max) pairs of the space-major passes (nullptr: frame-major kernels)

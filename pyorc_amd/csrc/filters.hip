@@ -283,6 +283,144 @@ __global__ __launch_bounds__(256) void norm_stretch_space_kernel(const uint8_t* 
   }
 }
 
+// ---- Frames.reduce_rolling (pyorc/api/frames.py:381-407) on uint8 frames ------------------------------------------
+//   roll = frames.rolling(time=samples).mean()          trailing window [t - samples + 1, t], NaN for t < samples - 1
+//   thres = maximum(frames - roll, 0);  out = (thres * 255 / max over the frame of thres).astype(uint8).where(roll != 0, 0)
+// all in float64.  The window sum of uint8 samples is an exact integer, so roll = sum / samples has one rounding whatever
+// the summation order; a lane keeps the running integer sums of its 32 pixels in registers and walks a run of frames
+// (space-major like the normalize passes above).  Two passes: per-wave maxima of thres -> norm_fold-style reduction ->
+// the stretch.  Frames t < samples - 1 (NaN.astype(uint8): 0 on x86) and frames whose maximum is 0 (0 / 0) come out 0.
+typedef u32x4n u32x4n_u __attribute__((aligned(1)));   // frames start at t * H * W: any byte alignment
+struct RollLane {
+  int64_t c[2];
+  int nv[2];         // valid pixels of the chunk: 16, 0 (outside the frame) or the frame's tail
+  int sum[2][16];
+  __device__ __forceinline__ void init(int64_t frame_elems) {
+    const int64_t base = (int64_t)blockIdx.x * NORM_SLICE;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      c[k] = base + ((int64_t)k * 256 + threadIdx.x) * 16;
+      const int64_t left = frame_elems - c[k];
+      nv[k] = left >= 16 ? 16 : (left > 0 ? (int)left : 0);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sum[k][e] = 0;
+    }
+  }
+  __device__ __forceinline__ u32x4n load(const uint8_t* __restrict__ img, int k) const {
+    if (nv[k] == 16) return *reinterpret_cast<const u32x4n_u*>(img + c[k]);
+    u32x4n w = {0u, 0u, 0u, 0u};
+    for (int e = 0; e < nv[k]; ++e) w[e >> 2] |= (uint32_t)img[c[k] + e] << (8 * (e & 3));
+    return w;
+  }
+  __device__ __forceinline__ void store(uint8_t* __restrict__ dst, int k, u32x4n o) const {
+    if (nv[k] == 16) { *reinterpret_cast<u32x4n_u*>(dst + c[k]) = o; return; }
+    for (int e = 0; e < nv[k]; ++e) dst[c[k] + e] = (uint8_t)((o[e >> 2] >> (8 * (e & 3))) & 0xffu);
+  }
+  // sum += sign * frame
+  __device__ __forceinline__ void add(const uint8_t* __restrict__ img, int sign) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (nv[k]) {
+        const u32x4n w = load(img, k);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sum[k][e] += sign * (int)((w[e >> 2] >> (8 * (e & 3))) & 0xffu);
+      }
+    }
+  }
+};
+
+template <bool STRETCH>
+__global__ __launch_bounds__(256) void rolling_kernel(const uint8_t* __restrict__ f, int64_t frame_elems, int n_frames, int samples,
+                                                      int seg_len, double* __restrict__ part, int n_ws,
+                                                      const double* __restrict__ frame_max, uint8_t* __restrict__ out) {
+  RollLane L;
+  L.init(frame_elems);
+  const int first = samples - 1;                                   // first frame with a complete window
+  const int t0 = max(blockIdx.y * seg_len, first), t1 = min((blockIdx.y + 1) * seg_len, n_frames);
+  const int ws = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (STRETCH) {                                                   // the frames without a complete window: zeros
+    for (int t = blockIdx.y * seg_len; t < min(t1, first); ++t) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (L.nv[k]) L.store(out + (int64_t)t * frame_elems, k, u32x4n{0u, 0u, 0u, 0u});
+    }
+  }
+  if (t0 >= t1) return;
+  for (int t = t0 - first; t < t0; ++t) L.add(f + (int64_t)t * frame_elems, 1);   // the window of frame t0 minus frame t0
+  const double n = (double)samples;
+  for (int t = t0; t < t1; ++t) {
+    const uint8_t* img = f + (int64_t)t * frame_elems;
+    L.add(img, 1);
+    double hi = 0.0;
+    const double fm = STRETCH ? frame_max[t] : 1.0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (L.nv[k]) {
+        const u32x4n w = L.load(img, k);
+        u32x4n o = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {   // pixels past a tail chunk read as 0 with sum 0: thres 0, never the maximum, not stored
+          const double x = (double)((w[e >> 2] >> (8 * (e & 3))) & 0xffu);
+          const double d = x - (double)L.sum[k][e] / n;
+          const double th = d > 0.0 ? d : 0.0;                      // np.maximum(d, 0)
+          if (STRETCH) {
+            const double q = th * 255.0 / fm;                       // NaN (0 / 0) -> 0
+            const uint32_t b = (q != q || L.sum[k][e] == 0) ? 0u : (uint32_t)(int)q;
+            o[e >> 2] |= (b & 0xffu) << (8 * (e & 3));
+          } else {
+            hi = th > hi ? th : hi;
+          }
+        }
+        if (STRETCH) L.store(out + (int64_t)t * frame_elems, k, o);
+      }
+    }
+    if (!STRETCH) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) { const double o2 = __shfl_xor(hi, off, 64); hi = o2 > hi ? o2 : hi; }
+      if ((threadIdx.x & 63) == 0) part[(int64_t)t * n_ws + ws] = hi;
+    }
+    L.add(f + (int64_t)(t - first) * frame_elems, -1);              // drop the oldest frame of the window
+  }
+}
+
+__global__ __launch_bounds__(256) void rolling_fold_kernel(const double* __restrict__ part, int n_ws, double* __restrict__ frame_max) {
+  const int t = blockIdx.x;
+  double hi = 0.0;
+  for (int i = threadIdx.x; i < n_ws; i += 256) { const double x = part[(int64_t)t * n_ws + i]; hi = x > hi ? x : hi; }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { const double o2 = __shfl_xor(hi, off, 64); hi = o2 > hi ? o2 : hi; }
+  __shared__ double red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = hi;
+  __syncthreads();
+  if (threadIdx.x == 0) frame_max[t] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+size_t reduce_rolling_scratch_bytes(int64_t frame_elems, int n_frames) {
+  const int64_t n_slices = (frame_elems + NORM_SLICE - 1) / NORM_SLICE;
+  return ((size_t)n_frames * (size_t)(4 * n_slices) + (size_t)n_frames) * sizeof(double);
+}
+
+// any frame size; scratch: reduce_rolling_scratch_bytes()
+hipError_t launch_reduce_rolling(const uint8_t* frames, int64_t frame_elems, int n_frames, int samples, double* scratch,
+                                 uint8_t* out, hipStream_t s) {
+  if (n_frames <= 0 || frame_elems <= 0) return hipSuccess;
+  const int n_slices = (int)((frame_elems + NORM_SLICE - 1) / NORM_SLICE), n_ws = 4 * n_slices;
+  int n_seg = std::max(1, std::min(n_frames / std::max(1, 4 * samples) + 1, (2048 + n_slices - 1) / n_slices));
+  const int seg_len = (n_frames + n_seg - 1) / n_seg;
+  n_seg = (n_frames + seg_len - 1) / seg_len;
+  double* part = scratch;
+  double* fm = scratch + (size_t)n_frames * n_ws;
+  hipError_t e = hipMemsetAsync(fm, 0, (size_t)n_frames * sizeof(double), s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(rolling_kernel<false>, dim3(n_slices, n_seg), dim3(256), 0, s, frames, frame_elems, n_frames, samples, seg_len, part, n_ws,
+                     (const double*)nullptr, (uint8_t*)nullptr);
+  if (n_frames >= samples)
+    hipLaunchKernelGGL(rolling_fold_kernel, dim3(n_frames - (samples - 1)), dim3(256), 0, s, part + (size_t)(samples - 1) * n_ws, n_ws, fm + (samples - 1));
+  hipLaunchKernelGGL(rolling_kernel<true>, dim3(n_slices, n_seg), dim3(256), 0, s, frames, frame_elems, n_frames, samples, seg_len, part, n_ws,
+                     (const double*)fm, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_time_diff(const void* frames, int dtype, int64_t frame_elems, int64_t n_frames, float thres, int use_abs,
                             float* out, hipStream_t s) {
   const int64_t n_out = (n_frames - 1) * frame_elems;

@@ -1179,6 +1179,41 @@ int lspiv_normalize(const uint8_t* frames, int64_t T, int64_t H, int64_t W, int 
   return LSPIV_OK;
 }
 
+int lspiv_reduce_rolling_dev(const uint8_t* d_frames, int64_t T, int64_t H, int64_t W, int samples, uint8_t* d_out, void* stream) {
+  if (!d_frames || !d_out) return fail(LSPIV_EINVAL, "NULL argument");
+  if (T < 1 || H <= 0 || W <= 0 || samples < 1 || T >= (1 << 24)) return fail(LSPIV_ESHAPE, "bad shape");
+  if (T < samples) return fail(LSPIV_EINVAL, "Amount of frames is smaller than requested rolling of %d samples", samples);
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  rc = ensure(&c->d_scratch, &c->scratch_cap, lspiv::reduce_rolling_scratch_bytes(H * W, (int)T));
+  if (rc) return rc;
+  hipError_t e = lspiv::launch_reduce_rolling(d_frames, H * W, (int)T, samples, (double*)c->d_scratch, d_out, s);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "reduce_rolling failed: %s", hipGetErrorString(e));
+  return LSPIV_OK;
+}
+
+int lspiv_reduce_rolling(const uint8_t* frames, int64_t T, int64_t H, int64_t W, int samples, uint8_t* out) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  if (!frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
+  if (T < 1 || H <= 0 || W <= 0) return fail(LSPIV_ESHAPE, "bad shape");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  const size_t b = (size_t)T * H * W;
+  rc = ensure(&c->d_frames, &c->frames_cap, b);
+  if (rc) return rc;
+  rc = ensure(&c->d_planes, &c->planes_cap, b);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_frames, frames, b, hipMemcpyHostToDevice, c->stream));
+  rc = lspiv_reduce_rolling_dev((const uint8_t*)c->d_frames, T, H, W, samples, (uint8_t*)c->d_planes, c->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out, c->d_planes, b, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
+
 static int blur_common_dev(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, int k1, int k2, float* d_out,
                            void* stream) {
   if (!d_frames || !d_out) return fail(LSPIV_EINVAL, "NULL argument");

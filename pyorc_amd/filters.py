@@ -24,6 +24,21 @@ def time_diff(frames, thres: float = 0.0, abs: bool = False) -> np.ndarray:
     return out
 
 
+def reduce_rolling(frames, samples: int = 25) -> np.ndarray:
+    """``Frames.reduce_rolling`` on uint8 frames: trailing rolling mean of ``samples`` frames removed, clipped at 0,
+    per-frame stretch to uint8 (the first ``samples - 1`` frames have no complete window and come out 0)."""
+    a = np.asarray(frames)
+    if a.dtype != np.uint8 or a.ndim != 3:
+        raise ValueError("reduce_rolling expects a (T, H, W) uint8 stack (grayscale camera frames)")
+    if len(a) < samples:
+        raise AssertionError(f"Amount of frames is smaller than requested rolling of {samples} samples")
+    a = np.ascontiguousarray(a)
+    _lib.require_device()
+    out = np.empty_like(a)
+    _lib.check(_lib.load().lspiv_reduce_rolling(_lib.ptr(a), a.shape[0], a.shape[1], a.shape[2], int(samples), _lib.ptr(out)))
+    return out
+
+
 def range(frames) -> np.ndarray:  # noqa: A001 -- the reference's method name
     """``Frames.range``: (T, H, W) -> (H, W) in the frames' own dtype, maximum minus minimum through time (NaN skipped)."""
     a = _lib.as_frames(frames)

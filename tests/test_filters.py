@@ -26,6 +26,9 @@ def test_oracle_filters_follow_reference_arithmetic():
     assert np.isnan(m[0, 0, 0]) and np.nanmin(m) == -5 and np.nanmax(m) == 5
     with pytest.raises(AssertionError):
         fo.normalize(fr[:5], samples=15)
+    rr = fo.reduce_rolling(np.array([[[10, 0]], [[20, 0]], [[60, 0]], [[10, 0]]], np.uint8), samples=2)
+    # rolling means 15, 40, 35: excesses 5, 20, 0 -> each frame stretched to its own maximum; mean 0 -> 0; frame 0 has no window
+    assert rr.dtype == np.uint8 and rr[:, 0, :].tolist() == [[0, 0], [255, 0], [255, 0], [0, 0]]
     r = fo.time_range(np.array([[[3, 200]], [[9, 7]], [[4, 255]]], np.uint8))
     assert r.dtype == np.uint8 and r.tolist() == [[6, 248]]                       # max - min through time, input dtype kept
 
@@ -62,6 +65,27 @@ def test_gpu_range_bit_exact(gpu, dtype, shape):
     assert got.dtype == fr.dtype and got.shape == fr.shape[1:] and np.array_equal(got, ref, equal_nan=True)
     if dtype != np.uint8:
         assert np.isnan(got[6, 8]) and not np.isnan(got[5, 7])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,samples", [((40, 130, 176), 25), ((31, 57, 83), 7), ((9, 16, 16), 9), ((12, 33, 41), 1),
+                                           ((300, 64, 96), 25)])
+def test_gpu_reduce_rolling_bit_exact(gpu, shape, samples):
+    """Frames.reduce_rolling (pyorc/api/frames.py:381-407): float64 arithmetic on exact integer window sums; frame sizes
+    with and without a 16-pixel tail, several time segments with their halo, a black region (rolling mean 0), a frame
+    brighter nowhere than its rolling mean (maximum 0)."""
+    from pyorc_amd import filters
+
+    fr = particle_stack(*shape, seed=15)
+    fr[:, :5, :7] = 0                                   # rolling mean 0 -> 0
+    if shape[0] > samples + 2:
+        fr[samples + 1] = 0                             # nothing above the rolling mean: 0 / 0 -> 0
+    got = filters.reduce_rolling(fr, samples)
+    ref = fo.reduce_rolling(fr, samples)
+    assert got.dtype == np.uint8 and np.array_equal(got, ref)
+    assert (got[: samples - 1] == 0).all() and got[samples - 1:].max() == (255 if samples > 1 else 0)   # samples = 1: frame - itself
+    with pytest.raises(AssertionError):
+        filters.reduce_rolling(fr[: samples - 1] if samples > 1 else fr[:0], samples)
 
 
 @pytest.mark.gpu
