@@ -33,6 +33,22 @@ def test_oracle_filters_follow_reference_arithmetic():
     assert r.dtype == np.uint8 and r.tolist() == [[6, 248]]                       # max - min through time, input dtype kept
 
 
+def test_filter_wrappers_validate_before_touching_the_device():
+    """Argument errors of the reference's filters come from the host wrapper, with the reference's messages, whether or
+    not a GPU is present (pyorc/api/frames.py:296-298, 397-398)."""
+    from pyorc_amd import filters
+
+    fr = particle_stack(6, 16, 24, seed=1)
+    with pytest.raises(AssertionError, match="smaller than requested rolling of 25 samples"):
+        filters.reduce_rolling(fr, samples=25)
+    with pytest.raises(ValueError, match="uint8"):
+        filters.reduce_rolling(fr.astype(np.float32), samples=2)
+    with pytest.raises(AssertionError, match="too small to provide 15 samples"):
+        filters.normalize(fr[:5], samples=15)
+    with pytest.raises(ValueError):
+        filters.range(fr[0])                                                   # not a (T, H, W) stack
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.uint8, np.float32, np.float64])
 def test_gpu_time_diff_bit_exact(gpu, dtype):
