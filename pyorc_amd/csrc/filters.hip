@@ -329,10 +329,31 @@ struct RollLane {
   }
 };
 
+// sum / n without the ~12-instruction IEEE division: q0 = sum * RN(1 / n), one Newton step on the exact remainder
+// (Markstein).  Whether that is the correctly rounded quotient for EVERY window sum 0 .. 255 n of this call is checked
+// exhaustively on the device first (rolling_check_kernel: at most 255 n + 1 values); the kernels take the division
+// path if a single one differs.
+__device__ __forceinline__ double div_small(double a, double n, double y) {
+  const double q0 = a * y;
+  const double r = fma(-n, q0, a);
+  return fma(r, y, q0);
+}
+__global__ void rolling_check_kernel(int samples, int* __restrict__ mismatch) {
+  const double n = (double)samples, y = 1.0 / n;
+  const int count = 255 * samples + 1;
+  int bad = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    const double a = (double)i;
+    bad |= (div_small(a, n, y) != a / n) ? 1 : 0;
+  }
+  if (bad) atomicOr(mismatch, 1);
+}
+
 template <bool STRETCH>
 __global__ __launch_bounds__(256) void rolling_kernel(const uint8_t* __restrict__ f, int64_t frame_elems, int n_frames, int samples,
                                                       int seg_len, double* __restrict__ part, int n_ws,
-                                                      const double* __restrict__ frame_max, uint8_t* __restrict__ out) {
+                                                      const double* __restrict__ frame_max, const int* __restrict__ mismatch,
+                                                      uint8_t* __restrict__ out) {
   RollLane L;
   L.init(frame_elems);
   const int first = samples - 1;                                   // first frame with a complete window
@@ -347,12 +368,14 @@ __global__ __launch_bounds__(256) void rolling_kernel(const uint8_t* __restrict_
   }
   if (t0 >= t1) return;
   for (int t = t0 - first; t < t0; ++t) L.add(f + (int64_t)t * frame_elems, 1);   // the window of frame t0 minus frame t0
-  const double n = (double)samples;
+  const double n = (double)samples, y = 1.0 / n;
+  const bool fast = *mismatch == 0;                                 // uniform
   for (int t = t0; t < t1; ++t) {
     const uint8_t* img = f + (int64_t)t * frame_elems;
     L.add(img, 1);
     double hi = 0.0;
     const double fm = STRETCH ? frame_max[t] : 1.0;
+    const double inv_fm = 1.0 / fm;                                 // one division per frame, not per pixel (inf for fm = 0)
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       if (L.nv[k]) {
@@ -361,11 +384,18 @@ __global__ __launch_bounds__(256) void rolling_kernel(const uint8_t* __restrict_
 #pragma unroll
         for (int e = 0; e < 16; ++e) {   // pixels past a tail chunk read as 0 with sum 0: thres 0, never the maximum, not stored
           const double x = (double)((w[e >> 2] >> (8 * (e & 3))) & 0xffu);
-          const double d = x - (double)L.sum[k][e] / n;
+          const double sm = (double)L.sum[k][e];
+          const double d = x - (fast ? div_small(sm, n, y) : sm / n);
           const double th = d > 0.0 ? d : 0.0;                      // np.maximum(d, 0)
           if (STRETCH) {
-            const double q = th * 255.0 / fm;                       // NaN (0 / 0) -> 0
-            const uint32_t b = (q != q || L.sum[k][e] == 0) ? 0u : (uint32_t)(int)q;
+            // (th * 255 / fm).astype(uint8): only the integer part matters.  num * RN(1 / fm) is within 1e-13 of the
+            // divided value, so its integer part is the same unless it lies within 1e-9 of an integer -- then divide.
+            const double num = th * 255.0;
+            const double qf = num * inv_fm;
+            int iq = (int)qf;
+            const double fr = qf - (double)iq;
+            if (fr < 1e-9 || fr > 1.0 - 1e-9) iq = (int)(num / fm);
+            const uint32_t b = (fm == 0.0 || L.sum[k][e] == 0) ? 0u : (uint32_t)iq;   // 0 / 0 -> NaN -> 0; where(roll != 0, 0)
             o[e >> 2] |= (b & 0xffu) << (8 * (e & 3));
           } else {
             hi = th > hi ? th : hi;
@@ -397,7 +427,7 @@ __global__ __launch_bounds__(256) void rolling_fold_kernel(const double* __restr
 
 size_t reduce_rolling_scratch_bytes(int64_t frame_elems, int n_frames) {
   const int64_t n_slices = (frame_elems + NORM_SLICE - 1) / NORM_SLICE;
-  return ((size_t)n_frames * (size_t)(4 * n_slices) + (size_t)n_frames) * sizeof(double);
+  return ((size_t)n_frames * (size_t)(4 * n_slices) + (size_t)n_frames + 1) * sizeof(double);   // partial maxima, frame maxima, flag
 }
 
 // any frame size; scratch: reduce_rolling_scratch_bytes()
@@ -410,14 +440,16 @@ hipError_t launch_reduce_rolling(const uint8_t* frames, int64_t frame_elems, int
   n_seg = (n_frames + seg_len - 1) / seg_len;
   double* part = scratch;
   double* fm = scratch + (size_t)n_frames * n_ws;
-  hipError_t e = hipMemsetAsync(fm, 0, (size_t)n_frames * sizeof(double), s);
+  int* flag = reinterpret_cast<int*>(fm + n_frames);
+  hipError_t e = hipMemsetAsync(fm, 0, (size_t)(n_frames + 1) * sizeof(double), s);   // frame maxima and the flag
   if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(rolling_check_kernel, dim3(std::min(64, (255 * samples + 256) / 256)), dim3(256), 0, s, samples, flag);
   hipLaunchKernelGGL(rolling_kernel<false>, dim3(n_slices, n_seg), dim3(256), 0, s, frames, frame_elems, n_frames, samples, seg_len, part, n_ws,
-                     (const double*)nullptr, (uint8_t*)nullptr);
+                     (const double*)nullptr, (const int*)flag, (uint8_t*)nullptr);
   if (n_frames >= samples)
     hipLaunchKernelGGL(rolling_fold_kernel, dim3(n_frames - (samples - 1)), dim3(256), 0, s, part + (size_t)(samples - 1) * n_ws, n_ws, fm + (samples - 1));
   hipLaunchKernelGGL(rolling_kernel<true>, dim3(n_slices, n_seg), dim3(256), 0, s, frames, frame_elems, n_frames, samples, seg_len, part, n_ws,
-                     (const double*)fm, out);
+                     (const double*)fm, (const int*)flag, out);
   return hipGetLastError();
 }
 
