@@ -98,8 +98,8 @@ def get_piv(frames, window_size=None, overlap=None, engine: str = "hip", ensembl
 
 
 def encode_int16(a: np.ndarray, scale: float = 0.01, fill: int = -9999) -> np.ndarray:
-    """netCDF packing of the result variables (pyorc/const.py:80): int16, scale 0.01, fill -9999."""
-    a = np.asarray(a, dtype=np.float32)
-    q = a / np.float32(scale)  # float32 arithmetic, like xarray's CF scale/offset encoder on float32 variables
-    q = np.where(np.isnan(q), np.float32(fill), np.around(q))
-    return np.clip(q, -32768, 32767).astype(np.int16)
+    """netCDF packing of the result variables (pyorc/const.py:80): int16, scale 0.01, fill -9999 -- on the GPU
+    (``lspiv_pack_int16``; no host implementation: without a device this raises like every other entry point)."""
+    from .project import pack_int16
+
+    return pack_int16(a, scale, fill)
