@@ -211,17 +211,15 @@ __global__ __launch_bounds__(256) void norm_minmax_space_kernel(const uint8_t* _
   L.init(mean, frame_elems);
   const int t0 = blockIdx.y * seg_len, t1 = min(t0 + seg_len, n_frames);
   const int ws = blockIdx.x * 4 + (threadIdx.x >> 6);
-#pragma unroll 4
-  for (int t = t0; t < t1; ++t) {   // frames are independent: four of them in flight per lane
-    const uint8_t* img = f + (int64_t)t * frame_elems;
+  // one frame: this lane's 32 differences -> wave minimum / maximum -> one pair per wave
+  auto reduce_frame = [&](int t, const u32x4n (&w)[2]) {
     float lo = 3.0e38f, hi = -3.0e38f;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       if (L.v[k]) {
-        const u32x4n w = *reinterpret_cast<const u32x4n*>(img + L.c[k]);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const float d = (float)((w[e >> 2] >> (8 * (e & 3))) & 0xffu) - L.m[k][e];
+          const float d = (float)((w[k][e >> 2] >> (8 * (e & 3))) & 0xffu) - L.m[k][e];
           lo = fminf(lo, d);
           hi = fmaxf(hi, d);
         }
@@ -233,6 +231,26 @@ __global__ __launch_bounds__(256) void norm_minmax_space_kernel(const uint8_t* _
       part[((int64_t)t * n_ws + ws) * 2] = lo;
       part[((int64_t)t * n_ws + ws) * 2 + 1] = hi;
     }
+  };
+  auto load_frame = [&](int t, u32x4n (&w)[2]) {
+    const uint8_t* img = f + (int64_t)t * frame_elems;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) w[k] = L.v[k] ? *reinterpret_cast<const u32x4n*>(img + L.c[k]) : u32x4n{0u, 0u, 0u, 0u};
+  };
+  // frames are independent: the loads of four of them are issued before the first reduction (the wave reductions are
+  // convergent operations, which keeps the compiler from unrolling this loop on its own)
+  int t = t0;
+  for (; t + 4 <= t1; t += 4) {
+    u32x4n w[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) load_frame(t + j, w[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) reduce_frame(t + j, w[j]);
+  }
+  for (; t < t1; ++t) {
+    u32x4n w[2];
+    load_frame(t, w);
+    reduce_frame(t, w);
   }
 }
 
