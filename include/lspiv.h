@@ -272,6 +272,9 @@ int lspiv_synth_particles_dev(void* d_frames, int64_t T, int64_t H, int64_t W, u
  * conventions (forward exp(-2 pi i jk/n), inverse exp(+...), both unnormalised); in / out: host arrays of count*n
  * interleaved (re, im) float pairs; n = 8, 16, 32, 64 or any even length 6..62 (the sizes lspiv_kernel_kind maps to 6 / 8). */
 int lspiv_debug_fft(int n, int inverse, const float* in, float* out, int64_t count);
+/* Test hook (host only): the segment length, in frame pairs, that the time-walking kernels use for a chunk of n_pairs
+ * pairs with n_win windows when `slots` lane groups run concurrently (rounds x iterations minimised). */
+int lspiv_debug_segment_length(int64_t n_win, int64_t n_pairs, int64_t slots);
 
 #ifdef __cplusplus
 }

@@ -111,6 +111,7 @@ SIGNATURES = {
     "lspiv_event_destroy": (_i32, [_vp]),
     "lspiv_synth_particles_dev": (_i32, [_vp, _i64, _i64, _i64, C.c_uint64, _f32]),
     "lspiv_debug_fft": (_i32, [_i32, _i32, _vp, _vp, _i64]),
+    "lspiv_debug_segment_length": (_i32, [_i64, _i64, _i64]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -225,6 +225,27 @@ hipError_t launch_peaks_from_planes(const float* planes, uint32_t n_planes, int 
 // LSPIV_WALK as an integer (0 per-pair kernels, 1 default walking kernels, n > 1 forced segment length): the value set
 // through lspiv_set_option("walk", v) if any, else the environment variable read at every launch, else 1
 int walk_setting();
+// Segment length (in frame pairs) of the time-walking kernels for a chunk.  The n_win * n_seg jobs run in rounds of
+// `slots` concurrent lane groups and a job of L pairs lasts L / 2 + 1 iterations (its first iteration yields one plane
+// only), so the launch takes ~ rounds * iterations: the old rule (shrink from 63 until there are >= 32 768 jobs) left
+// e.g. a 200-pair 1080p chunk at 7 rounds of 25 iterations where 9 rounds of 15 do the same work -- 23 % less time.
+// Candidates: odd lengths 3 .. 63 (an odd number of pairs = whole iterations) and the whole chunk as one segment.
+inline uint32_t walk_segment_length(uint32_t n_win, uint32_t n_pairs, uint32_t slots) {
+  uint32_t best_len = std::min<uint32_t>(63, n_pairs);
+  uint64_t best_cost = ~0ull;
+  auto consider = [&](uint32_t len) {
+    if (len < 1 || len > n_pairs) return;
+    const uint64_t n_seg = (n_pairs + len - 1) / len;
+    const uint64_t rounds = (n_seg * n_win + slots - 1) / slots;
+    const uint64_t cost = rounds * (len / 2 + 1) * 4096 + n_seg;   // ties: fewer segments (less first-iteration overhead)
+    if (cost < best_cost || (cost == best_cost && len > best_len)) { best_cost = cost; best_len = len; }
+  };
+  for (uint32_t len = 3; len <= 63; len += 2) consider(len);
+  if (n_pairs <= 64) consider(n_pairs);
+  return best_len;
+}
+// concurrent lane groups of a kernel that runs `waves_per_simd` waves with `groups` jobs per wave (CU count queried once)
+uint32_t job_slots(int waves_per_simd, int groups);
 // segments of the walking ENSEMBLE kernels: enough jobs for ~3 rounds of the chip, segments of an odd number of pairs
 inline void ensemble_segments(uint32_t n_win, uint32_t n_pairs, int window, uint32_t* seg_len, uint32_t* n_seg) {
   // quarter- / half-wave jobs at 4 / 3 waves/SIMD (32 x 32 with its partial sum in registers: 2); wave jobs at 2

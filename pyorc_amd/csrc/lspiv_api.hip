@@ -281,6 +281,16 @@ struct lspiv_ensemble {
 };
 
 static std::atomic<int> g_opt_walk{-1};   // lspiv_set_option("walk", v); -1: not set, fall back to the environment
+uint32_t lspiv::job_slots(int waves_per_simd, int groups) {
+  static const int cus = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) return 256;
+    return prop.multiProcessorCount;
+  }();
+  return (uint32_t)(cus * 4 * waves_per_simd * groups);
+}
+
 int lspiv::walk_setting() {
   const int v = g_opt_walk.load();
   if (v >= 0) return v;
@@ -1348,6 +1358,11 @@ int lspiv_synth_particles_dev(void* d_frames, int64_t T, int64_t H, int64_t W, u
   if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? LSPIV_ENOMEM : LSPIV_EHIP, "synth failed: %s", hipGetErrorString(e));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return LSPIV_OK;
+}
+
+int lspiv_debug_segment_length(int64_t n_win, int64_t n_pairs, int64_t slots) {
+  if (n_win < 1 || n_pairs < 1 || slots < 1 || n_win > 0x7fffffff || n_pairs > 0x7fffffff || slots > 0x7fffffff) return LSPIV_EINVAL;
+  return (int)lspiv::walk_segment_length((uint32_t)n_win, (uint32_t)n_pairs, (uint32_t)slots);
 }
 
 int lspiv_debug_fft(int n, int inverse, const float* in, float* out, int64_t count) {

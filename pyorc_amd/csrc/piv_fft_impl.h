@@ -1445,15 +1445,11 @@ static hipError_t launch_t(const PivParams& p, bool ensemble, hipStream_t s) {
     hipLaunchKernelGGL((piv_fft_ensemble_kernel<T, N, WANT_NZ>), dim3(blocks), dim3(BLOCK), G::LDS_BYTES, s, p);
     return hipGetLastError();
   }
-  // LSPIV_WALK: 0 = per-pair kernel; unset / 1 = time-walking kernel for 32 x 32 windows with segments sized to keep
-  // >= ~4 jobs per half-wave slot of the chip; n > 1 = segments of n pairs (odd values waste no half iteration)
+  // LSPIV_WALK: 0 = per-pair kernel; unset / 1 = time-walking kernel with the segment length that minimises rounds x
+  // iterations for this chunk (walk_segment_length); n > 1 = segments of n pairs (odd values waste no half iteration)
   const int walk = walk_setting();   // option or environment, read per launch
   if (walk != 0 && p.n_pairs >= 3) {
-    uint32_t seg_len = walk > 1 ? (uint32_t)walk : 63;
-    if (walk == 1) {
-      const uint64_t want_jobs = 4ull * 8192ull;
-      while (seg_len > 3 && (uint64_t)p.n_win * ((p.n_pairs + seg_len - 1) / seg_len) < want_jobs) seg_len -= 2;
-    }
+    uint32_t seg_len = walk > 1 ? (uint32_t)walk : walk_segment_length(p.n_win, p.n_pairs, job_slots(kWalkWaves<T, N>, G::GROUPS));
     seg_len = std::min(seg_len, p.n_pairs);
     const uint32_t n_seg = (p.n_pairs + seg_len - 1) / seg_len;
     const uint64_t wjobs = (uint64_t)n_seg * p.n_win;

@@ -258,3 +258,17 @@ def test_prime_factor_size_lists_agree(lib):
     assert on_disk == sorted(sizes_h + [8, 16, 32, 64])
     assert sizes_h == [n for n in range(2, 65) if lib.lspiv_kernel_kind(n, n) == 8]
     assert all(n % 2 == 0 and n & (n - 1) for n in sizes_h)        # even, not a power of two
+
+
+def test_walking_segment_length_minimises_rounds_times_iterations(lib):
+    """Host heuristic of the time-walking kernels (common.h::walk_segment_length): jobs = n_win * n_seg run in rounds of
+    `slots`, a job of L pairs lasts L // 2 + 1 iterations; odd lengths 3..63 or the whole chunk."""
+    f = lib.lspiv_debug_segment_length
+    cost = lambda n_win, P, slots, L: -(-(n_win * -(-P // L)) // slots) * (L // 2 + 1)
+    for n_win, P, slots in ((7854, 1000, 6144), (7854, 200, 6144), (7854, 50, 6144), (2544, 20, 6144), (14151, 500, 6144),
+                            (7488, 1000, 2048), (31806, 100, 6144), (10476, 3, 16384), (12, 1000, 6144), (7854, 64, 6144)):
+        L = f(n_win, P, slots)
+        cands = [c for c in range(3, 64, 2) if c <= P] + ([P] if P <= 64 else [])
+        assert L in cands and cost(n_win, P, slots, L) == min(cost(n_win, P, slots, c) for c in cands), (n_win, P, slots, L)
+    assert f(7854, 200, 6144) == 29 and cost(7854, 200, 6144, 29) == 135 and cost(7854, 200, 6144, 49) == 175   # the old choice: 49
+    assert f(0, 5, 5) == _lib.LSPIV_EINVAL
