@@ -112,7 +112,9 @@ def test_flow_is_recovered_on_particle_images():
     assert np.nanmedian(cm) > 0.4 and np.nanmedian(sn) > 3
 
 
-@pytest.mark.parametrize("ws,ov", [((32, 32), (16, 16)), ((10, 10), (5, 5)), ((24, 16), (12, 8)), ((64, 64), (48, 48))])
+@pytest.mark.parametrize("ws,ov", [((32, 32), (16, 16)), ((10, 10), (5, 5)), ((24, 16), (12, 8)), ((64, 64), (48, 48)),
+                                   ((24, 24), (12, 12)), ((20, 20), (10, 10)), ((6, 6), (3, 3)), ((48, 48), (24, 24)),
+                                   ((62, 62), (31, 31)), ((25, 25), (12, 12))])
 @pytest.mark.parametrize("dtype", [np.uint8, np.float32, np.float64])
 def test_c_port_matches_numpy_oracle(ws, ov, dtype):
     fr = particle_stack(3, 160, 192, seed=5, dtype=np.uint8)
