@@ -6,11 +6,18 @@
 A "step" is one pass of the hot path (lspiv_piv_pairs_dev: window gather + normalise + FFT
 cross-correlation + corr_max / s2n + sub-pixel peak, fused) over ONE batch of 1000 frame pairs
 per GPU that is already resident in HBM (BASELINE.json configs[1]).  With N > 1 every rank owns
-its own 1000-pair time block (weak scaling, BASELINE.json configs[4]); the only exchange is the
-RCCL all-gather of the packed (4, t, y, x) result block, software-pipelined one step behind the kernel.
+its own 1000-pair time block (BASELINE.json configs[4]: 8 x 1000 pairs on 8 GPUs; per-GPU work is fixed, so the
+line says "weak", and north_star's ">= 6.5x at 8 GPUs" is value(N=8) / value(N=1) of this very command); the only
+exchange is the RCCL all-gather of the packed (4, t, y, x) result block, software-pipelined one step behind the kernel.
 
-Prints ONE JSON line on rank 0 (see the task contract).  No PyTorch is needed for N = 1; for
-N > 1 torch.distributed is plumbing for the rendezvous, the barrier and the all-gather only.
+No PyTorch anywhere: kernels, streams, events and the RCCL exchange all go through the C ABI (include/lspiv.h).
+`python bench.py --gpus N` launches its N ranks itself; under `python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N` (RANK / LOCAL_RANK / WORLD_SIZE in the environment) it runs as one of them.  Either way rank 0
+prints ONE JSON line (see the task contract).
+
+At N = 1 the line also carries, measured after the timed region: the roofline of the dominant kernel, the CPU baseline
+(C oracle on a bounded sample, with the live parity check incl. the ill-posed windows), the other two single-GPU
+BASELINE configs (`config.other_configs`: C3 64x64 @ 75 %, C4 4K) and the host-fed (PCIe-inclusive) rates.
 """
 
 from __future__ import annotations
@@ -19,7 +26,9 @@ import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -29,7 +38,8 @@ sys.path.insert(0, ROOT)
 
 from pyorc_amd import _lib, window  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_VALU_TFLOPS = 157.3
 
 
 def parse():
@@ -43,8 +53,21 @@ def parse():
     ap.add_argument("--window", type=int, default=32)
     ap.add_argument("--overlap", type=int, default=16)
     ap.add_argument("--cpu-pairs", type=int, default=-1, help="pairs of the CPU-baseline sample (-1: auto, 0: skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other-configs and host-fed legs (N = 1)")
     ap.add_argument("--seed", type=int, default=20260927 + 2)
     return ap.parse_args()
+
+
+def flop_per_pair(ws: int, n_win: int) -> float:
+    """per window 3 real 2-D FFTs at 2.5 N log2 N (N = ws^2) + 6 ws (ws/2 + 1) for the cross
+    spectrum + 4 N for the normalisation."""
+    n = ws * ws
+    return n_win * (3 * 2.5 * n * np.log2(n) + 6 * ws * (ws // 2 + 1) + 4 * n)
+
+
+def kernel_name_for(ws: int, pairs: int) -> str:
+    walking = os.environ.get("LSPIV_WALK", "1") != "0" and ws % 2 == 0 and 6 <= ws <= 64
+    return f"piv_fft_{'walk_' if walking else ''}kernel<unsigned char, {ws}, false, false>"
 
 
 def measured_traffic(kernel_substr: str, pairs: int, H: int, W: int, window_size: int, overlap: int):
@@ -70,45 +93,147 @@ def measured_traffic(kernel_substr: str, pairs: int, H: int, W: int, window_size
     return best
 
 
-def cpu_baseline(frames_sample: np.ndarray, ws, ov, gpu_block):
-    """Time the CPU oracle on a bounded sample of the same stack; also a live parity check."""
-    from oracle import cpu_baseline as cb  # test infrastructure: baseline leg only
+def roofline_block(lib, kernel_ms: float, pairs: int, H: int, W: int, ws: int, ov: int, n_win: int) -> dict:
+    b_alg_pair = 2 * H * W * 1 + 16 * n_win  # SURVEY.md section 8d: both frames read once + 4 f32 per window
+    achieved = b_alg_pair * pairs / (kernel_ms * 1e-3) / 1e9
+    fpp = flop_per_pair(ws, n_win)
+    name = kernel_name_for(ws, pairs)
+    r = {
+        "bound": "hbm",
+        "kernel": name,
+        "achieved": round(achieved, 2),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5),
+        "traffic": None,
+        "algorithmic_bytes_per_launch": b_alg_pair * pairs,
+        "algorithmic_bytes_per_pair": b_alg_pair,
+        "kernel_ms_per_launch": round(kernel_ms, 4),
+        "note": "FFT path is FP32-VALU/LDS bound, not HBM bound (DESIGN.md section 4); secondary bound below",
+        "secondary": {"bound": "fp32-valu", "flop_per_pair": round(fpp),
+                      "achieved_tflops": round(fpp * pairs / (kernel_ms * 1e-3) / 1e12, 2), "peak_tflops": FP32_VALU_TFLOPS,
+                      "frac": round(fpp * pairs / (kernel_ms * 1e-3) / 1e12 / FP32_VALU_TFLOPS, 4)},
+    }
+    tr = measured_traffic(name.split(",")[0] + "," + name.split(",")[1] + ",", pairs, H, W, ws, ov)
+    if tr:
+        r["traffic"] = tr["bytes"]
+        r["traffic_source"] = f"profiles/{tr['source']} (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"
+    return r
 
-    return cb.run(frames_sample, ws, ov, gpu_block)
+
+def time_launches(lib, launch, reps: int) -> float:
+    """Average launch duration in ms, HIP events on the library's launch stream."""
+    ev0, ev1 = C.c_void_p(), C.c_void_p()
+    _lib.check(lib.lspiv_event_create(C.byref(ev0)))
+    _lib.check(lib.lspiv_event_create(C.byref(ev1)))
+    _lib.check(lib.lspiv_synchronize())
+    _lib.check(lib.lspiv_event_record(ev0))
+    for _ in range(reps):
+        launch()
+    _lib.check(lib.lspiv_event_record(ev1))
+    ms = C.c_float()
+    _lib.check(lib.lspiv_event_elapsed_ms(ev0, ev1, C.byref(ms)))
+    _lib.check(lib.lspiv_event_destroy(ev0))
+    _lib.check(lib.lspiv_event_destroy(ev1))
+    return ms.value / reps
+
+
+def other_config(lib, name: str, d_frames, pairs: int, H: int, W: int, ws: int, ov: int, reps: int = 3) -> dict:
+    """One more BASELINE.json single-GPU configuration on an HBM-resident stack: kernel time by HIP events."""
+    n_rows, n_cols = window.get_array_shape((H, W), (ws, ws), (ov, ov))
+    n_win = n_rows * n_cols
+    d_out = C.c_void_p()
+    _lib.check(lib.lspiv_dev_malloc(C.byref(d_out), 4 * pairs * n_win * 4))
+
+    def go():
+        _lib.check(lib.lspiv_piv_pairs_dev(d_frames, 0, pairs + 1, H, W, ws, ws, ov, ov, -1.0, d_out, None, None))
+
+    go()
+    _lib.check(lib.lspiv_synchronize())
+    ms = time_launches(lib, go, reps)
+    _lib.check(lib.lspiv_dev_free(d_out))
+    return {
+        "workload": name,
+        "pairs_per_s": round(pairs / (ms * 1e-3), 1),
+        "mvectors_per_s": round(pairs * n_win / (ms * 1e-3) / 1e6, 2),
+        "windows_per_pair": n_win,
+        "kernel": kernel_name_for(ws, pairs),
+        "kernel_ms": round(ms, 4),
+        "roofline": {k: v for k, v in roofline_block(lib, ms, pairs, H, W, ws, ov, n_win).items()
+                     if k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "secondary",
+                              "algorithmic_bytes_per_pair")},
+    }
+
+
+def host_fed_rates(lib, sample_u8: np.ndarray, ws, ov) -> dict:
+    """PCIe-inclusive rates of lspiv_piv_pairs (frames in pageable host memory -> results in host memory) for the three
+    frame dtypes pyorc hands over; never `value`."""
+    from pyorc_amd import piv
+
+    out = {}
+    for key, arr in (("u8", sample_u8), ("f32", sample_u8.astype(np.float32)), ("f64", sample_u8.astype(np.float64))):
+        piv.piv_pairs(arr[:3], ws, ov)  # workspaces
+        t0 = time.perf_counter()
+        piv.piv_pairs(arr, ws, ov)
+        out[key] = round((arr.shape[0] - 1) / (time.perf_counter() - t0), 1)
+    return out
+
+
+def spawn_ranks(a) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) and wait for them."""
+    tmp = tempfile.mkdtemp(prefix="lspiv_bench_")
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
+                   LSPIV_COMM_ID_FILE=os.path.join(tmp, "comm_id"))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        deadline = time.time() + float(os.environ.get("LSPIV_BENCH_TIMEOUT_S", "1800"))
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is not None:
+                    pending.remove(p)
+                    rc = rc or code
+            if rc or time.time() > deadline:
+                rc = rc or 124
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:   # exact PIDs of the ranks started above
+            if p.poll() is None:
+                p.kill()
+        for f in os.listdir(tmp):
+            os.unlink(os.path.join(tmp, f))
+        os.rmdir(tmp)
+    return rc
 
 
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(spawn_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {a.gpus} != WORLD_SIZE {world}")
-
-    if os.environ.get("LSPIV_BENCH_SAME_DEVICE"):  # plumbing test of the N>1 path on a 1-GPU box (not a measurement)
+    same_device = bool(os.environ.get("LSPIV_BENCH_SAME_DEVICE"))  # plumbing test of N > 1 on a 1-GPU box (not a measurement)
+    if same_device:
         local_rank = 0
-    dist = torch = None
-    use_dist = world > 1 or bool(os.environ.get("LSPIV_BENCH_FORCE_DIST"))  # FORCE_DIST: 1-rank plumbing test
-    if use_dist:
-        # torch FIRST: its wheel bundles its own libamdhip64 (SONAME libamdhip64.so.7).  Loaded first, the dynamic
-        # loader hands the same copy to liblspiv_hip.so; loaded second, the process would hold two HIP runtimes and
-        # the second one finds no GPU.
-        import torch
-        import torch.distributed as dist
-
-        torch.cuda.set_device(local_rank)
-        if "MASTER_ADDR" not in os.environ:
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-        _warm = torch.zeros(1, device="cuda")
-        dist.all_reduce(_warm)  # build the RCCL communicator now, whatever --warmup says
-        torch.cuda.synchronize()
+        os.environ.setdefault("LSPIV_COMM", "shm")   # RCCL refuses two ranks on one GPU
     lib = _lib.load()
     _lib.require_device()
     _lib.check(lib.lspiv_set_device(local_rank))
+    comm = None
+    use_comm = world > 1 or bool(os.environ.get("LSPIV_BENCH_FORCE_COMM"))  # FORCE_COMM: 1-rank RCCL plumbing test
+    if use_comm:
+        from pyorc_amd.comm import Comm
+
+        comm = Comm(rank, world)
 
     H, W, T = a.height, a.width, a.pairs + 1
     ws, ov = (a.window, a.window), (a.overlap, a.overlap)
@@ -116,72 +241,64 @@ def main():
     n_win = n_rows * n_cols
     n_tiles = a.pairs * n_win
 
-    # ---- device-resident synthetic stack + result block -------------------------------------
-    d_frames, d_out = C.c_void_p(), C.c_void_p()
-    if use_dist:
-        t_frames = torch.empty(T * H * W, dtype=torch.uint8, device="cuda")
-        t_out = torch.empty(4 * n_tiles, dtype=torch.float32, device="cuda")
-        t_all = torch.empty(world * 4 * n_tiles, dtype=torch.float32, device="cuda")
-        d_frames, d_out = C.c_void_p(t_frames.data_ptr()), C.c_void_p(t_out.data_ptr())
-    else:
-        _lib.check(lib.lspiv_dev_malloc(C.byref(d_frames), T * H * W))
-        _lib.check(lib.lspiv_dev_malloc(C.byref(d_out), 4 * n_tiles * 4))
+    # ---- device-resident synthetic stack + result block(s) ----------------------------------
+    def dev_alloc(nbytes):
+        p = C.c_void_p()
+        _lib.check(lib.lspiv_dev_malloc(C.byref(p), nbytes))
+        return p
+
+    d_frames = dev_alloc(T * H * W)
+    outs = [dev_alloc(4 * n_tiles * 4) for _ in range(2 if use_comm else 1)]
+    alls = [dev_alloc(world * 4 * n_tiles * 4) for _ in range(2)] if use_comm else []
+    d_out = outs[0]
     _lib.check(lib.lspiv_synth_particles_dev(d_frames, T, H, W, a.seed + rank, 0.02))
     _lib.check(lib.lspiv_synchronize())  # the generator ran on the library's stream; the steps may use another one
 
-    def launch_all():
-        _lib.check(lib.lspiv_piv_pairs_dev(d_frames, 0, T, H, W, ws[0], ws[1], ov[0], ov[1], -1.0, d_out, None, None))
+    def launch_all(out=None, stream=None):
+        _lib.check(lib.lspiv_piv_pairs_dev(d_frames, 0, T, H, W, ws[0], ws[1], ov[0], ov[1], -1.0, out or d_out, None, stream))
 
-    if not use_dist:
+    state = {"k": 0}
+    if not use_comm:
         step = launch_all
 
         def drain():
             pass
-
-        def sync():
-            _lib.check(lib.lspiv_synchronize())
-
-        def barrier():
-            pass
     else:
-        # Software pipeline over steps: step k's kernel (all 1000 pairs, one launch) runs while step k-1's result
-        # block is all-gathered over RCCL on a second stream.  Two result buffers; before a buffer is overwritten
-        # (two steps later) the compute stream waits for its gather.  Every gather issued inside the timed region
-        # completes inside it (drain() before the closing synchronize), so K steps = K kernels + K all-gathers.
-        comp = torch.cuda.Stream()   # non-default: its handle goes through the C ABI
-        comm = torch.cuda.Stream()
-        assert comp.cuda_stream != 0
-        outs = [t_out, torch.empty_like(t_out)]
-        alls = [t_all, torch.empty_like(t_all)]
-        pending = [None, None]
-        state = {"k": 0}
+        # Software pipeline over steps: step k's kernel (all 1000 pairs, one launch) runs on `comp` while step k-1's
+        # result block is all-gathered over RCCL on `comm_s`.  Two result buffers; before a buffer is overwritten (two
+        # steps later) the compute stream waits for its gather.  Every gather issued inside the timed region completes
+        # inside it (drain() before the closing synchronize), so K steps = K kernels + K all-gathers.
+        comp, comm_s = C.c_void_p(), C.c_void_p()
+        _lib.check(lib.lspiv_stream_create(C.byref(comp)))
+        _lib.check(lib.lspiv_stream_create(C.byref(comm_s)))
+        ev_done = [C.c_void_p(), C.c_void_p()]      # kernel of buffer b finished
+        ev_gathered = [C.c_void_p(), C.c_void_p()]  # gather of buffer b finished
+        for e in ev_done + ev_gathered:
+            _lib.check(lib.lspiv_event_create(C.byref(e)))
+        gathered_once = [False, False]
 
         def step():
             b = state["k"] & 1
-            with torch.cuda.stream(comp):
-                if pending[b] is not None:
-                    pending[b].wait()            # stream-level: comp waits until gather k-2 has read outs[b]
-                _lib.check(lib.lspiv_piv_pairs_dev(d_frames, 0, T, H, W, ws[0], ws[1], ov[0], ov[1], -1.0,
-                                                   C.c_void_p(outs[b].data_ptr()), None, C.c_void_p(comp.cuda_stream)))
-                ev = torch.cuda.Event()
-                ev.record(comp)
-            with torch.cuda.stream(comm):
-                comm.wait_event(ev)
-                pending[b] = dist.all_gather_into_tensor(alls[b], outs[b], async_op=True)
+            if gathered_once[b]:
+                _lib.check(lib.lspiv_stream_wait_event(comp, ev_gathered[b]))   # gather k-2 has read outs[b]
+            launch_all(outs[b], comp)
+            _lib.check(lib.lspiv_event_record_on(ev_done[b], comp))
+            _lib.check(lib.lspiv_stream_wait_event(comm_s, ev_done[b]))
+            comm.allgather_dev(outs[b].value, alls[b].value, 4 * n_tiles, np.float32, comm_s.value)
+            _lib.check(lib.lspiv_event_record_on(ev_gathered[b], comm_s))
+            gathered_once[b] = True
             state["k"] += 1
 
         def drain():
-            for w in pending:
-                if w is not None:
-                    w.wait()
-            torch.cuda.current_stream().wait_stream(comp)
-            torch.cuda.current_stream().wait_stream(comm)
+            _lib.check(lib.lspiv_stream_synchronize(comp))
+            _lib.check(lib.lspiv_stream_synchronize(comm_s))
 
-        def sync():
-            torch.cuda.synchronize()
+    def sync():
+        _lib.check(lib.lspiv_synchronize())
 
-        def barrier():
-            dist.barrier()
+    def barrier():
+        if comm is not None:
+            comm.barrier()
 
     for _ in range(a.warmup):
         step()
@@ -191,53 +308,36 @@ def main():
         step()
     drain(); sync(); barrier(); sync()
     dt = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    gathered = alls[(state["k"] - 1) & 1].clone() if use_dist else None
+    if comm is not None:
+        dt = float(comm.allreduce(np.array([dt], dtype=np.float64), 1)[0])   # MAX over ranks
 
     # ---- live kernel timing with HIP events on the launch stream (roofline leg, N-independent) --
-    ev0, ev1 = C.c_void_p(), C.c_void_p()
-    _lib.check(lib.lspiv_event_create(C.byref(ev0)))
-    _lib.check(lib.lspiv_event_create(C.byref(ev1)))
     reps = max(3, min(a.steps, 10))
-    _lib.check(lib.lspiv_synchronize())
-    _lib.check(lib.lspiv_event_record(ev0))
-    for _ in range(reps):
-        launch_all()
-    _lib.check(lib.lspiv_event_record(ev1))
-    ms = C.c_float()
-    _lib.check(lib.lspiv_event_elapsed_ms(ev0, ev1, C.byref(ms)))
-    kernel_ms = ms.value / reps
+    kernel_ms = time_launches(lib, launch_all, reps)
 
     dist_check = None
-    if use_dist:
+    if comm is not None and state["k"] > 0:
         # this rank's slice of the all-gathered block must equal its own single-launch result bit for bit;
-        # cheap, outside the timed region
-        torch.cuda.synchronize()
-        whole = t_out.view(-1)                          # launch_all (kernel-timing loop) wrote the same stack here
-        mine = gathered.view(world, -1)[rank]
-        same = (mine == whole) | (mine.isnan() & whole.isnan())
-        dist_check = bool(same.all().item())
+        # cheap, outside the timed region (launch_all in the kernel-timing loop wrote the same stack into d_out)
+        sync()
+        last = alls[(state["k"] - 1) & 1]
+        mine = np.empty(4 * n_tiles, dtype=np.uint32)
+        whole = np.empty(4 * n_tiles, dtype=np.uint32)
+        _lib.check(lib.lspiv_memcpy_d2h(_lib.ptr(mine), C.c_void_p(last.value + rank * 4 * n_tiles * 4), mine.nbytes))
+        _lib.check(lib.lspiv_memcpy_d2h(_lib.ptr(whole), d_out, whole.nbytes))
+        ok = np.array([1.0 if np.array_equal(mine, whole) else 0.0], dtype=np.float32)
+        dist_check = bool(comm.allreduce(ok, 0)[0] == world)   # true on every rank
     if rank != 0:
-        if use_dist:
-            dist.barrier()
-            dist.destroy_process_group()
+        if comm is not None:
+            comm.barrier()
+            comm.close()
         return
 
-    b_alg_pair = 2 * H * W * 1 + 16 * n_win  # SURVEY.md section 8d: both frames read once + 4 f32 per window
-    # the kernel the library dispatches this shape to (pyorc_amd/csrc/piv_fft_impl.h, launch_t): time-walking by default
-    # every even window 6..64 has FFT kernels of its own (walking by default); odd ones run embedded / direct kernels
-    walking = os.environ.get("LSPIV_WALK", "1") != "0" and a.window % 2 == 0 and 6 <= a.window <= 64 and a.pairs >= 3
-    kernel_name = f"piv_fft_{'walk_' if walking else ''}kernel<unsigned char, {a.window}, false, false>"
-    achieved = b_alg_pair * a.pairs / (kernel_ms * 1e-3) / 1e9
     pairs_per_s = world * a.pairs * a.steps / dt
+    is_c2 = (a.window, a.overlap, H, W) == (32, 16, 1080, 1920)
     out = {
         # BASELINE.json's metric; a non-default --window / --overlap / --height / --width run says what it measured
-        "metric": ("PIV frame-pairs/sec, 1080p 32x32@50% overlap (Mvectors/sec in config)"
-                   if (a.window, a.overlap, H, W) == (32, 16, 1080, 1920) else
+        "metric": ("PIV frame-pairs/sec, 1080p 32x32@50% overlap (Mvectors/sec in config)" if is_c2 else
                    f"PIV frame-pairs/sec, {H}x{W} frames, {a.window}x{a.window} windows @ overlap {a.overlap} (not the BASELINE.json metric)"),
         "value": round(pairs_per_s, 2),
         "unit": "frame-pairs/s",
@@ -253,54 +353,59 @@ def main():
         "config": {
             "workload": f"synthetic {H}x{W} uint8 particle stack, {a.pairs} frame-pairs per GPU, "
                         f"{a.window}x{a.window} windows @ overlap {a.overlap} ("
-                        + ("BASELINE.json configs[1]" if (a.window, a.overlap, H, W, a.pairs) == (32, 16, 1080, 1920, 1000)
-                           else "a variation of BASELINE.json configs[1]")
+                        + ("BASELINE.json configs[1]" if is_c2 and a.pairs == 1000 else "a variation of BASELINE.json configs[1]")
                         + ("; configs[4] sharding" if world > 1 else "") + ")",
             "frame_dtype": "u8",
             "windows_per_pair": n_win,
             "mvectors_per_s": round(pairs_per_s * n_win / 1e6, 3),
-            "parallelism": f"time-block shard x{world}, RCCL all-gather of (4,t,y,x) result" if use_dist else "single GPU",
-            **({"allgather_matches_single_launch": dist_check} if use_dist else {}),
+            "parallelism": (f"time-block shard x{world}, {comm.transport.upper()} all-gather of the (4,t,y,x) result block "
+                            f"through the C ABI (no torch)") if comm is not None else "single GPU",
+            "scaling_denominator": "per-GPU work fixed at --pairs: speed-up at N GPUs = value(N) / value(1) of this command "
+                                   "(north_star's >= 6.5x at 8 GPUs = 8000 pairs on 8 GPUs vs 1000 pairs on 1)",
         },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": kernel_name,
-            "achieved": round(achieved, 2),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": None,
-            "algorithmic_bytes_per_launch": b_alg_pair * a.pairs,
-            "algorithmic_bytes_per_pair": b_alg_pair,
-            "kernel_ms_per_launch": round(kernel_ms, 4),
-            "note": "FFT path is FP32-VALU/LDS bound, not HBM bound (DESIGN.md section 4); secondary bound below",
-            "secondary": {"bound": "fp32-valu", "flop_per_pair": 0.66e9,
-                          "achieved_tflops": round(0.66e9 * a.pairs / (kernel_ms * 1e-3) / 1e12, 2), "peak_tflops": 157.3},
-        },
+        "roofline": roofline_block(lib, kernel_ms, a.pairs, H, W, a.window, a.overlap, n_win),
     }
-    tr = measured_traffic(kernel_name.split(",")[0] + ",", a.pairs, H, W, a.window, a.overlap)
-    if tr:
-        out["roofline"]["traffic"] = tr["bytes"]
-        out["roofline"]["traffic_source"] = f"profiles/{tr['source']} (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"
+    if comm is not None:
+        out["config"]["comm"] = {"transport": comm.transport, "ranks_reported_by_transport": comm.backend_ranks,
+                                 "allgather_matches_single_launch": dist_check,
+                                 "allgather_bytes_per_rank_per_step": 4 * n_tiles * 4,
+                                 **({"same_device_plumbing_test": True} if same_device else {})}
     # ---- CPU baseline on a bounded sample of the same stack (rank 0, N = 1 only) --------------
     if world == 1 and a.cpu_pairs != 0:
-        n_s = a.cpu_pairs if a.cpu_pairs > 0 else None
-        from oracle import cpu_baseline as cb
+        from oracle import cpu_baseline as cb   # test infrastructure: baseline / parity leg only
 
-        n_s = cb.default_sample_pairs(H, W, ws) if n_s is None else n_s
+        n_s = cb.default_sample_pairs(H, W, ws) if a.cpu_pairs < 0 else a.cpu_pairs
         n_s = min(n_s, a.pairs)
         sample = np.empty((n_s + 1, H, W), dtype=np.uint8)
         _lib.check(lib.lspiv_memcpy_d2h(_lib.ptr(sample), d_frames, sample.nbytes))
         gpu_block = np.empty((4, a.pairs, n_rows, n_cols), dtype=np.float32)
         _lib.check(lib.lspiv_memcpy_d2h(_lib.ptr(gpu_block), d_out, gpu_block.nbytes))
-        base = cpu_baseline(sample, ws, ov, gpu_block[:, :n_s])
+        base = cb.run(sample, ws, ov, gpu_block[:, :n_s])
         out["cpu_baseline"] = base
         if base.get("value"):
             out["config"]["speedup_vs_cpu_baseline"] = round(pairs_per_s / base["value"], 1)
+    # ---- the other single-GPU BASELINE configs + host-fed rates (N = 1, default shape only) ----
+    if world == 1 and is_c2 and not a.no_extras:
+        others = [other_config(lib, "BASELINE.json configs[2]: 1080p, 64x64 windows @ 75 % overlap, same stack",
+                               d_frames, a.pairs, H, W, 64, 48)]
+        sample = np.empty((min(a.pairs, 60) + 1, H, W), dtype=np.uint8)
+        _lib.check(lib.lspiv_memcpy_d2h(_lib.ptr(sample), d_frames, sample.nbytes))
+        _lib.check(lib.lspiv_dev_free(d_frames))
+        d_frames = None
+        H4, W4 = 2160, 3840
+        d4 = dev_alloc((a.pairs + 1) * H4 * W4)
+        _lib.check(lib.lspiv_synth_particles_dev(d4, a.pairs + 1, H4, W4, a.seed + 2, 0.02))
+        others.append(other_config(lib, "BASELINE.json configs[3]: 4K (2160x3840), 32x32 windows @ 50 % overlap",
+                                   d4, a.pairs, H4, W4, 32, 16))
+        _lib.check(lib.lspiv_dev_free(d4))
+        out["config"]["other_configs"] = others
+        out["config"]["host_fed_pairs_per_s"] = {
+            **host_fed_rates(lib, sample, ws, ov),
+            "note": f"lspiv_piv_pairs on {sample.shape[0] - 1} pairs in pageable host memory, PCIe-inclusive; never `value`"}
     print(json.dumps(out), flush=True)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
 
 
 if __name__ == "__main__":

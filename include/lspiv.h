@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define LSPIV_ABI_VERSION 1
+#define LSPIV_ABI_VERSION 2
 
 /* status codes (mapped by the Python shim onto the reference's exception types) */
 #define LSPIV_OK            0
@@ -66,8 +66,10 @@ int         lspiv_set_device(int device);               /* per calling thread   
 int         lspiv_get_device(int* device);
 int         lspiv_device_name(int device, char* buf, size_t len);
 int         lspiv_synchronize(void);                    /* hipDeviceSynchronize             */
-/* run-time options: "walk" = 0 per-pair kernels (results independent of the time chunking, bit for bit), 1 the
- * default time-walking kernels, n > 1 forced segment length, -1 back to the LSPIV_WALK environment variable. */
+/* run-time options: "walk" = 1 the default time-walking kernels (segments anchored every lspiv_chunk_alignment pairs of
+ * the absolute pair index: results do not depend on the chunking as long as chunks start on such anchors), 0 per-pair
+ * kernels (independent of any chunking, ~23 % slower), n > 1 anchor length n, -1 back to the LSPIV_WALK environment
+ * variable. */
 int         lspiv_set_option(const char* name, int value);
 int         lspiv_get_option(const char* name, int* value);
 /* which kernel a window size dispatches to: 1 = FFT 32x32, 2 = FFT 64x64, 6 = FFT 8x8 / 16x16, 8 = prime-factor FFT
@@ -111,6 +113,22 @@ int lspiv_piv_pairs_dev(const void* d_frames, int dtype, int64_t T, int64_t H, i
                         int wy, int wx, int oy, int ox, float signal_threshold,
                         float* d_out, float* d_corr_planes, void* stream);
 
+/* Chunked callers (the time-chunk loop of pyorc/velocimetry/ffpiv.py:140,399-442; multi-GPU time blocks): the same two
+ * calls on a chunk whose first pair has index `pair_offset` in the caller's whole stack.  The reference computes every
+ * window independently, so its results cannot depend on the chunking; the default kernels here share transforms between
+ * consecutive pairs of a window in runs that start at multiples of lspiv_chunk_alignment() of the ABSOLUTE pair index.
+ * Chunks that start on such a multiple therefore reproduce, bit for bit, what one call over the whole stack returns
+ * (tested); a chunk that starts elsewhere is still correct but its first (alignment - offset % alignment) pairs may
+ * differ from the whole-stack run in the last float32 bit.  lspiv_piv_pairs[_dev] == these with pair_offset 0.
+ * lspiv_chunk_alignment: pairs; 1 for window sizes served by per-pair kernels and with option "walk" = 0.  Host-only. */
+int lspiv_chunk_alignment(int wy, int wx);
+int lspiv_piv_pairs_at(const void* frames, int dtype, int64_t T, int64_t H, int64_t W,
+                       int wy, int wx, int oy, int ox, float signal_threshold, int64_t pair_offset,
+                       float* u, float* v, float* corr_max, float* s2n, float* corr_planes);
+int lspiv_piv_pairs_dev_at(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W,
+                           int wy, int wx, int oy, int ox, float signal_threshold, int64_t pair_offset,
+                           float* d_out, float* d_corr_planes, void* stream);
+
 /* replaces ffpiv.u_v_displacement on an existing plane volume (pyorc/velocimetry/ffpiv.py:324,471):
  * planes (P, n_win, wy, wx) float32 -> u, v (P * n_win) float32 in pixels.                   */
 int lspiv_u_v_displacement(const float* corr_planes, int64_t P, int64_t n_win, int wy, int wx,
@@ -119,7 +137,8 @@ int lspiv_u_v_displacement(const float* corr_planes, int64_t P, int64_t n_win, i
 /* ---------------------------------------------------------------- ensemble correlation --- */
 /* replaces _get_ffpiv_mean (pyorc/velocimetry/ffpiv.py:182-376): corr_sum / corr_count stay in
  * HBM across chunks; per-pair corr_max / s2n (masked to 0 like ffpiv.py:238-241) are returned per
- * chunk for the time averages of ffpiv.py:284-286.                                          */
+ * chunk for the time averages of ffpiv.py:284-286.  The handle counts the pairs it has seen: chunks are
+ * consecutive, and chunkings whose boundaries are multiples of lspiv_chunk_alignment() give the same bits. */
 typedef struct lspiv_ensemble lspiv_ensemble;
 int lspiv_ensemble_begin(int64_t H, int64_t W, int wy, int wx, int oy, int ox, lspiv_ensemble** handle);
 int lspiv_ensemble_accumulate(lspiv_ensemble* handle, const void* frames, int dtype, int64_t T,
@@ -247,6 +266,38 @@ int lspiv_scale_velocity_dev(float* d_fields, int64_t T, int64_t n_vec, double r
 int lspiv_pack_int16(const float* values, int64_t n, float scale, int fill, int16_t* packed);
 int lspiv_pack_int16_dev(const float* d_values, int64_t n, float scale, int fill, int16_t* d_packed, void* stream);
 
+/* ---------------------------------------------------------------- multi-GPU exchange ------ */
+/* One process per GPU.  The reference is a single process: nothing is replaced here; frame
+ * pairs are independent (docs/user-guide/velocimetry/index.rst:12-13) and the time axis is already cut into chunks
+ * with a one-frame halo (pyorc/velocimetry/ffpiv.py:140), so rank r owns a contiguous block of pairs and the only
+ * exchange is ONE all-gather of the packed (4, t, y, x) result block -- or, in ensemble mode, one sum all-reduce of
+ * corr_sum / corr_count (ffpiv.py:361-363) before lspiv_ensemble_finish.
+ *   transport LSPIV_COMM_RCCL  RCCL over xGMI; librccl.so is loaded on first use; the communicator binds to the
+ *                              calling thread's current device (lspiv_set_device first);
+ *   transport LSPIV_COMM_SHM   POSIX shared memory on the node, staged through host memory: plumbing tests only
+ *                              (RCCL refuses two ranks on one GPU and needs a GPU; this one needs neither).
+ * Rendezvous: rank 0 calls lspiv_comm_unique_id and hands the LSPIV_COMM_ID_BYTES to the other ranks (file, pipe,
+ * environment); every rank then calls lspiv_comm_init.  "_dev" collectives take device pointers and are asynchronous
+ * on `stream` with RCCL; the others take host pointers and block.  count = elements PER RANK; recv of an all-gather
+ * holds world * count elements in rank order.  dtype LSPIV_F32 / LSPIV_F64; op LSPIV_COMM_SUM / LSPIV_COMM_MAX. */
+#define LSPIV_COMM_RCCL 0
+#define LSPIV_COMM_SHM 1
+#define LSPIV_COMM_SUM 0
+#define LSPIV_COMM_MAX 1
+#define LSPIV_COMM_ID_BYTES 128
+typedef struct lspiv_comm lspiv_comm;
+int lspiv_comm_unique_id(int transport, void* id /* LSPIV_COMM_ID_BYTES */);
+int lspiv_comm_init(int rank, int world, const void* id, int transport, lspiv_comm** comm);
+/* backend_ranks: the rank count the transport itself reports (ncclCommCount / attached shm ranks) */
+int lspiv_comm_info(lspiv_comm* comm, int* rank, int* world, int* transport, int* backend_ranks);
+int lspiv_comm_allgather_dev(lspiv_comm* comm, const void* d_send, void* d_recv, int64_t count, int dtype, void* stream);
+int lspiv_comm_allreduce_dev(lspiv_comm* comm, const void* d_send, void* d_recv, int64_t count, int dtype, int op,
+                             void* stream);
+int lspiv_comm_allgather(lspiv_comm* comm, const void* send, void* recv, int64_t count, int dtype);
+int lspiv_comm_allreduce(lspiv_comm* comm, const void* send, void* recv, int64_t count, int dtype, int op);
+int lspiv_comm_barrier(lspiv_comm* comm);
+int lspiv_comm_destroy(lspiv_comm* comm);
+
 /* ---------------------------------------------------------------- device-resident helpers  */
 /* For hosts that keep stacks in HBM (bench.py, one-process-per-GPU shards).                 */
 int lspiv_dev_malloc(void** d_ptr, size_t bytes);
@@ -262,6 +313,13 @@ int lspiv_event_create(void** ev);
 int lspiv_event_record(void* ev);
 int lspiv_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms); /* synchronises ev_stop */
 int lspiv_event_destroy(void* ev);
+/* extra HIP streams for hosts that overlap the result exchange with the next launch (bench.py --gpus N): every "_dev"
+ * entry point takes such a handle; events recorded on one stream can be waited for on another. */
+int lspiv_stream_create(void** stream);
+int lspiv_stream_destroy(void* stream);
+int lspiv_stream_synchronize(void* stream);             /* NULL = the library's launch stream */
+int lspiv_event_record_on(void* ev, void* stream);      /* NULL = the library's launch stream */
+int lspiv_stream_wait_event(void* stream, void* ev);    /* NULL = the library's launch stream */
 
 /* Synthetic particle-image stack rendered directly into HBM (SURVEY.md section 8d workload; test and
  * bench utility, not on the PIV path): N_p = density*H*W Gaussian particles (sigma 1.2 px)
@@ -272,9 +330,9 @@ int lspiv_synth_particles_dev(void* d_frames, int64_t T, int64_t H, int64_t W, u
  * conventions (forward exp(-2 pi i jk/n), inverse exp(+...), both unnormalised); in / out: host arrays of count*n
  * interleaved (re, im) float pairs; n = 8, 16, 32, 64 or any even length 6..62 (the sizes lspiv_kernel_kind maps to 6 / 8). */
 int lspiv_debug_fft(int n, int inverse, const float* in, float* out, int64_t count);
-/* Test hook (host only): the segment length, in frame pairs, that the time-walking kernels use for a chunk of n_pairs
- * pairs with n_win windows when `slots` lane groups run concurrently (rounds x iterations minimised). */
-int lspiv_debug_segment_length(int64_t n_win, int64_t n_pairs, int64_t slots);
+/* Test hook (host only): how the time-walking kernels cut a chunk of n_pairs pairs that starts at absolute pair index
+ * pair_offset into segments of seg_len pairs anchored at multiples of seg_len: pairs in the first segment, segment count. */
+int lspiv_debug_segments(int64_t n_pairs, int64_t pair_offset, int seg_len, int64_t* seg_first, int64_t* n_seg);
 
 #ifdef __cplusplus
 }

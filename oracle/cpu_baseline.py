@@ -83,4 +83,39 @@ def run(frames_sample: np.ndarray, ws, ov, gpu_block=None) -> dict:
         out["parity_nan_mismatch"] = nan_mismatch
         out["parity_windows_checked"] = int(ok.sum())
         out["parity_windows_ill_posed"] = int((~ok).sum())
+        out["parity_ill_posed"] = ill_posed_report(gpu_block, (u, v, cm, sn), ok)
     return out
+
+
+def ill_posed_report(gpu_block, ref, ok) -> dict:
+    """What the 1e-4 gate does NOT cover: the windows `c_oracle.well_posed` excludes (arg-max gap < 1e-5, a peak
+    neighbour < 2 % of the maximum, log-curvature < 0.05), graded on their own -- NaN-mask mismatches, the error
+    distribution of u, v and of corr / s2n, and how many of them a pyorc user would ever see: the share that passes
+    the default post-PIV masks `mask.corr(tolerance=0.1)` and `mask.s2n(tolerance=10)` (pyorc/api/mask.py:204,216)."""
+    bad = ~ok
+    n = int(bad.sum())
+    rep = {"windows": n}
+    if n == 0:
+        return rep
+    gu, gv, gc, gs = (np.asarray(a, dtype=np.float64) for a in gpu_block)
+    ru, rv, rc, rs = (np.asarray(a, dtype=np.float64) for a in ref)
+    rep["nan_mismatch_uv"] = int(((np.isnan(gu) != np.isnan(ru)) | (np.isnan(gv) != np.isnan(rv)))[bad].sum())
+    rep["nan_mismatch_corr_s2n"] = int(((np.isnan(gc) != np.isnan(rc)) | (np.isnan(gs) != np.isnan(rs)))[bad].sum())
+    with np.errstate(all="ignore"):
+        for name, g, r in (("u", gu, ru), ("v", gv, rv), ("corr", gc, rc), ("s2n", gs, rs)):
+            e = (np.abs(g - r) / np.maximum(np.abs(r), 0.05))[bad]
+            e = e[np.isfinite(e)]
+            if e.size:
+                rep[f"rel_err_{name}"] = {"p50": float(f"{np.percentile(e, 50):.3e}"), "p99": float(f"{np.percentile(e, 99):.3e}"),
+                                          "max": float(f"{e.max():.3e}"), "n": int(e.size)}
+        survive = bad & (rc >= 0.1) & (rs >= 10.0) & np.isfinite(ru) & np.isfinite(rv)   # NaN compares false
+        rep["survive_default_corr_s2n_masks"] = int(survive.sum())
+        rep["survive_share_of_ill_posed"] = float(f"{survive.sum() / n:.4f}")
+        if survive.any():
+            e = np.maximum(np.abs(gu - ru), np.abs(gv - rv))[survive]   # absolute, pixels: what reaches a velocity field
+            e = e[np.isfinite(e)]
+            if e.size:
+                rep["surviving_abs_err_px"] = {"p50": float(f"{np.percentile(e, 50):.3e}"), "p99": float(f"{np.percentile(e, 99):.3e}"),
+                                               "max": float(f"{e.max():.3e}")}
+            rep["surviving_nan_mismatch"] = int((np.isnan(gu) | np.isnan(gv))[survive].sum())
+    return rep

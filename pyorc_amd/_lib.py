@@ -61,6 +61,9 @@ SIGNATURES = {
     "lspiv_available_bytes": (_i32, [_pi64, _pi64]),
     "lspiv_piv_pairs": (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "lspiv_piv_pairs_dev": (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
+    "lspiv_chunk_alignment": (_i32, [_i32, _i32]),
+    "lspiv_piv_pairs_at": (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "lspiv_piv_pairs_dev_at": (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _i64, _vp, _vp, _vp]),
     "lspiv_u_v_displacement": (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _vp]),
     "lspiv_ensemble_begin": (_i32, [_i64, _i64, _i32, _i32, _i32, _i32, C.POINTER(_vp)]),
     "lspiv_ensemble_accumulate": (_i32, [_vp, _vp, _i32, _i64, _f32, _f32, _f32, _vp, _vp]),
@@ -109,9 +112,23 @@ SIGNATURES = {
     "lspiv_event_record": (_i32, [_vp]),
     "lspiv_event_elapsed_ms": (_i32, [_vp, _vp, C.POINTER(_f32)]),
     "lspiv_event_destroy": (_i32, [_vp]),
+    "lspiv_stream_create": (_i32, [C.POINTER(_vp)]),
+    "lspiv_stream_destroy": (_i32, [_vp]),
+    "lspiv_stream_synchronize": (_i32, [_vp]),
+    "lspiv_event_record_on": (_i32, [_vp, _vp]),
+    "lspiv_stream_wait_event": (_i32, [_vp, _vp]),
+    "lspiv_comm_unique_id": (_i32, [_i32, _vp]),
+    "lspiv_comm_init": (_i32, [_i32, _i32, _vp, _i32, C.POINTER(_vp)]),
+    "lspiv_comm_info": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "lspiv_comm_allgather_dev": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "lspiv_comm_allreduce_dev": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "lspiv_comm_allgather": (_i32, [_vp, _vp, _vp, _i64, _i32]),
+    "lspiv_comm_allreduce": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32]),
+    "lspiv_comm_barrier": (_i32, [_vp]),
+    "lspiv_comm_destroy": (_i32, [_vp]),
     "lspiv_synth_particles_dev": (_i32, [_vp, _i64, _i64, _i64, C.c_uint64, _f32]),
     "lspiv_debug_fft": (_i32, [_i32, _i32, _vp, _vp, _i64]),
-    "lspiv_debug_segment_length": (_i32, [_i64, _i64, _i64]),
+    "lspiv_debug_segments": (_i32, [_i64, _i64, _i32, _pi64, _pi64]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 namespace lspiv {
 
 // Division by a launch-invariant 32-bit divisor without the ~25-instruction expansion of `/`:
@@ -66,7 +68,10 @@ struct PivParams {
   float* part_sum;         // n_seg * n_win * wy * wx, or nullptr: the single-owner kernels
   float* part_cnt;         // n_seg * n_win
   uint32_t seg_len, n_seg; // pairs per segment (odd), number of segments
+  uint32_t seg_first;      // pairs in segment 0: seg_len, or what is left up to the next anchor when the chunk starts off-anchor
   uint32_t n_pairs;        // T-1
+  int64_t pair_offset;     // absolute index of the chunk's first pair in the caller's stack: the walking kernels cut
+                           // segments at multiples of the anchor length of THAT index, so results do not depend on the chunking
   FastDiv div_ncols;       // window index -> (row, col)
   FastDiv div_jobs;        // fft kernels: job index -> (pair, job in pair), divisor (n_win + 1) / 2
   FastDiv div_nwin;        // one-window-per-job kernels: job index -> (pair, window), divisor n_win
@@ -225,40 +230,29 @@ hipError_t launch_peaks_from_planes(const float* planes, uint32_t n_planes, int 
 // LSPIV_WALK as an integer (0 per-pair kernels, 1 default walking kernels, n > 1 forced segment length): the value set
 // through lspiv_set_option("walk", v) if any, else the environment variable read at every launch, else 1
 int walk_setting();
-// Segment length (in frame pairs) of the time-walking kernels for a chunk.  The n_win * n_seg jobs run in rounds of
-// `slots` concurrent lane groups and a job of L pairs lasts L / 2 + 1 iterations (its first iteration yields one plane
-// only), so the launch takes ~ rounds * iterations: the old rule (shrink from 63 until there are >= 32 768 jobs) left
-// e.g. a 200-pair 1080p chunk at 7 rounds of 25 iterations where 9 rounds of 15 do the same work -- 23 % less time.
-// Candidates: odd lengths 3 .. 63 (an odd number of pairs = whole iterations) and the whole chunk as one segment.
-inline uint32_t walk_segment_length(uint32_t n_win, uint32_t n_pairs, uint32_t slots) {
-  uint32_t best_len = std::min<uint32_t>(63, n_pairs);
-  uint64_t best_cost = ~0ull;
-  auto consider = [&](uint32_t len) {
-    if (len < 1 || len > n_pairs) return;
-    const uint64_t n_seg = (n_pairs + len - 1) / len;
-    const uint64_t rounds = (n_seg * n_win + slots - 1) / slots;
-    const uint64_t cost = rounds * (len / 2 + 1) * 4096 + n_seg;   // ties: fewer segments (less first-iteration overhead)
-    if (cost < best_cost || (cost == best_cost && len > best_len)) { best_cost = cost; best_len = len; }
-  };
-  for (uint32_t len = 3; len <= 63; len += 2) consider(len);
-  if (n_pairs <= 64) consider(n_pairs);
-  return best_len;
+// Segments of the time-walking kernels.  A job walks one window through a run of consecutive frame pairs and shares
+// every frame's spectrum between the two pairs it belongs to; which frames share transforms depends on where a run
+// starts, so the runs ("segments") are ANCHORED: they start at the absolute pair indices k * kWalkAnchor of the caller's
+// stack (PivParams::pair_offset + local index), whatever the chunk.  Two chunkings whose boundaries are multiples of the
+// anchor length (lspiv_chunk_alignment; the Python planner only makes such chunks) then run the very same jobs and give
+// the same bits, like the reference, which computes every window independently (pyorc/velocimetry/ffpiv.py:140,399-442).
+// A chunk that starts off-anchor gets a shorter first segment (correct, but its first pairs differ in the last bit from
+// an aligned run).  25: a job of L pairs lasts L / 2 + 1 iterations (its first iteration yields one plane only) and the
+// n_win * n_seg jobs run in rounds of as many lane groups as the chip holds; over chunks of 20 ... 4000 pairs and grids
+// of 2.5 k ... 32 k windows, rounds x iterations of L = 25 stays within 2.5 % of the best per-chunk choice at 1000 pairs
+// and within 6 % at 200 (59 ... 63, the best length for 1000-pair chunks, loses 15 - 40 % at 200).
+constexpr uint32_t kWalkAnchor = 25;
+struct WalkSegments { uint32_t seg_len, seg_first, n_seg; };
+inline WalkSegments walk_segments(uint32_t n_pairs, int64_t pair_offset, uint32_t seg_len) {
+  WalkSegments w;
+  w.seg_len = seg_len < 1 ? 1 : seg_len;
+  const uint32_t head = (uint32_t)(pair_offset % (int64_t)w.seg_len);
+  w.seg_first = std::min<uint32_t>(w.seg_len - head, n_pairs);
+  w.n_seg = 1 + (n_pairs - w.seg_first + w.seg_len - 1) / w.seg_len;
+  return w;
 }
 // concurrent lane groups of a kernel that runs `waves_per_simd` waves with `groups` jobs per wave (CU count queried once)
 uint32_t job_slots(int waves_per_simd, int groups);
-// segments of the walking ENSEMBLE kernels: enough jobs for ~3 rounds of the chip, segments of an odd number of pairs
-inline void ensemble_segments(uint32_t n_win, uint32_t n_pairs, int window, uint32_t* seg_len, uint32_t* n_seg) {
-  // quarter- / half-wave jobs at 4 / 3 waves/SIMD (32 x 32 with its partial sum in registers: 2); wave jobs at 2
-  const uint32_t slots = window <= 16 ? 16384u : window < 32 ? 8192u : window == 32 ? 4096u : 2048u;
-  uint32_t want = (3u * slots + n_win - 1) / n_win;
-  if (want < 1) want = 1;
-  uint32_t len = (n_pairs + want - 1) / want;
-  if (len < 3) len = 3;
-  len |= 1u;
-  if (len > n_pairs) len = n_pairs;
-  *seg_len = len;
-  *n_seg = (n_pairs + len - 1) / len;
-}
 hipError_t launch_ensemble_merge(const float* part_sum, const float* part_cnt, uint32_t n_seg, uint32_t n_win, int plane_elems,
                                  float* corr_sum, float* corr_count, hipStream_t s);
 hipError_t launch_ensemble_mean(const float* sum, const float* count, float min_count, uint32_t n_win,

@@ -263,6 +263,18 @@ int dispatch(const lspiv::PivParams& p, int dtype, bool ensemble, hipStream_t s)
 
 }  // namespace
 
+namespace lspiv_comm_detail {   // lspiv_comm.hip reports through the same thread-local message
+int comm_fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+}  // namespace lspiv_comm_detail
+
 struct lspiv_projection {
   int64_t src_h, src_w, dst_h, dst_w;
   int device;
@@ -278,6 +290,7 @@ struct lspiv_ensemble {
   float* d_count;  // n_win
   float* d_part;   // walking kernels: per-segment partial sums + counts (grow-only workspace)
   size_t part_cap;
+  int64_t pairs_done;   // pairs accumulated so far = absolute index of the next chunk's first pair (segment anchoring)
 };
 
 static std::atomic<int> g_opt_walk{-1};   // lspiv_set_option("walk", v); -1: not set, fall back to the environment
@@ -290,6 +303,9 @@ uint32_t lspiv::job_slots(int waves_per_simd, int groups) {
   }();
   return (uint32_t)(cus * 4 * waves_per_simd * groups);
 }
+
+// window kinds served by the time-walking kernels (every even square window 6 .. 64)
+static bool kind_walks(int kind) { return kind == 1 || kind == 2 || kind == 6 || kind == 8; }
 
 int lspiv::walk_setting() {
   const int v = g_opt_walk.load();
@@ -411,9 +427,19 @@ int lspiv_available_bytes(int64_t* free_bytes, int64_t* total_bytes) {
   return LSPIV_OK;
 }
 
-int lspiv_piv_pairs_dev(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, int wy, int wx, int oy,
-                        int ox, float signal_threshold, float* d_out, float* d_corr_planes, void* stream) {
+int lspiv_chunk_alignment(int wy, int wx) {
+  const int kind = lspiv_kernel_kind(wy, wx);
+  if (kind < 0) return kind;
+  const int walk = lspiv::walk_setting();
+  if (!kind_walks(kind) || walk == 0) return 1;
+  return walk > 1 ? walk : (int)lspiv::kWalkAnchor;
+}
+
+int lspiv_piv_pairs_dev_at(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, int wy, int wx, int oy,
+                           int ox, float signal_threshold, int64_t pair_offset, float* d_out, float* d_corr_planes,
+                           void* stream) {
   if (!d_frames || !d_out) return fail(LSPIV_EINVAL, "d_frames / d_out is NULL");
+  if (pair_offset < 0) return fail(LSPIV_EINVAL, "pair_offset %lld is negative", (long long)pair_offset);
   Grid g;
   int rc = make_grid(H, W, wy, wx, oy, ox, &g);
   if (rc) return rc;
@@ -423,6 +449,7 @@ int lspiv_piv_pairs_dev(const void* d_frames, int dtype, int64_t T, int64_t H, i
   lspiv::PivParams p;
   rc = fill_params(&p, d_frames, dtype, T, H, W, wy, wx, oy, ox, signal_threshold, g);
   if (rc) return rc;
+  p.pair_offset = pair_offset;
   p.u = d_out;
   p.v = d_out + (size_t)p.n_tiles;
   p.cmax = d_out + 2 * (size_t)p.n_tiles;
@@ -431,10 +458,17 @@ int lspiv_piv_pairs_dev(const void* d_frames, int dtype, int64_t T, int64_t H, i
   return dispatch(p, dtype, false, stream ? (hipStream_t)stream : c->stream);
 }
 
-int lspiv_piv_pairs(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, int wy, int wx, int oy, int ox,
-                    float signal_threshold, float* u, float* v, float* corr_max, float* s2n, float* corr_planes) {
+int lspiv_piv_pairs_dev(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, int wy, int wx, int oy,
+                        int ox, float signal_threshold, float* d_out, float* d_corr_planes, void* stream) {
+  return lspiv_piv_pairs_dev_at(d_frames, dtype, T, H, W, wy, wx, oy, ox, signal_threshold, 0, d_out, d_corr_planes, stream);
+}
+
+int lspiv_piv_pairs_at(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, int wy, int wx, int oy, int ox,
+                       float signal_threshold, int64_t pair_offset, float* u, float* v, float* corr_max, float* s2n,
+                       float* corr_planes) {
   std::lock_guard<std::mutex> host_lock(g_host_mu);
   if (!frames || !u || !v || !corr_max || !s2n) return fail(LSPIV_EINVAL, "NULL buffer");
+  if (pair_offset < 0) return fail(LSPIV_EINVAL, "pair_offset %lld is negative", (long long)pair_offset);
   Grid g;
   int rc = make_grid(H, W, wy, wx, oy, ox, &g);
   if (rc) return rc;
@@ -454,10 +488,10 @@ int lspiv_piv_pairs(const void* frames, int dtype, int64_t T, int64_t H, int64_t
     rc = ensure(&c->d_planes, &c->planes_cap, n_tiles * wy * wx * sizeof(float));
     if (rc) return rc;
   }
-  // Pipelined upload: the stack is copied through a two-slot pinned ring in sub-batches of whole frames; the
-  // kernel for the pairs of sub-batch k runs while sub-batch k+1 is staged and DMA'd.  With the per-pair kernels
-  // (LSPIV_WALK=0) this equals one launch over the whole stack bit for bit; the walking kernels see every sub-batch
-  // as a chunk of its own.
+  // Pipelined upload: the stack is copied through a two-slot pinned ring in sub-batches of whole frames; the kernel
+  // for the pairs that have become resident runs while the next sub-batch is staged and DMA'd.  Launches are cut at
+  // the anchors of the walking kernels' segments (multiples of lspiv_chunk_alignment of the absolute pair index), so
+  // the pipelined run issues exactly the jobs of one launch over the whole stack: same bits as lspiv_piv_pairs_dev_at.
   lspiv::PivParams base;
   rc = fill_params(&base, c->d_frames, dev_dtype, T, H, W, wy, wx, oy, ox, signal_threshold, g);
   if (rc) return rc;
@@ -468,6 +502,8 @@ int lspiv_piv_pairs(const void* frames, int dtype, int64_t T, int64_t H, int64_t
   if (rc) return rc;
   const int64_t fpb = std::max<int64_t>(1, (int64_t)(c->pinned_cap / frame_bytes));
   const bool src_pinned = dtype != LSPIV_F64 && is_pinned(frames);
+  const int64_t align = std::max(1, lspiv_chunk_alignment(wy, wx));
+  int64_t launched = 0;   // pairs [0, launched) have been issued
   int batch = 0;
   for (int64_t f0 = 0; f0 < T; ++batch) {
     const int64_t f1 = std::min<int64_t>(T, f0 + fpb);
@@ -485,10 +521,14 @@ int lspiv_piv_pairs(const void* frames, int dtype, int64_t T, int64_t H, int64_t
                            c->copy_stream));
     HIP_TRY(hipEventRecord(c->staged[slot], c->copy_stream));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->staged[slot], 0));
-    const int64_t p0 = std::max<int64_t>(f0 - 1, 0), p1 = f1 - 1;  // pairs whose two frames are resident
+    // pairs whose two frames are resident: [0, f1 - 1); issue up to the last anchor below that (everything at the end)
+    int64_t p1 = f1 - 1;
+    if (f1 < T) p1 = ((pair_offset + p1) / align) * align - pair_offset;
+    const int64_t p0 = launched;
     if (p1 > p0) {
       lspiv::PivParams p = base;
       p.frames = (const char*)c->d_frames + (size_t)p0 * frame_bytes;
+      p.pair_offset = pair_offset + p0;
       p.n_pairs = (uint32_t)(p1 - p0);
       p.n_tiles = (uint32_t)((p1 - p0) * n_win);
       p.u = c->d_out + p0 * n_win;
@@ -498,6 +538,7 @@ int lspiv_piv_pairs(const void* frames, int dtype, int64_t T, int64_t H, int64_t
       p.planes = corr_planes ? c->d_planes + (size_t)p0 * n_win * wy * wx : nullptr;
       rc = dispatch(p, dev_dtype, false, c->stream);
       if (rc) return rc;
+      launched = p1;
     }
     f0 = f1;
   }
@@ -510,6 +551,11 @@ int lspiv_piv_pairs(const void* frames, int dtype, int64_t T, int64_t H, int64_t
     HIP_TRY(hipMemcpyAsync(corr_planes, c->d_planes, n_tiles * wy * wx * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return LSPIV_OK;
+}
+
+int lspiv_piv_pairs(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, int wy, int wx, int oy, int ox,
+                    float signal_threshold, float* u, float* v, float* corr_max, float* s2n, float* corr_planes) {
+  return lspiv_piv_pairs_at(frames, dtype, T, H, W, wy, wx, oy, ox, signal_threshold, 0, u, v, corr_max, s2n, corr_planes);
 }
 
 int lspiv_u_v_displacement(const float* corr_planes, int64_t P, int64_t n_win, int wy, int wx, float* u, float* v) {
@@ -547,7 +593,7 @@ int lspiv_ensemble_begin(int64_t H, int64_t W, int wy, int wx, int oy, int ox, l
   if (rc) return rc;
   lspiv_ensemble* h = new lspiv_ensemble();
   h->H = H; h->W = W; h->wy = wy; h->wx = wx; h->oy = oy; h->ox = ox; h->g = g;
-  h->d_sum = nullptr; h->d_count = nullptr;
+  h->d_sum = nullptr; h->d_count = nullptr; h->d_part = nullptr; h->part_cap = 0; h->pairs_done = 0;
   HIP_TRY(hipGetDevice(&h->device));
   const size_t n_win = (size_t)g.n_rows * g.n_cols;
   void* p = nullptr;
@@ -576,8 +622,14 @@ static int ensemble_launch(lspiv_ensemble* h, DeviceCtx* c, const void* d_frames
   p.corr_sum = h->d_sum;
   p.corr_count = h->d_count;
   const int kind = lspiv_kernel_kind(h->wy, h->wx);
-  if ((kind == 1 || kind == 2 || kind == 6 || kind == 8) && lspiv::walk_setting() != 0 && p.n_pairs >= 3) {
-    lspiv::ensemble_segments(p.n_win, p.n_pairs, h->wy, &p.seg_len, &p.n_seg);
+  const int walk = lspiv::walk_setting();
+  p.pair_offset = h->pairs_done;
+  h->pairs_done += p.n_pairs;
+  if (kind_walks(kind) && walk != 0) {
+    // segments anchored at multiples of the anchor length of the absolute pair index (common.h): the partial sums, and
+    // the order they are merged in, are the same for every chunking whose boundaries are multiples of that length
+    const lspiv::WalkSegments w = lspiv::walk_segments(p.n_pairs, p.pair_offset, walk > 1 ? (uint32_t)walk : lspiv::kWalkAnchor);
+    p.seg_len = w.seg_len; p.seg_first = w.seg_first; p.n_seg = w.n_seg;
     const size_t plane = (size_t)h->wy * h->wx;
     const size_t need = (size_t)p.n_seg * p.n_win * (plane + 1) * sizeof(float);
     rc = ensure(&h->d_part, &h->part_cap, need);
@@ -623,6 +675,8 @@ int lspiv_ensemble_accumulate(lspiv_ensemble* h, const void* frames, int dtype, 
   rc = stage_ring(c, frame_bytes);
   if (rc) return rc;
   const int64_t fpb = std::max<int64_t>(1, (int64_t)(c->pinned_cap / frame_bytes));
+  const int64_t align = std::max(1, lspiv_chunk_alignment(h->wy, h->wx)), base_offset = h->pairs_done;
+  int64_t launched = 0;
   {
     int batch = 0;
     for (int64_t f0 = 0; f0 < T; ++batch) {
@@ -637,11 +691,15 @@ int lspiv_ensemble_accumulate(lspiv_ensemble* h, const void* frames, int dtype, 
       HIP_TRY(hipMemcpyAsync((char*)c->d_frames + (size_t)f0 * frame_bytes, c->pinned[slot], nb, hipMemcpyHostToDevice, c->copy_stream));
       HIP_TRY(hipEventRecord(c->staged[slot], c->copy_stream));
       HIP_TRY(hipStreamWaitEvent(c->stream, c->staged[slot], 0));
-      const int64_t p0 = std::max<int64_t>(f0 - 1, 0), p1 = f1 - 1;  // pairs whose two frames are resident
+      // pairs [0, f1 - 1) are resident; accumulate up to the last segment anchor below that (everything at the end)
+      int64_t p1 = f1 - 1;
+      if (f1 < T) p1 = ((base_offset + p1) / align) * align - base_offset;
+      const int64_t p0 = launched;
       if (p1 > p0) {
         rc = ensemble_launch(h, c, (const char*)c->d_frames + (size_t)p0 * frame_bytes, dev_dtype, p1 - p0 + 1, corr_min, s2n_min,
                              signal_threshold, c->d_out + p0 * n_win, c->d_out + n_tiles + p0 * n_win, c->stream);
         if (rc) return rc;
+        launched = p1;
       }
       f0 = f1;
     }
@@ -1349,6 +1407,41 @@ int lspiv_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms) {
 }
 int lspiv_event_destroy(void* ev) { if (ev) HIP_TRY(hipEventDestroy((hipEvent_t)ev)); return LSPIV_OK; }
 
+int lspiv_stream_create(void** stream) {
+  if (!stream) return fail(LSPIV_EINVAL, "stream is NULL");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  hipStream_t s;
+  HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = s;
+  return LSPIV_OK;
+}
+int lspiv_stream_destroy(void* stream) { if (stream) HIP_TRY(hipStreamDestroy((hipStream_t)stream)); return LSPIV_OK; }
+int lspiv_stream_synchronize(void* stream) {
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(stream ? (hipStream_t)stream : c->stream));
+  return LSPIV_OK;
+}
+int lspiv_event_record_on(void* ev, void* stream) {
+  if (!ev) return fail(LSPIV_EINVAL, "event is NULL");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord((hipEvent_t)ev, stream ? (hipStream_t)stream : c->stream));
+  return LSPIV_OK;
+}
+int lspiv_stream_wait_event(void* stream, void* ev) {
+  if (!ev) return fail(LSPIV_EINVAL, "event is NULL");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  HIP_TRY(hipStreamWaitEvent(stream ? (hipStream_t)stream : c->stream, (hipEvent_t)ev, 0));
+  return LSPIV_OK;
+}
+
 int lspiv_synth_particles_dev(void* d_frames, int64_t T, int64_t H, int64_t W, uint64_t seed, float density) {
   if (!d_frames || T < 1 || H < 8 || W < 8 || !(density > 0.0f)) return fail(LSPIV_EINVAL, "bad argument");
   DeviceCtx* c;
@@ -1360,9 +1453,12 @@ int lspiv_synth_particles_dev(void* d_frames, int64_t T, int64_t H, int64_t W, u
   return LSPIV_OK;
 }
 
-int lspiv_debug_segment_length(int64_t n_win, int64_t n_pairs, int64_t slots) {
-  if (n_win < 1 || n_pairs < 1 || slots < 1 || n_win > 0x7fffffff || n_pairs > 0x7fffffff || slots > 0x7fffffff) return LSPIV_EINVAL;
-  return (int)lspiv::walk_segment_length((uint32_t)n_win, (uint32_t)n_pairs, (uint32_t)slots);
+int lspiv_debug_segments(int64_t n_pairs, int64_t pair_offset, int seg_len, int64_t* seg_first, int64_t* n_seg) {
+  if (n_pairs < 1 || n_pairs > 0x7fffffff || pair_offset < 0 || seg_len < 1 || !seg_first || !n_seg) return LSPIV_EINVAL;
+  const lspiv::WalkSegments w = lspiv::walk_segments((uint32_t)n_pairs, pair_offset, (uint32_t)seg_len);
+  *seg_first = w.seg_first;
+  *n_seg = w.n_seg;
+  return LSPIV_OK;
 }
 
 int lspiv_debug_fft(int n, int inverse, const float* in, float* out, int64_t count) {

@@ -987,8 +987,8 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
 }
 
 template <typename T, int N, bool PLANES, bool WANT_NZ>
-__global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_kernel(PivParams p, uint32_t seg_len,
-                                                                                    uint32_t n_seg) {
+__global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_kernel(PivParams p) {
+  const uint32_t seg_len = p.seg_len, n_seg = p.n_seg;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using G = Geo<N>;
   const int lane = threadIdx.x & 63;
@@ -1010,8 +1010,9 @@ __global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_kernel
   job = job_valid ? job : n_seg * p.n_win - 1;
   const uint32_t seg = p.div_nwin.div(job);
   const uint32_t win = job - seg * p.n_win;
-  const uint32_t p0 = seg * seg_len;
-  const uint32_t p1 = min(p0 + seg_len, p.n_pairs);                  // pairs [p0, p1) = frames p0 .. p1
+  // segments are anchored at absolute pair indices (common.h, kWalkAnchor): segment 0 ends at the first anchor
+  const uint32_t p0 = seg == 0 ? 0u : p.seg_first + (seg - 1) * seg_len;
+  const uint32_t p1 = min(seg == 0 ? p.seg_first : p0 + seg_len, p.n_pairs);   // pairs [p0, p1) = frames p0 .. p1
   const uint32_t wrow = p.div_ncols.div(win);
   const uint32_t wcol = win - wrow * (uint32_t)p.n_cols;
   const T* row = static_cast<const T*>(p.frames) + ((int64_t)p0 * p.H + (int64_t)(wrow * p.sy + row_of<N>(lg))) * p.W +
@@ -1375,8 +1376,8 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsWaves<T, N>)) void piv_fft_walk_ens
   job = job_valid ? job : p.n_seg * p.n_win - 1;
   const uint32_t seg = p.div_nwin.div(job);
   const uint32_t win = job - seg * p.n_win;
-  const uint32_t p0 = seg * p.seg_len;
-  const uint32_t p1 = min(p0 + p.seg_len, p.n_pairs);
+  const uint32_t p0 = seg == 0 ? 0u : p.seg_first + (seg - 1) * p.seg_len;
+  const uint32_t p1 = min(seg == 0 ? p.seg_first : p0 + p.seg_len, p.n_pairs);
   const uint32_t wrow = p.div_ncols.div(win);
   const uint32_t wcol = win - wrow * (uint32_t)p.n_cols;
   const T* row = static_cast<const T*>(p.frames) + ((int64_t)p0 * p.H + (int64_t)(wrow * p.sy + row_of<N>(lg))) * p.W +
@@ -1445,19 +1446,19 @@ static hipError_t launch_t(const PivParams& p, bool ensemble, hipStream_t s) {
     hipLaunchKernelGGL((piv_fft_ensemble_kernel<T, N, WANT_NZ>), dim3(blocks), dim3(BLOCK), G::LDS_BYTES, s, p);
     return hipGetLastError();
   }
-  // LSPIV_WALK: 0 = per-pair kernel; unset / 1 = time-walking kernel with the segment length that minimises rounds x
-  // iterations for this chunk (walk_segment_length); n > 1 = segments of n pairs (odd values waste no half iteration)
+  // LSPIV_WALK: 0 = per-pair kernel; unset / 1 = time-walking kernel, segments anchored every kWalkAnchor pairs of the
+  // absolute pair index (results independent of the chunking); n > 1 = anchor length n (odd values waste no half iteration)
   const int walk = walk_setting();   // option or environment, read per launch
-  if (walk != 0 && p.n_pairs >= 3) {
-    uint32_t seg_len = walk > 1 ? (uint32_t)walk : walk_segment_length(p.n_win, p.n_pairs, job_slots(kWalkWaves<T, N>, G::GROUPS));
-    seg_len = std::min(seg_len, p.n_pairs);
-    const uint32_t n_seg = (p.n_pairs + seg_len - 1) / seg_len;
-    const uint64_t wjobs = (uint64_t)n_seg * p.n_win;
+  if (walk != 0) {
+    PivParams q = p;
+    const WalkSegments w = walk_segments(p.n_pairs, p.pair_offset, walk > 1 ? (uint32_t)walk : kWalkAnchor);
+    q.seg_len = w.seg_len; q.seg_first = w.seg_first; q.n_seg = w.n_seg;
+    const uint64_t wjobs = (uint64_t)w.n_seg * p.n_win;
     const uint32_t wblocks = (uint32_t)((wjobs + jobs_per_block - 1) / jobs_per_block);
     if (p.planes)
-      hipLaunchKernelGGL((piv_fft_walk_kernel<T, N, true, WANT_NZ>), dim3(wblocks), dim3(BLOCK), G::LDS_BYTES, s, p, seg_len, n_seg);
+      hipLaunchKernelGGL((piv_fft_walk_kernel<T, N, true, WANT_NZ>), dim3(wblocks), dim3(BLOCK), G::LDS_BYTES, s, q);
     else
-      hipLaunchKernelGGL((piv_fft_walk_kernel<T, N, false, WANT_NZ>), dim3(wblocks), dim3(BLOCK), G::LDS_BYTES, s, p, seg_len, n_seg);
+      hipLaunchKernelGGL((piv_fft_walk_kernel<T, N, false, WANT_NZ>), dim3(wblocks), dim3(BLOCK), G::LDS_BYTES, s, q);
     return hipGetLastError();
   }
   const uint32_t jobs = p.n_pairs * ((p.n_win + 1) / 2);

@@ -36,11 +36,13 @@ def _check_args(window_size, overlap, search_area_size, normalize, engine):
 
 
 def piv_pairs(imgs, window_size=(32, 32), overlap=(16, 16), signal_threshold: Optional[float] = None,
-              return_planes: bool = False):
+              return_planes: bool = False, pair_offset: int = 0):
     """Fused PIV of every consecutive frame pair of ``imgs`` (T, H, W).
 
     Returns ``(u, v, corr_max, s2n[, planes])``: float32 arrays (T-1, n_rows, n_cols); u, v in
     pixels (u = column shift, v = row shift).  Replaces pyorc/velocimetry/ffpiv.py:446-474.
+    ``pair_offset``: index of the chunk's first pair in the whole stack (``lspiv_piv_pairs_at``); chunks that start on
+    multiples of ``window.chunk_alignment`` reproduce the whole-stack result bit for bit.
     """
     lib = _lib.load()
     _lib.require_device()
@@ -54,10 +56,10 @@ def piv_pairs(imgs, window_size=(32, 32), overlap=(16, 16), signal_threshold: Op
     planes = None
     if return_planes:
         planes = np.empty((P, n_rows * n_cols, window_size[0], window_size[1]), dtype=np.float32)
-    _lib.check(lib.lspiv_piv_pairs(_lib.ptr(a), _lib.DTYPE_CODES[a.dtype], T, H, W, window_size[0], window_size[1],
-                                   overlap[0], overlap[1], _sig(signal_threshold),
-                                   _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.ptr(out[3]),
-                                   _lib.ptr(planes) if planes is not None else None))
+    _lib.check(lib.lspiv_piv_pairs_at(_lib.ptr(a), _lib.DTYPE_CODES[a.dtype], T, H, W, window_size[0], window_size[1],
+                                      overlap[0], overlap[1], _sig(signal_threshold), int(pair_offset),
+                                      _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.ptr(out[3]),
+                                      _lib.ptr(planes) if planes is not None else None))
     return (*out, planes) if return_planes else tuple(out)
 
 

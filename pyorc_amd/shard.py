@@ -5,16 +5,15 @@ reference already splits the time axis into chunks with a 1-frame halo
 (pyorc/velocimetry/ffpiv.py:140).  Sharding is the same cut, one level up: rank r of R owns the
 contiguous pair block [r P / R, (r+1) P / R) and therefore reads frames [r P / R, (r+1) P / R] --
 the halo frame is read redundantly, never communicated.  The only exchange is ONE all-gather of each
-rank's packed (4, p_local, n_rows, n_cols) float32 result block (u | v | corr_max | s2n) at the end
-(RCCL over xGMI with the "nccl" backend; "gloo" in the CPU tests).  Ensemble mode instead needs a
-sum all-reduce of corr_sum / corr_count, provided by ``allreduce_sum``.
+rank's packed (4, p_local, n_rows, n_cols) float32 result block (u | v | corr_max | s2n) at the end;
+ensemble mode instead needs a sum all-reduce of corr_sum / corr_count.
 
-torch.distributed is plumbing here (rendezvous + collectives); the compute callable is injected.
+The communicator is ``pyorc_amd.comm.Comm`` (RCCL over xGMI through the C ABI, no PyTorch); anything with
+``rank``, ``world``, ``allgather(arr)`` and ``allreduce(arr, op)`` works (the CPU tests also drive this module
+through a ``torch.distributed`` gloo adapter).  The compute callable is injected.
 
-With the "nccl" backend import torch (and initialise the process group) BEFORE the first call into
-``liblspiv_hip.so``: the PyTorch wheel bundles its own ``libamdhip64``; loaded first, the dynamic loader hands the
-same copy to the library, loaded second the process ends up with two HIP runtimes and the second one finds no GPU
-(bench.py does it in this order).
+Block boundaries are multiples of ``align`` pairs (``window.chunk_alignment``), so every rank starts on an anchor of
+the time-walking kernels' segments: the gathered result equals the single-GPU result bit for bit.
 """
 
 from __future__ import annotations
@@ -23,123 +22,106 @@ from typing import Callable, List, Optional, Tuple
 
 import numpy as np
 
+SUM, MAX = 0, 1
 
-def pair_block(n_pairs: int, rank: int, world: int) -> Tuple[int, int]:
-    """[start, stop) of the pairs owned by ``rank``; blocks are contiguous, ordered, sizes differ by <= 1."""
+
+def pair_block(n_pairs: int, rank: int, world: int, align: int = 1) -> Tuple[int, int]:
+    """[start, stop) of the pairs owned by ``rank``; blocks are contiguous and ordered; their sizes differ by at most
+    one ``align``-sized unit (boundaries are multiples of ``align``, the tail goes to the last non-empty block)."""
     if world < 1 or not (0 <= rank < world):
         raise ValueError(f"bad rank/world {rank}/{world}")
-    return (n_pairs * rank) // world, (n_pairs * (rank + 1)) // world
+    if align <= 1:
+        return (n_pairs * rank) // world, (n_pairs * (rank + 1)) // world
+    units = -(-n_pairs // align)  # ceil: the last unit may be short
+    a = min(((units * rank) // world) * align, n_pairs)
+    b = min(((units * (rank + 1)) // world) * align, n_pairs)
+    return a, b
 
 
-def frame_block(n_pairs: int, rank: int, world: int) -> Tuple[int, int]:
+def frame_block(n_pairs: int, rank: int, world: int, align: int = 1) -> Tuple[int, int]:
     """[start, stop) of the FRAMES rank needs: its pairs plus the one-frame halo."""
-    a, b = pair_block(n_pairs, rank, world)
+    a, b = pair_block(n_pairs, rank, world, align)
     return (a, b + 1) if b > a else (a, a)
 
 
-def block_sizes(n_pairs: int, world: int) -> List[int]:
-    return [pair_block(n_pairs, r, world)[1] - pair_block(n_pairs, r, world)[0] for r in range(world)]
+def block_sizes(n_pairs: int, world: int, align: int = 1) -> List[int]:
+    return [pair_block(n_pairs, r, world, align)[1] - pair_block(n_pairs, r, world, align)[0] for r in range(world)]
 
 
-def _dist():
-    import torch
-    import torch.distributed as dist
+def gather_blocks(local: np.ndarray, n_pairs: int, comm, align: int = 1) -> np.ndarray:
+    """All-gather per-rank result blocks (k, p_local, n_rows, n_cols) into (k, n_pairs, n_rows, n_cols).
 
-    return torch, dist
-
-
-def gather_blocks(local: np.ndarray, n_pairs: int, group=None, device=None) -> np.ndarray:
-    """All-gather per-rank result blocks (4, p_local, n_rows, n_cols) into (4, n_pairs, n_rows, n_cols).
-
-    Blocks may differ by one pair; they are padded to the largest block so that a single
-    ``all_gather_into_tensor`` moves everything (one large collective, not one per variable).
+    Blocks may differ in length; they are padded to the largest block so that ONE all-gather moves everything
+    (one large collective, not one per variable).
     """
-    torch, dist = _dist()
-    world = dist.get_world_size(group)
-    sizes = block_sizes(n_pairs, world)
+    sizes = block_sizes(n_pairs, comm.world, align)
     pmax = max(sizes)
     k, p_local, n_rows, n_cols = local.shape
-    if p_local != sizes[dist.get_rank(group)]:
-        raise ValueError(f"rank {dist.get_rank(group)} holds {p_local} pairs, expected {sizes[dist.get_rank(group)]}")
-    dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
-    send = torch.full((k, pmax, n_rows, n_cols), float("nan"), dtype=torch.float32, device=dev)
-    send[:, :p_local] = torch.as_tensor(np.ascontiguousarray(local, dtype=np.float32)).to(dev)
-    recv = torch.empty((world,) + tuple(send.shape), dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
-    recv = recv.cpu().numpy()
-    return np.concatenate([recv[r][:, :sizes[r]] for r in range(world)], axis=1)
+    if p_local != sizes[comm.rank]:
+        raise ValueError(f"rank {comm.rank} holds {p_local} pairs, expected {sizes[comm.rank]}")
+    send = np.full((k, pmax, n_rows, n_cols), np.nan, dtype=np.float32)
+    send[:, :p_local] = local
+    recv = comm.allgather(send)
+    return np.concatenate([recv[r][:, :sizes[r]] for r in range(comm.world)], axis=1)
 
 
-def allreduce_sum(arr: np.ndarray, group=None, device=None) -> np.ndarray:
-    """Sum an array over ranks (ensemble corr_sum / corr_count), same dtype and shape back."""
-    torch, dist = _dist()
-    dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
-    t = torch.as_tensor(np.ascontiguousarray(arr)).to(dev)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    return t.cpu().numpy()
-
-
-def sharded_piv(load_frames: Callable[[int, int], np.ndarray], n_pairs: int, window_size, overlap,
-                compute: Optional[Callable] = None, signal_threshold=None, group=None) -> np.ndarray:
+def sharded_piv(load_frames: Callable[[int, int], np.ndarray], n_pairs: int, window_size, overlap, comm,
+                compute: Optional[Callable] = None, signal_threshold=None, align: Optional[int] = None) -> np.ndarray:
     """Every rank computes its pair block and all ranks receive the full (4, n_pairs, n_rows, n_cols) block.
 
     ``load_frames(start, stop)`` returns frames [start, stop) as (T, H, W) -- each rank only ever touches its
-    own time block (+ halo).  ``compute(frames, window_size, overlap, signal_threshold)`` -> (u, v, corr_max,
-    s2n); default is the HIP engine (``pyorc_amd.piv.piv_pairs``).
+    own time block (+ halo).  ``compute(frames, window_size, overlap, signal_threshold, pair_offset=...)`` ->
+    (u, v, corr_max, s2n); default is the HIP engine (``pyorc_amd.piv.piv_pairs``).
     """
-    torch, dist = _dist()
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
     if compute is None:
         from . import piv
 
         compute = piv.piv_pairs
-    f0, f1 = frame_block(n_pairs, rank, world)
+    if align is None:
+        from . import window
+
+        align = window.chunk_alignment(window_size)
+    f0, f1 = frame_block(n_pairs, comm.rank, comm.world, align)
     if f1 - f0 >= 2:
-        u, v, cm, sn = compute(load_frames(f0, f1), window_size, overlap, signal_threshold)
+        u, v, cm, sn = compute(load_frames(f0, f1), window_size, overlap, signal_threshold, pair_offset=f0)
         local = np.stack([u, v, cm, sn]).astype(np.float32)
-        shape = np.array(local.shape[2:], dtype=np.int64)
+        shape = np.array(local.shape[2:], dtype=np.float64)
     else:
-        local, shape = None, np.zeros(2, dtype=np.int64)
+        local, shape = None, np.zeros(2, dtype=np.float64)
     # ranks without pairs (n_pairs < world) learn the grid shape from the others
-    shape = allreduce_max(shape, group)
+    shape = comm.allreduce(shape, MAX)
     if local is None:
         local = np.empty((4, 0, int(shape[0]), int(shape[1])), dtype=np.float32)
-    return gather_blocks(local, n_pairs, group)
-
-
-def allreduce_max(arr: np.ndarray, group=None) -> np.ndarray:
-    torch, dist = _dist()
-    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
-    t = torch.as_tensor(np.ascontiguousarray(arr)).to(dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-    return t.cpu().numpy()
+    return gather_blocks(local, n_pairs, comm, align)
 
 
 def sharded_ensemble(load_frames: Callable[[int, int], np.ndarray], n_pairs: int, make_ensemble: Callable[[], object],
-                     corr_min: float, s2n_min: float, count_min: float, signal_threshold=None, group=None):
+                     corr_min: float, s2n_min: float, count_min: float, comm, signal_threshold=None, n_chunks: int = 1,
+                     align: int = 1):
     """Ensemble correlation over the GPUs of a node (pyorc/velocimetry/ffpiv.py:182-376 sharded in time).
 
     Every rank accumulates its own pair block into its own ensemble object (``make_ensemble()`` -> an object with
     ``accumulate / export_state / import_state / finish``, e.g. ``pyorc_amd.piv.Ensemble``); corr_sum and corr_count
     are summed with ONE all-reduce each; every rank imports the total and finishes, so all ranks return the same
-    (u, v, corr_count, corr_max (P, n_win), s2n (P, n_win)).  ``n_frames`` of the count filter is the number of
-    ranks that contributed a chunk -- the reference counts CHUNKS there (quirk Q3, ffpiv.py:373).
+    (u, v, corr_count, corr_max (P, n_win), s2n (P, n_win)).
+
+    ``n_chunks`` is the ``n_frames`` of the count filter ``corr_count < count_min * n_frames`` -- the reference counts
+    CHUNKS there (quirk Q3, ffpiv.py:373,280-281).  It is an argument (what the single-process chunk planner yields,
+    ``len(velocimetry.plan_chunks(...)[1])``; 1 for a stack that fits one chunk), NOT the number of ranks: which
+    windows survive the filter must not depend on how many GPUs shared the work.
     """
-    torch, dist = _dist()
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
     ens = make_ensemble()
-    f0, f1 = frame_block(n_pairs, rank, world)
+    f0, f1 = frame_block(n_pairs, comm.rank, comm.world, align)
     if f1 - f0 >= 2:
         cm, sn = ens.accumulate(load_frames(f0, f1), corr_min, s2n_min, signal_threshold)
     else:
         cm = sn = None
     s, k = ens.export_state()
-    s = allreduce_sum(s, group)
-    k = allreduce_sum(k, group)
+    s = comm.allreduce(s, SUM)
+    k = comm.allreduce(k, SUM)
     ens.import_state(s, k)
-    n_chunks = int(allreduce_sum(np.array([1.0 if cm is not None else 0.0], dtype=np.float32), group)[0])
     u, v, cnt = ens.finish(count_min, n_chunks)
     n_win = k.size
     local = np.stack([cm, sn]).astype(np.float32)[:, :, None, :] if cm is not None else np.empty((2, 0, 1, n_win), np.float32)
-    per_pair = gather_blocks(local, n_pairs, group)  # (2, n_pairs, 1, n_win)
+    per_pair = gather_blocks(local, n_pairs, comm, align)  # (2, n_pairs, 1, n_win)
     return u, v, cnt, per_pair[0, :, 0], per_pair[1, :, 0]

@@ -1,13 +1,16 @@
 """Mirror of ``pyorc/velocimetry/ffpiv.py`` for ``engine="hip"``.
 
-``get_ffpiv`` keeps the reference's signature, chunk boundaries (time chunks with a 1-frame
-halo, pyorc/velocimetry/ffpiv.py:140), result layout (``s2n``, ``corr``, ``v_x``, ``v_y`` on
+``get_ffpiv`` keeps the reference's signature, time chunking with a 1-frame halo
+(pyorc/velocimetry/ffpiv.py:140), result layout (``s2n``, ``corr``, ``v_x``, ``v_y`` on
 ``(time, y, x)``, time = stamp of the 2nd frame of each pair, float32) and warnings/exceptions,
 but each chunk is ONE fused GPU call instead of cross_corr + numpy reductions +
 u_v_displacement over a materialised (T-1, n_win, wy, wx) volume.
 
 Differences, all deliberate and documented in DESIGN.md:
-  * the chunk size is planned against free HBM, not host RAM;
+  * the chunk size is planned against free HBM, not host RAM, and rounded down to a multiple of
+    ``window.chunk_alignment`` (>= one multiple): chunks then start on the anchors of the time-walking kernels'
+    segments, so the result is the same, bit for bit, whatever chunk size the planner or the user picked -- as in the
+    reference, which computes every window independently;
   * quirk Q1 (user ``chunksize`` raises NameError in the reference, ffpiv.py:127-140) is fixed;
   * quirk Q2 (chunks are computed twice, ffpiv.py:402-408) is not reproduced;
   * quirk Q3 (ensemble ``n_frames`` = number of CHUNKS, ffpiv.py:373) IS reproduced, because it
@@ -107,6 +110,21 @@ def plan_chunks(n_frames: int, req_mem: float, avail_mem: float, chunksize: Opti
     return chunksize, [(a, b) for a, b in slices if b - a >= 2]
 
 
+def aligned_slices(n_frames: int, chunksize: int, align: int, n_win: int = 1):
+    """Frame slices ``[(a, b), ...]`` of chunks whose first PAIR index ``a`` is a multiple of ``align``.
+
+    ``chunksize`` (frames per chunk as planned by :func:`plan_chunks`) is rounded down to a multiple of ``align``
+    pairs, at least one; chunk c owns pairs ``[c C, (c+1) C)`` and reads frames ``[c C, (c+1) C]`` -- the halo frame sits
+    at the end of a chunk instead of at its start (ffpiv.py:140), the union of pairs is the same.
+    """
+    n_pairs = n_frames - 1
+    C = max(align, (int(chunksize) // align) * align)
+    max_pairs = max(1, MAX_WINDOWS_PER_LAUNCH // max(n_win, 1))
+    if C > max_pairs:  # one launch indexes windows with 32 bits: shrink, aligned if possible
+        C = max(1, (max_pairs // align) * align) if max_pairs >= align else max_pairs
+    return [(p, min(p + C, n_pairs) + 1) for p in range(0, n_pairs, C)]
+
+
 def _dataset(data_vars, time, y, x, like):
     if _is_xr(like):
         return xr.Dataset({k: (["time", "y", "x"], v) for k, v in data_vars.items()},
@@ -152,7 +170,8 @@ def get_ffpiv(
     req_mem = window.required_memory(n_frames=n_frames, dim_size=dim_size, window_size=window_size,
                                      overlap=overlap, search_area_size=search_area_size, dtype=dtype)
     avail_mem = window.available_memory() / memory_factor
-    chunksize, slices = plan_chunks(n_frames, req_mem, avail_mem, chunksize, engine, n_win=n_rows * n_cols)
+    chunksize, ref_slices = plan_chunks(n_frames, req_mem, avail_mem, chunksize, engine, n_win=n_rows * n_cols)
+    slices = aligned_slices(n_frames, chunksize, window.chunk_alignment(window_size), n_win=n_rows * n_cols)
     if time is None:
         time = frames["time"] if _is_xr(frames) else np.arange(n_frames)
     dt_arr = np.asarray(_values(dt), dtype=np.float64)
@@ -161,7 +180,10 @@ def get_ffpiv(
     frames_chunks = [frames[a:b] for a, b in slices]
     args = (frames_chunks, slices, y, x, dt_arr, time, res_y, res_x, n_cols, n_rows, window_size, overlap)
     if ensemble_corr:
-        return _get_ffpiv_mean(*args, corr_min, s2n_min, count_min, signal_threshold, like=frames)
+        # quirk Q3 (ffpiv.py:373): the count filter is scaled with the number of CHUNKS -- of the reference's planner
+        # (same formula, fed with HBM figures), not of the aligned chunks actually launched
+        return _get_ffpiv_mean(*args, corr_min, s2n_min, count_min, signal_threshold, like=frames,
+                               n_chunks=len(ref_slices))
     return _get_ffpiv_timestep(*args, signal_threshold, like=frames)
 
 
@@ -174,7 +196,7 @@ def _get_ffpiv_timestep(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_c
         da = load_frame_chunk(frames_chunks[n])
         if len(da) >= 2:  # we need at least one image-pair to do PIV
             nb = a + len(da)  # load_frame_chunk may have dropped trailing frames
-            u, v, corr_max, s2n = piv.piv_pairs(_values(da), window_size, overlap, signal_threshold)
+            u, v, corr_max, s2n = piv.piv_pairs(_values(da), window_size, overlap, signal_threshold, pair_offset=a)
             if u.shape[1:] != (n_rows, n_cols):
                 raise ValueError(f"grid {u.shape[1:]} does not match coordinates ({n_rows}, {n_cols})")
             dt_chunk = dt[a:nb - 1][:, None, None]  # dt.sel(time=da.time[1:]), ffpiv.py:403-404
@@ -197,7 +219,7 @@ def _get_ffpiv_timestep(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_c
 
 
 def _get_ffpiv_mean(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_cols, n_rows, window_size, overlap,
-                    corr_min, s2n_min, count_min, signal_threshold, like=None):
+                    corr_min, s2n_min, count_min, signal_threshold, like=None, n_chunks=None):
     """Ensemble correlation of pyorc/velocimetry/ffpiv.py:182-376; corr_sum / corr_count stay in HBM."""
     dim_size = None
     ens = None
@@ -221,7 +243,8 @@ def _get_ffpiv_mean(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_cols,
             gc.collect()
         if ens is None:
             raise ValueError("no chunk with at least one frame pair")
-        n_frames = len(corr_chunks)  # quirk Q3: number of chunks, not pairs (ffpiv.py:373)
+        # quirk Q3: number of chunks, not pairs (ffpiv.py:373)
+        n_frames = len(corr_chunks) if n_chunks is None else n_chunks
         u, v, corr_count = ens.finish(count_min, n_frames)
     finally:
         if ens is not None:

@@ -69,3 +69,9 @@ def available_memory() -> int:
     free, total = C.c_int64(), C.c_int64()
     _lib.check(_lib.load().lspiv_available_bytes(C.byref(free), C.byref(total)))
     return free.value
+
+
+def chunk_alignment(window_size) -> int:
+    """Frame pairs between two anchors of the time-walking kernels (``lspiv_chunk_alignment``): time chunks that start
+    on a multiple of it reproduce the whole-stack result bit for bit.  1 for per-pair kernels.  Host-only."""
+    return _lib.check(_lib.load().lspiv_chunk_alignment(int(window_size[0]), int(window_size[1])))

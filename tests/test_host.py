@@ -28,7 +28,7 @@ def test_library_exports_every_header_symbol(lib):
         assert hasattr(lib, s), f"{s} declared in include/lspiv.h but not exported by liblspiv_hip.so"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes prototype in pyorc_amd/_lib.py"
     assert sorted(_lib.SIGNATURES) == syms
-    assert lib.lspiv_abi_version() == 1
+    assert lib.lspiv_abi_version() == 2
     assert b"gfx950" in lib.lspiv_version()
 
 
@@ -217,7 +217,7 @@ def test_xarray_branches_of_the_mirrors(monkeypatch):
         importlib.reload(mod)
     try:
         assert V.xr is fake_xarray
-        monkeypatch.setattr(V.piv, "piv_pairs", lambda fr, ws, ov, thr=None: tuple(a.astype(np.float32) for a in c_oracle.piv_pairs(np.asarray(fr), ws, ov, thr)))
+        monkeypatch.setattr(V.piv, "piv_pairs", lambda fr, ws, ov, thr=None, pair_offset=0: tuple(a.astype(np.float32) for a in c_oracle.piv_pairs(np.asarray(fr), ws, ov, thr)))
         monkeypatch.setattr(V.window, "available_memory", lambda: 1e12)
         fr = particle_stack(7, 96, 128, seed=3)
         t = np.arange(7) / 25.0
@@ -260,15 +260,87 @@ def test_prime_factor_size_lists_agree(lib):
     assert all(n % 2 == 0 and n & (n - 1) for n in sizes_h)        # even, not a power of two
 
 
-def test_walking_segment_length_minimises_rounds_times_iterations(lib):
-    """Host heuristic of the time-walking kernels (common.h::walk_segment_length): jobs = n_win * n_seg run in rounds of
-    `slots`, a job of L pairs lasts L // 2 + 1 iterations; odd lengths 3..63 or the whole chunk."""
-    f = lib.lspiv_debug_segment_length
-    cost = lambda n_win, P, slots, L: -(-(n_win * -(-P // L)) // slots) * (L // 2 + 1)
-    for n_win, P, slots in ((7854, 1000, 6144), (7854, 200, 6144), (7854, 50, 6144), (2544, 20, 6144), (14151, 500, 6144),
-                            (7488, 1000, 2048), (31806, 100, 6144), (10476, 3, 16384), (12, 1000, 6144), (7854, 64, 6144)):
-        L = f(n_win, P, slots)
-        cands = [c for c in range(3, 64, 2) if c <= P] + ([P] if P <= 64 else [])
-        assert L in cands and cost(n_win, P, slots, L) == min(cost(n_win, P, slots, c) for c in cands), (n_win, P, slots, L)
-    assert f(7854, 200, 6144) == 29 and cost(7854, 200, 6144, 29) == 135 and cost(7854, 200, 6144, 49) == 175   # the old choice: 49
-    assert f(0, 5, 5) == _lib.LSPIV_EINVAL
+def test_walking_segments_are_anchored_to_the_absolute_pair_index(lib):
+    """common.h::walk_segments: segments start at multiples of the anchor length of pair_offset + local index, so two
+    chunkings with aligned boundaries run the same jobs; an off-anchor chunk gets a shorter first segment."""
+    f = lib.lspiv_debug_segments
+
+    def cut(n_pairs, offset, L):
+        first, n_seg = C.c_int64(), C.c_int64()
+        assert f(n_pairs, offset, L, C.byref(first), C.byref(n_seg)) == 0
+        edges, p = [], 0
+        for s in range(n_seg.value):
+            q = min(p + (first.value if s == 0 else L), n_pairs)
+            edges.append((offset + p, offset + q))
+            p = q
+        assert p == n_pairs
+        return edges
+
+    L = window.chunk_alignment((32, 32))
+    assert L == 25 == window.chunk_alignment((64, 64)) == window.chunk_alignment((24, 24))
+    assert window.chunk_alignment((32, 16)) == 1 and window.chunk_alignment((31, 31)) == 1   # per-pair kernels
+    whole = cut(1000, 0, L)
+    assert whole[0] == (0, 25) and whole[-1] == (975, 1000) and len(whole) == 40
+    for bounds in ([0, 250, 500, 1000], [0, 25, 50, 975, 1000], [0, 100, 1000]):       # aligned chunkings: same segments
+        got = [e for a, b in zip(bounds, bounds[1:]) for e in cut(b - a, a, L)]
+        assert got == whole
+    assert cut(40, 10, L) == [(10, 25), (25, 50)]                                        # off-anchor start: short head
+    assert cut(7, 3, L) == [(3, 10)] and cut(1, 24, L) == [(24, 25)]
+    assert cut(60, 0, 63) == [(0, 60)]
+    assert f(0, 0, 25, None, None) == _lib.LSPIV_EINVAL
+
+
+def test_aligned_chunk_slices_cover_every_pair_once():
+    for n_frames, cs, align in [(1001, 334, 25), (1001, 5, 25), (21, 21, 25), (101, 50, 25), (77, 26, 1), (3, 5, 25), (52, 26, 25)]:
+        sl = velocimetry.aligned_slices(n_frames, cs, align)
+        assert sl[0][0] == 0 and sl[-1][1] == n_frames
+        assert all(a % align == 0 and b - a >= 2 for a, b in sl)
+        assert all(sl[i][1] - 1 == sl[i + 1][0] for i in range(len(sl) - 1))      # one shared (halo) frame
+        assert sum(b - a - 1 for a, b in sl) == n_frames - 1
+        assert all((b - a - 1) % align == 0 for a, b in sl[:-1])
+        assert max(b - a - 1 for a, b in sl) <= max(align, cs)
+    sl = velocimetry.aligned_slices(1001, 1001, 25, n_win=2**29)   # 32-bit window index per launch
+    assert all(b - a - 1 <= 3 for a, b in sl)
+
+
+def test_shard_blocks_start_on_anchors():
+    for n, w, al in [(8000, 8, 25), (1000, 8, 25), (1000, 3, 25), (30, 4, 25), (999, 2, 25), (100, 8, 1)]:
+        blocks = [shard.pair_block(n, r, w, al) for r in range(w)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == n
+        assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
+        assert all(a % al == 0 for a, b in blocks if b > a)
+        assert sorted(shard.block_sizes(n, w, al)) == sorted(b - a for a, b in blocks)
+    assert shard.block_sizes(8000, 8, 25) == [1000] * 8
+
+
+def test_product_has_no_torch_dependency():
+    """The multi-GPU path goes through lspiv_comm_* (RCCL dlopen'ed by the C library): nothing under pyorc_amd/ or in
+    bench.py imports torch (two HIP runtimes in one process was round 1's hazard)."""
+    files = [os.path.join(ROOT, "bench.py")]
+    for dirpath, _, names in os.walk(os.path.join(ROOT, "pyorc_amd")):
+        files += [os.path.join(dirpath, f) for f in names if f.endswith(".py")]
+    for f in files:
+        txt = open(f).read()
+        assert not re.search(r"^\s*(import torch|from torch)", txt, flags=re.M), f
+    code = "import sys; import pyorc_amd, pyorc_amd.comm, pyorc_amd.shard, pyorc_amd.velocimetry; assert 'torch' not in sys.modules"
+    subprocess.check_call([sys.executable, "-c", code], cwd=ROOT)
+
+
+def test_comm_argument_errors(lib):
+    h = C.c_void_p()
+    buf = C.create_string_buffer(128)
+    assert lib.lspiv_comm_unique_id(7, buf) == _lib.LSPIV_EINVAL
+    assert lib.lspiv_comm_unique_id(1, buf) == 0 and buf.raw[:8] == b"LSPIVSHM" and any(buf.raw[8:32])
+    assert lib.lspiv_comm_init(2, 2, buf, 1, C.byref(h)) == _lib.LSPIV_EINVAL
+    assert lib.lspiv_comm_init(0, 1, C.create_string_buffer(128), 1, C.byref(h)) == _lib.LSPIV_EINVAL   # not an shm id
+    assert lib.lspiv_comm_init(0, 1, buf, 1, C.byref(h)) == 0
+    r, w, t, n = C.c_int(-1), C.c_int(-1), C.c_int(-1), C.c_int(-1)
+    assert lib.lspiv_comm_info(h, C.byref(r), C.byref(w), C.byref(t), C.byref(n)) == 0
+    assert (r.value, w.value, t.value, n.value) == (0, 1, 1, 1)
+    a = np.arange(6, dtype=np.float32)
+    out = np.empty(6, np.float32)
+    assert lib.lspiv_comm_allreduce(h, _lib.ptr(a), _lib.ptr(out), 6, 1, 0) == 0 and np.array_equal(out, a)
+    assert lib.lspiv_comm_allreduce(h, _lib.ptr(a), _lib.ptr(out), 6, 0, 0) == _lib.LSPIV_EINVAL     # uint8: not a collective dtype
+    assert lib.lspiv_comm_allgather(h, _lib.ptr(a), _lib.ptr(out), 6, 1) == 0 and np.array_equal(out, a)
+    assert lib.lspiv_comm_barrier(h) == 0
+    assert lib.lspiv_comm_destroy(h) == 0

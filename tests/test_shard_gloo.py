@@ -1,7 +1,9 @@
-"""World-size-2 (and 3) gloo tests of the multi-GPU path on CPU: shard -> compute -> all-gather.
+"""World-size-2 (and 3) tests of the multi-GPU path on CPU: shard -> compute -> all-gather.
 
-The compute callable is the C oracle here (tests may use it); on the GPU box the same code path runs with the
-HIP engine and backend "nccl" (bench.py --gpus N).
+Two communicators drive the same `pyorc_amd.shard` code: the product one (`pyorc_amd.comm.Comm`, the C ABI's
+lspiv_comm_* entry points -- here over their shared-memory test transport, since RCCL needs GPUs) and a
+`torch.distributed` gloo adapter that lives in this file only.  The compute callable is the C oracle (tests may use
+it); on the GPU box the same code path runs with the HIP engine over RCCL (bench.py --gpus N).
 """
 import os
 import socket
@@ -25,16 +27,46 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _oracle_compute(frames, ws, ov, thr):
+def _oracle_compute(frames, ws, ov, thr, pair_offset=0):
     return c_oracle.piv_pairs(frames, ws, ov, thr, nthreads=1)
 
 
-def _worker(rank, world, port, n_frames, out_dir):
-    import torch.distributed as dist
+class GlooComm:
+    """torch.distributed (gloo) behind the interface of pyorc_amd.comm.Comm -- test-only."""
 
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    def __init__(self, rank, world, port):
+        import torch.distributed as dist
+
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        self.dist, self.rank, self.world = dist, rank, world
+
+    def allgather(self, arr):
+        t = torch.as_tensor(np.ascontiguousarray(arr))
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype)
+        self.dist.all_gather_into_tensor(out.view(-1), t.view(-1))
+        return out.numpy()
+
+    def allreduce(self, arr, op=shard.SUM):
+        t = torch.as_tensor(np.ascontiguousarray(arr).copy())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if op == shard.SUM else self.dist.ReduceOp.MAX)
+        return t.numpy()
+
+    def close(self):
+        self.dist.destroy_process_group()
+
+
+def _make_comm(kind, rank, world, port, out_dir):
+    if kind == "gloo":
+        return GlooComm(rank, world, port)
+    from pyorc_amd.comm import Comm
+
+    return Comm(rank, world, transport="shm", id_file=os.path.join(out_dir, "comm_id"), timeout=60)
+
+
+def _worker(rank, world, port, n_frames, out_dir, kind, align):
+    comm = _make_comm(kind, rank, world, port, out_dir)
     try:
         stack = particle_stack(n_frames, 96, 128, seed=42)
         touched = []
@@ -43,17 +75,19 @@ def _worker(rank, world, port, n_frames, out_dir):
             touched.append((a, b))
             return stack[a:b]
 
-        full = shard.sharded_piv(load, n_frames - 1, WS, OV, compute=_oracle_compute)
-        summed = shard.allreduce_sum(np.full((3, 2), rank + 1.0, np.float32))
-        np.savez(os.path.join(out_dir, f"r{rank}.npz"), full=full, touched=np.array(touched), summed=summed)
+        full = shard.sharded_piv(load, n_frames - 1, WS, OV, comm, compute=_oracle_compute, align=align)
+        summed = comm.allreduce(np.full((3, 2), rank + 1.0, np.float32), shard.SUM)
+        biggest = comm.allreduce(np.array([rank * 1.5], np.float64), shard.MAX)
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), full=full, touched=np.array(touched), summed=summed, biggest=biggest)
     finally:
-        dist.destroy_process_group()
+        comm.close()
 
 
-@pytest.mark.parametrize("world,n_frames", [(2, 7), (2, 6), (3, 3)])
-def test_sharded_piv_equals_single_process(tmp_path, world, n_frames):
+@pytest.mark.parametrize("kind", ["native-shm", "gloo"])
+@pytest.mark.parametrize("world,n_frames,align", [(2, 7, 1), (2, 6, 1), (3, 3, 1), (2, 8, 3), (3, 9, 5)])
+def test_sharded_piv_equals_single_process(tmp_path, world, n_frames, align, kind):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, n_frames, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, n_frames, str(tmp_path), kind, align), nprocs=world, join=True)
     stack = particle_stack(n_frames, 96, 128, seed=42)
     ref = np.stack(_oracle_compute(stack, WS, OV, None))
     n_pairs = n_frames - 1
@@ -61,12 +95,14 @@ def test_sharded_piv_equals_single_process(tmp_path, world, n_frames):
         d = np.load(os.path.join(tmp_path, f"r{r}.npz"))
         assert d["full"].shape == ref.shape
         assert np.array_equal(d["full"], ref, equal_nan=True)  # bit-identical on every rank
-        a, b = shard.frame_block(n_pairs, r, world)
+        a, b = shard.frame_block(n_pairs, r, world, align)
+        assert a % align == 0  # every block starts on an anchor of the time-walking kernels
         if b - a >= 2:
             assert d["touched"].tolist() == [[a, b]]  # a rank reads only its block + one halo frame
         else:
             assert d["touched"].size == 0
         assert np.all(d["summed"] == sum(range(1, world + 1)))
+        assert d["biggest"][0] == (world - 1) * 1.5
 
 
 class OracleEnsemble:
@@ -109,31 +145,26 @@ class OracleEnsemble:
         return u.astype(np.float32), v.astype(np.float32), self.k.astype(np.float32)
 
 
-def _ens_worker(rank, world, port, n_frames, out_dir):
-    import torch.distributed as dist
-
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _ens_worker(rank, world, port, n_frames, out_dir, kind):
+    comm = _make_comm(kind, rank, world, port, out_dir)
     try:
         stack = particle_stack(n_frames, 64, 96, seed=43)
         u, v, cnt, cm, sn = shard.sharded_ensemble(lambda a, b: stack[a:b], n_frames - 1,
-                                                   lambda: OracleEnsemble((64, 96), WS, OV), 0.2, 2.0, 0.2)
+                                                   lambda: OracleEnsemble((64, 96), WS, OV), 0.2, 2.0, 0.2, comm, n_chunks=2)
         np.savez(os.path.join(out_dir, f"e{rank}.npz"), u=u, v=v, cnt=cnt, cm=cm, sn=sn)
     finally:
-        dist.destroy_process_group()
+        comm.close()
 
 
+@pytest.mark.parametrize("kind", ["native-shm", "gloo"])
 @pytest.mark.parametrize("world,n_frames", [(2, 7), (3, 5)])
-def test_sharded_ensemble_equals_single_process(tmp_path, world, n_frames):
+def test_sharded_ensemble_equals_single_process(tmp_path, world, n_frames, kind):
     port = _free_port()
-    mp.spawn(_ens_worker, args=(world, port, n_frames, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_ens_worker, args=(world, port, n_frames, str(tmp_path), kind), nprocs=world, join=True)
     stack = particle_stack(n_frames, 64, 96, seed=43)
     ref = OracleEnsemble((64, 96), WS, OV)
     cm, sn = ref.accumulate(stack, 0.2, 2.0)
-    blocks = [shard.pair_block(n_frames - 1, r, world) for r in range(world)]
-    n_chunks = sum(1 for a, b in blocks if b > a)
-    u, v, cnt = ref.finish(0.2, n_chunks)
+    u, v, cnt = ref.finish(0.2, 2)   # n_chunks is an argument: the count filter does not depend on the world size
     for r in range(world):
         d = np.load(os.path.join(tmp_path, f"e{r}.npz"))
         assert np.array_equal(d["cnt"], cnt) and np.array_equal(d["cm"], cm) and np.array_equal(d["sn"], sn)
