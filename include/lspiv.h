@@ -69,7 +69,16 @@ int         lspiv_synchronize(void);                    /* hipDeviceSynchronize 
 /* run-time options: "walk" = 1 the default time-walking kernels (segments anchored every lspiv_chunk_alignment pairs of
  * the absolute pair index: results do not depend on the chunking as long as chunks start on such anchors), 0 per-pair
  * kernels (independent of any chunking, ~23 % slower), n > 1 anchor length n, -1 back to the LSPIV_WALK environment
- * variable. */
+ * variable.
+ * Three engine semantics could not be pinned on a real ffpiv run (ffpiv is absent from /root/reference, SURVEY.md
+ * section 8c A5 / A7); each is an option whose default is the oracle's reading, so that matching a real ffpiv is a
+ * one-line default flip (environment presets: LSPIV_BORDER_PEAK, LSPIV_SIGNAL_MODE, LSPIV_SIGNAL_POSITIVE):
+ *   "border_peak"      arg-max of a correlation plane on the plane border (no 3-point fit possible): 0 u = v = NaN
+ *                      (default), 1 the plane centre, i.e. zero displacement (OpenPIV's scalar routine), 2 the integer peak;
+ *   "signal_mode"      signal_threshold (pyorc/velocimetry/ffpiv.py:93-97) scores 0 each window PAIR: both windows need
+ *                      the fraction (default; CHANGELOG 0.9.5 "any of the 2 interrogation window in a window pair"), 1 each
+ *                      window POSITION over all frames of the chunk ("fraction of non-zero pixels in the window stack");
+ *   "signal_positive"  the score counts 0 samples != 0 ("non-zero pixels", default), 1 samples > 0 ("above zero"). */
 int         lspiv_set_option(const char* name, int value);
 int         lspiv_get_option(const char* name, int* value);
 /* which kernel a window size dispatches to: 1 = FFT 32x32, 2 = FFT 64x64, 6 = FFT 8x8 / 16x16, 8 = prime-factor FFT

@@ -54,6 +54,37 @@ import numpy as np
 
 EPS_PEAK = 1e-7  # [FFPIV-RESTATED] eps added to the plane before the log-Gaussian fit (A5)
 
+# The readings of ffpiv that nothing in /root/reference can decide.  The defaults are
+# the oracle's choice; the alternatives exist here AND in the HIP library (lspiv_set_option with the same names and
+# values) so that whichever a real ffpiv turns out to do is a one-line default flip, each covered by a GPU test:
+#   border_peak      0: arg-max on the plane border -> (nan, nan) (OpenPIV's vectorised routine); 1: -> the plane
+#                    centre, i.e. zero displacement (OpenPIV's scalar find_subpixel_peak_position returns
+#                    default_peak_position there); 2: -> the integer peak, no sub-pixel fit
+#   signal_mode      0: signal_threshold scores each window PAIR, both windows must reach the fraction (CHANGELOG.md:57-60
+#                    "any of the 2 interrogation window in a window pair"); 1: one score per window POSITION over the whole
+#                    chunk ("fraction of non-zero pixels in the window stack", pyorc/velocimetry/ffpiv.py:93-97)
+#   signal_positive  0: the score counts samples != 0 ("non-zero pixels"); 1: samples > 0 ("intensities above zero")
+SEMANTICS = {"border_peak": 0, "signal_mode": 0, "signal_positive": 0}
+
+
+class semantics:
+    """``with semantics(border_peak=1): ...`` -- evaluate the oracle under an alternative reading."""
+
+    def __init__(self, **kw):
+        unknown = set(kw) - set(SEMANTICS)
+        if unknown:
+            raise KeyError(f"unknown semantics {sorted(unknown)}")
+        self.kw = kw
+
+    def __enter__(self):
+        self.saved = dict(SEMANTICS)
+        SEMANTICS.update(self.kw)
+        return self
+
+    def __exit__(self, *exc):
+        SEMANTICS.clear()
+        SEMANTICS.update(self.saved)
+
 
 # ----------------------------------------------------------------------------------------------
 # ffpiv.window  [FFPIV-RESTATED]
@@ -166,9 +197,24 @@ def signal_mask(stack_a: np.ndarray, stack_b: np.ndarray, threshold: Optional[fl
     if threshold is None:
         return np.ones(stack_a.shape[:-2], dtype=bool)
     n = stack_a.shape[-1] * stack_a.shape[-2]
-    fa = np.count_nonzero(stack_a, axis=(-2, -1)) / n
-    fb = np.count_nonzero(stack_b, axis=(-2, -1)) / n
+    fa = _count_signal(stack_a) / n
+    fb = _count_signal(stack_b) / n
     return (fa >= threshold) & (fb >= threshold)
+
+
+def _count_signal(stack: np.ndarray) -> np.ndarray:
+    """Samples that count as signal per window: != 0, or > 0 under SEMANTICS["signal_positive"]."""
+    return ((stack > 0) if SEMANTICS["signal_positive"] else (stack != 0)).sum(axis=(-2, -1))
+
+
+def signal_mask_stack(stack: np.ndarray, threshold: Optional[float]) -> np.ndarray:
+    """SEMANTICS["signal_mode"] == 1: one flag per window POSITION, the fraction of signal samples of that position over
+    all frames of the chunk (float32 score like the HIP kernel: count / (T * wy * wx), compared in float32)."""
+    if threshold is None:
+        return np.ones(stack.shape[1], dtype=bool)
+    T, _, wy, wx = stack.shape
+    score = (_count_signal(stack).sum(axis=0).astype(np.float64) / (float(T) * wy * wx)).astype(np.float32)
+    return score >= np.float32(threshold)
 
 
 def cross_corr(imgs, window_size=(64, 64), overlap=(32, 32), search_area_size=None,
@@ -191,8 +237,9 @@ def cross_corr(imgs, window_size=(64, 64), overlap=(32, 32), search_area_size=No
     stack = sliding_window_stack(imgs, window_size, overlap)
     T = imgs.shape[0]
     corr = np.full((T - 1,) + stack.shape[1:], np.nan, dtype=np.float64)
+    keep_pos = signal_mask_stack(stack, signal_threshold) if SEMANTICS["signal_mode"] == 1 else None
     for t in range(T - 1):
-        keep = signal_mask(stack[t], stack[t + 1], signal_threshold)
+        keep = signal_mask(stack[t], stack[t + 1], signal_threshold) if keep_pos is None else keep_pos
         if keep.any():
             corr[t, keep] = ncc(stack[t, keep], stack[t + 1, keep])
     return x, y, corr
@@ -209,7 +256,8 @@ def peak_position(plane: np.ndarray) -> Tuple[float, float]:
     idx = int(np.argmax(plane))
     i, j = idx // wx, idx % wx
     if i == 0 or i == wy - 1 or j == 0 or j == wx - 1:
-        return np.nan, np.nan
+        mode = 0 if np.isnan(plane[i, j]) else SEMANTICS["border_peak"]   # a NaN plane stays NaN in every mode
+        return (np.nan, np.nan) if mode == 0 else (float(wy // 2), float(wx // 2)) if mode == 1 else (float(i), float(j))
     c = plane[i, j] + EPS_PEAK
     cl = plane[i - 1, j] + EPS_PEAK
     cr = plane[i + 1, j] + EPS_PEAK
@@ -263,6 +311,13 @@ def u_v_displacement(corr: np.ndarray, n_rows: int, n_cols: int, engine: str = "
     vf = np.full(P * n_win, np.nan)
     uf[r] = jj + dj - cj
     vf[r] = ii + di - ci
+    edge = ~ok & ~np.isnan(flat[np.arange(flat.shape[0]), idx])   # a NaN plane (skipped window) stays NaN in every mode
+    if SEMANTICS["border_peak"] == 1:      # plane centre: zero displacement
+        uf[edge] = 0.0
+        vf[edge] = 0.0
+    elif SEMANTICS["border_peak"] == 2:    # integer peak
+        uf[edge] = (j - cj)[edge]
+        vf[edge] = (i - ci)[edge]
     return uf.reshape(P, n_rows, n_cols), vf.reshape(P, n_rows, n_cols)
 
 

@@ -55,6 +55,11 @@ struct PivParams {
   uint32_t n_win;          // n_rows * n_cols
   uint32_t n_tiles;        // (T-1) * n_win
   float signal_threshold;  // < 0: off
+  // the three choices of the engine the oracle could not pin on a real ffpiv run, as
+  // run-time options so that the default can follow whatever ffpiv turns out to do (lspiv_set_option)
+  int border_mode;         // arg-max on the plane border: 0 NaN (default), 1 the plane centre (zero displacement), 2 the integer peak
+  int nz_positive;         // signal score counts samples != 0 (0, default) or > 0 (1)
+  const uint8_t* win_keep; // nullptr, or n_win flags of the "stack" signal mode: 0 = this window position is dropped
   float* u;                // each n_tiles float32
   float* v;
   float* cmax;
@@ -202,6 +207,14 @@ __device__ __forceinline__ float row_max(float x) {
 
 constexpr float kEpsPeak = 1e-7f;
 
+// what u, v become when the arg-max sits on the plane border (no 3-point fit possible there): (dx, dy) = the integer
+// peak minus the plane centre
+__device__ __forceinline__ void border_result(int mode, int dx, int dy, float& u, float& v) {
+  const float nanv = __builtin_nanf("");
+  u = mode == 0 ? nanv : mode == 1 ? 0.0f : (float)dx;
+  v = mode == 0 ? nanv : mode == 1 ? 0.0f : (float)dy;
+}
+
 // element -> float conversion of the three frame dtypes
 __device__ __forceinline__ float to_f32(uint8_t x) { return (float)x; }
 __device__ __forceinline__ float to_f32(float x) { return x; }
@@ -224,8 +237,10 @@ hipError_t launch_piv_direct(const PivParams& p, int dtype, bool ensemble, hipSt
 hipError_t launch_piv_embed16(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 hipError_t launch_piv_embed32(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 hipError_t launch_piv_embed64(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
-hipError_t launch_peaks_from_planes(const float* planes, uint32_t n_planes, int wy, int wx,
+hipError_t launch_peaks_from_planes(const float* planes, uint32_t n_planes, int wy, int wx, int border_mode,
                                     float* u, float* v, hipStream_t s);
+// "stack" signal mode: keep[w] = fraction of non-zero (or positive) samples of window position w over ALL frames >= thr
+hipError_t launch_window_signal(const void* frames, int dtype, int64_t T, const PivParams& p, float thr, uint8_t* keep, hipStream_t s);
 // mean[w][o] = count[w] < min_count ? NaN : sum[w][o] / count[w]   (pyorc/velocimetry/ffpiv.py:280-282)
 // LSPIV_WALK as an integer (0 per-pair kernels, 1 default walking kernels, n > 1 forced segment length): the value set
 // through lspiv_set_option("walk", v) if any, else the environment variable read at every launch, else 1

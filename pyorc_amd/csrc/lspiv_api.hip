@@ -81,6 +81,7 @@ struct DeviceCtx {
   float* d_out = nullptr;    size_t out_cap = 0;
   float* d_planes = nullptr; size_t planes_cap = 0;
   void* d_scratch = nullptr; size_t scratch_cap = 0;   // temporaries of *_dev entry points (normalize)
+  uint8_t* d_keep = nullptr; size_t keep_cap = 0;      // per-window flags of the "stack" signal mode
   void* pinned[2] = {nullptr, nullptr}; size_t pinned_cap = 0;  // H2D staging ring
   hipEvent_t staged[2] = {nullptr, nullptr};
   bool arch_ok = false;
@@ -210,6 +211,17 @@ int upload_stack(DeviceCtx* c, const void* frames, int dtype, int64_t T, int64_t
   return LSPIV_OK;
 }
 
+// the engine semantics that could not be pinned on a real ffpiv run: run-time options,
+// defaults = the oracle's reading; LSPIV_BORDER_PEAK / LSPIV_SIGNAL_MODE / LSPIV_SIGNAL_POSITIVE preset them
+int env_opt(const char* name, int lo, int hi) {
+  const char* e = getenv(name);
+  const int v = e ? atoi(e) : 0;
+  return v < lo || v > hi ? 0 : v;
+}
+std::atomic<int> g_opt_border{env_opt("LSPIV_BORDER_PEAK", 0, 2)};        // 0 NaN, 1 plane centre, 2 integer peak
+std::atomic<int> g_opt_signal_mode{env_opt("LSPIV_SIGNAL_MODE", 0, 1)};   // 0 per window pair, 1 per window position over the chunk
+std::atomic<int> g_opt_signal_pos{env_opt("LSPIV_SIGNAL_POSITIVE", 0, 1)}; // 0 samples != 0, 1 samples > 0
+
 int fill_params(lspiv::PivParams* p, const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, int wy, int wx,
                 int oy, int ox, float signal_threshold, const Grid& g) {
   if (dtype < 0 || dtype > 2) return fail(LSPIV_EINVAL, "dtype %d not in {0:u8, 1:f32, 2:f64}", dtype);
@@ -230,6 +242,8 @@ int fill_params(lspiv::PivParams* p, const void* d_frames, int dtype, int64_t T,
   p->n_tiles = (uint32_t)n_tiles;
   p->n_pairs = (uint32_t)(T - 1);
   p->signal_threshold = signal_threshold;
+  p->border_mode = g_opt_border.load();
+  p->nz_positive = g_opt_signal_pos.load();
   p->div_ncols = lspiv::FastDiv::make((uint32_t)g.n_cols);
   p->div_jobs = lspiv::FastDiv::make((uint32_t)((n_win + 1) / 2));
   p->div_nwin = lspiv::FastDiv::make((uint32_t)n_win);
@@ -294,6 +308,18 @@ struct lspiv_ensemble {
 };
 
 static std::atomic<int> g_opt_walk{-1};   // lspiv_set_option("walk", v); -1: not set, fall back to the environment
+// "stack" signal mode: one pass over the chunk's frames leaves a keep flag per window position; the PIV kernels then run
+// their threshold path with a pair threshold that always passes and consult the flags instead
+static int apply_signal_mode(DeviceCtx* c, lspiv::PivParams* p, int dtype, hipStream_t s) {
+  if (g_opt_signal_mode.load() != 1 || p->signal_threshold < 0.0f) return LSPIV_OK;
+  int rc = ensure(&c->d_keep, &c->keep_cap, (size_t)p->n_win);
+  if (rc) return rc;
+  hipError_t e = lspiv::launch_window_signal(p->frames, dtype, (int64_t)p->n_pairs + 1, *p, p->signal_threshold, c->d_keep, s);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  p->win_keep = c->d_keep;
+  p->signal_threshold = 0.0f;
+  return LSPIV_OK;
+}
 uint32_t lspiv::job_slots(int waves_per_simd, int groups) {
   static const int cus = [] {
     int dev = 0;
@@ -349,11 +375,29 @@ int lspiv_set_option(const char* name, int value) {
     g_opt_walk.store(value);
     return LSPIV_OK;
   }
+  if (strcmp(name, "border_peak") == 0) {
+    if (value < 0 || value > 2) return fail(LSPIV_EINVAL, "border_peak must be 0 (NaN), 1 (plane centre) or 2 (integer peak)");
+    g_opt_border.store(value);
+    return LSPIV_OK;
+  }
+  if (strcmp(name, "signal_mode") == 0) {
+    if (value < 0 || value > 1) return fail(LSPIV_EINVAL, "signal_mode must be 0 (per window pair) or 1 (per window position over the chunk)");
+    g_opt_signal_mode.store(value);
+    return LSPIV_OK;
+  }
+  if (strcmp(name, "signal_positive") == 0) {
+    if (value < 0 || value > 1) return fail(LSPIV_EINVAL, "signal_positive must be 0 (samples != 0) or 1 (samples > 0)");
+    g_opt_signal_pos.store(value);
+    return LSPIV_OK;
+  }
   return fail(LSPIV_EINVAL, "unknown option '%s'", name);
 }
 int lspiv_get_option(const char* name, int* value) {
   if (!name || !value) return fail(LSPIV_EINVAL, "NULL argument");
   if (strcmp(name, "walk") == 0) { *value = lspiv::walk_setting(); return LSPIV_OK; }
+  if (strcmp(name, "border_peak") == 0) { *value = g_opt_border.load(); return LSPIV_OK; }
+  if (strcmp(name, "signal_mode") == 0) { *value = g_opt_signal_mode.load(); return LSPIV_OK; }
+  if (strcmp(name, "signal_positive") == 0) { *value = g_opt_signal_pos.load(); return LSPIV_OK; }
   return fail(LSPIV_EINVAL, "unknown option '%s'", name);
 }
 
@@ -455,7 +499,10 @@ int lspiv_piv_pairs_dev_at(const void* d_frames, int dtype, int64_t T, int64_t H
   p.cmax = d_out + 2 * (size_t)p.n_tiles;
   p.s2n = d_out + 3 * (size_t)p.n_tiles;
   p.planes = d_corr_planes;
-  return dispatch(p, dtype, false, stream ? (hipStream_t)stream : c->stream);
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  rc = apply_signal_mode(c, &p, dtype, s);
+  if (rc) return rc;
+  return dispatch(p, dtype, false, s);
 }
 
 int lspiv_piv_pairs_dev(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, int wy, int wx, int oy,
@@ -503,6 +550,8 @@ int lspiv_piv_pairs_at(const void* frames, int dtype, int64_t T, int64_t H, int6
   const int64_t fpb = std::max<int64_t>(1, (int64_t)(c->pinned_cap / frame_bytes));
   const bool src_pinned = dtype != LSPIV_F64 && is_pinned(frames);
   const int64_t align = std::max(1, lspiv_chunk_alignment(wy, wx));
+  // "stack" signal mode scores a window position over ALL frames of the chunk: one launch once everything is resident
+  const bool whole_chunk_only = g_opt_signal_mode.load() == 1 && signal_threshold >= 0.0f;
   int64_t launched = 0;   // pairs [0, launched) have been issued
   int batch = 0;
   for (int64_t f0 = 0; f0 < T; ++batch) {
@@ -523,7 +572,7 @@ int lspiv_piv_pairs_at(const void* frames, int dtype, int64_t T, int64_t H, int6
     HIP_TRY(hipStreamWaitEvent(c->stream, c->staged[slot], 0));
     // pairs whose two frames are resident: [0, f1 - 1); issue up to the last anchor below that (everything at the end)
     int64_t p1 = f1 - 1;
-    if (f1 < T) p1 = ((pair_offset + p1) / align) * align - pair_offset;
+    if (f1 < T) p1 = whole_chunk_only ? 0 : ((pair_offset + p1) / align) * align - pair_offset;
     const int64_t p0 = launched;
     if (p1 > p0) {
       lspiv::PivParams p = base;
@@ -536,6 +585,8 @@ int lspiv_piv_pairs_at(const void* frames, int dtype, int64_t T, int64_t H, int6
       p.cmax = c->d_out + 2 * n_tiles + p0 * n_win;
       p.s2n = c->d_out + 3 * n_tiles + p0 * n_win;
       p.planes = corr_planes ? c->d_planes + (size_t)p0 * n_win * wy * wx : nullptr;
+      rc = apply_signal_mode(c, &p, dev_dtype, c->stream);
+      if (rc) return rc;
       rc = dispatch(p, dev_dtype, false, c->stream);
       if (rc) return rc;
       launched = p1;
@@ -574,7 +625,7 @@ int lspiv_u_v_displacement(const float* corr_planes, int64_t P, int64_t n_win, i
   rc = ensure(&c->d_out, &c->out_cap, 2 * (size_t)n * sizeof(float));
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(c->d_planes, corr_planes, pb, hipMemcpyHostToDevice, c->stream));
-  hipError_t e = lspiv::launch_peaks_from_planes(c->d_planes, (uint32_t)n, wy, wx, c->d_out, c->d_out + n, c->stream);
+  hipError_t e = lspiv::launch_peaks_from_planes(c->d_planes, (uint32_t)n, wy, wx, g_opt_border.load(), c->d_out, c->d_out + n, c->stream);
   if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
   HIP_TRY(hipMemcpyAsync(u, c->d_out, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(v, c->d_out + n, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -638,6 +689,8 @@ static int ensemble_launch(lspiv_ensemble* h, DeviceCtx* c, const void* d_frames
     p.part_sum = h->d_part;
     p.part_cnt = h->d_part + (size_t)p.n_seg * p.n_win * plane;
   }
+  rc = apply_signal_mode(c, &p, dtype, s);
+  if (rc) return rc;
   return dispatch(p, dtype, true, s);
 }
 
@@ -693,7 +746,7 @@ int lspiv_ensemble_accumulate(lspiv_ensemble* h, const void* frames, int dtype, 
       HIP_TRY(hipStreamWaitEvent(c->stream, c->staged[slot], 0));
       // pairs [0, f1 - 1) are resident; accumulate up to the last segment anchor below that (everything at the end)
       int64_t p1 = f1 - 1;
-      if (f1 < T) p1 = ((base_offset + p1) / align) * align - base_offset;
+      if (f1 < T) p1 = (g_opt_signal_mode.load() == 1 && signal_threshold >= 0.0f) ? 0 : ((base_offset + p1) / align) * align - base_offset;
       const int64_t p0 = launched;
       if (p1 > p0) {
         rc = ensemble_launch(h, c, (const char*)c->d_frames + (size_t)p0 * frame_bytes, dev_dtype, p1 - p0 + 1, corr_min, s2n_min,
@@ -726,7 +779,7 @@ int lspiv_ensemble_finish(lspiv_ensemble* h, float count_min, float n_frames, fl
   hipError_t e = lspiv::launch_ensemble_mean(h->d_sum, h->d_count, count_min * n_frames, (uint32_t)n_win,
                                              h->wy * h->wx, c->d_planes, c->stream);
   if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
-  e = lspiv::launch_peaks_from_planes(c->d_planes, (uint32_t)n_win, h->wy, h->wx, c->d_out, c->d_out + n_win, c->stream);
+  e = lspiv::launch_peaks_from_planes(c->d_planes, (uint32_t)n_win, h->wy, h->wx, g_opt_border.load(), c->d_out, c->d_out + n_win, c->stream);
   if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
   HIP_TRY(hipMemcpyAsync(u, c->d_out, n_win * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(v, c->d_out + n_win, n_win * sizeof(float), hipMemcpyDeviceToHost, c->stream));

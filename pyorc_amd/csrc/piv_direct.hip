@@ -67,7 +67,7 @@ __device__ __forceinline__ int block_sum_i(int v, int* red) {
 // Returns 1/std (0 if std == 0).
 template <typename T>
 __device__ __forceinline__ float stage_window(const T* src, int W, int wy, int wx, float* dst, int pitch, bool periodic,
-                                              float* red, int& nonzero, bool& finite) {
+                                              bool nz_pos, float* red, int& nonzero, bool& finite) {
   const int n = wy * wx;
   const float x0 = to_f32(src[0]);
   float s = 0.0f;
@@ -77,7 +77,7 @@ __device__ __forceinline__ float stage_window(const T* src, int W, int wy, int w
     const float v = to_f32(src[(int64_t)y * W + x]);
     dst[y * pitch + x] = v;
     s += v - x0;
-    nz += (v != 0.0f) ? 1 : 0;
+    nz += (nz_pos ? v > 0.0f : v != 0.0f) ? 1 : 0;
   }
   nonzero = block_sum_i(nz, reinterpret_cast<int*>(red));
   const float mean = x0 + block_sum(s, red) / (float)n;
@@ -164,10 +164,10 @@ __device__ __forceinline__ void plane_reduce(const float* plane, int n, float* r
 
 // sub-pixel peak of a plane addressed through `ld` (LDS or global), flat argmax index imax
 template <typename F>
-__device__ __forceinline__ void subpixel_generic(F ld, int wy, int wx, int imax, float& u, float& v) {
+__device__ __forceinline__ void subpixel_generic(F ld, int wy, int wx, int imax, int border_mode, float& u, float& v) {
   const int i = imax / wx, j = imax - i * wx;
   if (i <= 0 || i >= wy - 1 || j <= 0 || j >= wx - 1) {
-    u = v = __builtin_nanf("");
+    border_result(border_mode, j - wx / 2, i - wy / 2, u, v);
     return;
   }
   // same arithmetic as the fused FFT kernels (hardware log2 -- the fit is a ratio of log differences -- and a
@@ -192,13 +192,14 @@ __device__ __forceinline__ bool direct_pair(const PivParams& p, uint32_t pair, u
   const int64_t off = ((int64_t)pair * p.H + (int64_t)wrow * p.sy) * p.W + (int64_t)wcol * p.sx;
   int nza, nzb;
   bool finite = true;
-  const float inv_a = stage_window(frames + off, p.W, p.wy, p.wx, a, p.wx, false, red, nza, finite);
-  const float inv_b = stage_window(frames + off + p.frame_elems, p.W, p.wy, p.wx, b2, g.bpitch, true, red, nzb, finite);
+  const float inv_a = stage_window(frames + off, p.W, p.wy, p.wx, a, p.wx, false, p.nz_positive != 0, red, nza, finite);
+  const float inv_b = stage_window(frames + off + p.frame_elems, p.W, p.wy, p.wx, b2, g.bpitch, true, p.nz_positive != 0, red, nzb, finite);
   __syncthreads();
   bool ok = finite;
   if (p.signal_threshold >= 0.0f) {
     const float fa = (float)nza / (float)g.n, fb = (float)nzb / (float)g.n;
     ok = ok && (fa >= p.signal_threshold) && (fb >= p.signal_threshold);
+    if (p.win_keep) ok = ok && p.win_keep[win];   // "stack" mode: one score per window position (A7)
   }
   correlate_direct(a, b2, plane, p.wy, p.wx, g, inv_a * inv_b / (float)g.n);
   __syncthreads();
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(DBLOCK_MAX) void piv_direct_kernel(PivParams p) {
   float vmax, sum, u, v;
   int imax;
   plane_reduce(plane, g.n, red, vmax, imax, sum);
-  subpixel_generic([&](int o) { return plane[o]; }, p.wy, p.wx, imax, u, v);
+  subpixel_generic([&](int o) { return plane[o]; }, p.wy, p.wx, imax, p.border_mode, u, v);
   float cm = vmax, sn = vmax / (sum / (float)g.n);
   if (!ok) u = v = cm = sn = __builtin_nanf("");
   if (threadIdx.x == 0) {
@@ -293,7 +294,7 @@ hipError_t launch_piv_direct(const PivParams& p, int dtype, bool ensemble, hipSt
 
 // ---- ffpiv.u_v_displacement on a plane volume in HBM (pyorc/velocimetry/ffpiv.py:324,471) ------
 // np.argmax semantics: first maximum in row-major order, NaN counts as maximum.
-__global__ __launch_bounds__(64) void peaks_kernel(const float* planes, uint32_t n_planes, int wy, int wx,
+__global__ __launch_bounds__(64) void peaks_kernel(const float* planes, uint32_t n_planes, int wy, int wx, int border_mode,
                                                    float* u, float* v) {
   const uint32_t g = blockIdx.x;
   const int lane = threadIdx.x;
@@ -308,14 +309,57 @@ __global__ __launch_bounds__(64) void peaks_kernel(const float* planes, uint32_t
   }
   wave_argmax(best, bi);
   float uu, vv;
-  subpixel_generic([&](int o) { return pl[o]; }, wy, wx, bi, uu, vv);
+  // a NaN plane (a window skipped by the signal threshold) stays NaN whatever the border mode
+  subpixel_generic([&](int o) { return pl[o]; }, wy, wx, bi, pl[bi] != pl[bi] ? 0 : border_mode, uu, vv);
   if (lane == 0) { u[g] = uu; v[g] = vv; }
 }
 
-hipError_t launch_peaks_from_planes(const float* planes, uint32_t n_planes, int wy, int wx, float* u, float* v,
+hipError_t launch_peaks_from_planes(const float* planes, uint32_t n_planes, int wy, int wx, int border_mode, float* u, float* v,
                                     hipStream_t s) {
   if (n_planes == 0) return hipSuccess;
-  hipLaunchKernelGGL(peaks_kernel, dim3(n_planes), dim3(64), 0, s, planes, n_planes, wy, wx, u, v);
+  hipLaunchKernelGGL(peaks_kernel, dim3(n_planes), dim3(64), 0, s, planes, n_planes, wy, wx, border_mode, u, v);
+  return hipGetLastError();
+}
+
+// ---- "stack" signal mode (second reading of pyorc/velocimetry/ffpiv.py:93-97) ----------
+// One score per window POSITION: the fraction of non-zero (or positive) samples of that window over all T frames of the
+// chunk; positions below the threshold are dropped for every pair.  One block per window position, exact integer count.
+template <typename T>
+__global__ __launch_bounds__(256) void window_signal_kernel(const T* frames, int64_t n_frames, PivParams p, float thr,
+                                                            uint8_t* keep) {
+  __shared__ int red[8];
+  const uint32_t win = blockIdx.x;
+  const uint32_t wrow = win / (uint32_t)p.n_cols, wcol = win - wrow * (uint32_t)p.n_cols;
+  const T* base = frames + (int64_t)wrow * p.sy * p.W + (int64_t)wcol * p.sx;
+  const int n = p.wy * p.wx;
+  unsigned long long cnt = 0;
+  for (int64_t f = 0; f < n_frames; ++f) {
+    const T* src = base + f * p.frame_elems;
+    for (int o = threadIdx.x; o < n; o += blockDim.x) {
+      const int y = o / p.wx, x = o - y * p.wx;
+      const float v = to_f32(src[(int64_t)y * p.W + x]);
+      cnt += (p.nz_positive ? v > 0.0f : v != 0.0f) ? 1 : 0;
+    }
+  }
+  // counts fit 32 bits per lane for any realistic chunk; reduce in two steps to stay exact
+  int lo = (int)(cnt & 0xffffu), hi = (int)(cnt >> 16);
+  lo = block_sum_i(lo, red);
+  __syncthreads();
+  hi = block_sum_i(hi, red);
+  if (threadIdx.x == 0) {
+    const double total = (double)hi * 65536.0 + (double)lo;
+    const float score = (float)(total / ((double)n_frames * (double)n));
+    keep[win] = score >= thr ? 1 : 0;
+  }
+}
+
+hipError_t launch_window_signal(const void* frames, int dtype, int64_t T, const PivParams& p, float thr, uint8_t* keep, hipStream_t s) {
+  switch (dtype) {
+    case 0: hipLaunchKernelGGL(window_signal_kernel<uint8_t>, dim3(p.n_win), dim3(256), 0, s, (const uint8_t*)frames, T, p, thr, keep); break;
+    case 1: hipLaunchKernelGGL(window_signal_kernel<float>, dim3(p.n_win), dim3(256), 0, s, (const float*)frames, T, p, thr, keep); break;
+    case 2: hipLaunchKernelGGL(window_signal_kernel<double>, dim3(p.n_win), dim3(256), 0, s, (const double*)frames, T, p, thr, keep); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

@@ -241,13 +241,13 @@ __device__ __forceinline__ void center_u8(const RowRaw<uint8_t, N>& raw, float m
 
 // float rows: pairwise sum (a constant window gives its value, hence zero variance, exactly)
 template <int N>
-__device__ __forceinline__ float center_clip_f(float (&x)[N], bool want_nz, int& nonzero, bool& finite) {
+__device__ __forceinline__ float center_clip_f(float (&x)[N], bool want_nz, bool nz_pos, int& nonzero, bool& finite) {
   constexpr float inv_nn = 1.0f / Geo<N>::NN;
   const bool active = lane_active<N>(group_lane<N>());   // constant true for the power-of-two sizes
   if (want_nz) {
     int c = 0;
 #pragma unroll
-    for (int k = 0; k < N; ++k) c += (x[k] != 0.0f) ? 1 : 0;
+    for (int k = 0; k < N; ++k) c += (nz_pos ? x[k] > 0.0f : x[k] != 0.0f) ? 1 : 0;   // "non-zero" | "above zero" (A7)
     nonzero = group_sum_i<N>(active ? c : 0);
   }
   if constexpr (!Geo<N>::POW2) {   // N^2 is no power of two: shifted mean, so a constant window has exactly zero variance
@@ -270,25 +270,25 @@ __device__ __forceinline__ float center_clip_f(float (&x)[N], bool want_nz, int&
   return var > 0.0f ? __builtin_amdgcn_rsqf(var) : 0.0f;
 }
 template <int N>
-__device__ __forceinline__ float load_center(const RowRaw<float, N>& raw, float (&x)[N], bool want_nz, int& nonzero,
-                                             bool& finite) {
+__device__ __forceinline__ float load_center(const RowRaw<float, N>& raw, float (&x)[N], bool want_nz, bool nz_pos,
+                                             int& nonzero, bool& finite) {
 #pragma unroll
   for (int k = 0; k < N / 4; ++k) {
     const f32x4 v = *reinterpret_cast<const f32x4_u*>(raw.p + 4 * k);
     x[4 * k + 0] = v[0]; x[4 * k + 1] = v[1]; x[4 * k + 2] = v[2]; x[4 * k + 3] = v[3];
   }
   if constexpr (N % 4 == 2) { x[N - 2] = raw.p[N - 2]; x[N - 1] = raw.p[N - 1]; }
-  return center_clip_f<N>(x, want_nz, nonzero, finite);
+  return center_clip_f<N>(x, want_nz, nz_pos, nonzero, finite);
 }
 template <int N>
-__device__ __forceinline__ float load_center(const RowRaw<double, N>& raw, float (&x)[N], bool want_nz, int& nonzero,
-                                             bool& finite) {
+__device__ __forceinline__ float load_center(const RowRaw<double, N>& raw, float (&x)[N], bool want_nz, bool nz_pos,
+                                             int& nonzero, bool& finite) {
 #pragma unroll
   for (int k = 0; k < N / 2; ++k) {
     const f64x2 v = *reinterpret_cast<const f64x2_u*>(raw.p + 2 * k);
     x[2 * k + 0] = (float)v[0]; x[2 * k + 1] = (float)v[1];
   }
-  return center_clip_f<N>(x, want_nz, nonzero, finite);
+  return center_clip_f<N>(x, want_nz, nz_pos, nonzero, finite);
 }
 
 // Both windows of a pair -> xr = a'' (mean-offset, zero-clipped), xi = rho b''.
@@ -316,8 +316,8 @@ __device__ __forceinline__ bool below_threshold(int nza, int nzb, float thr) {
 }
 template <int N>
 __device__ __forceinline__ void prepare_pair(const RowRaw<uint8_t, N>& ra, const RowRaw<uint8_t, N>& rb,
-                                             float (&xr)[N], float (&xi)[N], bool want_nz, float thr, float& scale,
-                                             float& hi, bool& skip) {
+                                             float (&xr)[N], float (&xi)[N], bool want_nz, float thr, bool /*nz_pos*/,
+                                             float& scale, float& hi, bool& skip) {
   int nza = Geo<N>::NN, nzb = Geo<N>::NN;
   const RowStats sa = stats_u8<N>(ra, want_nz, nza);
   const RowStats sb = stats_u8<N>(rb, want_nz, nzb);
@@ -329,12 +329,12 @@ __device__ __forceinline__ void prepare_pair(const RowRaw<uint8_t, N>& ra, const
 }
 template <typename T, int N>
 __device__ __forceinline__ void prepare_pair(const RowRaw<T, N>& ra, const RowRaw<T, N>& rb, float (&xr)[N],
-                                             float (&xi)[N], bool want_nz, float thr, float& scale, float& hi,
-                                             bool& skip) {
+                                             float (&xi)[N], bool want_nz, float thr, bool nz_pos, float& scale,
+                                             float& hi, bool& skip) {
   bool finite = true;
   int nza = Geo<N>::NN, nzb = Geo<N>::NN;
-  const float inv_a = load_center<N>(ra, xr, want_nz, nza, finite);
-  const float inv_b = load_center<N>(rb, xi, want_nz, nzb, finite);
+  const float inv_a = load_center<N>(ra, xr, want_nz, nz_pos, nza, finite);
+  const float inv_b = load_center<N>(rb, xi, want_nz, nz_pos, nzb, finite);
   float rho;
   finish_pair<N>(inv_a, inv_b, rho, scale, hi);
 #pragma unroll
@@ -368,8 +368,8 @@ struct TileRef {
 // per-column scalar branches of the other version cost more than the ~200 extra multiplies).  Used by the 64-point
 // variant; in the 32-point variant it needs 40 more VGPRs (2 waves instead of 3) and loses.
 template <typename T, int N, bool WANT_NZ, bool PERIODIC>
-__device__ __forceinline__ float load_center_embed_bf(const T* row, int n, bool row_in, int lane0_byte, float (&x)[N],
-                                                   int& nonzero, bool& finite) {
+__device__ __forceinline__ float load_center_embed_bf(const T* row, int n, bool row_in, int lane0_byte, bool nz_pos,
+                                                      float (&x)[N], int& nonzero, bool& finite) {
   const float inv_nn = 1.0f / (float)(n * n);
   const float r = row_in ? 1.0f : 0.0f;
   int jm = 0;
@@ -389,7 +389,7 @@ __device__ __forceinline__ float load_center_embed_bf(const T* row, int n, bool 
   for (int j = 0; j < N; ++j) {
     const float m = j < n ? 1.0f : 0.0f;
     s = fmaf(x[j] - x0, m, s);
-    if (WANT_NZ) nz += (x[j] != 0.0f) ? m : 0.0f;
+    if (WANT_NZ) nz += (nz_pos ? x[j] > 0.0f : x[j] != 0.0f) ? m : 0.0f;
   }
   if (WANT_NZ) nonzero = group_sum_i<N>((int)(nz * r));
   const float mean = x0 + group_sum<N>(s * r) * inv_nn;
@@ -408,8 +408,8 @@ __device__ __forceinline__ float load_center_embed_bf(const T* row, int n, bool 
 }
 // uniform scalar branches on the column test (32-point variant)
 template <typename T, int N, bool WANT_NZ, bool PERIODIC>
-__device__ __forceinline__ float load_center_embed_br(const T* row, int n, bool row_in, int lane0_byte, float (&x)[N],
-                                                   int& nonzero, bool& finite) {
+__device__ __forceinline__ float load_center_embed_br(const T* row, int n, bool row_in, int lane0_byte, bool nz_pos,
+                                                      float (&x)[N], int& nonzero, bool& finite) {
   const float inv_nn = 1.0f / (float)(n * n);
   int jm = 0;
 #pragma unroll
@@ -429,7 +429,7 @@ __device__ __forceinline__ float load_center_embed_br(const T* row, int n, bool 
   for (int j = 0; j < N; ++j) {
     if (j < n) {
       s += x[j] - x0;
-      if (WANT_NZ) nz += (x[j] != 0.0f) ? 1 : 0;
+      if (WANT_NZ) nz += (nz_pos ? x[j] > 0.0f : x[j] != 0.0f) ? 1 : 0;
     }
   }
   if (WANT_NZ) nonzero = group_sum_i<N>(row_in ? nz : 0);
@@ -454,10 +454,10 @@ __device__ __forceinline__ float load_center_embed_br(const T* row, int n, bool 
 }
 
 template <typename T, int N, bool WANT_NZ, bool PERIODIC>
-__device__ __forceinline__ float load_center_embed(const T* row, int n, bool row_in, int lane0_byte, float (&x)[N],
-                                                   int& nonzero, bool& finite) {
-  if constexpr (N == 64) return load_center_embed_bf<T, N, WANT_NZ, PERIODIC>(row, n, row_in, lane0_byte, x, nonzero, finite);
-  else return load_center_embed_br<T, N, WANT_NZ, PERIODIC>(row, n, row_in, lane0_byte, x, nonzero, finite);
+__device__ __forceinline__ float load_center_embed(const T* row, int n, bool row_in, int lane0_byte, bool nz_pos,
+                                                   float (&x)[N], int& nonzero, bool& finite) {
+  if constexpr (N == 64) return load_center_embed_bf<T, N, WANT_NZ, PERIODIC>(row, n, row_in, lane0_byte, nz_pos, x, nonzero, finite);
+  else return load_center_embed_br<T, N, WANT_NZ, PERIODIC>(row, n, row_in, lane0_byte, nz_pos, x, nonzero, finite);
 }
 
 template <typename T, int N, bool WANT_NZ>
@@ -473,11 +473,12 @@ __device__ __forceinline__ void prepare_pair_embed(const PivParams& p, const Til
   const int lane0_byte = lane0_byte_of<N>();
   bool finite = true;
   int nza = 0, nzb = 0;
+  const bool nz_pos = p.nz_positive != 0;
   const float inv_a = load_center_embed<T, N, WANT_NZ, false>(frames + base + (int64_t)(row_in ? lg : 0) * p.W, n, row_in,
-                                                               lane0_byte, xr, nza, finite);
+                                                               lane0_byte, nz_pos, xr, nza, finite);
   __builtin_amdgcn_sched_barrier(0);   // one window after the other: only one raw row in flight next to the finished one
   const float inv_b = load_center_embed<T, N, WANT_NZ, true>(frames + base + p.frame_elems + (int64_t)(lg % n) * p.W, n,
-                                                              row_in, lane0_byte, xi, nzb, finite);
+                                                              row_in, lane0_byte, nz_pos, xi, nzb, finite);
   const bool dead = (inv_a == 0.0f) || (inv_b == 0.0f);
   const float rho = dead ? 0.0f : inv_b * __builtin_amdgcn_rcpf(inv_a);
   // plane = (unnormalised inverse N x N transform) / N^2 / n^2, and the cross-spectrum formula carries a factor 4
@@ -489,6 +490,7 @@ __device__ __forceinline__ void prepare_pair_embed(const PivParams& p, const Til
   if (WANT_NZ) {
     const float fa = (float)nza * inv_nn, fb = (float)nzb * inv_nn;
     skip = skip || !(fa >= p.signal_threshold && fb >= p.signal_threshold);
+    if (p.win_keep) skip = skip || !p.win_keep[t.win];   // "stack" mode: one score per window position (A7)
   }
 }
 
@@ -644,7 +646,8 @@ __device__ __forceinline__ void correlate_job(const PivParams& p, const TileRef 
       prepare_pair_embed<T, N, WANT_NZ>(p, t[k], lg, xr, xi, scale, hi[k], skip[k]);
     } else {
       if constexpr (sizeof(T) != 1) fetch_rows(k);
-      prepare_pair(raw[k][0], raw[k][1], xr, xi, want_nz, p.signal_threshold, scale, hi[k], skip[k]);
+      prepare_pair(raw[k][0], raw[k][1], xr, xi, want_nz, p.signal_threshold, p.nz_positive != 0, scale, hi[k], skip[k]);
+      if (WANT_NZ && p.win_keep) skip[k] = skip[k] || !p.win_keep[t[k].win];   // "stack" mode (A7)
     }
     fft_n<false>(xr, xi);              // along x
     transpose2<N>(buf, lg, xr, xi);    // lane = kx, regs = y
@@ -711,7 +714,7 @@ __device__ __forceinline__ float plane_max(const float (&c)[N], float& row_max) 
 // smallest shifted column of that row -- one lane per column compares its LDS sample, DPP min-reductions),
 // and fits the 3-point log-Gaussian.  u, v in pixels; NaN when the peak sits on the plane border.
 template <int N>
-__device__ __forceinline__ void find_peak(float* buf, int lg, const float (&c)[N], float vmax, float row_max,
+__device__ __forceinline__ void find_peak(float* buf, int lg, const float (&c)[N], float vmax, float row_max, int border_mode,
                                           float& u, float& v) {
   constexpr int LR = Geo<N>::LDS_ROW;
   constexpr int M = N - 1, C = N / 2, NONE = 1 << 12;
@@ -737,7 +740,7 @@ __device__ __forceinline__ void find_peak(float* buf, int lg, const float (&c)[N
   const float l0 = __builtin_amdgcn_logf(c0);
   v = (float)ip + gauss_offset_fast(__builtin_amdgcn_logf(cl), l0, __builtin_amdgcn_logf(cr)) - (float)C;
   u = (float)jp + gauss_offset_fast(__builtin_amdgcn_logf(cd), l0, __builtin_amdgcn_logf(cu)) - (float)C;
-  if (border) u = v = __builtin_nanf("");
+  if (border) border_result(border_mode, jp - C, ip - C, u, v);
 }
 
 template <int N>
@@ -834,7 +837,7 @@ __global__ __launch_bounds__(BLOCK, (kWavesPerSimd<T, N>)) void piv_fft_kernel(P
   {
     float row_max, u, v;
     const float vmax = plane_max<N>(xr, row_max);
-    find_peak<N>(buf, lg, xr, vmax, row_max, u, v);
+    find_peak<N>(buf, lg, xr, vmax, row_max, p.border_mode, u, v);
     float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean[0]);
     if (skip[0]) u = v = cm = sn = nanv;
     if (t[0].valid && lg == 0) {
@@ -845,7 +848,7 @@ __global__ __launch_bounds__(BLOCK, (kWavesPerSimd<T, N>)) void piv_fft_kernel(P
   {
     float row_max, u, v;
     const float vmax = plane_max<N>(xi, row_max);
-    find_peak<N>(buf, lg, xi, vmax, row_max, u, v);
+    find_peak<N>(buf, lg, xi, vmax, row_max, p.border_mode, u, v);
     float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean[1]);
     if (skip[1]) u = v = cm = sn = nanv;
     if (t[1].valid && lg == 0) {
@@ -874,7 +877,7 @@ __global__ __launch_bounds__(BLOCK, (kWavesPerSimd<T, N>)) void piv_fft_kernel(P
 // transforms with depends on where the segment starts, so results are bit-reproducible for a given chunk but differ
 // in the last float32 bit between different chunkings (the per-pair kernel does not; LSPIV_WALK=0 selects it).
 template <typename T, int N, bool WANT_NZ>
-__device__ __forceinline__ void prepare_one(const RowRaw<T, N>& raw, float (&x)[N], int& nonzero, bool& finite,
+__device__ __forceinline__ void prepare_one(const RowRaw<T, N>& raw, float (&x)[N], bool nz_pos, int& nonzero, bool& finite,
                                             bool& dead) {
   // every frame carries 1 / (2 N^2) on top of 1 / std, so each cross spectrum (a product of two frames' spectra)
   // comes out scaled by the 1 / (4 N^4) the planes need -- no multiply in the un-packing loop; a power of two for
@@ -885,7 +888,7 @@ __device__ __forceinline__ void prepare_one(const RowRaw<T, N>& raw, float (&x)[
     center_u8<N>(raw, st.mean, st.inv_std * kHalf, x);   // max((byte - mean) / std, 0) / (2 N^2); all zero for a constant window
     dead = st.inv_std == 0.0f;
   } else {
-    const float inv = load_center<N>(raw, x, WANT_NZ, nonzero, finite);
+    const float inv = load_center<N>(raw, x, WANT_NZ, nz_pos, nonzero, finite);
     const float g = inv * kHalf;
 #pragma unroll
     for (int j = 0; j < N; ++j) x[j] *= g;
@@ -930,9 +933,9 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
     RowRaw<T, N> raw0, raw1;
     raw0.fetch(row);
     raw1.fetch(has2 ? row + p.frame_elems : row);
-    prepare_one<T, N, WANT_NZ>(raw0, xr, nz0, fin0, dead0);
+    prepare_one<T, N, WANT_NZ>(raw0, xr, p.nz_positive != 0, nz0, fin0, dead0);
     LSPIV_WALK_SB;
-    prepare_one<T, N, WANT_NZ>(raw1, xi, nz1, fin1, dead1);
+    prepare_one<T, N, WANT_NZ>(raw1, xi, p.nz_positive != 0, nz1, fin1, dead1);
   }
   LSPIV_WALK_SB;
   fft_n<false>(xr, xi);              // along x
@@ -1019,6 +1022,7 @@ __global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_kernel
                  (int64_t)wcol * p.sx;
   const float nanv = __builtin_nanf("");
 
+  const bool win_dropped = WANT_NZ && p.win_keep && !p.win_keep[win];   // "stack" mode: one score per window position (A7)
   WalkCarry<N> carry;
   carry.reset();
   for (uint32_t f = p0; f <= p1; f += 2, row += 2 * p.frame_elems) {
@@ -1026,11 +1030,12 @@ __global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_kernel
     float xr[N], xi[N], mean_a, mean_b;
     bool skip_a, skip_b;
     walk_iteration<T, N, WANT_NZ>(p, row, has2, buf, lg, partner_byte, lane0_byte, carry, xr, xi, mean_a, mean_b, skip_a, skip_b);
+    if (WANT_NZ && win_dropped) skip_a = skip_b = true;
     const bool valid_a = job_valid && f > p0, valid_b = job_valid && has2;
     {
       float row_max, u, v;
       const float vmax = plane_max<N>(xr, row_max);
-      find_peak<N>(buf, lg, xr, vmax, row_max, u, v);
+      find_peak<N>(buf, lg, xr, vmax, row_max, p.border_mode, u, v);
       float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean_a);
       if (skip_a) u = v = cm = sn = nanv;
       if (valid_a && lg == 0) {
@@ -1041,7 +1046,7 @@ __global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_kernel
     {
       float row_max, u, v;
       const float vmax = plane_max<N>(xi, row_max);
-      find_peak<N>(buf, lg, xi, vmax, row_max, u, v);
+      find_peak<N>(buf, lg, xi, vmax, row_max, p.border_mode, u, v);
       float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean_b);
       if (skip_b) u = v = cm = sn = nanv;
       if (valid_b && lg == 0) {
@@ -1060,8 +1065,8 @@ __global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_kernel
 // The plane is parked in LDS un-shifted (row ky at buf[ky * LDS_ROW + kx]); the reference's plane is its fftshift,
 // shifted index = (k + n/2) mod n.  Same first-maximum rule and arithmetic as find_peak, with run-time n.
 template <int N>
-__device__ __forceinline__ void find_peak_embed(float* buf, int lg, const float (&c)[N], int n, float& vmax, float& mean,
-                                                float& u, float& v) {
+__device__ __forceinline__ void find_peak_embed(float* buf, int lg, const float (&c)[N], int n, int border_mode, float& vmax,
+                                                float& mean, float& u, float& v) {
   constexpr int LR = Geo<N>::LDS_ROW;
   constexpr int NONE = 1 << 12;
   f32x4* wrow = reinterpret_cast<f32x4*>(buf + lg * LR);
@@ -1097,7 +1102,7 @@ __device__ __forceinline__ void find_peak_embed(float* buf, int lg, const float 
   const float l0 = __builtin_amdgcn_logf(c0);
   v = (float)ip + gauss_offset_fast(__builtin_amdgcn_logf(cl), l0, __builtin_amdgcn_logf(cr)) - (float)C;
   u = (float)jp + gauss_offset_fast(__builtin_amdgcn_logf(cd), l0, __builtin_amdgcn_logf(cu)) - (float)C;
-  if (border) u = v = __builtin_nanf("");
+  if (border) border_result(border_mode, jp - C, ip - C, u, v);
 }
 
 // fft-shifted n x n plane out of the parked LDS copy (cross_corr's volume); call before the buffer is reused
@@ -1150,7 +1155,7 @@ __global__ __launch_bounds__(BLOCK, 2) void piv_fft_embed_kernel(PivParams p) {
 #pragma unroll
   for (int k = 0; k < (SINGLE ? 1 : 2); ++k) {
     float vmax, mean, u, v;
-    find_peak_embed<N>(buf, lg, k == 0 ? xr : xi, n, vmax, mean, u, v);
+    find_peak_embed<N>(buf, lg, k == 0 ? xr : xi, n, p.border_mode, vmax, mean, u, v);
     float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean);
     if (skip[k]) u = v = cm = sn = nanv;
     if (t[k].valid && lg == 0) {
@@ -1383,6 +1388,7 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsWaves<T, N>)) void piv_fft_walk_ens
   const T* row = static_cast<const T*>(p.frames) + ((int64_t)p0 * p.H + (int64_t)(wrow * p.sy + row_of<N>(lg))) * p.W +
                  (int64_t)wcol * p.sx;
   float* part = p.part_sum + (size_t)job * G::NN;
+  const bool win_dropped = WANT_NZ && p.win_keep && !p.win_keep[win];
   float cnt = 0.0f;
   float acc[kEnsRegAcc<N> ? N : 1];
   if constexpr (kEnsRegAcc<N>) {
@@ -1396,6 +1402,7 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsWaves<T, N>)) void piv_fft_walk_ens
     float xr[N], xi[N], mean[2];
     bool skip[2], keep[2];
     walk_iteration<T, N, WANT_NZ>(p, row, has2, buf, lg, partner_byte, lane0_byte, carry, xr, xi, mean[0], mean[1], skip[0], skip[1]);
+    if (WANT_NZ && win_dropped) skip[0] = skip[1] = true;
     const bool valid[2] = {job_valid && f > p0, job_valid && has2};
 #pragma unroll
     for (int k = 0; k < 2; ++k) {

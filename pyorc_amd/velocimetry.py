@@ -183,7 +183,7 @@ def get_ffpiv(
         # quirk Q3 (ffpiv.py:373): the count filter is scaled with the number of CHUNKS -- of the reference's planner
         # (same formula, fed with HBM figures), not of the aligned chunks actually launched
         return _get_ffpiv_mean(*args, corr_min, s2n_min, count_min, signal_threshold, like=frames,
-                               n_chunks=len(ref_slices))
+                               ref_slices=ref_slices)
     return _get_ffpiv_timestep(*args, signal_threshold, like=frames)
 
 
@@ -219,7 +219,7 @@ def _get_ffpiv_timestep(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_c
 
 
 def _get_ffpiv_mean(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_cols, n_rows, window_size, overlap,
-                    corr_min, s2n_min, count_min, signal_threshold, like=None, n_chunks=None):
+                    corr_min, s2n_min, count_min, signal_threshold, like=None, ref_slices=None):
     """Ensemble correlation of pyorc/velocimetry/ffpiv.py:182-376; corr_sum / corr_count stay in HBM."""
     dim_size = None
     ens = None
@@ -237,14 +237,19 @@ def _get_ffpiv_mean(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_cols,
             corr_max, s2n = ens.accumulate(arr, corr_min, s2n_min, signal_threshold)
             corr_chunks.append(corr_max)
             s2n_chunks.append(s2n)
-            t_first = time[a + 1:a + 2]  # quirk Q3: `time[0:1]` of the LAST chunk ends up on the result (ffpiv.py:336)
+            t_first = time[a + 1:a + 2]
             frames_chunks[n] = None
             del da
             gc.collect()
         if ens is None:
             raise ValueError("no chunk with at least one frame pair")
-        # quirk Q3: number of chunks, not pairs (ffpiv.py:373)
-        n_frames = len(corr_chunks) if n_chunks is None else n_chunks
+        # quirk Q3: `n_frames` is the number of CHUNKS, not pairs (ffpiv.py:373), and `time[0:1]` of the LAST chunk ends
+        # up on the result (ffpiv.py:336) -- both taken from the reference's own chunk plan, not from the aligned
+        # chunks that were launched, so neither depends on the segment anchoring
+        n_frames = len(corr_chunks)
+        if ref_slices:
+            n_frames = len(ref_slices)
+            t_first = time[ref_slices[-1][0] + 1:ref_slices[-1][0] + 2]
         u, v, corr_count = ens.finish(count_min, n_frames)
     finally:
         if ens is not None:

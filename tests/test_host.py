@@ -196,6 +196,13 @@ def test_walk_option_overrides_the_environment(lib, monkeypatch):
     assert pyorc_amd.get_option("walk") == 0
     with pytest.raises(_lib.LspivError):
         pyorc_amd.set_option("no-such-option", 1)
+    for name, hi in (("border_peak", 2), ("signal_mode", 1), ("signal_positive", 1)):   # the unpinned ffpiv readings (A5 / A7)
+        assert pyorc_amd.get_option(name) == 0
+        pyorc_amd.set_option(name, hi)
+        assert pyorc_amd.get_option(name) == hi
+        with pytest.raises(_lib.LspivError):
+            pyorc_amd.set_option(name, hi + 1)
+        pyorc_amd.set_option(name, 0)
 
 
 def test_xarray_branches_of_the_mirrors(monkeypatch):
