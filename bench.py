@@ -172,7 +172,7 @@ def host_fed_rates(lib, sample_u8: np.ndarray, ws, ov) -> dict:
 
     out = {}
     for key, arr in (("u8", sample_u8), ("f32", sample_u8.astype(np.float32)), ("f64", sample_u8.astype(np.float64))):
-        piv.piv_pairs(arr[:3], ws, ov)  # workspaces
+        piv.piv_pairs(arr, ws, ov)  # grows the library's workspaces and pinned ring, touches the pages
         t0 = time.perf_counter()
         piv.piv_pairs(arr, ws, ov)
         out[key] = round((arr.shape[0] - 1) / (time.perf_counter() - t0), 1)
@@ -216,6 +216,12 @@ def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         raise SystemExit(spawn_ranks(a))
+    # The JSON line must be the only thing on stdout, and native libraries write there too (RCCL prints a version banner
+    # through C stdio, flushed at exit, i.e. AFTER anything Python printed): keep the real stdout for the JSON line and
+    # point file descriptor 1 at stderr for everything else.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -388,7 +394,7 @@ def main():
     if world == 1 and is_c2 and not a.no_extras:
         others = [other_config(lib, "BASELINE.json configs[2]: 1080p, 64x64 windows @ 75 % overlap, same stack",
                                d_frames, a.pairs, H, W, 64, 48)]
-        sample = np.empty((min(a.pairs, 60) + 1, H, W), dtype=np.uint8)
+        sample = np.empty((min(a.pairs, 200) + 1, H, W), dtype=np.uint8)
         _lib.check(lib.lspiv_memcpy_d2h(_lib.ptr(sample), d_frames, sample.nbytes))
         _lib.check(lib.lspiv_dev_free(d_frames))
         d_frames = None
@@ -402,7 +408,7 @@ def main():
         out["config"]["host_fed_pairs_per_s"] = {
             **host_fed_rates(lib, sample, ws, ov),
             "note": f"lspiv_piv_pairs on {sample.shape[0] - 1} pairs in pageable host memory, PCIe-inclusive; never `value`"}
-    print(json.dumps(out), flush=True)
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:
         comm.barrier()
         comm.close()

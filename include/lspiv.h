@@ -54,8 +54,10 @@ extern "C" {
 #define LSPIV_F32 1
 #define LSPIV_F64 2
 
-/* largest interrogation window side the kernels accept (even sizes 4..LSPIV_MAX_WINDOW) */
-#define LSPIV_MAX_WINDOW 64
+/* largest interrogation window side the kernels accept.  2..64: register-resident kernels; above 64 (any parity, square
+ * or not, e.g. 96 x 96 and 128 x 128 for 4K footage): the LDS-resident DFT kernel, as long as 2 wy wx floats fit the
+ * 160 KB of a CU -- 128 x 128 does, 128 x 160 does not (LSPIV_EUNSUPPORTED). */
+#define LSPIV_MAX_WINDOW 128
 
 /* ---------------------------------------------------------------- library / device ------- */
 int         lspiv_abi_version(void);
@@ -83,8 +85,8 @@ int         lspiv_set_option(const char* name, int value);
 int         lspiv_get_option(const char* name, int* value);
 /* which kernel a window size dispatches to: 1 = FFT 32x32, 2 = FFT 64x64, 6 = FFT 8x8 / 16x16, 8 = prime-factor FFT
  * kernels (every other even square window 6..62), 7 / 4 / 5 = odd square windows (and 4x4) 4..7 / 9..15 / 21..31
- * embedded in the 16- / 32- / 64-point FFT kernels, 3 = direct spatial correlation (non-square, odd 17 / 19 / 33..63);
- * <0 = unsupported.  Host-only. */
+ * embedded in the 16- / 32- / 64-point FFT kernels, 3 = direct spatial correlation (non-square, odd 17 / 19 / 33..63),
+ * 9 = LDS-resident 2-D DFT (any window with a side above 64); <0 = unsupported.  Host-only. */
 int         lspiv_kernel_kind(int wy, int wx);
 
 /* ---------------------------------------------------------------- window grid (host) ----- */

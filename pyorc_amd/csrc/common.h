@@ -233,6 +233,9 @@ LSPIV_PFA_SIZES(LSPIV_PFA_DECL)
 hipError_t launch_piv_fft32(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 hipError_t launch_piv_fft64(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 hipError_t launch_piv_direct(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
+// windows above 64 px per side (any shape that fits LDS): packed 2-D DFT in LDS (piv_direct.hip)
+hipError_t launch_piv_dft(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
+bool piv_dft_fits(int wy, int wx);
 // square windows 4..16 / 17..31 through the 32- / 64-point transforms
 hipError_t launch_piv_embed16(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 hipError_t launch_piv_embed32(const PivParams& p, int dtype, bool ensemble, hipStream_t s);

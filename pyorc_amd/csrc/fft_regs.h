@@ -210,16 +210,25 @@ __device__ __forceinline__ void fft64(float (&xr)[64], float (&xi)[64]) {
     bfly8<INV>(r, i);
 #pragma unroll
     for (int k1 = 0; k1 < 8; ++k1) { xr[8 * k1 + n2] = r[k1]; xi[8 * k1 + n2] = i[k1]; }
+#if defined(LSPIV_FFT64_SB) && LSPIV_FFT64_SB
+    __builtin_amdgcn_sched_barrier(0);
+#endif
   }
   float yr[64], yi[64];
-  fft64_col<INV, 0>(xr, xi, yr, yi);
-  fft64_col<INV, 1>(xr, xi, yr, yi);
-  fft64_col<INV, 2>(xr, xi, yr, yi);
-  fft64_col<INV, 3>(xr, xi, yr, yi);
-  fft64_col<INV, 4>(xr, xi, yr, yi);
-  fft64_col<INV, 5>(xr, xi, yr, yi);
-  fft64_col<INV, 6>(xr, xi, yr, yi);
-  fft64_col<INV, 7>(xr, xi, yr, yi);
+  // LSPIV_FFT64_SB: scheduling barriers between the eight column transforms -- left alone the scheduler interleaves
+  // several of them for ILP, which keeps up to 128 + 128 values live and pushes the caller's carried spectrum to scratch
+#ifndef LSPIV_FFT64_SB
+#define LSPIV_FFT64_SB 0
+#endif
+#define LSPIV_FFT64_BAR do { if (LSPIV_FFT64_SB) __builtin_amdgcn_sched_barrier(0); } while (0)
+  fft64_col<INV, 0>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
+  fft64_col<INV, 1>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
+  fft64_col<INV, 2>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
+  fft64_col<INV, 3>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
+  fft64_col<INV, 4>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
+  fft64_col<INV, 5>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
+  fft64_col<INV, 6>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
+  fft64_col<INV, 7>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
 #pragma unroll
   for (int k = 0; k < 64; ++k) { xr[k] = yr[k]; xi[k] = yi[k]; }
 }

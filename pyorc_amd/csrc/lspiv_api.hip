@@ -269,6 +269,7 @@ int dispatch(const lspiv::PivParams& p, int dtype, bool ensemble, hipStream_t s)
     case 1: e = lspiv::launch_piv_fft32(p, dtype, ensemble, s); break;
     case 2: e = lspiv::launch_piv_fft64(p, dtype, ensemble, s); break;
     case 3: e = lspiv::launch_piv_direct(p, dtype, ensemble, s); break;
+    case 9: e = lspiv::launch_piv_dft(p, dtype, ensemble, s); break;
     default: return fail(LSPIV_EUNSUPPORTED, "no kernel for window %dx%d", p.wy, p.wx);
   }
   if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -403,6 +404,7 @@ int lspiv_get_option(const char* name, int* value) {
 
 int lspiv_kernel_kind(int wy, int wx) {
   if (wy < 2 || wx < 2 || wy > LSPIV_MAX_WINDOW || wx > LSPIV_MAX_WINDOW) return LSPIV_EUNSUPPORTED;
+  if (wy > 64 || wx > 64) return lspiv::piv_dft_fits(wy, wx) ? 9 : LSPIV_EUNSUPPORTED;   // LDS-resident 2-D DFT, any shape
   if (wy == 32 && wx == 32) return 1;
   if (wy == 64 && wx == 64) return 2;
   if (wy == 16 && wx == 16) return 6;

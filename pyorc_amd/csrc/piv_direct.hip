@@ -283,6 +283,250 @@ static hipError_t launch_t(const PivParams& p, bool ensemble, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---- windows above 64 px per side (and any shape that fits LDS): packed 2-D DFT of the window pair, in LDS -----------
+// ffpiv.cross_corr has no upper bound on the window (pyorc/api/frames.py:159-168 takes it free-form from the camera
+// configuration; 4K footage is routinely processed with 96 / 128 px windows).  Such a window no longer fits the
+// lane-per-row register layout of the fused FFT kernels (a 128-sample complex row is 256 VGPRs), so it lives in LDS:
+//     z = a'' + i b''  (both windows normalised to unit variance, scaled 1 / n)         n = wy wx, 2 n floats of LDS
+//     Z = DFT2(z), in place;   R[k] = conj(A[k]) B[k]  from  Z[k], Z[-k]  (in place, a thread owns the pair k, -k)
+//     c = Re IDFT2(R)  ->  clip, fft-shift, max / mean / first arg-max / 3-point fit  (the direct kernel's epilogue)
+// The 1-D transforms are plain DFT sums, out[k] = sum_n x[n] w^{n k}, register-blocked 4 lines x 4 frequencies per thread
+// (16 LDS reads feed 64 FMAs), twiddles from a per-block table (computed in double, rounded once): O(n^1.5) instead of
+// O(n log n), but any length works -- even, odd, prime, non-square -- with one kernel and no size-specific code, and
+// 128 x 128 complex samples (128 KB) fit the 160 KB of a CU.  Each window pair is computed on its own: results do not
+// depend on the time chunking.  A block is 512 threads; every pass computes all outputs into registers before anything
+// is written back, so the transforms run in place.
+constexpr int FBLOCK = 512;
+constexpr int FTILES = 2;   // 4 x 4 output tiles per thread and pass: 512 x 2 x 16 = 16 384 outputs = 128 x 128
+
+struct DftGeo {
+  int n, pitch;   // samples per window; LDS row pitch (odd: the four rows of a tile fall on different banks)
+  __host__ __device__ DftGeo(int wy, int wx) : n(wy * wx), pitch(wx | 1) {}
+  // re plane | im plane | (cos, sin) tables for x and y | reduction scratch
+  __host__ __device__ size_t lds_floats(int wy, int wx) const { return (size_t)2 * wy * pitch + 2 * (size_t)(wx + wy) + 24; }
+};
+
+// in-place 1-D DFTs of `n_lines` lines of `len` elements: element e of line l at [l * lstride + e * estride];
+// tw[2 m] = cos(2 pi m / len), tw[2 m + 1] = sin(2 pi m / len); forward: exp(-i), INV: exp(+i); unnormalised
+template <bool INV>
+__device__ __forceinline__ void dft_pass(float* re, float* im, int len, int n_lines, int estride, int lstride, const float* tw) {
+  const int ntk = (len + 3) >> 2, ntl = (n_lines + 3) >> 2, ntiles = ntk * ntl;
+  float ar[FTILES][4][4], ai[FTILES][4][4];
+  int l0[FTILES], k0[FTILES];
+#pragma unroll
+  for (int t = 0; t < FTILES; ++t) {
+    const int tile = (int)threadIdx.x + t * FBLOCK;
+    const bool on = tile < ntiles;
+    const int tl = on ? tile / ntk : 0, tk = on ? tile - tl * ntk : 0;
+    l0[t] = 4 * tl; k0[t] = 4 * tk;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ar[t][j][q] = ai[t][j][q] = 0.0f;
+    if (!on) continue;
+    int lo[4], kq[4], idx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lo[j] = min(l0[t] + j, n_lines - 1) * lstride;   // edge tiles recompute the last line / frequency
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { kq[q] = min(k0[t] + q, len - 1); idx[q] = 0; }
+    for (int n = 0; n < len; ++n) {
+      float zr[4], zi[4], c[4], sn[4];
+      const int eo = n * estride;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { zr[j] = re[lo[j] + eo]; zi[j] = im[lo[j] + eo]; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        c[q] = tw[2 * idx[q]];
+        sn[q] = INV ? -tw[2 * idx[q] + 1] : tw[2 * idx[q] + 1];
+        idx[q] += kq[q];
+        idx[q] = idx[q] >= len ? idx[q] - len : idx[q];   // (n kq) mod len, kept incrementally
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {   // (zr + i zi)(c - i s)
+          ar[t][j][q] = fmaf(zr[j], c[q], fmaf(zi[j], sn[q], ar[t][j][q]));
+          ai[t][j][q] = fmaf(zi[j], c[q], fmaf(-zr[j], sn[q], ai[t][j][q]));
+        }
+    }
+  }
+  __syncthreads();   // every output is in registers: the lines may be overwritten
+#pragma unroll
+  for (int t = 0; t < FTILES; ++t) {
+    const int tile = (int)threadIdx.x + t * FBLOCK;
+    if (tile >= ntiles) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (l0[t] + j < n_lines && k0[t] + q < len) {
+          const int o = (l0[t] + j) * lstride + (k0[t] + q) * estride;
+          re[o] = ar[t][j][q];
+          im[o] = ai[t][j][q];
+        }
+  }
+  __syncthreads();
+}
+
+// one window pair -> clipped, fft-shifted plane in `plane` (n floats, aliases the imaginary plane).  false: NaN plane.
+template <typename T>
+__device__ __forceinline__ bool dft_pair(const PivParams& p, uint32_t pair, uint32_t win, float* smem, const DftGeo& g, float*& plane,
+                                         float*& red) {
+  const int wy = p.wy, wx = p.wx, P = g.pitch;
+  float* re = smem;
+  float* im = re + wy * P;
+  float* twx = im + wy * P;
+  float* twy = twx + 2 * wx;
+  red = twy + 2 * wy;
+  plane = im;
+  const T* frames = static_cast<const T*>(p.frames);
+  const uint32_t wrow = win / (uint32_t)p.n_cols, wcol = win - wrow * (uint32_t)p.n_cols;
+  const int64_t off = ((int64_t)pair * p.H + (int64_t)wrow * p.sy) * p.W + (int64_t)wcol * p.sx;
+  for (int m = threadIdx.x; m < wx + wy; m += blockDim.x) {   // twiddles: double precision, rounded once
+    const bool isx = m < wx;
+    const int k = isx ? m : m - wx, L = isx ? wx : wy;
+    double sv, cv;
+    sincospi(2.0 * (double)k / (double)L, &sv, &cv);
+    float* tw = isx ? twx : twy;
+    tw[2 * k] = (float)cv;
+    tw[2 * k + 1] = (float)sv;
+  }
+  int nza, nzb;
+  bool finite = true;
+  const float inv_a = stage_window(frames + off, p.W, wy, wx, re, P, false, p.nz_positive != 0, red, nza, finite);
+  const float inv_b = stage_window(frames + off + p.frame_elems, p.W, wy, wx, im, P, false, p.nz_positive != 0, red, nzb, finite);
+  __syncthreads();
+  bool ok = finite;
+  if (p.signal_threshold >= 0.0f) {
+    const float fa = (float)nza / (float)g.n, fb = (float)nzb / (float)g.n;
+    ok = ok && (fa >= p.signal_threshold) && (fb >= p.signal_threshold);
+    if (p.win_keep) ok = ok && p.win_keep[win];
+  }
+  // unit variance and 1 / n on each window: both spectra are O(1) (balanced packing) and the product of two of them
+  // carries the 1 / n^2 the plane needs; a zero-variance window gives an exactly-zero plane
+  const bool dead = inv_a == 0.0f || inv_b == 0.0f;
+  const float ga = dead ? 0.0f : inv_a / (float)g.n, gb = dead ? 0.0f : inv_b / (float)g.n;
+  for (int o = threadIdx.x; o < g.n; o += blockDim.x) {
+    const int y = o / wx, x = o - y * wx;
+    re[y * P + x] *= ga;
+    im[y * P + x] *= gb;
+  }
+  __syncthreads();
+  dft_pass<false>(re, im, wx, wy, 1, P, twx);   // along x, one line per row
+  dft_pass<false>(re, im, wy, wx, P, 1, twy);   // along y, one line per column -> Z[ky][kx]
+  // cross spectrum in place: the thread that owns k also owns -k (k <= -k in row-major order)
+  for (int o = threadIdx.x; o < g.n; o += blockDim.x) {
+    const int ky = o / wx, kx = o - ky * wx;
+    const int my = ky == 0 ? 0 : wy - ky, mx = kx == 0 ? 0 : wx - kx;
+    const int om = my * wx + mx;
+    if (o > om) continue;
+    const int a0 = ky * P + kx, a1 = my * P + mx;
+    const float zr = re[a0], zi = im[a0], mr = re[a1], mi = im[a1];
+    const float Ar = 0.5f * (zr + mr), Ai = 0.5f * (zi - mi);      // A = (Z[k] + conj Z[-k]) / 2
+    const float Br = 0.5f * (zi + mi), Bi = -0.5f * (zr - mr);     // B = (Z[k] - conj Z[-k]) / 2i
+    const float Rr = Ar * Br + Ai * Bi, Ri = Ar * Bi - Ai * Br;    // conj(A) B
+    re[a0] = Rr; im[a0] = (o == om) ? 0.0f : Ri;                   // self-conjugate bins are real
+    if (o != om) { re[a1] = Rr; im[a1] = -Ri; }
+  }
+  __syncthreads();
+  dft_pass<true>(re, im, wy, wx, P, 1, twy);    // along ky
+  dft_pass<true>(re, im, wx, wy, 1, P, twx);    // along kx -> correlation at lag (dy, dx) in re[dy][dx]
+  const int cy = wy / 2, cx = wx / 2;
+  const float hi = dead ? 0.0f : 1.0f;
+  for (int o = threadIdx.x; o < g.n; o += blockDim.x) {            // clip, fft-shift into the (now free) imaginary plane
+    const int ip = o / wx, jp = o - ip * wx;
+    const int dy = ip - cy < 0 ? ip - cy + wy : ip - cy, dx = jp - cx < 0 ? jp - cx + wx : jp - cx;
+    im[o] = __builtin_amdgcn_fmed3f(re[dy * P + dx], 0.0f, hi);
+  }
+  __syncthreads();
+  return ok;
+}
+
+template <typename T>
+__global__ __launch_bounds__(FBLOCK) void piv_dft_kernel(PivParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const DftGeo g(p.wy, p.wx);
+  const uint32_t t = blockIdx.x;
+  const uint32_t pair = t / p.n_win, win = t - pair * p.n_win;
+  float *plane, *red;
+  const bool ok = dft_pair<T>(p, pair, win, smem, g, plane, red);
+  float vmax, sum, u, v;
+  int imax;
+  plane_reduce(plane, g.n, red, vmax, imax, sum);
+  subpixel_generic([&](int o) { return plane[o]; }, p.wy, p.wx, imax, p.border_mode, u, v);
+  float cm = vmax, sn = vmax / (sum / (float)g.n);
+  if (!ok) u = v = cm = sn = __builtin_nanf("");
+  if (threadIdx.x == 0) {
+    p.u[t] = u; p.v[t] = v; p.cmax[t] = cm; p.s2n[t] = sn;
+  }
+  if (p.planes) {
+    float* dst = p.planes + (size_t)t * g.n;
+    for (int o = threadIdx.x; o < g.n; o += blockDim.x) dst[o] = ok ? plane[o] : __builtin_nanf("");
+  }
+}
+
+// ensemble: one block owns one window and walks the chunk's pairs in order (as piv_direct_ensemble_kernel)
+template <typename T>
+__global__ __launch_bounds__(FBLOCK) void piv_dft_ensemble_kernel(PivParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const DftGeo g(p.wy, p.wx);
+  const uint32_t win = blockIdx.x;
+  float* dst = p.corr_sum + (size_t)win * g.n;
+  float cnt = 0.0f;
+  for (uint32_t pair = 0; pair < p.n_pairs; ++pair) {
+    float *plane, *red;
+    const bool ok = dft_pair<T>(p, pair, win, smem, g, plane, red);
+    float vmax, sum;
+    int imax;
+    plane_reduce(plane, g.n, red, vmax, imax, sum);
+    float cm = vmax, sn = vmax / (sum / (float)g.n);
+    const bool keep = ok && (cm >= p.corr_min) && (sn >= p.s2n_min);
+    cm = keep ? cm : 0.0f;
+    sn = keep ? sn : 0.0f;
+    cnt += (cm > 1e-6f) ? 1.0f : 0.0f;
+    if (threadIdx.x == 0) {
+      p.cmax[(size_t)pair * p.n_win + win] = cm;
+      p.s2n[(size_t)pair * p.n_win + win] = sn;
+    }
+    if (keep)
+      for (int o = threadIdx.x; o < g.n; o += blockDim.x) dst[o] += plane[o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) p.corr_count[win] += cnt;
+}
+
+size_t piv_dft_lds_bytes(int wy, int wx) { return DftGeo(wy, wx).lds_floats(wy, wx) * sizeof(float); }
+bool piv_dft_fits(int wy, int wx) {
+  const int tiles = ((wy + 3) / 4) * ((wx + 3) / 4);
+  return tiles <= FBLOCK * FTILES && piv_dft_lds_bytes(wy, wx) <= (size_t)160 * 1024 - 512;
+}
+
+template <typename T>
+static hipError_t launch_dft_t(const PivParams& p, bool ensemble, hipStream_t s) {
+  const size_t lds = piv_dft_lds_bytes(p.wy, p.wx);
+  hipError_t e;
+  if (ensemble) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&piv_dft_ensemble_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(piv_dft_ensemble_kernel<T>, dim3(p.n_win), dim3(FBLOCK), lds, s, p);
+  } else {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&piv_dft_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(piv_dft_kernel<T>, dim3(p.n_tiles), dim3(FBLOCK), lds, s, p);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_piv_dft(const PivParams& p, int dtype, bool ensemble, hipStream_t s) {
+  if (!piv_dft_fits(p.wy, p.wx)) return hipErrorInvalidValue;
+  switch (dtype) {
+    case 0: return launch_dft_t<uint8_t>(p, ensemble, s);
+    case 1: return launch_dft_t<float>(p, ensemble, s);
+    case 2: return launch_dft_t<double>(p, ensemble, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t launch_piv_direct(const PivParams& p, int dtype, bool ensemble, hipStream_t s) {
   switch (dtype) {
     case 0: return launch_t<uint8_t>(p, ensemble, s);

@@ -247,6 +247,54 @@ def test_fused_results_equal_two_step_results(gpu):
         assert np.array_equal(cm.ravel(), corr.max(axis=(-1, -2)).ravel())
 
 
+# ------------------------------------------------------------------ windows above 64 px --------------
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32, np.float64])
+@pytest.mark.parametrize("ws,ov", [((96, 96), (48, 48)), ((128, 128), (64, 64)), ((128, 128), (96, 32)), ((66, 66), (33, 33)),
+                                   ((100, 100), (50, 50)), ((97, 97), (40, 40)), ((128, 80), (64, 40)), ((72, 120), (0, 60))])
+def test_windows_above_64_vs_oracle(gpu, ws, ov, dtype):
+    """ffpiv.cross_corr takes any window (pyorc/api/frames.py:159-168): sizes above 64 px -- 96 and 128 for 4K footage,
+    but also odd, non-square and 2 x prime sizes -- run the LDS-resident DFT kernel; planes, NaN masks, corr / s2n and
+    the sub-pixel peaks against the oracle, with a signal threshold, an empty frame and a constant corner in the stack."""
+    H, Wd = 2 * ws[0] + 7, 2 * ws[1] + ws[1] // 2 + 3
+    fr = particle_stack(4, H, Wd, seed=ws[0] + ws[1], density=0.03)
+    if dtype == np.uint8:
+        check_against_oracle(fr, ws, ov, min_ok=0.5, plane_tol=4e-6)
+        check_against_oracle(fr, ws, ov, thr=0.12, min_ok=0.0, plane_tol=4e-6)
+    else:
+        f = (fr.astype(dtype) - 21.5) * 0.37
+        f[2] = 1.5                                       # a constant frame: both pairs that touch it are dead
+        f[:, : ws[0] // 2, : ws[1]] = -0.75              # a constant corner
+        check_against_oracle(f, ws, ov, thr=0.25, min_ok=0.0, plane_tol=4e-6)
+
+
+@pytest.mark.parametrize("ws", [96, 128])
+def test_windows_above_64_get_piv_and_ensemble(gpu, ws):
+    """96 / 128 px windows through the accessor-shaped entry point: per-timestep (chunked: per-pair kernel, alignment 1)
+    and ensemble mode against the oracle's get_ffpiv."""
+    from pyorc_amd import frames as F
+    from pyorc_amd import window
+
+    assert window.chunk_alignment((ws, ws)) == 1
+    fr = particle_stack(6, 2 * ws + 20, 3 * ws, seed=ws, density=0.03)
+    t = np.arange(6) / 30.0
+    got = F.get_piv(fr, ws, time=t, resolution=0.01)
+    part = F.get_piv(fr, ws, time=t, resolution=0.01, chunksize=2)
+    ref = po.get_ffpiv(fr, np.diff(t), (ws, ws), (ws // 2, ws // 2), 0.01, 0.01)
+    for k in ("v_x", "v_y", "corr", "s2n"):
+        assert np.array_equal(got[k], part[k], equal_nan=True), k
+        assert np.array_equal(np.isnan(got[k]), np.isnan(ref[k])), k
+    assert rel_err(got["corr"], ref["corr"].astype(np.float64)) <= TOL and rel_err(got["s2n"], ref["s2n"].astype(np.float64)) <= TOL
+    floor = 0.05 * 0.01 * 30
+    assert rel_err(got["v_x"], ref["v_x"].astype(np.float64), floor=floor) <= 2e-4
+    assert rel_err(got["v_y"], ref["v_y"].astype(np.float64), floor=floor) <= 2e-4
+    ens = F.get_piv(fr, ws, time=t, resolution=0.01, ensemble_corr=True, corr_min=0.1, s2n_min=1.5)
+    eref = po.get_ffpiv(fr, np.diff(t), (ws, ws), (ws // 2, ws // 2), 0.01, 0.01, ensemble_corr=True, corr_min=0.1, s2n_min=1.5)
+    for k in ("v_x", "v_y", "corr", "s2n"):
+        assert np.array_equal(np.isnan(ens[k]), np.isnan(eref[k])), k
+    assert rel_err(ens["corr"], eref["corr"].astype(np.float64)) <= TOL
+    assert rel_err(ens["v_x"], eref["v_x"].astype(np.float64), floor=floor) <= 2e-4
+
+
 # ------------------------------------------------------------------ unpinned engine semantics (A5 / A7) ---
 @pytest.mark.parametrize("ws", [(32, 32), (64, 64), (24, 24), (16, 16), (9, 9), (27, 27), (24, 16)])
 @pytest.mark.parametrize("opt,val", [("border_peak", 1), ("border_peak", 2), ("signal_mode", 1), ("signal_positive", 1)])

@@ -6,7 +6,7 @@ TAG=${1:-r1}
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 5 --warmup 1 --cpu-pairs 0 --no-extras ${BENCH_ARGS}"
+CMD="python $R/bench.py --steps 20 --warmup 3 --cpu-pairs 0 --no-extras ${BENCH_ARGS}"
 KF='--kernel-include-regex piv_'
 run() { name=$1; shift; timeout 600 rocprofv3 "$@" --output-format csv -d /tmp/prof_$name -o $name -- $CMD > $OUT/$name.log 2>&1; \
         find /tmp/prof_$name -name "*.csv" -size -8M -exec cp {} $OUT/ \; ; }
