@@ -179,6 +179,40 @@ def host_fed_rates(lib, sample_u8: np.ndarray, ws, ov) -> dict:
     return out
 
 
+def camera_to_velocity_rates(cam: np.ndarray, ws, ov) -> dict:
+    """End to end from raw uint8 camera frames in host memory to velocities in host memory, through the accessor-shaped
+    entry points: (a) the stages hand HBM-resident stacks to each other (DeviceFrames: one H2D of the camera bytes,
+    filters.normalize -> Projection.project_frames -> frames.get_piv, results D2H); (b) every stage returns a host stack
+    and the ortho frames reach get_piv as float64, which is what pyorc's project_numpy really hands over."""
+    from pyorc_amd import DeviceFrames, filters, frames as F
+    from pyorc_amd.project import Projection
+    from pyorc_amd.synth import projection_maps
+
+    T, H, W = cam.shape
+    maps = projection_maps((H, W), (H, W), tilt=0.1, seed=1)
+    p = Projection((H, W), (H, W), *maps)
+    t = np.arange(T) / 30.0
+
+    def device_chain():
+        d = p.project_frames(filters.normalize(DeviceFrames.from_host(cam), 15))
+        return F.get_piv(d, ws[0], overlap=ov, time=t, resolution=0.01)
+
+    def host_chain():
+        o = p.project_frames(filters.normalize(cam, 15)).astype(np.float64)
+        return F.get_piv(o, ws[0], overlap=ov, time=t, resolution=0.01)
+
+    out = {}
+    for key, fn in (("device_resident_stages", device_chain), ("host_stacks_float64", host_chain)):
+        fn()
+        t0 = time.perf_counter()
+        r = fn()
+        out[key] = round((T - 1) / (time.perf_counter() - t0), 1)
+    p.close()
+    out["note"] = (f"{T - 1} pairs of {H}x{W} uint8 camera frames in pageable host memory -> normalize(15) -> orthoprojection "
+                   f"(synthetic homography, group means) -> get_piv {ws[0]}x{ws[1]}; PCIe-inclusive, never `value`")
+    return out
+
+
 def spawn_ranks(a) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) and wait for them."""
     tmp = tempfile.mkdtemp(prefix="lspiv_bench_")
@@ -408,6 +442,7 @@ def main():
         out["config"]["host_fed_pairs_per_s"] = {
             **host_fed_rates(lib, sample, ws, ov),
             "note": f"lspiv_piv_pairs on {sample.shape[0] - 1} pairs in pageable host memory, PCIe-inclusive; never `value`"}
+        out["config"]["camera_to_velocity_pairs_per_s"] = camera_to_velocity_rates(sample, ws, ov)
     os.write(json_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:
         comm.barrier()

@@ -8,7 +8,8 @@ interfaces around it:
   pyorc_amd.piv           <-> ffpiv                   (cross_corr, u_v_displacement + fused piv_pairs)
   pyorc_amd.velocimetry   <-> pyorc.velocimetry.ffpiv (get_ffpiv: chunking, halo, ensemble, px -> m/s)
   pyorc_amd.frames        <-> pyorc.api.frames        (get_piv, engine="hip")
-  pyorc_amd.shard                                      (frame-pair sharding over the GPUs of a node)
+  pyorc_amd.shard / comm                               (frame-pair sharding over the GPUs of a node, RCCL through the C ABI)
+  pyorc_amd.device                                     (DeviceFrames: HBM-resident stacks, so normalize -> project -> get_piv never leaves the GPU)
 """
 
 __version__ = "0.1.0"
@@ -16,3 +17,4 @@ __version__ = "0.1.0"
 from . import window  # noqa: F401
 from .piv import cross_corr, piv_pairs, u_v_displacement  # noqa: F401
 from ._lib import get_option, pinned_empty, set_option  # noqa: F401,E402
+from .device import DeviceFrames  # noqa: F401,E402

@@ -1,0 +1,128 @@
+"""HBM-resident frame stacks: what lets a recipe ``normalize -> project -> get_piv`` stay on the GPU.
+
+In pyorc every stage hands a full host stack to the next one (``Frames.normalize`` uint8 -> ``Frames.project`` float64,
+x8 the camera bytes -> ``Frames.get_piv``; pyorc/api/frames.py:279-306, 199-277, 114-197), and ``get_ffpiv`` loads every
+time chunk into host memory (pyorc/velocimetry/ffpiv.py:13-21).  Host-fed, the MI355X engine is PCIe-bound at a few
+thousand pairs/s (float64: ~4 k) against ~150 k pairs/s from HBM.  ``DeviceFrames`` is a (T, H, W) stack that lives
+in HBM; the mirrors in ``pyorc_amd.filters``, ``pyorc_amd.project.Projection`` and ``pyorc_amd.frames.get_piv`` /
+``velocimetry.get_ffpiv`` accept it wherever they accept a numpy stack, call the ``*_dev`` entry points of the C ABI
+and hand a ``DeviceFrames`` (or, for ``get_piv``, the usual result) back:
+
+    f = DeviceFrames.from_host(camera_frames_uint8)          # the only host -> device copy
+    f = filters.normalize(f, 15)                             # uint8, HBM
+    f = projection.project_frames(f)                         # float32 ortho frames, HBM
+    ds = frames.get_piv(f, 32, time=t, resolution=0.01)      # results on the host
+
+Slicing along time (``f[a:b]``) is a view (pointer arithmetic), which is all the chunk loop of ``get_ffpiv`` needs.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Tuple
+
+import numpy as np
+
+from . import _lib
+
+
+class _Allocation:
+    """One lspiv_dev_malloc block, freed when the last stack / view that uses it goes away."""
+
+    def __init__(self, nbytes: int):
+        self.ptr = C.c_void_p()
+        _lib.require_device()
+        _lib.check(_lib.load().lspiv_dev_malloc(C.byref(self.ptr), max(int(nbytes), 1)))
+        self.nbytes = int(nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib.load().lspiv_dev_free(self.ptr)
+                self.ptr = C.c_void_p()
+        except Exception:
+            pass
+
+
+class DeviceFrames:
+    """(T, H, W) frame stack in HBM: ``shape``, ``dtype``, ``len()``, time slicing (views), ``to_host()``."""
+
+    def __init__(self, alloc: _Allocation, offset: int, shape: Tuple[int, int, int], dtype):
+        self._alloc, self._offset = alloc, int(offset)
+        self.shape = (int(shape[0]), int(shape[1]), int(shape[2]))
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in _lib.DTYPE_CODES:
+            raise TypeError(f"device stacks are uint8 / float32 / float64, got {self.dtype}")
+
+    # ---- construction ------------------------------------------------------------------------
+    @classmethod
+    def empty(cls, shape, dtype=np.uint8) -> "DeviceFrames":
+        dt = np.dtype(dtype)
+        return cls(_Allocation(int(np.prod(shape)) * dt.itemsize), 0, shape, dt)
+
+    @classmethod
+    def from_host(cls, frames) -> "DeviceFrames":
+        a = _lib.as_frames(frames)
+        d = cls.empty(a.shape, a.dtype)
+        _lib.check(_lib.load().lspiv_memcpy_h2d(d.c_ptr, _lib.ptr(a), a.nbytes))
+        return d
+
+    # ---- array-like surface ------------------------------------------------------------------
+    @property
+    def ptr(self) -> int:
+        return self._alloc.ptr.value + self._offset
+
+    @property
+    def c_ptr(self) -> C.c_void_p:
+        return C.c_void_p(self.ptr)
+
+    @property
+    def ndim(self) -> int:
+        return 3
+
+    @property
+    def nbytes(self) -> int:
+        return int(np.prod(self.shape)) * self.dtype.itemsize
+
+    @property
+    def dtype_code(self) -> int:
+        return _lib.DTYPE_CODES[self.dtype]
+
+    def __len__(self) -> int:
+        return self.shape[0]
+
+    def __getitem__(self, key):
+        """Time slices are views; an integer index gives a one-frame view (used for ``frames[0].shape``)."""
+        if isinstance(key, (int, np.integer)):
+            k = int(key) + (self.shape[0] if key < 0 else 0)
+            if not 0 <= k < self.shape[0]:
+                raise IndexError(key)
+            return _FrameView(self.shape[1:], self.dtype)
+        if not isinstance(key, slice):
+            raise TypeError("DeviceFrames supports integer indices and contiguous time slices")
+        a, b, step = key.indices(self.shape[0])
+        if step != 1:
+            raise ValueError("DeviceFrames slices must be contiguous (step 1)")
+        b = max(a, b)
+        frame_bytes = self.shape[1] * self.shape[2] * self.dtype.itemsize
+        return DeviceFrames(self._alloc, self._offset + a * frame_bytes, (b - a,) + self.shape[1:], self.dtype)
+
+    def to_host(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=self.dtype)
+        if out.size:
+            _lib.check(_lib.load().lspiv_memcpy_d2h(_lib.ptr(out), self.c_ptr, out.nbytes))
+        return out
+
+    def __repr__(self) -> str:
+        return f"DeviceFrames(shape={self.shape}, dtype={self.dtype}, hbm=0x{self.ptr:x})"
+
+
+class _FrameView:
+    """What ``frames[0]`` needs to be for the accessor code: something with ``.shape``."""
+
+    def __init__(self, shape, dtype):
+        self.shape, self.dtype = tuple(shape), dtype
+
+
+def is_device(obj) -> bool:
+    return isinstance(obj, DeviceFrames)

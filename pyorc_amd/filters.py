@@ -12,10 +12,17 @@ from __future__ import annotations
 import numpy as np
 
 from . import _lib
+from .device import DeviceFrames, is_device
 
 
 def time_diff(frames, thres: float = 0.0, abs: bool = False) -> np.ndarray:
-    """``Frames.time_diff``: (T, H, W) -> (T-1, H, W) float32; values <= thres (and NaN) become 0."""
+    """``Frames.time_diff``: (T, H, W) -> (T-1, H, W) float32; values <= thres (and NaN) become 0.
+    A ``DeviceFrames`` stack stays in HBM (``lspiv_time_diff_dev``) -- so do all the filters below."""
+    if is_device(frames):
+        T, H, W = frames.shape
+        out = DeviceFrames.empty((T - 1, H, W), np.float32)
+        _lib.check(_lib.load().lspiv_time_diff_dev(frames.c_ptr, frames.dtype_code, T, H, W, float(thres), int(bool(abs)), out.c_ptr, None))
+        return out
     a = _lib.as_frames(frames)
     _lib.require_device()
     out = np.empty((a.shape[0] - 1,) + a.shape[1:], dtype=np.float32)
@@ -27,11 +34,15 @@ def time_diff(frames, thres: float = 0.0, abs: bool = False) -> np.ndarray:
 def reduce_rolling(frames, samples: int = 25) -> np.ndarray:
     """``Frames.reduce_rolling`` on uint8 frames: trailing rolling mean of ``samples`` frames removed, clipped at 0,
     per-frame stretch to uint8 (the first ``samples - 1`` frames have no complete window and come out 0)."""
-    a = np.asarray(frames)
+    a = frames if is_device(frames) else np.asarray(frames)
     if a.dtype != np.uint8 or a.ndim != 3:
         raise ValueError("reduce_rolling expects a (T, H, W) uint8 stack (grayscale camera frames)")
     if len(a) < samples:
         raise AssertionError(f"Amount of frames is smaller than requested rolling of {samples} samples")
+    if is_device(a):
+        out = DeviceFrames.empty(a.shape, np.uint8)
+        _lib.check(_lib.load().lspiv_reduce_rolling_dev(a.c_ptr, a.shape[0], a.shape[1], a.shape[2], int(samples), out.c_ptr, None))
+        return out
     a = np.ascontiguousarray(a)
     _lib.require_device()
     out = np.empty_like(a)
@@ -41,6 +52,11 @@ def reduce_rolling(frames, samples: int = 25) -> np.ndarray:
 
 def range(frames) -> np.ndarray:  # noqa: A001 -- the reference's method name
     """``Frames.range``: (T, H, W) -> (H, W) in the frames' own dtype, maximum minus minimum through time (NaN skipped)."""
+    if is_device(frames):
+        out = np.empty(frames.shape[1:], dtype=frames.dtype)
+        d_out = DeviceFrames.empty((1,) + frames.shape[1:], frames.dtype)
+        _lib.check(_lib.load().lspiv_time_range_dev(frames.c_ptr, frames.dtype_code, *frames.shape, d_out.c_ptr, None))
+        return d_out.to_host()[0]
     a = _lib.as_frames(frames)
     _lib.require_device()
     out = np.empty(a.shape[1:], dtype=a.dtype)
@@ -50,6 +66,12 @@ def range(frames) -> np.ndarray:  # noqa: A001 -- the reference's method name
 
 def minmax(frames, min=-np.inf, max=np.inf) -> np.ndarray:
     """``Frames.minmax`` on float32 frames: ``np.maximum(np.minimum(x, max), min)`` (NaN propagates)."""
+    if is_device(frames):
+        if frames.dtype != np.float32:
+            raise ValueError("minmax on a device stack expects float32 frames (the output of edge_detect / smooth / time_diff)")
+        out = DeviceFrames.empty(frames.shape, np.float32)
+        _lib.check(_lib.load().lspiv_minmax_dev(frames.c_ptr, int(np.prod(frames.shape)), float(min), float(max), out.c_ptr, None))
+        return out
     a = np.ascontiguousarray(frames, dtype=np.float32)
     _lib.require_device()
     out = np.empty_like(a)
@@ -59,11 +81,15 @@ def minmax(frames, min=-np.inf, max=np.inf) -> np.ndarray:
 
 def normalize(frames, samples: int = 15) -> np.ndarray:
     """``Frames.normalize`` on uint8 frames: sampled temporal mean removed, per-frame stretch to uint8."""
-    a = np.asarray(frames)
+    a = frames if is_device(frames) else np.asarray(frames)
     if a.dtype != np.uint8 or a.ndim != 3:
         raise ValueError("normalize expects a (T, H, W) uint8 stack (grayscale camera frames)")
     if round(len(a) / samples) == 0:
         raise AssertionError(f"Amount of frames is too small to provide {samples} samples")
+    if is_device(a):
+        out = DeviceFrames.empty(a.shape, np.uint8)
+        _lib.check(_lib.load().lspiv_normalize_dev(a.c_ptr, a.shape[0], a.shape[1], a.shape[2], int(samples), out.c_ptr, None))
+        return out
     a = np.ascontiguousarray(a)
     _lib.require_device()
     out = np.empty_like(a)
@@ -72,6 +98,16 @@ def normalize(frames, samples: int = 15) -> np.ndarray:
 
 
 def _blur(frames, k1: int, k2: int) -> np.ndarray:
+    if is_device(frames):
+        T, H, W = frames.shape
+        out = DeviceFrames.empty(frames.shape, np.float32)
+        lib = _lib.load()
+        if k2:
+            rc = lib.lspiv_edge_detect_dev(frames.c_ptr, frames.dtype_code, T, H, W, k1, k2, out.c_ptr, None)
+        else:
+            rc = lib.lspiv_gaussian_blur_dev(frames.c_ptr, frames.dtype_code, T, H, W, k1, out.c_ptr, None)
+        _lib.check(rc)
+        return out
     a = np.asarray(frames)
     single = a.ndim == 2
     a = _lib.as_frames(a[None] if single else a)

@@ -5,9 +5,10 @@ Two ways in:
 * ``get_piv(frames, ...)`` -- a function with the accessor's parameters.  ``frames`` is either an
   ``xr.DataArray`` produced by pyorc (then camera configuration, resolution, coordinates and
   attributes are taken from it exactly like the reference does, and an ``xr.Dataset`` comes back), or
-  a plain ``(T, H, W)`` array plus ``time`` / ``resolution`` keywords (then a ``PivResult`` dict comes
-  back; this is what the tests and the benchmark use, since neither xarray nor pyorc exist on the
-  GPU box).
+  a plain ``(T, H, W)`` array -- or a ``pyorc_amd.device.DeviceFrames`` stack that already lives in HBM, e.g. the
+  output of ``filters.normalize`` -> ``Projection.project_frames`` on device stacks: the recipe then never bounces
+  through host float64 -- plus ``time`` / ``resolution`` keywords (then a ``PivResult`` dict comes back; this is what
+  the tests and the benchmark use, since neither xarray nor pyorc exist on the GPU box).
 * the two-line patch of INTEGRATION.md, which makes ``frames.frames.get_piv(engine="hip")`` of an
   unmodified pyorc call :func:`pyorc_amd.velocimetry.get_ffpiv`.
 
@@ -76,7 +77,8 @@ def get_piv(frames, window_size=None, overlap=None, engine: str = "hip", ensembl
         dt = t.diff(dim="time")
         xs, ys = frames["x"].values, frames["y"].values
     else:
-        frames = np.asarray(frames)
+        if not velocimetry.is_device(frames):   # DeviceFrames: HBM-resident stack, used as it is
+            frames = np.asarray(frames)
         t = np.arange(frames.shape[0], dtype=np.float64) if time is None else np.asarray(time, dtype=np.float64)
         dt = np.diff(t)
         xs = ys = None

@@ -17,6 +17,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 from . import _lib, window
+from .device import is_device
 
 ENGINES = ("hip",)
 
@@ -46,12 +47,14 @@ def piv_pairs(imgs, window_size=(32, 32), overlap=(16, 16), signal_threshold: Op
     """
     lib = _lib.load()
     _lib.require_device()
-    a = _lib.as_frames(imgs)
+    a = imgs if is_device(imgs) else _lib.as_frames(imgs)
     T, H, W = a.shape
     n_rows, n_cols = window.get_array_shape((H, W), window_size, overlap)
     if T < 2 or n_rows < 1 or n_cols < 1:
         raise ValueError(f"need >= 2 frames at least one window large, got {a.shape} for window {window_size}")
     P = T - 1
+    if is_device(a):   # HBM-resident stack: no staging, one launch, only the result block crosses PCIe
+        return _piv_pairs_device(a, window_size, overlap, signal_threshold, return_planes, pair_offset, n_rows, n_cols)
     out = [np.empty((P, n_rows, n_cols), dtype=np.float32) for _ in range(4)]
     planes = None
     if return_planes:
@@ -61,6 +64,24 @@ def piv_pairs(imgs, window_size=(32, 32), overlap=(16, 16), signal_threshold: Op
                                       _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.ptr(out[3]),
                                       _lib.ptr(planes) if planes is not None else None))
     return (*out, planes) if return_planes else tuple(out)
+
+
+def _piv_pairs_device(a, window_size, overlap, signal_threshold, return_planes, pair_offset, n_rows, n_cols):
+    from .device import DeviceFrames
+
+    lib = _lib.load()
+    T, H, W = a.shape
+    P, n_win = T - 1, n_rows * n_cols
+    d_out = DeviceFrames.empty((4, P, n_win), np.float32)
+    d_planes = DeviceFrames.empty((P * n_win, window_size[0], window_size[1]), np.float32) if return_planes else None
+    _lib.check(lib.lspiv_piv_pairs_dev_at(a.c_ptr, a.dtype_code, T, H, W, window_size[0], window_size[1], overlap[0], overlap[1],
+                                          _sig(signal_threshold), int(pair_offset), d_out.c_ptr,
+                                          d_planes.c_ptr if d_planes is not None else None, None))
+    res = d_out.to_host().reshape(4, P, n_rows, n_cols)     # lspiv_memcpy_d2h runs on, and waits for, the library's stream
+    out = tuple(np.ascontiguousarray(res[k]) for k in range(4))
+    if return_planes:
+        return (*out, d_planes.to_host().reshape(P, n_win, window_size[0], window_size[1]))
+    return out
 
 
 def cross_corr(imgs, window_size=(64, 64), overlap=(32, 32), search_area_size=None, normalize=False,
@@ -110,11 +131,18 @@ class Ensemble:
 
     def accumulate(self, imgs, corr_min: float, s2n_min: float, signal_threshold: Optional[float] = None):
         """Add one frame chunk; returns masked per-pair (corr_max, s2n), each (T-1, n_win) float32."""
-        a = _lib.as_frames(imgs)
-        if a.shape[1:] != self.dim_size:
+        a = imgs if is_device(imgs) else _lib.as_frames(imgs)
+        if tuple(a.shape[1:]) != self.dim_size:
             raise ValueError(f"chunk shape {a.shape[1:]} != ensemble shape {self.dim_size}")
         P = a.shape[0] - 1
         n_win = self.n_rows * self.n_cols
+        if is_device(a):
+            from .device import DeviceFrames
+
+            d = DeviceFrames.empty((2, P, n_win), np.float32)
+            self.accumulate_dev(a.ptr, a.dtype, a.shape[0], corr_min, s2n_min, d.ptr, signal_threshold)
+            res = d.to_host()
+            return np.ascontiguousarray(res[0]), np.ascontiguousarray(res[1])
         cm = np.empty((P, n_win), dtype=np.float32)
         sn = np.empty((P, n_win), dtype=np.float32)
         _lib.check(_lib.load().lspiv_ensemble_accumulate(self._h, _lib.ptr(a), _lib.DTYPE_CODES[a.dtype], a.shape[0],

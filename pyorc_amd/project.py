@@ -16,6 +16,7 @@ from typing import Optional
 import numpy as np
 
 from . import _lib
+from .device import DeviceFrames, is_device
 
 
 def _i64(a) -> np.ndarray:
@@ -48,7 +49,14 @@ class Projection:
                                                _lib.ptr(ui), ui.size, C.byref(self._h)))
 
     def project_frames(self, frames) -> np.ndarray:
-        """(T, Hc, Wc) or (Hc, Wc) camera frames -> (T, Ho, Wo) float32 (``project_numpy`` + ``fillna(0)``)."""
+        """(T, Hc, Wc) or (Hc, Wc) camera frames -> (T, Ho, Wo) float32 (``project_numpy`` + ``fillna(0)``).
+        A ``DeviceFrames`` stack is projected in HBM and a ``DeviceFrames`` comes back."""
+        if is_device(frames):
+            if frames.shape[1:] != self.src_shape:
+                raise ValueError(f"frames are {frames.shape[1:]}, projection expects {self.src_shape}")
+            out = DeviceFrames.empty((frames.shape[0],) + self.dst_shape, np.float32)
+            self.project_frames_dev(frames.ptr, frames.dtype, frames.shape[0], out.ptr)
+            return out
         a = np.asarray(frames)
         single = a.ndim == 2
         a = _lib.as_frames(a[None] if single else a)

@@ -29,6 +29,7 @@ from typing import Literal, Optional, Tuple
 import numpy as np
 
 from . import piv, window
+from .device import is_device
 
 try:  # xarray is optional: the GPU box image does not ship it
     import xarray as xr
@@ -79,7 +80,9 @@ def load_frame_chunk(da):
         return load_frame_chunk(da[:-1])
 
 
-def _values(da) -> np.ndarray:
+def _values(da):
+    if is_device(da):
+        return da   # HBM-resident chunk (a view): handed to the *_dev entry points as it is
     return da.values if hasattr(da, "values") else np.asarray(da)
 
 
@@ -154,7 +157,9 @@ def get_ffpiv(
 ):
     """Compute time-resolved (or ensemble) PIV on the MI355X; signature of pyorc's ``get_ffpiv`` (ffpiv.py:24-42).
 
-    ``frames``: ``xr.DataArray (time, y, x)`` or ``(T, H, W)`` array; ``dt``: time step per pair (``T-1``,
+    ``frames``: ``xr.DataArray (time, y, x)``, a ``(T, H, W)`` array, or a ``pyorc_amd.device.DeviceFrames`` stack that
+    already lives in HBM (the output of ``pyorc_amd.filters`` / ``Projection.project_frames`` on device stacks: no
+    chunk is staged through the host then, each chunk is one launch on a view of the stack); ``dt``: time step per pair (``T-1``,
     seconds; an ``xr.DataArray`` on ``time[1:]`` in pyorc); ``time``: frame time stamps when ``frames`` is a
     plain array (default ``arange(T)``).  Returns Dataset / PivResult with ``s2n, corr, v_x, v_y``.
     """
@@ -232,7 +237,7 @@ def _get_ffpiv_mean(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_cols,
                 continue
             arr = _values(da)
             if ens is None:
-                dim_size = arr.shape[1:]
+                dim_size = tuple(arr.shape[1:])
                 ens = piv.Ensemble(dim_size, window_size, overlap)
             corr_max, s2n = ens.accumulate(arr, corr_min, s2n_min, signal_threshold)
             corr_chunks.append(corr_max)

@@ -187,6 +187,60 @@ def test_gpu_camera_to_velocity_chain_equals_stage_by_stage(gpu):
     p.close()
 
 
+@pytest.mark.gpu
+def test_gpu_get_piv_on_device_stacks_equals_the_chain_and_the_host_path(gpu):
+    """The accessor-shaped call on HBM-resident stacks: DeviceFrames -> filters.normalize -> Projection.project_frames ->
+    frames.get_piv(engine="hip") never bounces through the host, and returns, bit for bit, what the fixed chain
+    (pipeline.CameraToVelocity) and the host-fed mirrors return -- per-timestep (several chunk sizes) and ensemble."""
+    import pyorc_amd
+    from pyorc_amd import DeviceFrames, filters, frames as F
+    from pyorc_amd.pipeline import CameraToVelocity
+    from pyorc_amd.project import Projection
+    from pyorc_amd.synth import projection_maps
+
+    src, dst = (240, 320), (128, 160)
+    cam = (particle_stack(40, src[0], src[1], seed=28, density=0.04) * 0.6 + 50).astype(np.uint8)
+    maps = projection_maps(src, dst, tilt=0.25, seed=6)
+    t = np.arange(40) / 25.0
+    p = Projection(src, dst, *maps)
+    # host-fed: every stage returns a numpy stack
+    host = F.get_piv(p.project_frames(filters.normalize(cam, 15)), 32, time=t, resolution=0.02)
+    # device-resident: one H2D of the camera frames, results back
+    d_cam = DeviceFrames.from_host(cam)
+    assert d_cam.shape == cam.shape and len(d_cam[3:10]) == 7 and np.array_equal(d_cam[3:10].to_host(), cam[3:10])
+    d_norm = filters.normalize(d_cam, 15)
+    d_ortho = p.project_frames(d_norm)
+    assert isinstance(d_ortho, DeviceFrames) and d_ortho.dtype == np.float32 and d_ortho.shape == (40,) + dst
+    assert np.array_equal(d_norm.to_host(), filters.normalize(cam, 15))
+    dev = F.get_piv(d_ortho, 32, time=t, resolution=0.02)
+    for k in ("v_x", "v_y", "corr", "s2n"):
+        assert np.array_equal(dev[k], host[k], equal_nan=True), k
+    assert np.array_equal(dev.coords["time"], host.coords["time"])
+    for cs in (5, 26, 30):
+        part = F.get_piv(d_ortho, 32, time=t, resolution=0.02, chunksize=cs)
+        for k in ("v_x", "v_y", "corr", "s2n"):
+            assert np.array_equal(part[k], host[k], equal_nan=True), (cs, k)
+    with CameraToVelocity(src, dst, *maps, window_size=(32, 32), overlap=(16, 16), normalize_samples=15) as chain:
+        u, v, cm, sn = chain.run(cam)
+    assert np.array_equal(cm, dev["corr"], equal_nan=True) and np.array_equal(sn, dev["s2n"], equal_nan=True)
+    dt = np.diff(t)[:, None, None]
+    assert np.array_equal((u * 0.02 / dt).astype(np.float32), dev["v_x"], equal_nan=True)
+    # the other filters and ensemble mode on device stacks
+    e_host = filters.minmax(filters.edge_detect(filters.normalize(cam, 15), 1, 2), -5, 5)
+    e_dev = filters.minmax(filters.edge_detect(d_norm, 1, 2), -5, 5)
+    assert np.array_equal(e_dev.to_host(), e_host)
+    assert np.array_equal(filters.time_diff(d_cam, 2.0).to_host(), filters.time_diff(cam, 2.0))
+    assert np.array_equal(filters.smooth(d_cam, 2).to_host(), filters.smooth(cam, 2))
+    assert np.array_equal(filters.range(d_cam), filters.range(cam))
+    ens_h = F.get_piv(p.project_frames(e_host), 32, time=t, resolution=0.02, ensemble_corr=True, corr_min=0.1, s2n_min=1.5)
+    ens_d = F.get_piv(p.project_frames(e_dev), 32, time=t, resolution=0.02, ensemble_corr=True, corr_min=0.1, s2n_min=1.5)
+    for k in ("v_x", "v_y", "corr", "s2n"):
+        assert np.array_equal(ens_d[k], ens_h[k], equal_nan=True), k
+    u2, v2, _, _ = pyorc_amd.piv_pairs(d_ortho, (32, 32), (16, 16))
+    assert np.array_equal(u2, u, equal_nan=True)
+    p.close()
+
+
 def test_oracle_gaussian_blur_matches_scipy_mirror_correlation():
     from scipy.ndimage import correlate1d
 
