@@ -190,6 +190,22 @@ int lspiv_project_frames_dev(lspiv_projection* handle, const void* d_frames, int
                              void* stream);
 int lspiv_projection_destroy(lspiv_projection* handle);
 
+/* N1, method "cv" -- replaces pyorc.project.project_cv (pyorc/project.py:56-120): cv2.undistort(img, camera_matrix,
+ * dist_coeffs) (pyorc/cv.py:1392-1413) followed by cv2.warpPerspective(img, M, (dst_w, dst_h), flags=INTER_AREA)
+ * (pyorc/cv.py:993-1013; OpenCV turns INTER_AREA into INTER_LINEAR there).  OpenCV's published algorithm is restated --
+ * initUndistortRectifyMap / the inverted homography evaluated in double, source coordinates quantised to 1/32 pixel,
+ * fixed-point bilinear blend (2^15 weights, round half up) for uint8 and the float32 weight table for float32 frames,
+ * BORDER_CONSTANT 0 -- NOT pinned against a real cv2 (absent here).  camera_matrix 3x3 row-major or NULL (no
+ * undistortion step); dist_coeffs k1 k2 p1 p2 [k3 [k4 k5 k6]] (n_dist 0, 4, 5 or 8); M the 3x3 source-to-destination
+ * homography of cv2.getPerspectiveTransform (pyorc/cv.py:769-795).  Frames uint8 or float32; the output has the dtype
+ * of the input, (T, dst_h, dst_w), like the reference (pyorc/project.py:112). */
+typedef struct lspiv_remap lspiv_remap;
+int lspiv_project_cv_create(int64_t src_h, int64_t src_w, int64_t dst_h, int64_t dst_w, const double* camera_matrix,
+                            const double* dist_coeffs, int n_dist, const double* M, lspiv_remap** handle);
+int lspiv_project_cv_frames(lspiv_remap* handle, const void* frames, int dtype, int64_t T, void* out);
+int lspiv_project_cv_frames_dev(lspiv_remap* handle, const void* d_frames, int dtype, int64_t T, void* d_out, void* stream);
+int lspiv_project_cv_destroy(lspiv_remap* handle);
+
 /* N2 -- element-wise pre-processing filters the reference writes in plain numpy (bit-reproducible):
  *   lspiv_time_diff   Frames.time_diff (pyorc/api/frames.py:409-436): out (T-1,H,W) float32 = f32(frame t+1) - f32(frame t),
  *                     values <= thres and NaN -> 0, |.| if use_abs

@@ -76,6 +76,10 @@ SIGNATURES = {
     "lspiv_project_frames": (_i32, [_vp, _vp, _i32, _i64, _vp]),
     "lspiv_project_frames_dev": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp]),
     "lspiv_projection_destroy": (_i32, [_vp]),
+    "lspiv_project_cv_create": (_i32, [_i64, _i64, _i64, _i64, _vp, _vp, _i32, _vp, C.POINTER(_vp)]),
+    "lspiv_project_cv_frames": (_i32, [_vp, _vp, _i32, _i64, _vp]),
+    "lspiv_project_cv_frames_dev": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp]),
+    "lspiv_project_cv_destroy": (_i32, [_vp]),
     "lspiv_time_diff": (_i32, [_vp, _i32, _i64, _i64, _i64, _f32, _i32, _vp]),
     "lspiv_time_diff_dev": (_i32, [_vp, _i32, _i64, _i64, _i64, _f32, _i32, _vp, _vp]),
     "lspiv_time_range": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp]),

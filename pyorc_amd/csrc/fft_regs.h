@@ -200,6 +200,12 @@ __device__ __forceinline__ void fft64_col(const float (&xr)[64], const float (&x
   for (int k2 = 0; k2 < 8; ++k2) { yr[K1 + 8 * k2] = r[k2]; yi[K1 + 8 * k2] = i[k2]; }
 }
 
+// LSPIV_FFT64_SB: scheduling barriers between the butterflies of the two stages -- left alone the scheduler interleaves
+// several column transforms for ILP, which stretches live ranges in the register-bound 64 x 64 kernels
+#ifndef LSPIV_FFT64_SB
+#define LSPIV_FFT64_SB 1
+#endif
+#define LSPIV_FFT64_BAR do { if (LSPIV_FFT64_SB) __builtin_amdgcn_sched_barrier(0); } while (0)
 template <bool INV>
 __device__ __forceinline__ void fft64(float (&xr)[64], float (&xi)[64]) {
 #pragma unroll
@@ -210,17 +216,9 @@ __device__ __forceinline__ void fft64(float (&xr)[64], float (&xi)[64]) {
     bfly8<INV>(r, i);
 #pragma unroll
     for (int k1 = 0; k1 < 8; ++k1) { xr[8 * k1 + n2] = r[k1]; xi[8 * k1 + n2] = i[k1]; }
-#if defined(LSPIV_FFT64_SB) && LSPIV_FFT64_SB
-    __builtin_amdgcn_sched_barrier(0);
-#endif
+    if (LSPIV_FFT64_SB) __builtin_amdgcn_sched_barrier(0);
   }
   float yr[64], yi[64];
-  // LSPIV_FFT64_SB: scheduling barriers between the eight column transforms -- left alone the scheduler interleaves
-  // several of them for ILP, which keeps up to 128 + 128 values live and pushes the caller's carried spectrum to scratch
-#ifndef LSPIV_FFT64_SB
-#define LSPIV_FFT64_SB 0
-#endif
-#define LSPIV_FFT64_BAR do { if (LSPIV_FFT64_SB) __builtin_amdgcn_sched_barrier(0); } while (0)
   fft64_col<INV, 0>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
   fft64_col<INV, 1>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
   fft64_col<INV, 2>(xr, xi, yr, yi); LSPIV_FFT64_BAR;

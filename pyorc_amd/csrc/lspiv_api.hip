@@ -941,6 +941,170 @@ int lspiv_projection_destroy(lspiv_projection* h) {
   return LSPIV_OK;
 }
 
+// ---- project_cv (N1, method="cv"): cv2.undistort + cv2.warpPerspective restated as two fixed-point bilinear remaps ---
+struct lspiv_remap {
+  int64_t src_h, src_w, dst_h, dst_w;
+  bool undistort;
+  int *d_mx1, *d_my1, *d_mx2, *d_my2;      // integer source coordinates of the undistortion map / of the warp map
+  uint16_t *d_mf1, *d_mf2;                 // 1/32-pixel fraction index fy * 32 + fx
+  void* d_tmp; size_t tmp_cap;             // undistorted frames of one call (grow-only)
+};
+
+namespace {
+// saturate_cast<int>(double): round half to even, saturating
+int64_t cv_round(double v) {
+  if (!(v == v)) return 0;
+  if (v >= 2147483647.0) return 2147483647;
+  if (v <= -2147483648.0) return -2147483648LL;
+  return (int64_t)std::nearbyint(v);
+}
+bool invert3(const double* m, double* o) {
+  const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+  const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+  if (det == 0.0 || !(det == det)) return false;
+  const double r = 1.0 / det;
+  o[0] = (e * i - f * h) * r; o[1] = (c * h - b * i) * r; o[2] = (b * f - c * e) * r;
+  o[3] = (f * g - d * i) * r; o[4] = (a * i - c * g) * r; o[5] = (c * d - a * f) * r;
+  o[6] = (d * h - e * g) * r; o[7] = (b * g - a * h) * r; o[8] = (a * e - b * d) * r;
+  return true;
+}
+int upload_map(const std::vector<int>& mx, const std::vector<int>& my, const std::vector<uint16_t>& mf, int** d_mx, int** d_my,
+               uint16_t** d_mf) {
+  const size_t n = mx.size();
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, n * sizeof(int))); *d_mx = (int*)p;
+  HIP_TRY(hipMalloc(&p, n * sizeof(int))); *d_my = (int*)p;
+  HIP_TRY(hipMalloc(&p, n * sizeof(uint16_t))); *d_mf = (uint16_t*)p;
+  HIP_TRY(hipMemcpy(*d_mx, mx.data(), n * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(*d_my, my.data(), n * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(*d_mf, mf.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice));
+  return LSPIV_OK;
+}
+int clamp_short(int64_t v) { return (int)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }   // OpenCV keeps the integer part as short
+}  // namespace
+
+int lspiv_project_cv_create(int64_t src_h, int64_t src_w, int64_t dst_h, int64_t dst_w, const double* camera_matrix,
+                            const double* dist_coeffs, int n_dist, const double* M, lspiv_remap** handle) {
+  if (!handle || !M) return fail(LSPIV_EINVAL, "NULL argument");
+  if (src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0 || src_h * src_w >= (int64_t)1 << 31 || dst_h * dst_w >= (int64_t)1 << 31)
+    return fail(LSPIV_ESHAPE, "bad projection shape");
+  if (n_dist != 0 && n_dist != 4 && n_dist != 5 && n_dist != 8)
+    return fail(LSPIV_EINVAL, "dist_coeffs must hold 0, 4, 5 or 8 values (k1 k2 p1 p2 [k3 [k4 k5 k6]]), got %d", n_dist);
+  if (n_dist > 0 && (!dist_coeffs || !camera_matrix)) return fail(LSPIV_EINVAL, "distortion coefficients need a camera matrix");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  lspiv_remap* h = new lspiv_remap();
+  memset(h, 0, sizeof(*h));
+  h->src_h = src_h; h->src_w = src_w; h->dst_h = dst_h; h->dst_w = dst_w;
+  h->undistort = camera_matrix != nullptr;
+  if (h->undistort) {
+    // initUndistortRectifyMap(K, dist, R = I, newK = K, size, CV_16SC2): the row walk _x += ir[0] included
+    double ir[9];
+    if (!invert3(camera_matrix, ir)) { delete h; return fail(LSPIV_EINVAL, "camera matrix is singular"); }
+    double k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n_dist; ++i) k[i] = dist_coeffs[i];
+    const double k1 = k[0], k2 = k[1], p1 = k[2], p2 = k[3], k3 = k[4], k4 = k[5], k5 = k[6], k6 = k[7];
+    const double fx = camera_matrix[0], fy = camera_matrix[4], u0 = camera_matrix[2], v0 = camera_matrix[5];
+    const size_t n = (size_t)(src_h * src_w);
+    std::vector<int> mx(n), my(n);
+    std::vector<uint16_t> mf(n);
+    for (int64_t i = 0; i < src_h; ++i) {
+      double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+      for (int64_t j = 0; j < src_w; ++j, _x += ir[0], _y += ir[3], _w += ir[6]) {
+        const double w = 1.0 / _w, x = _x * w, y = _y * w;
+        const double x2 = x * x, y2 = y * y, r2 = x2 + y2, _2xy = 2 * x * y;
+        const double kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2);
+        const double xd = x * kr + p1 * _2xy + p2 * (r2 + 2 * x2), yd = y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy;
+        const int64_t iu = cv_round((fx * xd + u0) * 32.0), iv = cv_round((fy * yd + v0) * 32.0);
+        const size_t o = (size_t)(i * src_w + j);
+        mx[o] = clamp_short(iu >> 5); my[o] = clamp_short(iv >> 5);
+        mf[o] = (uint16_t)((iv & 31) * 32 + (iu & 31));
+      }
+    }
+    rc = upload_map(mx, my, mf, &h->d_mx1, &h->d_my1, &h->d_mf1);
+    if (rc) { lspiv_project_cv_destroy(h); return rc; }
+  }
+  {
+    // cv2.warpPerspective(src, M, (dst_w, dst_h), INTER_AREA -> INTER_LINEAR): M is inverted, 64-pixel column blocks
+    double Mi[9];
+    if (!invert3(M, Mi)) { lspiv_project_cv_destroy(h); return fail(LSPIV_EINVAL, "homography is singular"); }
+    const size_t n = (size_t)(dst_h * dst_w);
+    std::vector<int> mx(n), my(n);
+    std::vector<uint16_t> mf(n);
+    for (int64_t y = 0; y < dst_h; ++y)
+      for (int64_t xb = 0; xb < dst_w; xb += 64) {
+        const double X0 = Mi[0] * xb + Mi[1] * y + Mi[2], Y0 = Mi[3] * xb + Mi[4] * y + Mi[5], W0 = Mi[6] * xb + Mi[7] * y + Mi[8];
+        for (int64_t x1 = 0; x1 < 64 && xb + x1 < dst_w; ++x1) {
+          double W = W0 + Mi[6] * x1;
+          W = W != 0.0 ? 32.0 / W : 0.0;
+          const double fX = std::max(-2147483648.0, std::min(2147483647.0, (X0 + Mi[0] * x1) * W));
+          const double fY = std::max(-2147483648.0, std::min(2147483647.0, (Y0 + Mi[3] * x1) * W));
+          const int64_t X = cv_round(fX), Y = cv_round(fY);
+          const size_t o = (size_t)(y * dst_w + xb + x1);
+          mx[o] = clamp_short(X >> 5); my[o] = clamp_short(Y >> 5);
+          mf[o] = (uint16_t)((Y & 31) * 32 + (X & 31));
+        }
+      }
+    rc = upload_map(mx, my, mf, &h->d_mx2, &h->d_my2, &h->d_mf2);
+    if (rc) { lspiv_project_cv_destroy(h); return rc; }
+  }
+  *handle = h;
+  return LSPIV_OK;
+}
+
+int lspiv_project_cv_frames_dev(lspiv_remap* h, const void* d_frames, int dtype, int64_t T, void* d_out, void* stream) {
+  if (!h || !d_frames || !d_out) return fail(LSPIV_EINVAL, "NULL argument");
+  if (dtype != LSPIV_U8 && dtype != LSPIV_F32) return fail(LSPIV_EINVAL, "project_cv takes uint8 or float32 frames (cv2 keeps the frame dtype)");
+  if (T < 0 || T >= (int64_t)1 << 28) return fail(LSPIV_ESHAPE, "bad frame count");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  const int64_t n_src = h->src_h * h->src_w, n_dst = h->dst_h * h->dst_w;
+  const void* src = d_frames;
+  hipError_t e;
+  if (h->undistort) {
+    rc = ensure(&h->d_tmp, &h->tmp_cap, (size_t)T * n_src * elem_size(dtype));
+    if (rc) return rc;
+    e = lspiv::launch_remap(d_frames, dtype, n_src, (int)h->src_h, (int)h->src_w, (int)T, h->d_mx1, h->d_my1, h->d_mf1, h->d_tmp, (int)n_src, s);
+    if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+    src = h->d_tmp;
+  }
+  e = lspiv::launch_remap(src, dtype, n_src, (int)h->src_h, (int)h->src_w, (int)T, h->d_mx2, h->d_my2, h->d_mf2, d_out, (int)n_dst, s);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return LSPIV_OK;
+}
+
+int lspiv_project_cv_frames(lspiv_remap* h, const void* frames, int dtype, int64_t T, void* out) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  if (!h || !frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
+  if (dtype != LSPIV_U8 && dtype != LSPIV_F32) return fail(LSPIV_EINVAL, "project_cv takes uint8 or float32 frames (cv2 keeps the frame dtype)");
+  if (T <= 0) return LSPIV_OK;
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  const size_t fb = (size_t)T * h->src_h * h->src_w * elem_size(dtype), ob = (size_t)T * h->dst_h * h->dst_w * elem_size(dtype);
+  rc = ensure(&c->d_frames, &c->frames_cap, fb);
+  if (rc) return rc;
+  rc = ensure(&c->d_planes, &c->planes_cap, ob);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_frames, frames, fb, hipMemcpyHostToDevice, c->stream));
+  rc = lspiv_project_cv_frames_dev(h, c->d_frames, dtype, T, c->d_planes, c->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out, c->d_planes, ob, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
+
+int lspiv_project_cv_destroy(lspiv_remap* h) {
+  if (!h) return LSPIV_OK;
+  for (void* p : {(void*)h->d_mx1, (void*)h->d_my1, (void*)h->d_mf1, (void*)h->d_mx2, (void*)h->d_my2, (void*)h->d_mf2, h->d_tmp})
+    if (p) hipFree(p);
+  delete h;
+  return LSPIV_OK;
+}
+
 int lspiv_pack_int16_dev(const float* d_values, int64_t n, float scale, int fill, int16_t* d_packed, void* stream) {
   if (!d_values || !d_packed) return fail(LSPIV_EINVAL, "NULL argument");
   if (n < 0 || !(scale > 0.0f) || fill < -32768 || fill > 32767) return fail(LSPIV_EINVAL, "bad argument");

@@ -788,8 +788,11 @@ __device__ __forceinline__ void store_plane_rows(float* dst, int lg, const float
 #define LSPIV_WALK_WAVES_MID 3
 #endif
 // walking kernels: the carried spectrum costs 32 x 32 one wave per SIMD
+#ifndef LSPIV_WALK_WAVES_64
+#define LSPIV_WALK_WAVES_64 2
+#endif
 template <typename T, int N>
-constexpr int kWalkWaves = N <= 16 ? 4 : (N < 32 && sizeof(T) < 8) ? LSPIV_WALK_WAVES_MID : (N == 32 && sizeof(T) < 8) ? LSPIV_WALK_WAVES : 2;
+constexpr int kWalkWaves = N <= 16 ? 4 : (N < 32 && sizeof(T) < 8) ? LSPIV_WALK_WAVES_MID : (N == 32 && sizeof(T) < 8) ? LSPIV_WALK_WAVES : N == 64 ? LSPIV_WALK_WAVES_64 : 2;
 template <typename T, int N>
 constexpr int kWavesPerSimd = N <= 16 ? 4 : N <= 24 ? LSPIV_WAVES_MID : (N == 32 && sizeof(T) == 1) ? LSPIV_WAVES_32U8 : (N == 32 && sizeof(T) == 4) ? LSPIV_WAVES_32F : 2;
 
@@ -896,14 +899,14 @@ __device__ __forceinline__ void prepare_one(const RowRaw<T, N>& raw, float (&x)[
   }
 }
 
+// Scheduling barriers between the phases of a walking iteration (conversion | FFT | transpose | FFT | un-pack | FFT |
+// transpose | FFT | epilogue): they stop the scheduler from stretching live ranges across phases.  32 x 32: removed the
+// last spills at 3 waves/SIMD (+7 %); 64 x 64 (256 VGPRs, 2 waves/SIMD, the carried spectrum is spilled across the
+// inverse transform either way): 50 -> 44 spilled registers and +2.8 %, +3.7 % together with the barriers inside fft64
+// (LSPIV_FFT64_SB; interleaved A/B on one box, 1080p 64 x 64 @ 75 %: 28.7 k -> 29.8 k pairs/s).  The other sizes were
+// measured without and are left alone.
 #ifndef LSPIV_WALK_SB
-#ifndef LSPIV_WALK_SB_MIN
-#define LSPIV_WALK_SB_MIN 32
-#endif
-#ifndef LSPIV_WALK_SB_MAX
-#define LSPIV_WALK_SB_MAX 32
-#endif
-#define LSPIV_WALK_SB do { if constexpr (N >= LSPIV_WALK_SB_MIN && N <= LSPIV_WALK_SB_MAX) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define LSPIV_WALK_SB do { if constexpr (N == 32 || N == 64) __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif
 
 // what a walking job carries from one iteration to the next

@@ -105,6 +105,62 @@ hipError_t launch_project(const void* frames, int dtype, int64_t src_elems, int 
   return hipGetLastError();
 }
 
+// ---- project_cv (pyorc/project.py:56-120): cv2.undistort + cv2.warpPerspective as fixed-point bilinear remaps ----------
+// OpenCV's remap with INTER_LINEAR: source coordinates quantised to 1/32 pixel (the maps are built on the host in double,
+// lspiv_api.hip), 8-bit images blended with integer weights that sum to 2^15 and rounded + 2^14 >> 15, float images with the
+// float32 weight table, neighbours outside the image count as 0 (BORDER_CONSTANT).  Thread = destination pixel, F frames
+// per thread so that the map entry is read once per F frames.  No FMA contraction: the float path reproduces
+// ((p00 w00 + p01 w01) + p10 w10) + p11 w11 in float32.
+#pragma clang fp contract(off)
+template <typename T, int F>
+__global__ __launch_bounds__(256) void remap_kernel(const T* __restrict__ frames, int64_t src_elems, int Hs, int Ws, int n_frames,
+                                                     const int* __restrict__ mx, const int* __restrict__ my,
+                                                     const uint16_t* __restrict__ mf, T* __restrict__ out, int n_out) {
+  const int t0 = blockIdx.y * F;
+  const int nt = min(n_frames - t0, F);
+  for (int o = blockIdx.x * 256 + threadIdx.x; o < n_out; o += gridDim.x * 256) {
+    const int ix = mx[o], iy = my[o];
+    const int fr = mf[o], fx = fr & 31, fy = fr >> 5;
+    const bool x0 = ix >= 0 && ix < Ws, x1 = ix + 1 >= 0 && ix + 1 < Ws, y0 = iy >= 0 && iy < Hs, y1 = iy + 1 >= 0 && iy + 1 < Hs;
+    const int64_t base = (int64_t)iy * Ws + ix;
+    const T* img = frames + (int64_t)t0 * src_elems;
+    T* dst = out + (int64_t)t0 * n_out + o;
+    if (!((x0 || x1) && (y0 || y1))) {                 // wholly outside: border value
+      for (int t = 0; t < nt; ++t) dst[(int64_t)t * n_out] = (T)0;
+      continue;
+    }
+    for (int t = 0; t < nt; ++t, img += src_elems) {
+      const T p00 = (x0 && y0) ? img[base] : (T)0, p01 = (x1 && y0) ? img[base + 1] : (T)0;
+      const T p10 = (x0 && y1) ? img[base + Ws] : (T)0, p11 = (x1 && y1) ? img[base + Ws + 1] : (T)0;
+      if constexpr (sizeof(T) == 1) {
+        const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+        const int acc = (int)p00 * w00 + (int)p01 * w01 + (int)p10 * w10 + (int)p11 * w11;
+        dst[(int64_t)t * n_out] = (T)((acc + (1 << 14)) >> 15);
+      } else {
+        const float a = (float)fx / 32.0f, b = (float)fy / 32.0f;
+        const float w00 = (1.0f - a) * (1.0f - b), w01 = a * (1.0f - b), w10 = (1.0f - a) * b, w11 = a * b;
+        dst[(int64_t)t * n_out] = (T)((((float)p00 * w00 + (float)p01 * w01) + (float)p10 * w10) + (float)p11 * w11);
+      }
+    }
+  }
+}
+
+hipError_t launch_remap(const void* frames, int dtype, int64_t src_elems, int Hs, int Ws, int n_frames, const int* mx, const int* my,
+                        const uint16_t* mf, void* out, int n_out, hipStream_t s) {
+  if (n_frames <= 0 || n_out <= 0) return hipSuccess;
+  constexpr int F = 8;
+  const dim3 grid((unsigned)std::min((n_out + 255) / 256, 4096), (unsigned)((n_frames + F - 1) / F));
+  if (dtype == 0)
+    hipLaunchKernelGGL((remap_kernel<uint8_t, F>), grid, dim3(256), 0, s, (const uint8_t*)frames, src_elems, Hs, Ws, n_frames, mx, my, mf,
+                       (uint8_t*)out, n_out);
+  else if (dtype == 1)
+    hipLaunchKernelGGL((remap_kernel<float, F>), grid, dim3(256), 0, s, (const float*)frames, src_elems, Hs, Ws, n_frames, mx, my, mf,
+                       (float*)out, n_out);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 // int16 packing of result variables (pyorc/const.py:80: dtype int16, scale_factor 0.01, _FillValue -9999), the
 // arithmetic xarray applies on to_netcdf: float32 data / float32(scale) -> NaN -> fill -> np.around -> int16.
 __global__ void pack_int16_kernel(const float* __restrict__ in, int64_t n, float scale, int fill, int16_t* __restrict__ out) {

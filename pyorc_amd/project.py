@@ -1,4 +1,4 @@
-"""Mirror of ``pyorc/project.py`` (``img_to_ortho`` / ``project_numpy``) on the MI355X -- SURVEY.md section 8f row N1.
+"""Mirror of ``pyorc/project.py`` (``img_to_ortho`` / ``project_numpy`` and ``project_cv``) on the MI355X -- SURVEY.md section 8f row N1.
 
 The camera-geometry part stays in pyorc: ``CameraConfig.map_idx_img_ortho`` and ``map_mean_idx_img_ortho``
 (pyorc/api/cameraconfig.py:739-860) produce the index maps; this module consumes them.  ``Projection`` uploads the
@@ -81,6 +81,71 @@ class Projection:
             self.close()
         except Exception:
             pass
+
+
+class ProjectionCV:
+    """``Frames.project(method="cv")`` (pyorc/project.py:56-120): ``cv2.undistort`` + ``cv2.warpPerspective`` on the GPU.
+
+    ``camera_matrix`` (3x3) and ``dist_coeffs`` (k1 k2 p1 p2 [k3 [k4 k5 k6]]) are ``CameraConfig.camera_matrix`` /
+    ``.dist_coeffs``; ``M`` is the source-to-destination homography pyorc builds with ``cv.get_M_2D(src, dst)``
+    (pyorc/cv.py:769-795) from the undistorted bounding-box corners; ``dst_shape`` = (len(y), len(x)).  The output keeps
+    the dtype of the frames (uint8 / float32) like the reference.  OpenCV's fixed-point remap is restated, not pinned
+    against a real cv2 (see include/lspiv.h)."""
+
+    def __init__(self, src_shape, dst_shape, camera_matrix, dist_coeffs, M):
+        lib = _lib.load()
+        _lib.require_device()
+        self.src_shape = (int(src_shape[0]), int(src_shape[1]))
+        self.dst_shape = (int(dst_shape[0]), int(dst_shape[1]))
+        K = None if camera_matrix is None else np.ascontiguousarray(np.asarray(camera_matrix, dtype=np.float64).reshape(9))
+        d = np.zeros(0) if dist_coeffs is None else np.ascontiguousarray(np.asarray(dist_coeffs, dtype=np.float64).ravel())
+        Mh = np.ascontiguousarray(np.asarray(M, dtype=np.float64).reshape(9))
+        self._h = C.c_void_p()
+        _lib.check(lib.lspiv_project_cv_create(self.src_shape[0], self.src_shape[1], self.dst_shape[0], self.dst_shape[1],
+                                               _lib.ptr(K) if K is not None else None, _lib.ptr(d) if d.size else None, d.size,
+                                               _lib.ptr(Mh), C.byref(self._h)))
+
+    def project_frames(self, frames):
+        """(T, Hc, Wc) or (Hc, Wc) uint8 / float32 frames -> (T, Ho, Wo) of the same dtype; DeviceFrames stay in HBM."""
+        if is_device(frames):
+            if frames.shape[1:] != self.src_shape or frames.dtype == np.float64:
+                raise ValueError(f"expected uint8 / float32 frames of shape {self.src_shape}, got {frames.shape[1:]} {frames.dtype}")
+            out = DeviceFrames.empty((frames.shape[0],) + self.dst_shape, frames.dtype)
+            _lib.check(_lib.load().lspiv_project_cv_frames_dev(self._h, frames.c_ptr, frames.dtype_code, frames.shape[0], out.c_ptr, None))
+            return out
+        a = np.asarray(frames)
+        single = a.ndim == 2
+        a = a[None] if single else a
+        if a.dtype != np.uint8:
+            a = a.astype(np.float32)   # cv2 would keep float64; the kernels compute in float32 like every other stage
+        a = np.ascontiguousarray(a)
+        if a.shape[1:] != self.src_shape:
+            raise ValueError(f"frames are {a.shape[1:]}, projection expects {self.src_shape}")
+        out = np.empty((a.shape[0],) + self.dst_shape, dtype=a.dtype)
+        _lib.check(_lib.load().lspiv_project_cv_frames(self._h, _lib.ptr(a), _lib.DTYPE_CODES[a.dtype], a.shape[0], _lib.ptr(out)))
+        return out[0] if single else out
+
+    def close(self):
+        if self._h:
+            _lib.load().lspiv_project_cv_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def project_cv(frames, camera_matrix, dist_coeffs, M, dst_shape):
+    """One-shot form of :class:`ProjectionCV` (the arithmetic of pyorc/project.py:56-120 on a frame stack)."""
+    a = frames if is_device(frames) else np.asarray(frames)
+    src_shape = a.shape[-2:]
+    p = ProjectionCV(src_shape, dst_shape, camera_matrix, dist_coeffs, M)
+    try:
+        return p.project_frames(a)
+    finally:
+        p.close()
 
 
 def img_to_ortho(img, x, y, idx_img, idx_ortho, src_idx=None, uidx=None, norm_idx=None) -> np.ndarray:

@@ -6,6 +6,7 @@ import pytest
 
 from oracle import piv_oracle as po
 from oracle import project_oracle as pro
+from pyorc_amd import _lib
 from pyorc_amd.synth import particle_stack, projection_maps
 
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "project_golden.npz"))
@@ -151,3 +152,67 @@ def test_gpu_pack_int16_bit_exact(gpu):
     from pyorc_amd import frames
 
     assert np.array_equal(frames.encode_int16(a), po.encode_int16(a))      # the reference-shaped name is the same kernel
+
+
+# ---------------------------------------------------------------------------------- project_cv (method="cv") ----
+def _cv_case():
+    K = np.array([[820.0, 0.0, 330.5], [0.0, 815.0, 236.25], [0.0, 0.0, 1.0]])
+    dist = [-0.21, 0.07, 0.0012, -0.0008, -0.01]
+    M = np.array([[0.52, 0.031, 12.3], [0.014, 0.61, 4.7], [1.3e-5, 2.1e-5, 1.0]])
+    return K, dist, M
+
+
+def test_project_cv_oracle_properties():
+    """The restated cv2.undistort / cv2.warpPerspective(INTER_AREA -> INTER_LINEAR): identity maps reproduce the image,
+    a half-pixel translation averages neighbours with round-half-up, outside samples are 0, dtype is kept."""
+    from oracle import project_oracle as pj
+
+    rng = np.random.default_rng(3)
+    img = (rng.random((96, 128)) * 255).astype(np.uint8)
+    K = np.array([[300.0, 0, 64], [0, 300.0, 48], [0, 0, 1]])
+    m = pj.undistort_map(K, [], img.shape)
+    assert np.array_equal(m[0], np.tile(np.arange(128), (96, 1))) and not m[2].any()
+    assert np.array_equal(pj.remap_linear(img, *m), img)
+    assert np.array_equal(pj.remap_linear(img, *pj.warp_map(np.eye(3), img.shape)), img)
+    o = pj.remap_linear(img, *pj.warp_map(np.array([[1, 0, 2.5], [0, 1, 1], [0, 0, 1.0]]), img.shape))
+    assert np.array_equal(o[1:, 3:], (img[:-1, :-3].astype(int) + img[:-1, 1:-2] + 1) // 2)
+    assert not o[0].any() and not o[:, :2].any()                       # BORDER_CONSTANT 0
+    Kc, dist, M = _cv_case()
+    big = (rng.random((3, 480, 640)) * 255).astype(np.uint8)
+    out = pj.project_cv(big, Kc, dist, M, (300, 400))
+    assert out.shape == (3, 300, 400) and out.dtype == np.uint8 and 60 < out.mean() < 140
+    outf = pj.project_cv(big.astype(np.float32), Kc, dist, M, (300, 400))
+    assert outf.dtype == np.float32 and np.abs(outf - out).max() <= 1.5    # the uint8 path rounds twice
+    with pytest.raises(ValueError):
+        pj.undistort_map(Kc, [0.1, 0.2, 0.3], (4, 4))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_gpu_project_cv_matches_oracle(gpu, dtype):
+    """lspiv_project_cv_* == the oracle's restatement of cv2.undistort + cv2.warpPerspective bit for bit (same maps in
+    double on both sides, same fixed-point / float32 blend), host and device-resident stacks, with and without the
+    undistortion step, including destinations that fall outside the source image."""
+    from oracle import project_oracle as pj
+    from pyorc_amd import DeviceFrames
+    from pyorc_amd.project import ProjectionCV, project_cv
+
+    Kc, dist, M = _cv_case()
+    rng = np.random.default_rng(11)
+    fr = (rng.random((5, 480, 640)) * 255).astype(np.uint8)
+    fr = fr if dtype == np.uint8 else (fr.astype(np.float32) - 100.5) * 0.25
+    for K_, d_, M_, shape in ((Kc, dist, M, (300, 400)), (Kc, [], M, (300, 400)), (None, None, M, (211, 317)),
+                              (Kc, dist[:4], np.array([[1.4, 0.1, -80.0], [-0.05, 1.2, -30.0], [1e-4, -2e-4, 1.0]]), (480, 640))):
+        ref = pj.project_cv(fr, K_ if K_ is not None else np.eye(3), d_ if d_ is not None else [], M_, shape) if K_ is not None \
+            else np.stack([pj.remap_linear(f, *pj.warp_map(M_, shape)) for f in fr])
+        p = ProjectionCV(fr.shape[1:], shape, K_, d_, M_)
+        got = p.project_frames(fr)
+        assert got.dtype == ref.dtype and got.shape == ref.shape
+        assert np.array_equal(got, ref)
+        dev = p.project_frames(DeviceFrames.from_host(fr))
+        assert np.array_equal(dev.to_host(), ref)
+        assert np.array_equal(p.project_frames(fr[0]), ref[0])
+        p.close()
+    assert np.array_equal(project_cv(fr, Kc, dist, M, (300, 400)), pj.project_cv(fr, Kc, dist, M, (300, 400)))
+    with pytest.raises(_lib.LspivError):
+        ProjectionCV((480, 640), (10, 10), Kc, [0.1, 0.2, 0.3], M)

@@ -10,7 +10,10 @@ CMD="python $R/bench.py --steps 20 --warmup 3 --cpu-pairs 0 --no-extras ${BENCH_
 KF='--kernel-include-regex piv_'
 run() { name=$1; shift; timeout 600 rocprofv3 "$@" --output-format csv -d /tmp/prof_$name -o $name -- $CMD > $OUT/$name.log 2>&1; \
         find /tmp/prof_$name -name "*.csv" -size -8M -exec cp {} $OUT/ \; ; }
+# the trace pass runs 100 timed steps so that the cold first launches do not weigh on the kernel's mean duration
+CMD_SAVE=$CMD; CMD="python $R/bench.py --steps 100 --warmup 3 --cpu-pairs 0 --no-extras ${BENCH_ARGS}"
 run trace --kernel-trace --stats
+CMD=$CMD_SAVE
 run pmc_fetch $KF --pmc FETCH_SIZE
 run pmc_write $KF --pmc WRITE_SIZE
 run pmc_sq1 $KF --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
