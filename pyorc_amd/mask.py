@@ -124,7 +124,9 @@ class Mask:
         for i, k in enumerate(VARS):
             new = block[i] if has_time else block[i, 0]
             if xr is not None and isinstance(self._obj, xr.Dataset):
-                self._obj[k] = (self._obj[k].dims, new)
+                # copy(data=...) keeps the variable's attrs and encoding (units, standard_name, the int16 scale / fill
+                # of set_encoding), which a (dims, ndarray) assignment would drop
+                self._obj[k] = self._obj[k].copy(data=new.reshape(self._obj[k].shape))
             else:
                 self._obj[k] = new
 

@@ -39,6 +39,12 @@ class DataArray:
         self.loaded += 1
         return self
 
+    def copy(self, data=None):
+        """xarray.DataArray.copy(data=...): same dims / coords / attrs / encoding, new values."""
+        out = DataArray(self.values.copy() if data is None else data, self.dims, self.coords, self.attrs)
+        out.encoding = dict(getattr(self, "encoding", {}))
+        return out
+
     def diff(self, dim):
         assert self.dims == (dim,)
         return DataArray(np.diff(self.values), self.dims, {dim: self.values[1:]})

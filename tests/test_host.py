@@ -246,8 +246,11 @@ def test_xarray_branches_of_the_mirrors(monkeypatch):
         monkeypatch.setattr(M, "apply_mask", lambda block, mask: __import__("oracle.mask_oracle", fromlist=["x"]).apply(block, mask))
         m = M.Mask(ds).corr(tolerance=0.3)
         assert isinstance(m, fake_xarray.DataArray) and m.dims == ("time", "y", "x") and m.values.dtype == bool
+        ds["v_x"].attrs["units"] = "m s-1"                       # per-variable attrs / encoding survive an in-place mask
+        ds["v_x"].encoding = {"dtype": "int16", "scale_factor": 0.01, "_FillValue": -9999}
         M.Mask(ds).corr(tolerance=0.3, inplace=True)
         assert isinstance(ds["v_x"], fake_xarray.DataArray) and np.isnan(ds["v_x"].values[~m.values]).all()
+        assert ds["v_x"].attrs["units"] == "m s-1" and ds["v_x"].encoding["scale_factor"] == 0.01
     finally:
         monkeypatch.undo()
         for mod in (V, F, M):
