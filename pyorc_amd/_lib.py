@@ -157,9 +157,22 @@ def load() -> C.CDLL:
     return lib
 
 
+class LspivValueError(LspivError, ValueError):
+    """LSPIV_EINVAL / LSPIV_ESHAPE / LSPIV_EUNSUPPORTED: what the reference reports as ``ValueError`` (include/lspiv.h)."""
+
+
+class LspivMemoryError(LspivError, MemoryError):
+    """LSPIV_ENOMEM."""
+
+
+_ERROR_TYPES = {LSPIV_EINVAL: LspivValueError, LSPIV_ESHAPE: LspivValueError, LSPIV_EUNSUPPORTED: LspivValueError,
+                LSPIV_ENOMEM: LspivMemoryError}
+
+
 def check(rc: int) -> int:
+    """Negative status -> the exception type include/lspiv.h maps it to (always an ``LspivError`` as well)."""
     if rc < 0:
-        raise LspivError(rc, load().lspiv_last_error().decode("utf-8", "replace"))
+        raise _ERROR_TYPES.get(rc, LspivError)(rc, load().lspiv_last_error().decode("utf-8", "replace"))
     return rc
 
 

@@ -1571,6 +1571,25 @@ int lspiv_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes) {
   DeviceCtx* c;
   int rc = get_ctx(&c);
   if (rc) return rc;
+  if (bytes >= ((size_t)64 << 20) && !is_pinned(h_src)) {
+    // a large pageable source (a frame stack): through the two-slot pinned ring, staging threads overlapped with the
+    // DMA of the previous slice, like the host entry points -- ~2x the rate of a plain pageable hipMemcpy
+    std::lock_guard<std::mutex> host_lock(g_host_mu);
+    rc = stage_ring(c, 1);
+    if (rc) return rc;
+    const size_t slice = c->pinned_cap;
+    int batch = 0;
+    for (size_t off = 0; off < bytes; off += slice, ++batch) {
+      const int slot = batch & 1;
+      const size_t nb = std::min(slice, bytes - off);
+      if (batch >= 2) HIP_TRY(hipEventSynchronize(c->staged[slot]));
+      staged_copy(c->pinned[slot], (const char*)h_src + off, nb);
+      HIP_TRY(hipMemcpyAsync((char*)d_dst + off, c->pinned[slot], nb, hipMemcpyHostToDevice, c->copy_stream));
+      HIP_TRY(hipEventRecord(c->staged[slot], c->copy_stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->copy_stream));
+    return LSPIV_OK;
+  }
   HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return LSPIV_OK;
