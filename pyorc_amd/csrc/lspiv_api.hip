@@ -1577,6 +1577,7 @@ int lspiv_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes) {
     std::lock_guard<std::mutex> host_lock(g_host_mu);
     rc = stage_ring(c, 1);
     if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));   // the DMA runs on the copy stream: earlier kernels may still use d_dst
     const size_t slice = c->pinned_cap;
     int batch = 0;
     for (size_t off = 0; off < bytes; off += slice, ++batch) {

@@ -527,11 +527,26 @@ __device__ __forceinline__ void lds_row_write(float* row, const float (&c)[N]) {
 // the buffer (ds_write_b32, the lanes of a group hit consecutive banks), then reads buffer row r =
 // tile column r with ds_read_b128 (row stride N+4 dwords: 16-byte aligned, and the 16 lanes of a b128
 // group land on 16 distinct 4-bank slots since (N/4+1) l mod 16 is a bijection).
+// LSPIV_TR_ASM (N = 32): the column scatter as ds_write_b32 with immediate offsets off ONE base register.  Left to the
+// compiler the 32 stores are paired into ds_write2_b32, whose 8-bit offsets reach only 1 KB, so it keeps six extra base
+// addresses in VGPRs for the whole loop -- registers the 4-waves-per-SIMD build of the walking kernel does not have.
+#ifndef LSPIV_TR_ASM
+#define LSPIV_TR_ASM 0
+#endif
+template <int N, int J>
+__device__ __forceinline__ void lds_scatter_asm(unsigned addr, const float (&x)[N]) {
+  if constexpr (J < N) {
+    asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(addr), "v"(x[J]), "n"(J * Geo<N>::LDS_ROW * 4) : "memory");
+    lds_scatter_asm<N, J + 1>(addr, x);
+  }
+}
 template <int N>
 __device__ __forceinline__ void transpose_plane(float* buf, int lg, float (&x)[N]) {
   constexpr int LR = Geo<N>::LDS_ROW;
   float* wcol = buf + lg;
-  if (lane_active<N>(lg)) {
+  if constexpr (LSPIV_TR_ASM && N == 32) {
+    lds_scatter_asm<N, 0>((unsigned)(size_t)wcol, x);
+  } else if (lane_active<N>(lg)) {
 #pragma unroll
     for (int j = 0; j < N; ++j) wcol[j * LR] = x[j];
   }

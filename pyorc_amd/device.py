@@ -26,19 +26,76 @@ import numpy as np
 from . import _lib
 
 
+class _Pool:
+    """Caching allocator behind DeviceFrames: hipMalloc / hipFree of a 0.4 - 1.7 GB stack cost milliseconds each, and a
+    recipe allocates one stack per stage per chunk.  Freed blocks are kept (bucketed by size, rounded up to 1/8 of a power
+    of two) and handed out again; at most ``limit`` bytes stay cached (``LSPIV_POOL_BYTES``, default 16 GiB of the 288 GB;
+    0 disables the cache), ``release()`` gives everything back."""
+
+    def __init__(self):
+        import os
+
+        self.limit = int(os.environ.get("LSPIV_POOL_BYTES", 16 << 30))
+        self.free = {}      # bucket size -> [raw pointer values]
+        self.cached = 0
+
+    @staticmethod
+    def bucket(nbytes: int) -> int:
+        n = max(int(nbytes), 256)
+        step = 1 << max(n.bit_length() - 4, 8)      # 1/8 .. 1/16 of the size: <= 12.5 % of slack
+        return (n + step - 1) // step * step
+
+    def take(self, nbytes: int):
+        b = self.bucket(nbytes)
+        lst = self.free.get(b)
+        if lst:
+            self.cached -= b
+            return C.c_void_p(lst.pop()), b
+        p = C.c_void_p()
+        rc = _lib.load().lspiv_dev_malloc(C.byref(p), b)
+        if rc == _lib.LSPIV_ENOMEM and self.cached:   # give the cache back and retry once
+            self.release()
+            rc = _lib.load().lspiv_dev_malloc(C.byref(p), b)
+        _lib.check(rc)
+        return p, b
+
+    def give(self, ptr: C.c_void_p, b: int):
+        if self.cached + b <= self.limit:
+            self.free.setdefault(b, []).append(ptr.value)
+            self.cached += b
+        else:
+            _lib.load().lspiv_dev_free(ptr)
+
+    def release(self):
+        lib = _lib.load()
+        for lst in self.free.values():
+            for v in lst:
+                lib.lspiv_dev_free(C.c_void_p(v))
+        self.free, self.cached = {}, 0
+
+
+_pool = _Pool()
+
+
+def release_pool() -> None:
+    """Return every cached HBM block of the DeviceFrames allocator to the driver."""
+    _lib.check(_lib.load().lspiv_synchronize())
+    _pool.release()
+
+
 class _Allocation:
-    """One lspiv_dev_malloc block, freed when the last stack / view that uses it goes away."""
+    """One HBM block, handed back to the pool when the last stack / view that uses it goes away.  Work on the library's
+    stream is stream-ordered, so a block may be reused by the next stage while the previous kernels still run."""
 
     def __init__(self, nbytes: int):
-        self.ptr = C.c_void_p()
         _lib.require_device()
-        _lib.check(_lib.load().lspiv_dev_malloc(C.byref(self.ptr), max(int(nbytes), 1)))
+        self.ptr, self._bucket = _pool.take(nbytes)
         self.nbytes = int(nbytes)
 
     def __del__(self):
         try:
             if self.ptr:
-                _lib.load().lspiv_dev_free(self.ptr)
+                _pool.give(self.ptr, self._bucket)
                 self.ptr = C.c_void_p()
         except Exception:
             pass
