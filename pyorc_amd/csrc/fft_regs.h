@@ -60,27 +60,33 @@ __device__ __forceinline__ void twiddle64(float& xr, float& xi) {
   }
 }
 
+// CLAMP: the outputs of the LAST butterfly stage of an inverse transform are correlation-plane samples, which the
+// caller clips to [0, 1]; written as med3(x, 0, 1) of the final add / sub, the clip folds into the VALU clamp modifier of
+// that instruction (v_add_f32 ... clamp) and costs nothing.
+template <bool CLAMP>
+__device__ __forceinline__ float out01(float x) { return CLAMP ? __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f) : x; }
+
 // radix-4 butterfly, natural-order outputs
-template <bool INV>
+template <bool INV, bool CLAMP = false>
 __device__ __forceinline__ void bfly4(float& r0, float& i0, float& r1, float& i1,
                                       float& r2, float& i2, float& r3, float& i3) {
   float ar = r0 + r2, ai = i0 + i2;
   float br = r0 - r2, bi = i0 - i2;
   float cr = r1 + r3, ci = i1 + i3;
   float dr = r1 - r3, di = i1 - i3;
-  r0 = ar + cr; i0 = ai + ci;
-  r2 = ar - cr; i2 = ai - ci;
+  r0 = out01<CLAMP>(ar + cr); i0 = out01<CLAMP>(ai + ci);
+  r2 = out01<CLAMP>(ar - cr); i2 = out01<CLAMP>(ai - ci);
   if constexpr (!INV) {  // X1 = b - i d, X3 = b + i d
-    r1 = br + di; i1 = bi - dr;
-    r3 = br - di; i3 = bi + dr;
+    r1 = out01<CLAMP>(br + di); i1 = out01<CLAMP>(bi - dr);
+    r3 = out01<CLAMP>(br - di); i3 = out01<CLAMP>(bi + dr);
   } else {               // X1 = b + i d, X3 = b - i d
-    r1 = br - di; i1 = bi + dr;
-    r3 = br + di; i3 = bi - dr;
+    r1 = out01<CLAMP>(br - di); i1 = out01<CLAMP>(bi + dr);
+    r3 = out01<CLAMP>(br + di); i3 = out01<CLAMP>(bi - dr);
   }
 }
 
 // radix-8 butterfly on 8 values (natural order in, natural order out)
-template <bool INV>
+template <bool INV, bool CLAMP = false>
 __device__ __forceinline__ void bfly8(float (&r)[8], float (&i)[8]) {
   // even / odd radix-4
   bfly4<INV>(r[0], i[0], r[2], i[2], r[4], i[4], r[6], i[6]);  // E0..E3 in slots 0,2,4,6
@@ -100,8 +106,8 @@ __device__ __forceinline__ void bfly8(float (&r)[8], float (&i)[8]) {
   float orr[4] = {r[1], r[3], r[5], r[7]}, oi[4] = {i[1], i[3], i[5], i[7]};
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    r[k] = er[k] + orr[k];     i[k] = ei[k] + oi[k];
-    r[k + 4] = er[k] - orr[k]; i[k + 4] = ei[k] - oi[k];
+    r[k] = out01<CLAMP>(er[k] + orr[k]);     i[k] = out01<CLAMP>(ei[k] + oi[k]);
+    r[k + 4] = out01<CLAMP>(er[k] - orr[k]); i[k + 4] = out01<CLAMP>(ei[k] - oi[k]);
   }
 }
 
@@ -119,7 +125,7 @@ struct TwiddleRow {
 
 // ---- length-16 transform: n = 4 n1 + n2, k = k1 + 4 k2 ------------------------------------------------
 //   X[k1 + 4 k2] = DFT4_{n2}( W16^{n2 k1} * DFT4_{n1} x[4 n1 + n2] ),  W16 = W64^4
-template <bool INV>
+template <bool INV, bool CLAMP = false>
 __device__ __forceinline__ void fft16(float (&xr)[16], float (&xi)[16]) {
 #pragma unroll
   for (int n2 = 0; n2 < 4; ++n2)
@@ -132,7 +138,7 @@ __device__ __forceinline__ void fft16(float (&xr)[16], float (&xi)[16]) {
   for (int k1 = 0; k1 < 4; ++k1) {
     float r0 = xr[4 * k1], i0 = xi[4 * k1], r1 = xr[4 * k1 + 1], i1 = xi[4 * k1 + 1];
     float r2 = xr[4 * k1 + 2], i2 = xi[4 * k1 + 2], r3 = xr[4 * k1 + 3], i3 = xi[4 * k1 + 3];
-    bfly4<INV>(r0, i0, r1, i1, r2, i2, r3, i3);
+    bfly4<INV, CLAMP>(r0, i0, r1, i1, r2, i2, r3, i3);
     yr[k1] = r0; yi[k1] = i0; yr[k1 + 4] = r1; yi[k1 + 4] = i1; yr[k1 + 8] = r2; yi[k1 + 8] = i2; yr[k1 + 12] = r3; yi[k1 + 12] = i3;
   }
 #pragma unroll
@@ -141,7 +147,7 @@ __device__ __forceinline__ void fft16(float (&xr)[16], float (&xi)[16]) {
 
 // ---- length-32 transform, in place, natural order in and out --------------------------------
 // n = 8 n1 + n2, k = k1 + 4 k2:  X[k1 + 4 k2] = DFT8_{n2}( W32^{n2 k1} * DFT4_{n1} x[8 n1 + n2] )
-template <bool INV>
+template <bool INV, bool CLAMP = false>
 __device__ __forceinline__ void fft32(float (&xr)[32], float (&xi)[32]) {
 #pragma unroll
   for (int n2 = 0; n2 < 8; ++n2)
@@ -152,7 +158,7 @@ __device__ __forceinline__ void fft32(float (&xr)[32], float (&xi)[32]) {
     float r[8], i[8];
 #pragma unroll
     for (int n2 = 0; n2 < 8; ++n2) { r[n2] = xr[n2]; i[n2] = xi[n2]; }
-    bfly8<INV>(r, i);
+    bfly8<INV, CLAMP>(r, i);
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) { yr[4 * k2] = r[k2]; yi[4 * k2] = i[k2]; }
   }
@@ -161,7 +167,7 @@ __device__ __forceinline__ void fft32(float (&xr)[32], float (&xi)[32]) {
 #pragma unroll
     for (int n2 = 0; n2 < 8; ++n2) { r[n2] = xr[8 + n2]; i[n2] = xi[8 + n2]; }
     TwiddleRow<INV, 8, 1, 2>::template apply<1>(r, i);
-    bfly8<INV>(r, i);
+    bfly8<INV, CLAMP>(r, i);
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) { yr[1 + 4 * k2] = r[k2]; yi[1 + 4 * k2] = i[k2]; }
   }
@@ -170,7 +176,7 @@ __device__ __forceinline__ void fft32(float (&xr)[32], float (&xi)[32]) {
 #pragma unroll
     for (int n2 = 0; n2 < 8; ++n2) { r[n2] = xr[16 + n2]; i[n2] = xi[16 + n2]; }
     TwiddleRow<INV, 8, 2, 2>::template apply<1>(r, i);
-    bfly8<INV>(r, i);
+    bfly8<INV, CLAMP>(r, i);
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) { yr[2 + 4 * k2] = r[k2]; yi[2 + 4 * k2] = i[k2]; }
   }
@@ -179,7 +185,7 @@ __device__ __forceinline__ void fft32(float (&xr)[32], float (&xi)[32]) {
 #pragma unroll
     for (int n2 = 0; n2 < 8; ++n2) { r[n2] = xr[24 + n2]; i[n2] = xi[24 + n2]; }
     TwiddleRow<INV, 8, 3, 2>::template apply<1>(r, i);
-    bfly8<INV>(r, i);
+    bfly8<INV, CLAMP>(r, i);
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) { yr[3 + 4 * k2] = r[k2]; yi[3 + 4 * k2] = i[k2]; }
   }
@@ -188,14 +194,14 @@ __device__ __forceinline__ void fft32(float (&xr)[32], float (&xi)[32]) {
 }
 
 // ---- length-64 transform: n = 8 n1 + n2, k = k1 + 8 k2 --------------------------------------
-template <bool INV, int K1>
+template <bool INV, int K1, bool CLAMP = false>
 __device__ __forceinline__ void fft64_col(const float (&xr)[64], const float (&xi)[64],
                                           float (&yr)[64], float (&yi)[64]) {
   float r[8], i[8];
 #pragma unroll
   for (int n2 = 0; n2 < 8; ++n2) { r[n2] = xr[8 * K1 + n2]; i[n2] = xi[8 * K1 + n2]; }
   TwiddleRow<INV, 8, K1, 1>::template apply<1>(r, i);
-  bfly8<INV>(r, i);
+  bfly8<INV, CLAMP>(r, i);
 #pragma unroll
   for (int k2 = 0; k2 < 8; ++k2) { yr[K1 + 8 * k2] = r[k2]; yi[K1 + 8 * k2] = i[k2]; }
 }
@@ -206,7 +212,7 @@ __device__ __forceinline__ void fft64_col(const float (&xr)[64], const float (&x
 #define LSPIV_FFT64_SB 1
 #endif
 #define LSPIV_FFT64_BAR do { if (LSPIV_FFT64_SB) __builtin_amdgcn_sched_barrier(0); } while (0)
-template <bool INV>
+template <bool INV, bool CLAMP = false>
 __device__ __forceinline__ void fft64(float (&xr)[64], float (&xi)[64]) {
 #pragma unroll
   for (int n2 = 0; n2 < 8; ++n2) {
@@ -219,14 +225,14 @@ __device__ __forceinline__ void fft64(float (&xr)[64], float (&xi)[64]) {
     if (LSPIV_FFT64_SB) __builtin_amdgcn_sched_barrier(0);
   }
   float yr[64], yi[64];
-  fft64_col<INV, 0>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
-  fft64_col<INV, 1>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
-  fft64_col<INV, 2>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
-  fft64_col<INV, 3>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
-  fft64_col<INV, 4>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
-  fft64_col<INV, 5>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
-  fft64_col<INV, 6>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
-  fft64_col<INV, 7>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
+  fft64_col<INV, 0, CLAMP>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
+  fft64_col<INV, 1, CLAMP>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
+  fft64_col<INV, 2, CLAMP>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
+  fft64_col<INV, 3, CLAMP>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
+  fft64_col<INV, 4, CLAMP>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
+  fft64_col<INV, 5, CLAMP>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
+  fft64_col<INV, 6, CLAMP>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
+  fft64_col<INV, 7, CLAMP>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
 #pragma unroll
   for (int k = 0; k < 64; ++k) { xr[k] = yr[k]; xi[k] = yi[k]; }
 }

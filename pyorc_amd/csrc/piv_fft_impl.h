@@ -220,27 +220,30 @@ __device__ __forceinline__ RowStats stats_u8(const RowRaw<uint8_t, N>& raw, bool
   return st;
 }
 
-// x = max((byte - mean) * g, 0), g >= 0: convert + fma + max per sample
-template <int N>
+// x = max((byte - mean) * g, 0), g >= 0: convert + fma + max per sample.  BELOW1: the caller guarantees every result
+// is < 1 (the walking kernels fold 1 / (2 N^2) into g, and |x - mean| / std <= sqrt(N^2 - 1) for any window), so the
+// lower clip can be written as med3(., 0, 1), which folds into the clamp modifier of the FMA: convert + fma per sample.
+template <bool BELOW1> __device__ __forceinline__ float clip0(float v) { return BELOW1 ? __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f) : fmaxf(v, 0.0f); }
+template <int N, bool BELOW1 = false>
 __device__ __forceinline__ void center_u8(const RowRaw<uint8_t, N>& raw, float mean, float g, float (&x)[N]) {
   const float off = -mean * g;
 #pragma unroll
   for (int k = 0; k < N / 4; ++k) {
     const uint32_t w = raw.w[k];
-    x[4 * k + 0] = fmaxf(fmaf((float)(w & 0xffu), g, off), 0.0f);
-    x[4 * k + 1] = fmaxf(fmaf((float)((w >> 8) & 0xffu), g, off), 0.0f);
-    x[4 * k + 2] = fmaxf(fmaf((float)((w >> 16) & 0xffu), g, off), 0.0f);
-    x[4 * k + 3] = fmaxf(fmaf((float)(w >> 24), g, off), 0.0f);
+    x[4 * k + 0] = clip0<BELOW1>(fmaf((float)(w & 0xffu), g, off));
+    x[4 * k + 1] = clip0<BELOW1>(fmaf((float)((w >> 8) & 0xffu), g, off));
+    x[4 * k + 2] = clip0<BELOW1>(fmaf((float)((w >> 16) & 0xffu), g, off));
+    x[4 * k + 3] = clip0<BELOW1>(fmaf((float)(w >> 24), g, off));
   }
   if constexpr (N % 4 == 2) {
     const uint32_t w = raw.w[N / 4];
-    x[N - 2] = fmaxf(fmaf((float)(w & 0xffu), g, off), 0.0f);
-    x[N - 1] = fmaxf(fmaf((float)((w >> 8) & 0xffu), g, off), 0.0f);
+    x[N - 2] = clip0<BELOW1>(fmaf((float)(w & 0xffu), g, off));
+    x[N - 1] = clip0<BELOW1>(fmaf((float)((w >> 8) & 0xffu), g, off));
   }
 }
 
 // float rows: pairwise sum (a constant window gives its value, hence zero variance, exactly)
-template <int N>
+template <int N, bool DEFER_CLIP = false>
 __device__ __forceinline__ float center_clip_f(float (&x)[N], bool want_nz, bool nz_pos, int& nonzero, bool& finite) {
   constexpr float inv_nn = 1.0f / Geo<N>::NN;
   const bool active = lane_active<N>(group_lane<N>());   // constant true for the power-of-two sizes
@@ -262,14 +265,14 @@ __device__ __forceinline__ float center_clip_f(float (&x)[N], bool want_nz, bool
   for (int k = 0; k < N; ++k) {
     const float d = x[k] - mean;
     acc[k & 3] = fmaf(d, d, acc[k & 3]);
-    x[k] = fmaxf(d, 0.0f);
+    x[k] = DEFER_CLIP ? d : fmaxf(d, 0.0f);   // DEFER_CLIP: the caller clips while it scales (prepare_one)
   }
   const float ssq = group_sum<N>(active ? (acc[0] + acc[1]) + (acc[2] + acc[3]) : 0.0f);
   finite = finite && (fabsf(s) <= 3.0e38f) && (ssq <= 3.0e38f);
   const float var = ssq * inv_nn;
   return var > 0.0f ? __builtin_amdgcn_rsqf(var) : 0.0f;
 }
-template <int N>
+template <int N, bool DEFER_CLIP = false>
 __device__ __forceinline__ float load_center(const RowRaw<float, N>& raw, float (&x)[N], bool want_nz, bool nz_pos,
                                              int& nonzero, bool& finite) {
 #pragma unroll
@@ -278,9 +281,9 @@ __device__ __forceinline__ float load_center(const RowRaw<float, N>& raw, float 
     x[4 * k + 0] = v[0]; x[4 * k + 1] = v[1]; x[4 * k + 2] = v[2]; x[4 * k + 3] = v[3];
   }
   if constexpr (N % 4 == 2) { x[N - 2] = raw.p[N - 2]; x[N - 1] = raw.p[N - 1]; }
-  return center_clip_f<N>(x, want_nz, nz_pos, nonzero, finite);
+  return center_clip_f<N, DEFER_CLIP>(x, want_nz, nz_pos, nonzero, finite);
 }
-template <int N>
+template <int N, bool DEFER_CLIP = false>
 __device__ __forceinline__ float load_center(const RowRaw<double, N>& raw, float (&x)[N], bool want_nz, bool nz_pos,
                                              int& nonzero, bool& finite) {
 #pragma unroll
@@ -288,7 +291,7 @@ __device__ __forceinline__ float load_center(const RowRaw<double, N>& raw, float
     const f64x2 v = *reinterpret_cast<const f64x2_u*>(raw.p + 2 * k);
     x[2 * k + 0] = (float)v[0]; x[2 * k + 1] = (float)v[1];
   }
-  return center_clip_f<N>(x, want_nz, nz_pos, nonzero, finite);
+  return center_clip_f<N, DEFER_CLIP>(x, want_nz, nz_pos, nonzero, finite);
 }
 
 // Both windows of a pair -> xr = a'' (mean-offset, zero-clipped), xi = rho b''.
@@ -560,6 +563,13 @@ __device__ __forceinline__ void transpose2(float* buf, int lg, float (&xr)[N], f
   transpose_plane<N>(buf, lg, xi);
 }
 
+// inverse transform whose outputs are clipped to [0, 1] for free (clamp modifier of the last butterfly stage) -- the power-of-two
+// sizes; kClampInFft<N> tells the callers whether they still have to clip
+template <int N> constexpr bool kClampInFft = N == 8 || N == 16 || N == 32 || N == 64;
+__device__ __forceinline__ void ifft_clamped(float (&xr)[8], float (&xi)[8]) { bfly8<true, true>(xr, xi); }
+__device__ __forceinline__ void ifft_clamped(float (&xr)[16], float (&xi)[16]) { fft16<true, true>(xr, xi); }
+__device__ __forceinline__ void ifft_clamped(float (&xr)[32], float (&xi)[32]) { fft32<true, true>(xr, xi); }
+__device__ __forceinline__ void ifft_clamped(float (&xr)[64], float (&xi)[64]) { fft64<true, true>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[8], float (&xi)[8]) { bfly8<INV>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[16], float (&xi)[16]) { fft16<INV>(xr, xi); }
 template <bool INV> __device__ __forceinline__ void fft_n(float (&xr)[32], float (&xi)[32]) { fft32<INV>(xr, xi); }
@@ -759,7 +769,7 @@ __device__ __forceinline__ void find_peak(float* buf, int lg, const float (&c)[N
 }
 
 template <int N>
-__device__ __forceinline__ void store_plane_rows(float* dst, int lg, const float (&c)[N], bool nan_plane) {
+__device__ __forceinline__ void store_plane_rows(float* dst, int lg, const float (&c)[N], bool nan_plane, bool zero_plane = false) {
   // shifted row i' = (y + N/2) % N receives columns x = N/2..N-1, 0..N/2-1
   if (!lane_active<N>(lg)) return;
   float* row = dst + wrap_n<N>(lg + N / 2) * N;
@@ -769,7 +779,7 @@ __device__ __forceinline__ void store_plane_rows(float* dst, int lg, const float
     for (int q = 0; q < N / 4; ++q) {
       f32x4 v;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = nan_plane ? nanv : c[(4 * q + e + N / 2) % N];
+      for (int e = 0; e < 4; ++e) v[e] = nan_plane ? nanv : zero_plane ? 0.0f : c[(4 * q + e + N / 2) % N];
       *reinterpret_cast<f32x4*>(row + 4 * q) = v;
     }
   } else {   // rows of N = 4 m + 2 floats are 8-byte aligned only
@@ -777,7 +787,7 @@ __device__ __forceinline__ void store_plane_rows(float* dst, int lg, const float
     for (int q = 0; q < N / 2; ++q) {
       f32x2 v;
 #pragma unroll
-      for (int e = 0; e < 2; ++e) v[e] = nan_plane ? nanv : c[(2 * q + e + N / 2) % N];
+      for (int e = 0; e < 2; ++e) v[e] = nan_plane ? nanv : zero_plane ? 0.0f : c[(2 * q + e + N / 2) % N];
       *reinterpret_cast<f32x2*>(row + 2 * q) = v;
     }
   }
@@ -903,13 +913,14 @@ __device__ __forceinline__ void prepare_one(const RowRaw<T, N>& raw, float (&x)[
   constexpr float kHalf = 1.0f / (2.0f * (float)Geo<N>::NN);
   if constexpr (sizeof(T) == 1) {
     const RowStats st = stats_u8<N>(raw, WANT_NZ, nonzero);
-    center_u8<N>(raw, st.mean, st.inv_std * kHalf, x);   // max((byte - mean) / std, 0) / (2 N^2); all zero for a constant window
+    center_u8<N, true>(raw, st.mean, st.inv_std * kHalf, x);   // max((byte - mean) / std, 0) / (2 N^2) < 1; all zero for a constant window
     dead = st.inv_std == 0.0f;
   } else {
-    const float inv = load_center<N>(raw, x, WANT_NZ, nz_pos, nonzero, finite);
+    // max(d, 0) * g == max(d * g, 0) exactly (g >= 0), and d * g < 1 (see center_u8): the clip rides on the multiply
+    const float inv = load_center<N, true>(raw, x, WANT_NZ, nz_pos, nonzero, finite);
     const float g = inv * kHalf;
 #pragma unroll
-    for (int j = 0; j < N; ++j) x[j] *= g;
+    for (int j = 0; j < N; ++j) x[j] = __builtin_amdgcn_fmed3f(x[j] * g, 0.0f, 1.0f);
     dead = inv == 0.0f;
   }
 }
@@ -942,7 +953,8 @@ struct WalkCarry {
 template <typename T, int N, bool WANT_NZ>
 __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row, bool has2, float* buf, int lg,
                                                int partner_byte, int lane0_byte, WalkCarry<N>& c, float (&xr)[N],
-                                               float (&xi)[N], float& mean_a, float& mean_b, bool& skip_a, bool& skip_b) {
+                                               float (&xi)[N], float& mean_a, float& mean_b, bool& skip_a, bool& skip_b,
+                                               bool& dead_a, bool& dead_b) {
   using G = Geo<N>;
   constexpr int H = N / 2;
   bool dead0, dead1, fin0 = true, fin1 = true;
@@ -989,14 +1001,23 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
   LSPIV_WALK_SB;
   transpose2<N>(buf, lg, xr, xi);      // lane = y, regs = kx
   LSPIV_WALK_SB;
-  fft_n<true>(xr, xi);                 // along kx -> c_a + i c_b
-  LSPIV_WALK_SB;
-  const bool dead_a = c.prev_dead || dead0, dead_b = dead0 || dead1;
-  const float hi_a = dead_a ? 0.0f : 1.0f, hi_b = dead_b ? 0.0f : 1.0f;
+  dead_a = c.prev_dead || dead0;
+  dead_b = dead0 || dead1;
+  if constexpr (kClampInFft<N>) {
+    // clip [0, 1] rides on the last butterfly stage (clamp modifier).  A pair with a zero-variance window has an
+    // exactly-zero cross spectrum, but its plane shares the inverse transform with the other pair's and would come out
+    // as rounding noise of that one: the callers override such a pair's results (corr 0, s2n / u / v NaN, zero plane)
+    ifft_clamped(xr, xi);              // along kx -> c_a + i c_b
+    LSPIV_WALK_SB;
+  } else {
+    fft_n<true>(xr, xi);
+    LSPIV_WALK_SB;
+    const float hi_a = dead_a ? 0.0f : 1.0f, hi_b = dead_b ? 0.0f : 1.0f;
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
-    xr[j] = __builtin_amdgcn_fmed3f(xr[j], 0.0f, hi_a);
-    xi[j] = __builtin_amdgcn_fmed3f(xi[j], 0.0f, hi_b);
+    for (int j = 0; j < N; ++j) {
+      xr[j] = __builtin_amdgcn_fmed3f(xr[j], 0.0f, hi_a);
+      xi[j] = __builtin_amdgcn_fmed3f(xi[j], 0.0f, hi_b);
+    }
   }
   skip_a = !(c.prev_finite && fin0);
   skip_b = !(fin0 && fin1);
@@ -1046,8 +1067,9 @@ __global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_kernel
   for (uint32_t f = p0; f <= p1; f += 2, row += 2 * p.frame_elems) {
     const bool has2 = f + 1 <= p1;
     float xr[N], xi[N], mean_a, mean_b;
-    bool skip_a, skip_b;
-    walk_iteration<T, N, WANT_NZ>(p, row, has2, buf, lg, partner_byte, lane0_byte, carry, xr, xi, mean_a, mean_b, skip_a, skip_b);
+    bool skip_a, skip_b, dead_a, dead_b;
+    walk_iteration<T, N, WANT_NZ>(p, row, has2, buf, lg, partner_byte, lane0_byte, carry, xr, xi, mean_a, mean_b, skip_a, skip_b,
+                                  dead_a, dead_b);
     if (WANT_NZ && win_dropped) skip_a = skip_b = true;
     const bool valid_a = job_valid && f > p0, valid_b = job_valid && has2;
     {
@@ -1055,6 +1077,7 @@ __global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_kernel
       const float vmax = plane_max<N>(xr, row_max);
       find_peak<N>(buf, lg, xr, vmax, row_max, p.border_mode, u, v);
       float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean_a);
+      if (dead_a) { u = v = sn = nanv; cm = 0.0f; }   // zero-variance window: an exactly-zero plane (corr 0, s2n 0/0, peak on the border)
       if (skip_a) u = v = cm = sn = nanv;
       if (valid_a && lg == 0) {
         const uint32_t g = (f - 1) * p.n_win + win;
@@ -1066,6 +1089,7 @@ __global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_kernel
       const float vmax = plane_max<N>(xi, row_max);
       find_peak<N>(buf, lg, xi, vmax, row_max, p.border_mode, u, v);
       float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean_b);
+      if (dead_b) { u = v = sn = nanv; cm = 0.0f; }
       if (skip_b) u = v = cm = sn = nanv;
       if (valid_b && lg == 0) {
         const uint32_t g = f * p.n_win + win;
@@ -1073,8 +1097,8 @@ __global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_kernel
       }
     }
     if constexpr (PLANES) {
-      if (valid_a) store_plane_rows<N>(p.planes + ((size_t)(f - 1) * p.n_win + win) * G::NN, lg, xr, skip_a);
-      if (valid_b) store_plane_rows<N>(p.planes + ((size_t)f * p.n_win + win) * G::NN, lg, xi, skip_b);
+      if (valid_a) store_plane_rows<N>(p.planes + ((size_t)(f - 1) * p.n_win + win) * G::NN, lg, xr, skip_a, dead_a);
+      if (valid_b) store_plane_rows<N>(p.planes + ((size_t)f * p.n_win + win) * G::NN, lg, xi, skip_b, dead_b);
     }
   }
 }
@@ -1418,15 +1442,16 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsWaves<T, N>)) void piv_fft_walk_ens
   for (uint32_t f = p0; f <= p1; f += 2, row += 2 * p.frame_elems) {
     const bool has2 = f + 1 <= p1;
     float xr[N], xi[N], mean[2];
-    bool skip[2], keep[2];
-    walk_iteration<T, N, WANT_NZ>(p, row, has2, buf, lg, partner_byte, lane0_byte, carry, xr, xi, mean[0], mean[1], skip[0], skip[1]);
+    bool skip[2], keep[2], dead[2];
+    walk_iteration<T, N, WANT_NZ>(p, row, has2, buf, lg, partner_byte, lane0_byte, carry, xr, xi, mean[0], mean[1], skip[0], skip[1],
+                                  dead[0], dead[1]);
     if (WANT_NZ && win_dropped) skip[0] = skip[1] = true;
     const bool valid[2] = {job_valid && f > p0, job_valid && has2};
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       float row_max;
       const float vmax = plane_max<N>(k == 0 ? xr : xi, row_max);
-      float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean[k]);
+      float cm = dead[k] ? 0.0f : vmax, sn = dead[k] ? __builtin_nanf("") : vmax * __builtin_amdgcn_rcpf(mean[k]);   // dead: zero plane
       keep[k] = valid[k] && !skip[k] && (cm >= p.corr_min) && (sn >= p.s2n_min);  // NaN s2n compares false
       cm = keep[k] ? cm : 0.0f;
       sn = keep[k] ? sn : 0.0f;
