@@ -718,11 +718,12 @@ __device__ __forceinline__ void correlate_job(const PivParams& p, const TileRef 
 // Row maximum of a plane held as lane = y, reg = x (v_max3 tree) reduced over the group -> plane maximum.
 template <int N>
 __device__ __forceinline__ float plane_max(const float (&c)[N], float& row_max) {
-  float m[N / 2];
+  // v_max3 tree from the first level on: N values -> ceil(N / 3) -> ... (32 values: 11 + 4 + 2 instructions)
+  float m[N];
 #pragma unroll
-  for (int k = 0; k < N / 2; ++k) m[k] = fmaxf(c[2 * k], c[2 * k + 1]);
+  for (int k = 0; k < N; ++k) m[k] = c[k];
 #pragma unroll
-  for (int w = N / 2; w > 1;) {
+  for (int w = N; w > 1;) {
     const int t = w / 3, rem = w - 3 * t;
 #pragma unroll
     for (int k = 0; k < t; ++k) m[k] = fmaxf(fmaxf(m[3 * k], m[3 * k + 1]), m[3 * k + 2]);
@@ -982,11 +983,12 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
     const float mr = bperm_f(partner_byte, xr[kn]);
     const float mi = bperm_f(partner_byte, xi[kn]);
     const float pr = xr[ky] + mr, pi = xi[ky] - mi;     // 2 F_f      (each with its frame's 1 / (2 N^2))
-    const float qr = xi[ky] + mi, qi = mr - xr[ky];     // 2 F_{f+1}
     const float ar = c.fpr[ky] * pr + c.fpi[ky] * pi, ai = c.fpr[ky] * pi - c.fpi[ky] * pr;   // conj(F_prev) P
+    // the new carry is formed AFTER the last use of the old one, straight into its place: no copies on the loop back-edge
+    c.fpr[ky] = xi[ky] + mi;                            // 2 F_{f+1}
+    c.fpi[ky] = mr - xr[ky];
+    const float qr = c.fpr[ky], qi = c.fpi[ky];
     const float br = pr * qr + pi * qi, bi = pr * qi - pi * qr;                               // conj(P) Q
-    c.fpr[ky] = qr;
-    c.fpi[ky] = qi;
     xr[ky] = ar - bi;                // (R_a + i R_b)[ky][kx]
     xi[ky] = ai + br;
     if (ky >= 1 && ky < H) {         // rows above N/2: conj of (R_a - i R_b) at the mirrored lane
