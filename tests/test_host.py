@@ -359,3 +359,15 @@ def test_comm_argument_errors(lib):
     assert lib.lspiv_comm_allgather(h, _lib.ptr(a), _lib.ptr(out), 6, 1) == 0 and np.array_equal(out, a)
     assert lib.lspiv_comm_barrier(h) == 0
     assert lib.lspiv_comm_destroy(h) == 0
+
+
+def test_bench_fails_loudly_without_a_gpu():
+    """`python bench.py [--gpus N]` launches its own ranks; without a gfx950 device every rank must fail with the library's
+    error (no CPU fallback, no JSON line on stdout, non-zero exit status) instead of hanging in a rendezvous."""
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    for extra in ([], ["--gpus", "2"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"] + extra,
+                           capture_output=True, text=True, timeout=120, cwd=ROOT)
+        assert r.returncode != 0 and r.stdout.strip() == ""
+        assert "no gfx950" in r.stderr
