@@ -14,6 +14,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "fft_regs.h"
 
 namespace lspiv {
 
@@ -299,9 +300,11 @@ static hipError_t launch_t(const PivParams& p, bool ensemble, hipStream_t s) {
 constexpr int FBLOCK = 512;
 constexpr int FTILES = 2;   // 4 x 4 output tiles per thread and pass: 512 x 2 x 16 = 16 384 outputs = 128 x 128
 
+__host__ __device__ inline int fourstep_m(int wy, int wx);
 struct DftGeo {
-  int n, pitch;   // samples per window; LDS row pitch (odd: the four rows of a tile fall on different banks)
-  __host__ __device__ DftGeo(int wy, int wx) : n(wy * wx), pitch(wx | 1) {}
+  int n, pitch;   // samples per window; LDS row pitch (odd: the four rows of a tile fall on different banks; four-step
+                  // passes read 16 bytes at a time: wx + 4)
+  __host__ __device__ DftGeo(int wy, int wx) : n(wy * wx), pitch(fourstep_m(wy, wx) ? wx + 4 : (wx | 1)) {}
   // re plane | im plane | (cos, sin) tables for x and y | reduction scratch
   __host__ __device__ size_t lds_floats(int wy, int wx) const { return (size_t)2 * wy * pitch + 2 * (size_t)(wx + wy) + 24; }
 };
@@ -368,8 +371,85 @@ __device__ __forceinline__ void dft_pass(float* re, float* im, int len, int n_li
   __syncthreads();
 }
 
+// ---- four-step transforms for the common large sizes: N = R x M with a register FFT of length M ------------------------
+// X[k1 + R k2] = sum_{n2 < M} w_M^{n2 k2} [ sum_{n1 < R} x[M n1 + n2] w_N^{k1 (M n1 + n2)} ]: a thread owns one line and one k1;
+// it walks the line once (N complex multiply-adds, the R-point DFT and the twiddle in one table factor), runs the
+// length-M register transform of fft_regs.h on its M partial sums and has M outputs -- N R tasks of ~1 200 instructions
+// per pass instead of N^2 / 32 tasks of ~12 000 in dft_pass.  Lanes of a wave own consecutive lines of the same k1, so
+// the twiddle reads are broadcasts and the transposed stores (output (line, k) goes to [k][line]: the next pass reads
+// rows again) are conflict-free; the lines are read 16 bytes at a time.  Square windows only (the transposes alternate).
+template <bool INV> __device__ __forceinline__ void fs_fft(float (&r)[32], float (&i)[32]) { fft32<INV>(r, i); }
+template <bool INV> __device__ __forceinline__ void fs_fft(float (&r)[24], float (&i)[24]) { fft_pfa<INV, 3, 8>(r, i); }
+template <bool INV> __device__ __forceinline__ void fs_fft(float (&r)[20], float (&i)[20]) { fft_pfa<INV, 5, 4>(r, i); }
+template <bool INV> __device__ __forceinline__ void fs_fft(float (&r)[28], float (&i)[28]) { fft_pfa<INV, 7, 4>(r, i); }
+template <bool INV> __device__ __forceinline__ void fs_fft(float (&r)[30], float (&i)[30]) { fft_pfa<INV, 15, 2>(r, i); }
+
+typedef float fs_f32x4 __attribute__((ext_vector_type(4)));
+typedef float fs_f32x2 __attribute__((ext_vector_type(2)));
+
+template <bool INV, int M>
+__device__ __forceinline__ void fs_pass(float* re, float* im, int N, int R, int pitch, const float* tw) {
+  constexpr int VEC = M % 4 == 0 ? 4 : 2;
+  float ar[M], ai[M];
+#pragma unroll
+  for (int q = 0; q < M; ++q) ar[q] = ai[q] = 0.0f;
+  const int t = (int)threadIdx.x;
+  const bool on = t < N * R;
+  const int k1 = on ? t / N : 0, line = on ? t - k1 * N : 0;
+  if (on) {
+    const float* lr = re + line * pitch;
+    const float* li = im + line * pitch;
+    int idx = 0;                                            // (k1 n) mod N
+    for (int n1 = 0; n1 < R; ++n1, lr += M, li += M) {
+#pragma unroll
+      for (int n2 = 0; n2 < M; n2 += VEC) {
+        float xr[VEC], xi[VEC];
+        if constexpr (VEC == 4) {
+          const fs_f32x4 a = *reinterpret_cast<const fs_f32x4*>(lr + n2), b = *reinterpret_cast<const fs_f32x4*>(li + n2);
+          xr[0] = a[0]; xr[1] = a[1]; xr[2] = a[2]; xr[3] = a[3]; xi[0] = b[0]; xi[1] = b[1]; xi[2] = b[2]; xi[3] = b[3];
+        } else {
+          const fs_f32x2 a = *reinterpret_cast<const fs_f32x2*>(lr + n2), b = *reinterpret_cast<const fs_f32x2*>(li + n2);
+          xr[0] = a[0]; xr[1] = a[1]; xi[0] = b[0]; xi[1] = b[1];
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const fs_f32x2 w = *reinterpret_cast<const fs_f32x2*>(tw + 2 * idx);
+          const float c = w[0], sn = INV ? -w[1] : w[1];
+          idx += k1;
+          idx = idx >= N ? idx - N : idx;
+          ar[n2 + e] = fmaf(xr[e], c, fmaf(xi[e], sn, ar[n2 + e]));     // (xr + i xi)(c - i s)
+          ai[n2 + e] = fmaf(xi[e], c, fmaf(-xr[e], sn, ai[n2 + e]));
+        }
+      }
+    }
+    fs_fft<INV>(ar, ai);
+  }
+  __syncthreads();   // every output is in registers: the buffer may be overwritten
+  if (on) {
+#pragma unroll
+    for (int k2 = 0; k2 < M; ++k2) {
+      const int o = (k1 + R * k2) * pitch + line;           // transposed: the next pass reads rows again
+      re[o] = ar[k2];
+      im[o] = ai[k2];
+    }
+  }
+  __syncthreads();
+}
+
+// the register-FFT length the four-step passes use for a square window of side n (0: none, take the DFT passes)
+__host__ __device__ inline int fourstep_m(int wy, int wx) {
+  if (wy != wx) return 0;
+  const int n = wy;
+  const int cand[5] = {32, 24, 30, 20, 28};
+  for (int i = 0; i < 5; ++i) {
+    const int m = cand[i];
+    if (n % m == 0 && n / m >= 2 && n * (n / m) <= FBLOCK) return m;
+  }
+  return 0;
+}
+
 // one window pair -> clipped, fft-shifted plane in `plane` (n floats, aliases the imaginary plane).  false: NaN plane.
-template <typename T>
+template <typename T, int M>
 __device__ __forceinline__ bool dft_pair(const PivParams& p, uint32_t pair, uint32_t win, float* smem, const DftGeo& g, float*& plane,
                                          float*& red) {
   const int wy = p.wy, wx = p.wx, P = g.pitch;
@@ -412,8 +492,13 @@ __device__ __forceinline__ bool dft_pair(const PivParams& p, uint32_t pair, uint
     im[y * P + x] *= gb;
   }
   __syncthreads();
-  dft_pass<false>(re, im, wx, wy, 1, P, twx);   // along x, one line per row
-  dft_pass<false>(re, im, wy, wx, P, 1, twy);   // along y, one line per column -> Z[ky][kx]
+  if constexpr (M > 0) {
+    fs_pass<false, M>(re, im, wx, wx / M, P, twx);   // along x, written transposed
+    fs_pass<false, M>(re, im, wx, wx / M, P, twx);   // along y, transposed back -> Z[ky][kx]
+  } else {
+    dft_pass<false>(re, im, wx, wy, 1, P, twx);   // along x, one line per row
+    dft_pass<false>(re, im, wy, wx, P, 1, twy);   // along y, one line per column -> Z[ky][kx]
+  }
   // cross spectrum in place: the thread that owns k also owns -k (k <= -k in row-major order)
   for (int o = threadIdx.x; o < g.n; o += blockDim.x) {
     const int ky = o / wx, kx = o - ky * wx;
@@ -429,8 +514,13 @@ __device__ __forceinline__ bool dft_pair(const PivParams& p, uint32_t pair, uint
     if (o != om) { re[a1] = Rr; im[a1] = -Ri; }
   }
   __syncthreads();
-  dft_pass<true>(re, im, wy, wx, P, 1, twy);    // along ky
-  dft_pass<true>(re, im, wx, wy, 1, P, twx);    // along kx -> correlation at lag (dy, dx) in re[dy][dx]
+  if constexpr (M > 0) {
+    fs_pass<true, M>(re, im, wx, wx / M, P, twx);
+    fs_pass<true, M>(re, im, wx, wx / M, P, twx);
+  } else {
+    dft_pass<true>(re, im, wy, wx, P, 1, twy);    // along ky
+    dft_pass<true>(re, im, wx, wy, 1, P, twx);    // along kx -> correlation at lag (dy, dx) in re[dy][dx]
+  }
   const int cy = wy / 2, cx = wx / 2;
   const float hi = dead ? 0.0f : 1.0f;
   for (int o = threadIdx.x; o < g.n; o += blockDim.x) {            // clip, fft-shift into the (now free) imaginary plane
@@ -442,14 +532,14 @@ __device__ __forceinline__ bool dft_pair(const PivParams& p, uint32_t pair, uint
   return ok;
 }
 
-template <typename T>
+template <typename T, int M>
 __global__ __launch_bounds__(FBLOCK) void piv_dft_kernel(PivParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const DftGeo g(p.wy, p.wx);
   const uint32_t t = blockIdx.x;
   const uint32_t pair = t / p.n_win, win = t - pair * p.n_win;
   float *plane, *red;
-  const bool ok = dft_pair<T>(p, pair, win, smem, g, plane, red);
+  const bool ok = dft_pair<T, M>(p, pair, win, smem, g, plane, red);
   float vmax, sum, u, v;
   int imax;
   plane_reduce(plane, g.n, red, vmax, imax, sum);
@@ -466,7 +556,7 @@ __global__ __launch_bounds__(FBLOCK) void piv_dft_kernel(PivParams p) {
 }
 
 // ensemble: one block owns one window and walks the chunk's pairs in order (as piv_direct_ensemble_kernel)
-template <typename T>
+template <typename T, int M>
 __global__ __launch_bounds__(FBLOCK) void piv_dft_ensemble_kernel(PivParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const DftGeo g(p.wy, p.wx);
@@ -475,7 +565,7 @@ __global__ __launch_bounds__(FBLOCK) void piv_dft_ensemble_kernel(PivParams p) {
   float cnt = 0.0f;
   for (uint32_t pair = 0; pair < p.n_pairs; ++pair) {
     float *plane, *red;
-    const bool ok = dft_pair<T>(p, pair, win, smem, g, plane, red);
+    const bool ok = dft_pair<T, M>(p, pair, win, smem, g, plane, red);
     float vmax, sum;
     int imax;
     plane_reduce(plane, g.n, red, vmax, imax, sum);
@@ -501,20 +591,33 @@ bool piv_dft_fits(int wy, int wx) {
   return tiles <= FBLOCK * FTILES && piv_dft_lds_bytes(wy, wx) <= (size_t)160 * 1024 - 512;
 }
 
-template <typename T>
-static hipError_t launch_dft_t(const PivParams& p, bool ensemble, hipStream_t s) {
+template <typename T, int M>
+static hipError_t launch_dft_tm(const PivParams& p, bool ensemble, hipStream_t s) {
   const size_t lds = piv_dft_lds_bytes(p.wy, p.wx);
   hipError_t e;
   if (ensemble) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&piv_dft_ensemble_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&piv_dft_ensemble_kernel<T, M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(piv_dft_ensemble_kernel<T>, dim3(p.n_win), dim3(FBLOCK), lds, s, p);
+    hipLaunchKernelGGL((piv_dft_ensemble_kernel<T, M>), dim3(p.n_win), dim3(FBLOCK), lds, s, p);
   } else {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&piv_dft_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&piv_dft_kernel<T, M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(piv_dft_kernel<T>, dim3(p.n_tiles), dim3(FBLOCK), lds, s, p);
+    hipLaunchKernelGGL((piv_dft_kernel<T, M>), dim3(p.n_tiles), dim3(FBLOCK), lds, s, p);
   }
   return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_dft_t(const PivParams& p, bool ensemble, hipStream_t s) {
+  static const bool no_fourstep = getenv("LSPIV_NO_FOURSTEP") != nullptr;   // A/B and cross-check: DFT passes for every size
+  switch (no_fourstep ? 0 : fourstep_m(p.wy, p.wx)) {
+    case 32: return launch_dft_tm<T, 32>(p, ensemble, s);
+    case 24: return launch_dft_tm<T, 24>(p, ensemble, s);
+    case 30: return launch_dft_tm<T, 30>(p, ensemble, s);
+    case 20: return launch_dft_tm<T, 20>(p, ensemble, s);
+    case 28: return launch_dft_tm<T, 28>(p, ensemble, s);
+    default: return launch_dft_tm<T, 0>(p, ensemble, s);
+  }
 }
 
 hipError_t launch_piv_dft(const PivParams& p, int dtype, bool ensemble, hipStream_t s) {

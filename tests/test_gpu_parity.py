@@ -250,11 +250,15 @@ def test_fused_results_equal_two_step_results(gpu):
 # ------------------------------------------------------------------ windows above 64 px --------------
 @pytest.mark.parametrize("dtype", [np.uint8, np.float32, np.float64])
 @pytest.mark.parametrize("ws,ov", [((96, 96), (48, 48)), ((128, 128), (64, 64)), ((128, 128), (96, 32)), ((66, 66), (33, 33)),
-                                   ((100, 100), (50, 50)), ((97, 97), (40, 40)), ((128, 80), (64, 40)), ((72, 120), (0, 60))])
+                                   ((100, 100), (50, 50)), ((97, 97), (40, 40)), ((128, 80), (64, 40)), ((72, 120), (0, 60)),
+                                   ((72, 72), (36, 36)), ((80, 80), (40, 40)), ((84, 84), (42, 42)), ((90, 90), (45, 45)),
+                                   ((112, 112), (56, 56)), ((120, 120), (60, 60))])
 def test_windows_above_64_vs_oracle(gpu, ws, ov, dtype):
     """ffpiv.cross_corr takes any window (pyorc/api/frames.py:159-168): sizes above 64 px -- 96 and 128 for 4K footage,
     but also odd, non-square and 2 x prime sizes -- run the LDS-resident DFT kernel; planes, NaN masks, corr / s2n and
-    the sub-pixel peaks against the oracle, with a signal threshold, an empty frame and a constant corner in the stack."""
+    the sub-pixel peaks against the oracle, with a signal threshold, an empty frame and a constant corner in the stack.
+    Square sizes N = R x M with a register FFT of length M (72 ... 128: 3 x 24, 4 x 20, 3 x 28, 3 x 30, 3 x 32, 5 x 20, 4 x 28,
+    4 x 30, 4 x 32) take the four-step passes, everything else the plain DFT passes; LSPIV_NO_FOURSTEP=1 cross-checks."""
     H, Wd = 2 * ws[0] + 7, 2 * ws[1] + ws[1] // 2 + 3
     fr = particle_stack(4, H, Wd, seed=ws[0] + ws[1], density=0.03)
     if dtype == np.uint8:
