@@ -1,0 +1,59 @@
+"""bench.py end to end on the GPU box, small shapes: the JSON contract, the self-launched multi-rank path and the native
+communicator (RCCL with one rank; two ranks over the shared-memory transport -- RCCL refuses two ranks on one GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--pairs", "60", "--height", "256", "--width", "384", "--steps", "3", "--warmup", "1"]
+
+
+def run_bench(args, env_extra=None):
+    env = dict(os.environ, **(env_extra or {}))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, cwd=ROOT, env=env,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]            # ONE JSON line on stdout, nothing else (RCCL's banner goes to stderr)
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_json_contract_single_gpu(gpu):
+    d = run_bench(SMALL + ["--cpu-pairs", "4"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "frame-pairs/s" and d["value"] > 0
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["higher_is_better"] is True
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert r["algorithmic_bytes_per_pair"] == 2 * 256 * 384 + 16 * d["config"]["windows_per_pair"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+    assert c["parity_nan_mismatch"] == 0 and c["parity_max_rel_err_vs_oracle"] <= 1e-4 and "parity_ill_posed" in c
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks_and_gathers_over_the_native_comm(gpu):
+    """`python bench.py --gpus 2` starts two ranks itself; on a 1-GPU box they share the device over the shared-memory
+    transport (LSPIV_BENCH_SAME_DEVICE): sharding, pipelined all-gather, max-over-ranks timing and the bit check."""
+    d = run_bench(SMALL + ["--gpus", "2"], {"LSPIV_BENCH_SAME_DEVICE": "1"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
+    comm = d["config"]["comm"]
+    assert comm["transport"] == "shm" and comm["ranks_reported_by_transport"] == 2
+    assert comm["allgather_matches_single_launch"] is True and comm["same_device_plumbing_test"] is True
+    assert comm["allgather_bytes_per_rank_per_step"] == 4 * 4 * 60 * d["config"]["windows_per_pair"]
+
+
+@pytest.mark.gpu
+def test_bench_over_rccl_with_one_rank(gpu):
+    """The RCCL transport itself (librccl.so dlopen'ed by the C library, ncclCommInitRank, ncclAllGather on a second
+    stream, all-reduce for the timing), with the one rank a 1-GPU box allows."""
+    d = run_bench(SMALL + ["--gpus", "1", "--cpu-pairs", "0", "--no-extras"], {"LSPIV_BENCH_FORCE_COMM": "1"})
+    comm = d["config"]["comm"]
+    assert comm["transport"] == "rccl" and comm["ranks_reported_by_transport"] == 1
+    assert comm["allgather_matches_single_launch"] is True

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [11, 12])
+@pytest.mark.parametrize("seed", [11, 12, 13])
 def test_fuzz_parity(gpu, seed):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), str(seed), "40"],
                          capture_output=True, text=True, cwd=ROOT)
