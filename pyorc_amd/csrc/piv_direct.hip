@@ -486,11 +486,25 @@ __device__ __forceinline__ bool dft_pair(const PivParams& p, uint32_t pair, uint
   // carries the 1 / n^2 the plane needs; a zero-variance window gives an exactly-zero plane
   const bool dead = inv_a == 0.0f || inv_b == 0.0f;
   const float ga = dead ? 0.0f : inv_a / (float)g.n, gb = dead ? 0.0f : inv_b / (float)g.n;
+  // The clipped windows are non-negative, so their mean (the DC bin) is ~20x a typical AC bin, and every term of the
+  // transform sums carries rounding noise relative to IT.  The mean only shifts the plane by a constant,
+  //     sum_x (a~ + ma)(x) (b~ + mb)(x + d) = sum_x a~(x) b~(x + d) + n ma mb,
+  // so the transforms run on the de-meaned windows and the constant n^2 ma mb is added back before the clip.
+  float sa = 0.0f, sb = 0.0f;
   for (int o = threadIdx.x; o < g.n; o += blockDim.x) {
     const int y = o / wx, x = o - y * wx;
-    re[y * P + x] *= ga;
-    im[y * P + x] *= gb;
+    sa += re[y * P + x];
+    sb += im[y * P + x];
   }
+  const float ma = block_sum(sa, red) * ga / (float)g.n;   // means of the SCALED windows
+  __syncthreads();
+  const float mb = block_sum(sb, red) * gb / (float)g.n;
+  for (int o = threadIdx.x; o < g.n; o += blockDim.x) {
+    const int y = o / wx, x = o - y * wx;
+    re[y * P + x] = re[y * P + x] * ga - ma;
+    im[y * P + x] = im[y * P + x] * gb - mb;
+  }
+  const float plane_dc = (float)g.n * (float)g.n * ma * mb;
   __syncthreads();
   if constexpr (M > 0) {
     fs_pass<false, M>(re, im, wx, wx / M, P, twx);   // along x, written transposed
@@ -526,7 +540,7 @@ __device__ __forceinline__ bool dft_pair(const PivParams& p, uint32_t pair, uint
   for (int o = threadIdx.x; o < g.n; o += blockDim.x) {            // clip, fft-shift into the (now free) imaginary plane
     const int ip = o / wx, jp = o - ip * wx;
     const int dy = ip - cy < 0 ? ip - cy + wy : ip - cy, dx = jp - cx < 0 ? jp - cx + wx : jp - cx;
-    im[o] = __builtin_amdgcn_fmed3f(re[dy * P + dx], 0.0f, hi);
+    im[o] = __builtin_amdgcn_fmed3f(re[dy * P + dx] + plane_dc, 0.0f, hi);
   }
   __syncthreads();
   return ok;

@@ -252,23 +252,29 @@ def test_fused_results_equal_two_step_results(gpu):
 @pytest.mark.parametrize("ws,ov", [((96, 96), (48, 48)), ((128, 128), (64, 64)), ((128, 128), (96, 32)), ((66, 66), (33, 33)),
                                    ((100, 100), (50, 50)), ((97, 97), (40, 40)), ((128, 80), (64, 40)), ((72, 120), (0, 60)),
                                    ((72, 72), (36, 36)), ((80, 80), (40, 40)), ((84, 84), (42, 42)), ((90, 90), (45, 45)),
-                                   ((112, 112), (56, 56)), ((120, 120), (60, 60))])
+                                   ((112, 112), (56, 56)), ((120, 120), (60, 60)),
+                                   ((41, 41), (20, 20)), ((63, 63), (31, 31)), ((64, 32), (32, 16)), ((49, 33), (10, 30))])
 def test_windows_above_64_vs_oracle(gpu, ws, ov, dtype):
     """ffpiv.cross_corr takes any window (pyorc/api/frames.py:159-168): sizes above 64 px -- 96 and 128 for 4K footage,
     but also odd, non-square and 2 x prime sizes -- run the LDS-resident DFT kernel; planes, NaN masks, corr / s2n and
     the sub-pixel peaks against the oracle, with a signal threshold, an empty frame and a constant corner in the stack.
     Square sizes N = R x M with a register FFT of length M (72 ... 128: 3 x 24, 4 x 20, 3 x 28, 3 x 30, 3 x 32, 5 x 20, 4 x 28,
-    4 x 30, 4 x 32) take the four-step passes, everything else the plain DFT passes; LSPIV_NO_FOURSTEP=1 cross-checks."""
+    4 x 30, 4 x 32) take the four-step passes, everything else the plain DFT passes; LSPIV_NO_FOURSTEP=1 cross-checks.
+    The DFT passes also serve the non-square and odd windows below 64 px from 1600 samples on (41 x 41, 63 x 63, 64 x 32)."""
     H, Wd = 2 * ws[0] + 7, 2 * ws[1] + ws[1] // 2 + 3
     fr = particle_stack(4, H, Wd, seed=ws[0] + ws[1], density=0.03)
+    # planes out of the LDS-resident transforms carry ~4e-6 of absolute float32 noise (the register FFT kernels: 2e-6; the
+    # plain DFT passes sum up to 128 terms in sequence), so the sub-pixel gate takes the windows whose peak neighbours
+    # reach 5 % of the maximum -- the fuzz tool's rule for every size
+    kw = dict(plane_tol=4e-6, min_neighbour=0.05)
     if dtype == np.uint8:
-        check_against_oracle(fr, ws, ov, min_ok=0.5, plane_tol=4e-6)
-        check_against_oracle(fr, ws, ov, thr=0.12, min_ok=0.0, plane_tol=4e-6)
+        check_against_oracle(fr, ws, ov, min_ok=0.5, **kw)
+        check_against_oracle(fr, ws, ov, thr=0.12, min_ok=0.0, **kw)
     else:
         f = (fr.astype(dtype) - 21.5) * 0.37
         f[2] = 1.5                                       # a constant frame: both pairs that touch it are dead
         f[:, : ws[0] // 2, : ws[1]] = -0.75              # a constant corner
-        check_against_oracle(f, ws, ov, thr=0.25, min_ok=0.0, plane_tol=4e-6)
+        check_against_oracle(f, ws, ov, thr=0.25, min_ok=0.0, **kw)
 
 
 @pytest.mark.parametrize("ws", [96, 128])
