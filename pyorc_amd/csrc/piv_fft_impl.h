@@ -533,6 +533,9 @@ __device__ __forceinline__ void lds_row_write(float* row, const float (&c)[N]) {
 // LSPIV_TR_ASM (N = 32): the column scatter as ds_write_b32 with immediate offsets off ONE base register.  Left to the
 // compiler the 32 stores are paired into ds_write2_b32, whose 8-bit offsets reach only 1 KB, so it keeps six extra base
 // addresses in VGPRs for the whole loop -- registers the 4-waves-per-SIMD build of the walking kernel does not have.
+#ifndef LSPIV_X_NOCARRY
+#define LSPIV_X_NOCARRY 0
+#endif
 #ifndef LSPIV_TR_ASM
 #define LSPIV_TR_ASM 0
 #endif
@@ -1039,11 +1042,16 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
     const float mr = bperm_f(partner_byte, xr[kn]);
     const float mi = bperm_f(partner_byte, xi[kn]);
     const float pr = xr[ky] + mr, pi = xi[ky] - mi;     // 2 F_f      (each with its frame's 1 / (2 N^2))
+#if LSPIV_X_NOCARRY   // EXPERIMENT (wrong results): what the kernel would run at if the carry cost no registers
+    const float ar = 0.75f * pr + 0.5f * pi, ai = 0.75f * pi - 0.5f * pr;
+    const float qr = xi[ky] + mi, qi = mr - xr[ky];
+#else
     const float ar = c.fpr[ky] * pr + c.fpi[ky] * pi, ai = c.fpr[ky] * pi - c.fpi[ky] * pr;   // conj(F_prev) P
     // the new carry is formed AFTER the last use of the old one, straight into its place: no copies on the loop back-edge
     c.fpr[ky] = xi[ky] + mi;                            // 2 F_{f+1}
     c.fpi[ky] = mr - xr[ky];
     const float qr = c.fpr[ky], qi = c.fpi[ky];
+#endif
     const float br = pr * qr + pi * qi, bi = pr * qi - pi * qr;                               // conj(P) Q
     xr[ky] = ar - bi;                // (R_a + i R_b)[ky][kx]
     xi[ky] = ai + br;
