@@ -693,7 +693,7 @@ static int ensemble_launch(lspiv_ensemble* h, DeviceCtx* c, const void* d_frames
     const size_t need = (size_t)p.n_seg * p.n_win * (plane + 1) * sizeof(float);
     rc = ensure(&h->d_part, &h->part_cap, need);
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(h->d_part, 0, need, s));
+    // not zeroed: every (segment, window) job writes its whole slot and its count (first iteration stores, later ones add)
     p.part_sum = h->d_part;
     p.part_cnt = h->d_part + (size_t)p.n_seg * p.n_win * plane;
   }

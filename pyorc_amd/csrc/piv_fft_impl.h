@@ -1385,14 +1385,15 @@ static hipError_t launch_embed(const PivParams& p, int dtype, bool ensemble, hip
 // single owner) so the kernel keeps the register budget of the per-timestep kernel.
 template <int N>
 __device__ __forceinline__ void accumulate_planes(float* dst, int lg, const float (&c0)[N], bool keep0,
-                                                  const float (&c1)[N], bool keep1) {
-  // corr_sum is kept in fft-shifted layout (what u_v_displacement expects)
+                                                  const float (&c1)[N], bool keep1, bool init = false) {
+  // corr_sum is kept in fft-shifted layout (what u_v_displacement expects); `init`: the slot holds nothing yet, start from 0
   if (!lane_active<N>(lg)) return;
   float* row = dst + wrap_n<N>(lg + N / 2) * N;
   if constexpr (N % 4 == 0) {
 #pragma unroll
     for (int qd = 0; qd < N / 4; ++qd) {
-      f32x4 acc = *reinterpret_cast<f32x4*>(row + 4 * qd);
+      f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (!init) acc = *reinterpret_cast<f32x4*>(row + 4 * qd);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int j = (4 * qd + e + N / 2) % N;
@@ -1404,7 +1405,8 @@ __device__ __forceinline__ void accumulate_planes(float* dst, int lg, const floa
   } else {
 #pragma unroll
     for (int qd = 0; qd < N / 2; ++qd) {
-      f32x2 acc = *reinterpret_cast<f32x2*>(row + 2 * qd);
+      f32x2 acc = {0.0f, 0.0f};
+      if (!init) acc = *reinterpret_cast<f32x2*>(row + 2 * qd);
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int j = (2 * qd + e + N / 2) % N;
@@ -1505,6 +1507,7 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsWaves<T, N>)) void piv_fft_walk_ens
   }
   WalkCarry<N> carry;
   carry.reset();
+  bool first = job_valid;   // the slot is not zeroed beforehand: the job's first iteration stores, the later ones add
   for (uint32_t f = p0; f <= p1; f += 2, row += 2 * p.frame_elems) {
     const bool has2 = f + 1 <= p1;
     float xr[N], xi[N], mean[2];
@@ -1535,7 +1538,8 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsWaves<T, N>)) void piv_fft_walk_ens
         acc[j] += keep[1] ? xi[j] : 0.0f;
       }
     } else {
-      if (keep[0] || keep[1]) accumulate_planes<N>(part, lg, xr, keep[0], xi, keep[1]);
+      if (first || keep[0] || keep[1]) accumulate_planes<N>(part, lg, xr, keep[0], xi, keep[1], first);
+      first = false;
     }
   }
   if constexpr (kEnsRegAcc<N>) {

@@ -483,7 +483,8 @@ def test_get_ffpiv_ensemble_vs_oracle(gpu, kw):
         assert np.array_equal(got.coords["time"], t[ref["pair_index"]])
 
 
-@pytest.mark.parametrize("n,T", [(24, 6), (10, 7), (16, 5), (26, 4), (48, 4), (20, 5), (12, 6), (40, 4), (36, 3), (28, 5), (34, 3), (6, 5), (18, 4), (30, 3), (-10, 7), (-26, 4), (-1034, 3), (62, 3), (42, 4), (8, 6)])
+@pytest.mark.parametrize("n,T", [(24, 6), (10, 7), (16, 5), (26, 4), (48, 4), (20, 5), (12, 6), (40, 4), (36, 3), (28, 5), (34, 3), (6, 5), (18, 4), (30, 3), (-10, 7), (-26, 4), (-1034, 3), (62, 3), (42, 4), (8, 6),
+                                 (64, 5), (64, 29), (48, 28), (32, 28)])   # long ones: several anchored segments, partial sums merged
 def test_ensemble_other_window_size(gpu, monkeypatch, n, T):
     """Ensemble mode of the 16-point and the prime-factor FFT kernels (6 ... 48), of the direct kernel (34 with both switches) and, with
     LSPIV_NO_PFA=1 (negative n), of the embedded kernels (10: 32-point variant, two pairs per iteration incl. an odd pair
