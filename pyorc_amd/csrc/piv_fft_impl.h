@@ -272,15 +272,19 @@ __device__ __forceinline__ float center_clip_f(float (&x)[N], bool want_nz, bool
   const float var = ssq * inv_nn;
   return var > 0.0f ? __builtin_amdgcn_rsqf(var) : 0.0f;
 }
+template <int N>
+__device__ __forceinline__ void load_row_f32(const float* p, float (&x)[N]) {
+#pragma unroll
+  for (int k = 0; k < N / 4; ++k) {
+    const f32x4 v = *reinterpret_cast<const f32x4_u*>(p + 4 * k);
+    x[4 * k + 0] = v[0]; x[4 * k + 1] = v[1]; x[4 * k + 2] = v[2]; x[4 * k + 3] = v[3];
+  }
+  if constexpr (N % 4 == 2) { x[N - 2] = p[N - 2]; x[N - 1] = p[N - 1]; }
+}
 template <int N, bool DEFER_CLIP = false>
 __device__ __forceinline__ float load_center(const RowRaw<float, N>& raw, float (&x)[N], bool want_nz, bool nz_pos,
                                              int& nonzero, bool& finite) {
-#pragma unroll
-  for (int k = 0; k < N / 4; ++k) {
-    const f32x4 v = *reinterpret_cast<const f32x4_u*>(raw.p + 4 * k);
-    x[4 * k + 0] = v[0]; x[4 * k + 1] = v[1]; x[4 * k + 2] = v[2]; x[4 * k + 3] = v[3];
-  }
-  if constexpr (N % 4 == 2) { x[N - 2] = raw.p[N - 2]; x[N - 1] = raw.p[N - 1]; }
+  load_row_f32<N>(raw.p, x);
   return center_clip_f<N, DEFER_CLIP>(x, want_nz, nz_pos, nonzero, finite);
 }
 template <int N, bool DEFER_CLIP = false>
@@ -948,6 +952,10 @@ __device__ __forceinline__ void prepare_one(const RowRaw<T, N>& raw, float (&x)[
 #ifndef LSPIV_STAGE_F32
 #define LSPIV_STAGE_F32 0
 #endif
+#ifndef LSPIV_F32_EARLY
+#define LSPIV_F32_EARLY 1
+#endif
+template <int N> constexpr bool kF32Early = LSPIV_F32_EARLY && Geo<N>::FULL;
 template <int N> constexpr bool kStageF32 = LSPIV_STAGE_F32 && Geo<N>::FULL && N % 4 == 0 && N >= 16 && N <= 32;
 template <int N>
 __device__ __forceinline__ void fetch_rows_coalesced(const float* win /* window origin in its frame */, int W, int lg, float (&x)[N]) {
@@ -1014,6 +1022,25 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
     dead0 = inv0 == 0.0f;
     LSPIV_WALK_SB;
     stage_rows<N>(buf, lg, xi);
+    const float inv1 = center_clip_f<N, true>(xi, WANT_NZ, p.nz_positive != 0, nz1, fin1);
+    const float g1 = inv1 * kHalf;
+#pragma unroll
+    for (int j = 0; j < N; ++j) xi[j] = __builtin_amdgcn_fmed3f(xi[j] * g1, 0.0f, 1.0f);
+    dead1 = inv1 == 0.0f;
+  } else if constexpr (sizeof(T) == 4 && kF32Early<N>) {
+    // float32 rows: the loads of BOTH frames are in flight before the first is consumed (they land in xr / xi, the registers
+    // they are converted in), so an iteration waits for memory once instead of twice
+    constexpr float kHalf = 1.0f / (2.0f * (float)G::NN);
+    const float* r0 = reinterpret_cast<const float*>(row);
+    const float* r1 = has2 ? r0 + p.frame_elems : r0;
+    load_row_f32<N>(r0, xr);
+    load_row_f32<N>(r1, xi);
+    const float inv0 = center_clip_f<N, true>(xr, WANT_NZ, p.nz_positive != 0, nz0, fin0);
+    const float g0 = inv0 * kHalf;
+#pragma unroll
+    for (int j = 0; j < N; ++j) xr[j] = __builtin_amdgcn_fmed3f(xr[j] * g0, 0.0f, 1.0f);
+    dead0 = inv0 == 0.0f;
+    LSPIV_WALK_SB;
     const float inv1 = center_clip_f<N, true>(xi, WANT_NZ, p.nz_positive != 0, nz1, fin1);
     const float g1 = inv1 * kHalf;
 #pragma unroll
