@@ -182,7 +182,8 @@ def host_fed_rates(lib, sample_u8: np.ndarray, ws, ov) -> dict:
 def camera_to_velocity_rates(cam: np.ndarray, ws, ov) -> dict:
     """End to end from raw uint8 camera frames in host memory to velocities in host memory, through the accessor-shaped
     entry points: (a) the stages hand HBM-resident stacks to each other (DeviceFrames: one H2D of the camera bytes,
-    filters.normalize -> Projection.project_frames -> frames.get_piv, results D2H); (b) every stage returns a host stack
+    filters.normalize -> Projection.project_frames -> frames.get_piv, results D2H); (a') the same stages as the fixed chain
+    pipeline.CameraToVelocity, in one piece and with the upload streamed in time chunks under the kernels of the previous chunk; (b) every stage returns a host stack
     and the ortho frames reach get_piv as float64, which is what pyorc's project_numpy really hands over."""
     from pyorc_amd import DeviceFrames, filters, frames as F
     from pyorc_amd.project import Projection
@@ -201,12 +202,17 @@ def camera_to_velocity_rates(cam: np.ndarray, ws, ov) -> dict:
         o = p.project_frames(filters.normalize(cam, 15)).astype(np.float64)
         return F.get_piv(o, ws[0], overlap=ov, time=t, resolution=0.01)
 
+    from pyorc_amd.pipeline import CameraToVelocity
+    chain = CameraToVelocity((H, W), (H, W), *maps, window_size=ws, overlap=ov, normalize_samples=15)
+
     out = {}
-    for key, fn in (("device_resident_stages", device_chain), ("host_stacks_float64", host_chain)):
+    for key, fn in (("device_resident_stages", device_chain), ("streamed_chain", lambda: chain.run(cam, streamed=True)),
+                    ("one_piece_chain", lambda: chain.run(cam, streamed=False)), ("host_stacks_float64", host_chain)):
         fn()
         t0 = time.perf_counter()
         r = fn()
         out[key] = round((T - 1) / (time.perf_counter() - t0), 1)
+    chain.close()
     p.close()
     out["note"] = (f"{T - 1} pairs of {H}x{W} uint8 camera frames in pageable host memory -> normalize(15) -> orthoprojection "
                    f"(synthetic homography, group means) -> get_piv {ws[0]}x{ws[1]}; PCIe-inclusive, never `value`")

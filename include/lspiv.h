@@ -238,6 +238,13 @@ int lspiv_minmax(const float* frames, int64_t n, float lo, float hi, float* out)
 int lspiv_minmax_dev(const float* d_frames, int64_t n, float lo, float hi, float* d_out, void* stream);
 int lspiv_normalize(const uint8_t* frames, int64_t T, int64_t H, int64_t W, int samples, uint8_t* out);
 int lspiv_normalize_dev(const uint8_t* d_frames, int64_t T, int64_t H, int64_t W, int samples, uint8_t* d_out, void* stream);
+/* The two halves of lspiv_normalize_dev, for a stack that arrives in pieces (pyorc_amd/pipeline.py streams the camera frames
+ * in while earlier ones are processed): the float32 mean plane (H,W) of frames [::round(T/samples)] of a T-frame stack of
+ * which only those frames need to be resident yet, and the per-frame stretch of any run of frames against a given mean plane.
+ * mean + apply over the whole stack == lspiv_normalize_dev bit for bit (the stretch uses per-frame statistics only). */
+int lspiv_normalize_mean_dev(const uint8_t* d_frames, int64_t T, int64_t H, int64_t W, int samples, float* d_mean, void* stream);
+int lspiv_normalize_apply_dev(const uint8_t* d_frames, int64_t T, int64_t H, int64_t W, const float* d_mean, uint8_t* d_out,
+                              void* stream);
 int lspiv_reduce_rolling(const uint8_t* frames, int64_t T, int64_t H, int64_t W, int samples, uint8_t* out);
 int lspiv_reduce_rolling_dev(const uint8_t* d_frames, int64_t T, int64_t H, int64_t W, int samples, uint8_t* d_out, void* stream);
 

@@ -88,6 +88,8 @@ SIGNATURES = {
     "lspiv_minmax_dev": (_i32, [_vp, _i64, _f32, _f32, _vp, _vp]),
     "lspiv_normalize": (_i32, [_vp, _i64, _i64, _i64, _i32, _vp]),
     "lspiv_normalize_dev": (_i32, [_vp, _i64, _i64, _i64, _i32, _vp, _vp]),
+    "lspiv_normalize_mean_dev": (_i32, [_vp, _i64, _i64, _i64, _i32, _vp, _vp]),
+    "lspiv_normalize_apply_dev": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "lspiv_reduce_rolling": (_i32, [_vp, _i64, _i64, _i64, _i32, _vp]),
     "lspiv_reduce_rolling_dev": (_i32, [_vp, _i64, _i64, _i64, _i32, _vp, _vp]),
     "lspiv_gaussian_blur": (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _vp]),

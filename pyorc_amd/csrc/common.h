@@ -298,6 +298,10 @@ hipError_t launch_time_range(const void* frames, int dtype, int64_t frame_elems,
 size_t normalize_part_bytes(int64_t frame_elems, int n_frames);
 hipError_t launch_normalize(const uint8_t* frames, int64_t frame_elems, int n_frames, int interval, float* d_mean,
                             int* d_mn, int* d_mx, float* d_part, uint8_t* out, hipStream_t s);
+// the two halves of launch_normalize: the float32 mean of frames [::interval], and the per-frame stretch against a given mean
+hipError_t launch_sample_mean(const uint8_t* frames, int64_t frame_elems, int n_frames, int interval, float* d_mean, hipStream_t s);
+hipError_t launch_normalize_apply(const uint8_t* frames, int64_t frame_elems, int n_frames, const float* d_mean, int* d_mn,
+                                  int* d_mx, float* d_part, uint8_t* out, hipStream_t s);
 // Gaussian blur (ksize_b == 0) or band filter blur(ksize_b) - blur(ksize_a); odd sizes 1..31
 hipError_t launch_blur(const void* frames, int dtype, int n_frames, int H, int W, int ksize_a, int ksize_b, float* out,
                        hipStream_t s);

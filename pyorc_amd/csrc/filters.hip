@@ -519,11 +519,24 @@ size_t normalize_part_bytes(int64_t frame_elems, int n_frames) {
   return (size_t)n_frames * (size_t)(4 * n_slices) * 2 * sizeof(float);
 }
 
-hipError_t launch_normalize(const uint8_t* frames, int64_t frame_elems, int n_frames, int interval, float* d_mean,
-                            int* d_mn, int* d_mx, float* d_part, uint8_t* out, hipStream_t s) {
+hipError_t launch_sample_mean(const uint8_t* frames, int64_t frame_elems, int n_frames, int interval, float* d_mean, hipStream_t s) {
   if (n_frames <= 0 || frame_elems <= 0) return hipSuccess;
   hipLaunchKernelGGL(sample_mean_kernel, dim3((unsigned)((frame_elems + 255) / 256)), dim3(256), 0, s, frames, frame_elems,
                      n_frames, interval, d_mean);
+  return hipGetLastError();
+}
+
+hipError_t launch_normalize(const uint8_t* frames, int64_t frame_elems, int n_frames, int interval, float* d_mean,
+                            int* d_mn, int* d_mx, float* d_part, uint8_t* out, hipStream_t s) {
+  const hipError_t e = launch_sample_mean(frames, frame_elems, n_frames, interval, d_mean, s);
+  if (e != hipSuccess) return e;
+  return launch_normalize_apply(frames, frame_elems, n_frames, d_mean, d_mn, d_mx, d_part, out, s);
+}
+
+// passes 2 and 3 on their own: per-frame statistics only, so a stack may be normalised in pieces against one mean plane
+hipError_t launch_normalize_apply(const uint8_t* frames, int64_t frame_elems, int n_frames, const float* d_mean, int* d_mn,
+                                  int* d_mx, float* d_part, uint8_t* out, hipStream_t s) {
+  if (n_frames <= 0 || frame_elems <= 0) return hipSuccess;
   hipError_t e = hipMemsetAsync(d_mn, 0x7f, (size_t)n_frames * sizeof(int), s);   // 0x7f7f7f7f: a huge positive float
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(d_mx, 0x80, (size_t)n_frames * sizeof(int), s);               // 0x80808080: a negative ordinal

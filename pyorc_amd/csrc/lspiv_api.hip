@@ -1425,13 +1425,48 @@ int lspiv_minmax(const float* frames, int64_t n, float lo, float hi, float* out)
   return LSPIV_OK;
 }
 
+// Frames.normalize's sampling interval round(T / samples), Python rounding (half to even); 0 = too few frames
+static long normalize_interval(int64_t T, int samples) {
+  const double ratio = (double)T / (double)samples;
+  long iv = std::lround(ratio);
+  if (ratio - std::floor(ratio) == 0.5) iv = ((long)std::floor(ratio) % 2 == 0) ? (long)std::floor(ratio) : (long)std::floor(ratio) + 1;
+  return iv;
+}
+
+int lspiv_normalize_mean_dev(const uint8_t* d_frames, int64_t T, int64_t H, int64_t W, int samples, float* d_mean, void* stream) {
+  if (!d_frames || !d_mean) return fail(LSPIV_EINVAL, "NULL argument");
+  if (T < 1 || H <= 0 || W <= 0 || samples < 1 || T >= 65536) return fail(LSPIV_ESHAPE, "bad shape");
+  const long iv = normalize_interval(T, samples);
+  if (iv == 0) return fail(LSPIV_EINVAL, "Amount of frames is too small to provide %d samples", samples);
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  HIP_TRY(lspiv::launch_sample_mean(d_frames, H * W, (int)T, (int)iv, d_mean, stream ? (hipStream_t)stream : c->stream));
+  return LSPIV_OK;
+}
+
+int lspiv_normalize_apply_dev(const uint8_t* d_frames, int64_t T, int64_t H, int64_t W, const float* d_mean, uint8_t* d_out,
+                              void* stream) {
+  if (!d_frames || !d_mean || !d_out) return fail(LSPIV_EINVAL, "NULL argument");
+  if (T < 1 || H <= 0 || W <= 0 || T >= 65536) return fail(LSPIV_ESHAPE, "bad shape");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  const size_t mm_bytes = ((size_t)2 * T * sizeof(int) + 255) & ~(size_t)255;
+  rc = ensure(&c->d_scratch, &c->scratch_cap, mm_bytes + lspiv::normalize_part_bytes(H * W, (int)T));   // same-stream rule below
+  if (rc) return rc;
+  int* d_mm = (int*)c->d_scratch;
+  float* d_part = (float*)((char*)c->d_scratch + mm_bytes);
+  hipError_t e = lspiv::launch_normalize_apply(d_frames, H * W, (int)T, d_mean, d_mm, d_mm + T, d_part, d_out,
+                                               stream ? (hipStream_t)stream : c->stream);
+  if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? LSPIV_ENOMEM : LSPIV_EHIP, "normalize failed: %s", hipGetErrorString(e));
+  return LSPIV_OK;
+}
+
 int lspiv_normalize_dev(const uint8_t* d_frames, int64_t T, int64_t H, int64_t W, int samples, uint8_t* d_out, void* stream) {
   if (!d_frames || !d_out) return fail(LSPIV_EINVAL, "NULL argument");
   if (T < 1 || H <= 0 || W <= 0 || samples < 1 || T >= 65536) return fail(LSPIV_ESHAPE, "bad shape");
-  const long interval = std::lround((double)T / (double)samples);  // Python round(): half to even
-  const double ratio = (double)T / (double)samples;
-  long iv = interval;
-  if (ratio - std::floor(ratio) == 0.5) iv = ((long)std::floor(ratio) % 2 == 0) ? (long)std::floor(ratio) : (long)std::floor(ratio) + 1;
+  const long iv = normalize_interval(T, samples);
   if (iv == 0) return fail(LSPIV_EINVAL, "Amount of frames is too small to provide %d samples", samples);
   DeviceCtx* c;
   int rc = get_ctx(&c);
@@ -1577,14 +1612,15 @@ int lspiv_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes) {
   DeviceCtx* c;
   int rc = get_ctx(&c);
   if (rc) return rc;
-  if (bytes >= ((size_t)64 << 20) && !is_pinned(h_src)) {
-    // a large pageable source (a frame stack): through the two-slot pinned ring, staging threads overlapped with the
-    // DMA of the previous slice, like the host entry points -- ~2x the rate of a plain pageable hipMemcpy
+  if (bytes >= ((size_t)16 << 20) && !is_pinned(h_src)) {
+    // a large pageable source (a frame stack, or a time chunk of one): through the two-slot pinned ring, staging threads
+    // overlapped with the DMA of the previous slice, like the host entry points -- ~2x the rate of a plain pageable
+    // hipMemcpy.  At least four slices per call, so that the un-overlapped first staging step stays a small part of it.
     std::lock_guard<std::mutex> host_lock(g_host_mu);
     rc = stage_ring(c, 1);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));   // the DMA runs on the copy stream: earlier kernels may still use d_dst
-    const size_t slice = c->pinned_cap;
+    const size_t slice = std::min(c->pinned_cap, std::max((size_t)4 << 20, ((bytes / 4) + 4095) & ~(size_t)4095));
     int batch = 0;
     for (size_t off = 0; off < bytes; off += slice, ++batch) {
       const int slot = batch & 1;

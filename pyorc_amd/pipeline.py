@@ -11,7 +11,14 @@ block in HBM and calls only ``*_dev`` entry points of the C ABI:
                      -> lspiv_pack_int16_dev (optional) -> D2H (16 B or 8 B per vector)
 
 Every stage is the same kernel the stand-alone mirrors (``filters``, ``project``, ``piv``) call, so the chain is
-bit-identical to running them one by one (tested).  The camera-geometry index maps are pyorc's
+bit-identical to running them one by one (tested).
+
+The upload is the longest single step of the chain (1080p: 415 MB per 200 frames at ~45 GB/s of PCIe against ~9 ms of
+kernels), so ``run`` streams by default: the frames ``normalize`` samples go first (their mean plane is all the filter needs
+of the rest of the stack), then the stack arrives in time chunks cut on multiples of ``lspiv_chunk_alignment`` pairs, and
+while chunk k+1 crosses PCIe on the library's copy stream, chunk k runs normalise -> [edge] -> project -> PIV on a compute
+stream of the chain's own; the result block of chunk k-1 goes back in between.  Every stage is per-frame (or, the PIV,
+anchored to the absolute pair index), so the streamed run returns the bits of the one-piece run (tested).  The camera-geometry index maps are pyorc's
 (``CameraConfig.map_idx_img_ortho`` / ``map_mean_idx_img_ortho``).  With ``normalize_samples=15, edge_detect=(1, 2),
 minmax=(-5, 5)`` the chain is the whole ``frames:`` + ``get_piv`` part of the Ngwerere recipe.
 """
@@ -67,13 +74,15 @@ class CameraToVelocity:
         if self.n_rows < 1 or self.n_cols < 1:
             raise ValueError("ortho frame smaller than the interrogation window")
         self.projection = Projection(self.cam_shape, self.ortho_shape, idx_img, idx_ortho, src_idx, uidx, norm_idx)
-        self._cam, self._norm, self._edge, self._ortho, self._out, self._packed = (_DevBuf() for _ in range(6))
+        self._cam, self._norm, self._edge, self._ortho, self._out, self._packed, self._mean = (_DevBuf() for _ in range(7))
+        self._comp = None                                   # compute stream of the streamed run
 
-    def run(self, frames, packed: bool = False):
+    def run(self, frames, packed: bool = False, streamed: Optional[bool] = None, n_chunks: int = 8):
         """Returns (u, v, corr_max, s2n) float32, or their int16 packing (scale 0.01, fill -9999) when ``packed``.
 
-        Note ``packed`` encodes the PIXEL displacements; pyorc packs velocities in m/s -- scale by res/dt on the host
-        first (``velocimetry.get_ffpiv``) when that is what goes to disk.
+        ``streamed`` (default: stacks of 64 MiB and more): upload in ``n_chunks`` time chunks overlapped with the kernels of
+        the previous chunk; same bits as the one-piece run.  Note ``packed`` encodes the PIXEL displacements; pyorc packs
+        velocities in m/s -- scale by res/dt on the host first (``velocimetry.get_ffpiv``) when that is what goes to disk.
         """
         a = np.ascontiguousarray(frames)
         if a.dtype != np.uint8 or a.ndim != 3 or a.shape[1:] != self.cam_shape:
@@ -81,6 +90,14 @@ class CameraToVelocity:
         T = a.shape[0]
         if T < 2:
             raise ValueError("need at least two frames")
+        if self.normalize_samples and round(T / self.normalize_samples) == 0:
+            raise AssertionError(f"Amount of frames is too small to provide {self.normalize_samples} samples")
+        if streamed is None:
+            streamed = a.nbytes >= (64 << 20)
+        if streamed:
+            bounds = self._chunk_bounds(T - 1, n_chunks)
+            if len(bounds) > 2:
+                return self._run_streamed(a, bounds, packed)
         lib = _lib.load()
         n_cam = self.cam_shape[0] * self.cam_shape[1]
         n_ortho = self.ortho_shape[0] * self.ortho_shape[1]
@@ -89,8 +106,6 @@ class CameraToVelocity:
         _lib.check(lib.lspiv_memcpy_h2d(d_cam, _lib.ptr(a), a.nbytes))
         src = d_cam
         if self.normalize_samples:
-            if round(T / self.normalize_samples) == 0:
-                raise AssertionError(f"Amount of frames is too small to provide {self.normalize_samples} samples")
             src = self._norm.ensure(T * n_cam)
             _lib.check(lib.lspiv_normalize_dev(d_cam, T, self.cam_shape[0], self.cam_shape[1], self.normalize_samples, src, None))
         src_dtype = np.uint8
@@ -120,10 +135,95 @@ class CameraToVelocity:
             _lib.check(lib.lspiv_memcpy_d2h(_lib.ptr(res), d_out, res.nbytes))
         return res[0], res[1], res[2], res[3]
 
+    def _chunk_bounds(self, n_pairs: int, n_chunks: int):
+        """Pair indices where the time chunks start (+ n_pairs): multiples of the kernels' anchor length, so that the chunked
+        PIV returns the bits of one call (include/lspiv.h, lspiv_chunk_alignment)."""
+        align = max(1, int(_lib.load().lspiv_chunk_alignment(self.window_size[0], self.window_size[1])))
+        per = -(-n_pairs // max(1, int(n_chunks)))          # ceil
+        per = max(align, -(-per // align) * align)
+        return list(range(0, n_pairs, per)) + [n_pairs]
+
+    def _run_streamed(self, a: np.ndarray, bounds, packed: bool):
+        lib = _lib.load()
+        T = a.shape[0]
+        Hc, Wc = self.cam_shape
+        n_cam, n_ortho, n_win = Hc * Wc, self.ortho_shape[0] * self.ortho_shape[1], self.n_rows * self.n_cols
+        n_vec = (T - 1) * n_win
+        d_cam = self._cam.ensure(T * n_cam)
+        d_norm = self._norm.ensure(T * n_cam) if self.normalize_samples else None
+        d_edge = self._edge.ensure(T * n_cam * 4) if self.edge_detect else None
+        if self.minmax and not self.edge_detect:
+            raise ValueError("minmax in the chain follows edge_detect (float32 frames); uint8 frames are not thresholded")
+        d_ortho = self._ortho.ensure(T * n_ortho * 4)
+        d_out = self._out.ensure(4 * n_vec * 4)             # chunk k's (4, pairs_k, n_win) block at float offset 4 * p_k * n_win
+        d_pk = self._packed.ensure(4 * n_vec * 2) if packed else None
+        if self._comp is None:
+            self._comp = C.c_void_p()
+            _lib.check(lib.lspiv_stream_create(C.byref(self._comp)))
+        comp = self._comp
+        at = lambda base, off: C.c_void_p(base.value + off)
+
+        if self.normalize_samples:
+            # the sampled frames first, each to its place in the stack; their mean plane is all normalize needs of the rest
+            iv = round(T / self.normalize_samples)
+            for t in range(0, T, iv):
+                _lib.check(lib.lspiv_memcpy_h2d(at(d_cam, t * n_cam), _lib.ptr(a[t]), n_cam))
+            d_mean = self._mean.ensure(n_cam * 4)
+            _lib.check(lib.lspiv_normalize_mean_dev(d_cam, T, Hc, Wc, self.normalize_samples, d_mean, comp))
+            _lib.check(lib.lspiv_stream_synchronize(comp))  # the chunks below overwrite those frames (with the same bytes)
+
+        res = np.empty((4, T - 1, self.n_rows, self.n_cols), dtype=np.int16 if packed else np.float32)
+        events = []
+
+        def fetch(k):                                       # result block of chunk k -> its rows of `res`
+            p0, p1 = bounds[k], bounds[k + 1]
+            blk = np.empty((4, p1 - p0, self.n_rows, self.n_cols), dtype=res.dtype)
+            _lib.check(lib.lspiv_stream_wait_event(None, events[k]))
+            src = at(d_pk, 4 * p0 * n_win * 2) if packed else at(d_out, 4 * p0 * n_win * 4)
+            _lib.check(lib.lspiv_memcpy_d2h(_lib.ptr(blk), src, blk.nbytes))
+            res[:, p0:p1] = blk
+
+        for k in range(len(bounds) - 1):
+            p0, p1 = bounds[k], bounds[k + 1]
+            f0, f1 = (0 if k == 0 else p0 + 1), p1 + 1      # the frames this chunk brings in; frame p0 came with chunk k-1
+            n_new = f1 - f0
+            _lib.check(lib.lspiv_memcpy_h2d(at(d_cam, f0 * n_cam), _lib.ptr(a[f0:f1]), n_new * n_cam))   # blocking; chunk k-1 computes meanwhile
+            src, src_dtype, esz = at(d_cam, f0 * n_cam), np.uint8, 1
+            if self.normalize_samples:
+                dst = at(d_norm, f0 * n_cam)
+                _lib.check(lib.lspiv_normalize_apply_dev(src, n_new, Hc, Wc, d_mean, dst, comp))
+                src = dst
+            if self.edge_detect:
+                dst = at(d_edge, f0 * n_cam * 4)
+                _lib.check(lib.lspiv_edge_detect_dev(src, 0, n_new, Hc, Wc, self.edge_detect[0], self.edge_detect[1], dst, comp))
+                src, src_dtype, esz = dst, np.float32, 4
+                if self.minmax:
+                    _lib.check(lib.lspiv_minmax_dev(src, n_new * n_cam, self.minmax[0], self.minmax[1], src, comp))
+            self.projection.project_frames_dev(src.value, src_dtype, n_new, d_ortho.value + f0 * n_ortho * 4, comp.value)
+            blk_out = at(d_out, 4 * p0 * n_win * 4)
+            _lib.check(lib.lspiv_piv_pairs_dev_at(at(d_ortho, p0 * n_ortho * 4), 1, p1 - p0 + 1, self.ortho_shape[0],
+                                                  self.ortho_shape[1], self.window_size[0], self.window_size[1], self.overlap[0],
+                                                  self.overlap[1], self.signal_threshold, p0, blk_out, None, comp))
+            if packed:
+                _lib.check(lib.lspiv_pack_int16_dev(blk_out, 4 * (p1 - p0) * n_win, 0.01, -9999, at(d_pk, 4 * p0 * n_win * 2), comp))
+            ev = C.c_void_p()
+            _lib.check(lib.lspiv_event_create(C.byref(ev)))
+            _lib.check(lib.lspiv_event_record_on(ev, comp))
+            events.append(ev)
+            if k >= 1:
+                fetch(k - 1)
+        fetch(len(bounds) - 2)
+        for ev in events:
+            lib.lspiv_event_destroy(ev)
+        return res[0], res[1], res[2], res[3]
+
     def close(self):
         self.projection.close()
-        for b in (self._cam, self._norm, self._edge, self._ortho, self._out, self._packed):
+        for b in (self._cam, self._norm, self._edge, self._ortho, self._out, self._packed, self._mean):
             b.free()
+        if self._comp is not None:
+            _lib.load().lspiv_stream_destroy(self._comp)
+            self._comp = None
 
     def __enter__(self):
         return self

@@ -192,11 +192,21 @@ def get_ffpiv(
     return _get_ffpiv_timestep(*args, signal_threshold, like=frames)
 
 
+def _to_velocity(disp: np.ndarray, res, dt_chunk: np.ndarray) -> np.ndarray:
+    """``(disp * res / dt).astype(float32)`` of ffpiv.py:418-419 with the same arithmetic (the product in whatever type numpy
+    gives it, the division in float64, one rounding to float32) but without the two float64 temporaries of the one-liner."""
+    prod = disp * res
+    out = prod if prod.dtype == np.float32 else np.empty(prod.shape, dtype=np.float32)
+    np.divide(prod, dt_chunk, out=out, dtype=np.float64, casting="same_kind")
+    return out
+
+
 def _get_ffpiv_timestep(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_cols, n_rows, window_size, overlap,
                         signal_threshold, like=None):
     """Per-chunk loop of pyorc/velocimetry/ffpiv.py:379-443 (one fused GPU call per chunk)."""
     parts = {"s2n": [], "corr": [], "v_x": [], "v_y": []}
     times = []
+    on_device = is_device(like)
     for n, (a, b) in enumerate(slices):
         da = load_frame_chunk(frames_chunks[n])
         if len(da) >= 2:  # we need at least one image-pair to do PIV
@@ -205,17 +215,18 @@ def _get_ffpiv_timestep(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_c
             if u.shape[1:] != (n_rows, n_cols):
                 raise ValueError(f"grid {u.shape[1:]} does not match coordinates ({n_rows}, {n_cols})")
             dt_chunk = dt[a:nb - 1][:, None, None]  # dt.sel(time=da.time[1:]), ffpiv.py:403-404
-            # u and v to meter per second (float64 maths, float32 storage: ffpiv.py:418-419)
-            parts["v_x"].append((u * res_x / dt_chunk).astype(np.float32))
-            parts["v_y"].append((v * res_y / dt_chunk).astype(np.float32))
+            # u and v to meter per second (float64 division, float32 storage: ffpiv.py:418-419)
+            parts["v_x"].append(_to_velocity(u, res_x, dt_chunk))
+            parts["v_y"].append(_to_velocity(v, res_y, dt_chunk))
             parts["corr"].append(corr_max)
             parts["s2n"].append(s2n)
             times.append(time[a + 1:nb])
-        # remove chunk safely from memory
+        # remove chunk safely from memory (host chunks, as the reference does; a device stack holds no host memory)
         frames_chunks[n] = None
         del da
-        gc.collect()
-    data = {k: np.concatenate(vv, axis=0) for k, vv in parts.items()}
+        if not on_device:
+            gc.collect()
+    data = {k: vv[0] if len(vv) == 1 else np.concatenate(vv, axis=0) for k, vv in parts.items()}
     if _is_xr(like):
         t = xr.concat(times, dim="time")
     else:
@@ -245,7 +256,8 @@ def _get_ffpiv_mean(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_cols,
             t_first = time[a + 1:a + 2]
             frames_chunks[n] = None
             del da
-            gc.collect()
+            if not is_device(like):
+                gc.collect()
         if ens is None:
             raise ValueError("no chunk with at least one frame pair")
         # quirk Q3: `n_frames` is the number of CHUNKS, not pairs (ffpiv.py:373), and `time[0:1]` of the LAST chunk ends

@@ -188,6 +188,31 @@ def test_gpu_camera_to_velocity_chain_equals_stage_by_stage(gpu):
 
 
 @pytest.mark.gpu
+def test_gpu_streamed_chain_equals_one_piece(gpu):
+    """CameraToVelocity.run(streamed=True): sampled frames first, then time chunks cut on the kernels' anchors, upload of
+    chunk k+1 overlapped with the kernels of chunk k -- the bits of the one-piece run, for every recipe, float and packed."""
+    from pyorc_amd.pipeline import CameraToVelocity
+    from pyorc_amd.synth import projection_maps
+
+    src, dst = (120, 160), (96, 128)
+    cam = (particle_stack(83, src[0], src[1], seed=28, density=0.04) * 0.6 + 50).astype(np.uint8)
+    maps = projection_maps(src, dst, tilt=0.2, seed=6)
+    for kw in (dict(), dict(normalize_samples=15), dict(normalize_samples=7, edge_detect=(1, 2), minmax=(-5, 5)),
+               dict(normalize_samples=15, window_size=(20, 20), overlap=(10, 10)), dict(edge_detect=(1, 3))):
+        with CameraToVelocity(src, dst, *maps, **kw) as chain:
+            assert len(chain._chunk_bounds(82, 8)) >= 4
+            for packed in (False, True):
+                ref = chain.run(cam, packed=packed, streamed=False)
+                for n_chunks in (8, 3):
+                    got = chain.run(cam, packed=packed, streamed=True, n_chunks=n_chunks)
+                    for a, b in zip(ref, got):
+                        assert a.dtype == b.dtype and np.array_equal(a, b, equal_nan=True), (kw, packed, n_chunks)
+            short = chain.run(cam[:12], streamed=True)           # fewer pairs than one anchor: falls back to one piece
+            for a, b in zip(chain.run(cam[:12], streamed=False), short):
+                assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.gpu
 def test_gpu_get_piv_on_device_stacks_equals_the_chain_and_the_host_path(gpu):
     """The accessor-shaped call on HBM-resident stacks: DeviceFrames -> filters.normalize -> Projection.project_frames ->
     frames.get_piv(engine="hip") never bounces through the host, and returns, bit for bit, what the fixed chain
