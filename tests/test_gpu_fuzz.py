@@ -16,3 +16,15 @@ def test_fuzz_parity(gpu, seed):
                          capture_output=True, text=True, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "40 cases, 0 failures" in out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [21, 22])
+def test_fuzz_callers(gpu, seed):
+    """tools/fuzz_modes.py: get_piv per time step (chunked == one call bit for bit, both vs the oracle's get_ffpiv), ensemble
+    mode with random chunk sizes / thresholds, and the plane volume, over random sizes, dtypes and shapes."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_modes.py"), str(seed), "60"],
+                         capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "60 cases, 0 failures" in out.stdout
+
