@@ -28,3 +28,13 @@ def test_fuzz_callers(gpu, seed):
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "60 cases, 0 failures" in out.stdout
 
+
+@pytest.mark.gpu
+def test_fuzz_rows(gpu):
+    """tools/fuzz_rows.py: filters, both projections, masks and int16 packing against their oracles over random shapes
+    (odd widths, single frames, tiny frames), dtypes and parameters."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_rows.py"), "31", "150"],
+                         capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "150 cases, 0 failures" in out.stdout
+
