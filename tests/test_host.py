@@ -330,6 +330,25 @@ def test_shard_blocks_start_on_anchors():
     assert shard.block_sizes(8000, 8, 25) == [1000] * 8
 
 
+def test_streamed_chain_cuts_chunks_on_anchors(lib):
+    """pipeline.CameraToVelocity._chunk_bounds: the time chunks of the streamed run start on multiples of the kernels'
+    anchor length (so the chunked PIV returns the bits of one call) and cover every pair once; sizes without anchors
+    (per-pair kernels) are cut evenly.  Host logic only: no device needed."""
+    from types import SimpleNamespace
+
+    from pyorc_amd.pipeline import CameraToVelocity
+
+    for ws, n_pairs, n_chunks in (((32, 32), 200, 8), ((32, 32), 1000, 8), ((64, 64), 82, 8), ((32, 32), 24, 8), ((32, 32), 26, 3),
+                                  ((128, 128), 40, 8), ((33, 33), 10, 4), ((24, 24), 999, 5)):
+        b = CameraToVelocity._chunk_bounds(SimpleNamespace(window_size=ws), n_pairs, n_chunks)
+        align = lib.lspiv_chunk_alignment(*ws)
+        assert b[0] == 0 and b[-1] == n_pairs and all(x < y for x, y in zip(b, b[1:])), (ws, b)
+        assert all(x % align == 0 for x in b[:-1]), (ws, align, b)
+        assert len(b) - 1 <= max(1, n_chunks) and (len(b) - 1 == 1 or n_pairs > align)
+    assert CameraToVelocity._chunk_bounds(SimpleNamespace(window_size=(32, 32)), 200, 8) == [0, 25, 50, 75, 100, 125, 150, 175, 200]
+    assert CameraToVelocity._chunk_bounds(SimpleNamespace(window_size=(128, 128)), 40, 8) == [0, 5, 10, 15, 20, 25, 30, 35, 40]
+
+
 def test_product_has_no_torch_dependency():
     """The multi-GPU path goes through lspiv_comm_* (RCCL dlopen'ed by the C library): nothing under pyorc_amd/ or in
     bench.py imports torch (two HIP runtimes in one process was round 1's hazard)."""
