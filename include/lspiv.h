@@ -86,8 +86,8 @@ int         lspiv_get_option(const char* name, int* value);
 /* which kernel a window size dispatches to: 1 = FFT 32x32, 2 = FFT 64x64, 6 = FFT 8x8 / 16x16, 8 = prime-factor FFT
  * kernels (every other even square window 6..62), 7 / 4 / 5 = odd square windows (and 4x4) 4..7 / 9..15 / 21..31
  * embedded in the 16- / 32- / 64-point FFT kernels, 3 = direct spatial correlation (non-square and odd 17 / 19 / 33..63
- * windows of fewer than 1600 samples), 9 = LDS-resident 2-D transform (any window with a side above 64, and the non-square /
- * odd ones from 1600 samples on); <0 = unsupported.  Host-only. */
+ * windows of fewer than 1500 samples), 9 = LDS-resident 2-D transform (any window with a side above 64, and the non-square /
+ * odd ones from 1500 samples on); <0 = unsupported.  Host-only. */
 int         lspiv_kernel_kind(int wy, int wx);
 
 /* ---------------------------------------------------------------- window grid (host) ----- */

@@ -434,10 +434,11 @@ int lspiv_kernel_kind(int wy, int wx) {
   // crossover between 20 and 22, tools/direct_bench.py)
   if (!no_embed && wy == wx && wy > 20 && wy < 32) return 5;
   // what is left -- non-square windows, odd 17 / 19 / 33 .. 63: the direct spatial kernel costs wy wx multiply-adds per plane
-  // sample, the LDS-resident DFT passes (wy + wx) complex ones.  Measured on 785 x 875 frames (tools/gpu_ab_direct.sh; M window
-  // pairs/s, direct | DFT): 35 x 35 14.0 | 10.7, 48 x 32 10.4 | 9.7, 41 x 41 8.1 | 9.4, 64 x 32 6.0 | 8.3, 49 x 49 3.6 | 7.9,
-  // 63 x 63 1.6 | 6.1 -- the DFT kernel takes over from 1600 samples per window (LSPIV_DFT_MIN_AREA)
-  static const int dft_min_area = getenv("LSPIV_DFT_MIN_AREA") ? atoi(getenv("LSPIV_DFT_MIN_AREA")) : 1600;
+  // sample, the LDS-resident DFT passes (wy + wx) complex ones, a composite length in two shorter passes.  Measured on
+  // 785 x 875 frames (tools/gpu_ab_direct.sh; M window pairs/s, direct | DFT): 40 x 24 23.2 | 13.1, 35 x 35 14.0 | 12.2,
+  // 48 x 32 10.4 | 11.9, 41 x 41 8.1 | 9.2, 64 x 32 6.1 | 11.3, 49 x 49 3.6 | 10.7, 63 x 63 1.6 | 7.2 -- the DFT kernel takes over
+  // from 1500 samples per window (LSPIV_DFT_MIN_AREA)
+  static const int dft_min_area = getenv("LSPIV_DFT_MIN_AREA") ? atoi(getenv("LSPIV_DFT_MIN_AREA")) : 1500;
   if (wy * wx >= dft_min_area && lspiv::piv_dft_fits(wy, wx)) return 9;
   return 3;
 }

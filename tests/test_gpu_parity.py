@@ -253,14 +253,19 @@ def test_fused_results_equal_two_step_results(gpu):
                                    ((100, 100), (50, 50)), ((97, 97), (40, 40)), ((128, 80), (64, 40)), ((72, 120), (0, 60)),
                                    ((72, 72), (36, 36)), ((80, 80), (40, 40)), ((84, 84), (42, 42)), ((90, 90), (45, 45)),
                                    ((112, 112), (56, 56)), ((120, 120), (60, 60)),
-                                   ((41, 41), (20, 20)), ((63, 63), (31, 31)), ((64, 32), (32, 16)), ((49, 33), (10, 30))])
+                                   ((41, 41), (20, 20)), ((63, 63), (31, 31)), ((64, 32), (32, 16)), ((49, 33), (10, 30)),
+                                   # composite lengths in two passes: 7 x 14, 2 x 37, 6 x 19 and 9 x 14 (their padded tiles need
+                                   # two rounds), 5 x 25, 10 x 11 with 8 x 11
+                                   ((98, 98), (49, 49)), ((74, 74), (37, 37)), ((114, 114), (57, 57)), ((126, 126), (63, 63)),
+                                   ((125, 125), (60, 60)), ((110, 88), (55, 44))])
 def test_windows_above_64_vs_oracle(gpu, ws, ov, dtype):
     """ffpiv.cross_corr takes any window (pyorc/api/frames.py:159-168): sizes above 64 px -- 96 and 128 for 4K footage,
     but also odd, non-square and 2 x prime sizes -- run the LDS-resident DFT kernel; planes, NaN masks, corr / s2n and
     the sub-pixel peaks against the oracle, with a signal threshold, an empty frame and a constant corner in the stack.
     Square sizes N = R x M with a register FFT of length M (72 ... 128: 3 x 24, 4 x 20, 3 x 28, 3 x 30, 3 x 32, 5 x 20, 4 x 28,
-    4 x 30, 4 x 32) take the four-step passes, everything else the plain DFT passes; LSPIV_NO_FOURSTEP=1 cross-checks.
-    The DFT passes also serve the non-square and odd windows below 64 px from 1600 samples on (41 x 41, 63 x 63, 64 x 32)."""
+    4 x 30, 4 x 32) take the four-step passes, everything else the DFT passes (a composite length as two shorter passes);
+    LSPIV_NO_FOURSTEP=1 cross-checks.
+    The DFT passes also serve the non-square and odd windows below 64 px from 1500 samples on (41 x 41, 63 x 63, 64 x 32)."""
     H, Wd = 2 * ws[0] + 7, 2 * ws[1] + ws[1] // 2 + 3
     fr = particle_stack(4, H, Wd, seed=ws[0] + ws[1], density=0.03)
     # planes out of the LDS-resident transforms carry ~4e-6 of absolute float32 noise (the register FFT kernels: 2e-6; the

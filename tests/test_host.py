@@ -75,8 +75,9 @@ def test_kernel_dispatch_table(lib):
     assert all(lib.lspiv_kernel_kind(n, n) == 8 for n in range(6, 64, 2) if n not in (8, 16, 32))   # prime-factor FFT kernels
     assert lib.lspiv_kernel_kind(24, 16) == 3 and lib.lspiv_kernel_kind(35, 35) == 3   # direct: non-square, odd 33..63
     assert lib.lspiv_kernel_kind(17, 17) == 3 and lib.lspiv_kernel_kind(19, 19) == 3   # direct: cheaper than 2 x FFT64
-    assert lib.lspiv_kernel_kind(48, 32) == 3 and lib.lspiv_kernel_kind(39, 39) == 3   # < 1600 samples: direct
-    assert lib.lspiv_kernel_kind(41, 41) == 9 and lib.lspiv_kernel_kind(64, 32) == 9 and lib.lspiv_kernel_kind(63, 63) == 9   # DFT passes
+    assert lib.lspiv_kernel_kind(40, 32) == 3 and lib.lspiv_kernel_kind(37, 37) == 3   # < 1500 samples: direct
+    assert lib.lspiv_kernel_kind(48, 32) == 9 and lib.lspiv_kernel_kind(39, 39) == 9   # from 1500 samples on: DFT passes
+    assert lib.lspiv_kernel_kind(41, 41) == 9 and lib.lspiv_kernel_kind(64, 32) == 9 and lib.lspiv_kernel_kind(63, 63) == 9
     assert lib.lspiv_kernel_kind(64, 64) == 2
     assert lib.lspiv_kernel_kind(128, 128) == 9 and lib.lspiv_kernel_kind(256, 256) == _lib.LSPIV_EUNSUPPORTED   # LDS-resident DFT up to 128
 
