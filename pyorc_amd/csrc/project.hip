@@ -129,6 +129,33 @@ __global__ __launch_bounds__(256) void remap_kernel(const T* __restrict__ frames
       for (int t = 0; t < nt; ++t) dst[(int64_t)t * n_out] = (T)0;
       continue;
     }
+    if (x0 && x1 && y0 && y1 && nt == F) {
+      // the common pixel: all four neighbours inside, a full group of frames.  Every load of the F frames is issued before
+      // the first result is formed (the per-frame loop below pays a load-use latency per frame); the two neighbours of a
+      // row are one 2-pixel load (unaligned loads are fine on global memory).
+      typedef T pair_t __attribute__((ext_vector_type(2), aligned(sizeof(T))));
+      pair_t top[F], bot[F];
+#pragma unroll
+      for (int t = 0; t < F; ++t) {
+        top[t] = *reinterpret_cast<const pair_t*>(img + (int64_t)t * src_elems + base);
+        bot[t] = *reinterpret_cast<const pair_t*>(img + (int64_t)t * src_elems + base + Ws);
+      }
+      if constexpr (sizeof(T) == 1) {
+        const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+#pragma unroll
+        for (int t = 0; t < F; ++t) {
+          const int acc = (int)top[t][0] * w00 + (int)top[t][1] * w01 + (int)bot[t][0] * w10 + (int)bot[t][1] * w11;
+          dst[(int64_t)t * n_out] = (T)((acc + (1 << 14)) >> 15);
+        }
+      } else {
+        const float a = (float)fx / 32.0f, b = (float)fy / 32.0f;
+        const float w00 = (1.0f - a) * (1.0f - b), w01 = a * (1.0f - b), w10 = (1.0f - a) * b, w11 = a * b;
+#pragma unroll
+        for (int t = 0; t < F; ++t)
+          dst[(int64_t)t * n_out] = (T)((((float)top[t][0] * w00 + (float)top[t][1] * w01) + (float)bot[t][0] * w10) + (float)bot[t][1] * w11);
+      }
+      continue;
+    }
     for (int t = 0; t < nt; ++t, img += src_elems) {
       const T p00 = (x0 && y0) ? img[base] : (T)0, p01 = (x1 && y0) ? img[base + 1] : (T)0;
       const T p10 = (x0 && y1) ? img[base + Ws] : (T)0, p11 = (x1 && y1) ? img[base + Ws + 1] : (T)0;
