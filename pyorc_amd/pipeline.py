@@ -14,7 +14,7 @@ Every stage is the same kernel the stand-alone mirrors (``filters``, ``project``
 bit-identical to running them one by one (tested).
 
 The upload is the longest single step of the chain (1080p: 415 MB per 200 frames at ~45 GB/s of PCIe against ~9 ms of
-kernels), so ``run`` streams by default: the frames ``normalize`` samples go first (their mean plane is all the filter needs
+kernels), so ``run`` can stream (by default where the kernels weigh enough): the frames ``normalize`` samples go first (their mean plane is all the filter needs
 of the rest of the stack), then the stack arrives in time chunks cut on multiples of ``lspiv_chunk_alignment`` pairs, and
 while chunk k+1 crosses PCIe on the library's copy stream, chunk k runs normalise -> [edge] -> project -> PIV on a compute
 stream of the chain's own; the result block of chunk k-1 goes back in between.  Every stage is per-frame (or, the PIV,
@@ -80,7 +80,7 @@ class CameraToVelocity:
     def run(self, frames, packed: bool = False, streamed: Optional[bool] = None, n_chunks: int = 8):
         """Returns (u, v, corr_max, s2n) float32, or their int16 packing (scale 0.01, fill -9999) when ``packed``.
 
-        ``streamed`` (default: stacks of 64 MiB and more): upload in ``n_chunks`` time chunks overlapped with the kernels of
+        ``streamed`` (default: stacks of 64 MiB and more with windows above 32 px or the edge filter): upload in ``n_chunks`` time chunks overlapped with the kernels of
         the previous chunk; same bits as the one-piece run.  Note ``packed`` encodes the PIXEL displacements; pyorc packs
         velocities in m/s -- scale by res/dt on the host first (``velocimetry.get_ffpiv``) when that is what goes to disk.
         """
@@ -93,7 +93,9 @@ class CameraToVelocity:
         if self.normalize_samples and round(T / self.normalize_samples) == 0:
             raise AssertionError(f"Amount of frames is too small to provide {self.normalize_samples} samples")
         if streamed is None:
-            streamed = a.nbytes >= (64 << 20)
+            # worth it where the kernels weigh about as much as the upload (measured): windows above
+            # 32 px or the edge filter; at 32 x 32 the chain is 80 % upload and the chunking only costs
+            streamed = a.nbytes >= (64 << 20) and (min(self.window_size) > 32 or self.edge_detect is not None)
         if streamed:
             bounds = self._chunk_bounds(T - 1, n_chunks)
             if len(bounds) > 2:
