@@ -279,6 +279,10 @@ hipError_t launch_ensemble_mean(const float* sum, const float* count, float min_
 hipError_t launch_project(const void* frames, int dtype, int64_t src_elems, int n_frames, const int* nn_src,
                           const int* grp_of, const int* grp_off, const int* grp_src, float* out, int n_out,
                           hipStream_t s);
+// uint8 frames through the quad-window plan (two 8-byte source windows per four output cells, project.hip)
+hipError_t launch_project_win(const uint8_t* frames, int64_t src_elems, int n_frames, const int* qlo1, const int* qlo2,
+                              const uint32_t* qdesc, const int* slow_q, int n_slow, const int* nn_src, const int* grp_of,
+                              const int* grp_off, const int* grp_src, float* out, int n_out, hipStream_t s);
 // project_cv: one fixed-point bilinear remap (cv2.remap INTER_LINEAR, BORDER_CONSTANT 0); dtype 0 (uint8) or 1 (float32), output of the same type
 hipError_t launch_remap(const void* frames, int dtype, int64_t src_elems, int Hs, int Ws, int n_frames, const int* mx, const int* my,
                         const uint16_t* mf, void* out, int n_out, hipStream_t s);

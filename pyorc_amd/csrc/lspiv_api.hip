@@ -302,6 +302,9 @@ struct lspiv_projection {
   int64_t src_h, src_w, dst_h, dst_w;
   int device;
   int *d_nn, *d_grp_of, *d_grp_off, *d_grp_src;
+  int *d_qlo1 = nullptr, *d_qlo2 = nullptr;   // quad-window plan for uint8 frames (project.hip), nullptr: not built
+  uint32_t* d_qdesc = nullptr;
+  int* d_slow_q = nullptr; int n_slow = 0;    // the quads that plan leaves to the per-cell kernel
 };
 
 struct lspiv_ensemble {
@@ -903,6 +906,48 @@ int lspiv_projection_create(int64_t src_h, int64_t src_w, int64_t dst_h, int64_t
   if (e == hipSuccess) e = up(&h->d_grp_of, grp_of);
   if (e == hipSuccess) e = up(&h->d_grp_off, off);
   if (e == hipSuccess) e = up(&h->d_grp_src, members);
+  // quad-window plan (uint8 frames): per four consecutive output cells two 8-byte source windows and, per cell, window +
+  // byte.  Built when the grid has whole quads and most of them fit (a smooth homography: a few source bytes per quad,
+  // one camera row or two); LSPIV_PROJECT_ONE_CELL=1 keeps the one-cell kernel for A/B.
+  if (e == hipSuccess && n_out % 4 == 0 && n_src >= 8 && !getenv("LSPIV_PROJECT_ONE_CELL")) {
+    const size_t nq = (size_t)n_out / 4;
+    std::vector<int> qlo1(nq, 0), qlo2(nq, 0);
+    std::vector<int> qdesc(nq, 0), slow;
+    size_t fit = 0;
+    for (size_t q = 0; q < nq; ++q) {
+      const int* v = &nn[4 * q];
+      bool ok = true;
+      for (int k = 0; k < 4; ++k) ok = ok && grp_of[4 * q + k] < 0;
+      int lo1 = -1, lo2 = -1;
+      for (int k = 0; k < 4 && ok; ++k)
+        if (v[k] >= 0 && (lo1 < 0 || v[k] < lo1)) lo1 = v[k];
+      for (int k = 0; k < 4 && ok; ++k)
+        if (v[k] >= 0 && v[k] - lo1 > 7 && (lo2 < 0 || v[k] < lo2)) lo2 = v[k];
+      for (int k = 0; k < 4 && ok; ++k)
+        if (v[k] >= 0 && v[k] - lo1 > 7 && v[k] - lo2 > 7) ok = false;
+      if (!ok) { qdesc[q] = (int)0x80000000u; slow.push_back((int)q); continue; }
+      if (lo1 < 0) lo1 = 0;
+      if (lo2 < 0) lo2 = lo1;
+      const int w1 = (int)std::min<int64_t>(lo1, n_src - 8), w2 = (int)std::min<int64_t>(lo2, n_src - 8);   // windows end inside the frame
+      uint32_t d = 0;
+      for (int k = 0; k < 4; ++k) {
+        if (v[k] < 0) continue;
+        const bool second = v[k] - lo1 > 7;
+        d |= ((uint32_t)(v[k] - (second ? w2 : w1)) | (second ? 8u : 0u) | 16u) << (5 * k);
+      }
+      qlo1[q] = w1; qlo2[q] = w2; qdesc[q] = (int)d;
+      ++fit;
+    }
+    if (fit * 10 >= nq * 9) {
+      e = up(&h->d_qlo1, qlo1);
+      if (e == hipSuccess) e = up(&h->d_qlo2, qlo2);
+      int* dd = nullptr;
+      if (e == hipSuccess) e = up(&dd, qdesc);
+      h->d_qdesc = reinterpret_cast<uint32_t*>(dd);
+      if (e == hipSuccess) e = up(&h->d_slow_q, slow);
+      h->n_slow = (int)slow.size();
+    }
+  }
   if (e != hipSuccess) {
     lspiv_projection_destroy(h);
     return fail(e == hipErrorOutOfMemory ? LSPIV_ENOMEM : LSPIV_EHIP, "projection plan upload: %s", hipGetErrorString(e));
@@ -918,8 +963,12 @@ int lspiv_project_frames_dev(lspiv_projection* h, const void* d_frames, int dtyp
   DeviceCtx* c;
   int rc = get_ctx(&c);
   if (rc) return rc;
-  hipError_t e = lspiv::launch_project(d_frames, dtype, h->src_h * h->src_w, (int)T, h->d_nn, h->d_grp_of, h->d_grp_off,
-                                       h->d_grp_src, d_out, (int)(h->dst_h * h->dst_w), stream ? (hipStream_t)stream : c->stream);
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  const bool win = dtype == 0 && h->d_qdesc && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
+  hipError_t e = win ? lspiv::launch_project_win((const uint8_t*)d_frames, h->src_h * h->src_w, (int)T, h->d_qlo1, h->d_qlo2, h->d_qdesc,
+                                                  h->d_slow_q, h->n_slow, h->d_nn, h->d_grp_of, h->d_grp_off, h->d_grp_src, d_out, (int)(h->dst_h * h->dst_w), s)
+                     : lspiv::launch_project(d_frames, dtype, h->src_h * h->src_w, (int)T, h->d_nn, h->d_grp_of, h->d_grp_off,
+                                             h->d_grp_src, d_out, (int)(h->dst_h * h->dst_w), s);
   if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
   return LSPIV_OK;
 }
@@ -952,6 +1001,10 @@ int lspiv_projection_destroy(lspiv_projection* h) {
   if (h->d_grp_of) hipFree(h->d_grp_of);
   if (h->d_grp_off) hipFree(h->d_grp_off);
   if (h->d_grp_src) hipFree(h->d_grp_src);
+  if (h->d_qlo1) hipFree(h->d_qlo1);
+  if (h->d_qlo2) hipFree(h->d_qlo2);
+  if (h->d_qdesc) hipFree(h->d_qdesc);
+  if (h->d_slow_q) hipFree(h->d_slow_q);
   delete h;
   return LSPIV_OK;
 }

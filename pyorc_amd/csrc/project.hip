@@ -92,6 +92,95 @@ static void launch_project_t(const T* frames, int64_t src_elems, int n_frames, c
 #undef LSPIV_PROJ
 }
 
+// uint8 camera frames, quads of four consecutive output cells (n_out % 4 == 0).  The one-cell kernel above moves 64 B per
+// load instruction and 256 B per store instruction, and an identity plan shows that this, not HBM, holds it at 2.5 TB/s
+// (a four-sample load + float4 store variant runs the identity at 5.2 TB/s).  A real homography has no four consecutive
+// sources, but the sources of a quad lie within a few bytes of each other, in one camera row or -- where the row changes
+// inside the quad -- in two: the host plan (lspiv_projection_create) stores per quad two 8-byte window starts and, per cell,
+// which window and which byte.  A thread then loads two 8-byte windows per frame (512 B per wave-instruction), picks its
+// four samples with shifts and stores one float4.  Quads that do not fit (a group mean, sources further apart) are
+// listed for project_slow_kernel.
+template <int F>
+__global__ __launch_bounds__(256) void project_win_kernel(const uint8_t* __restrict__ frames, int64_t src_elems, int n_frames,
+                                                          const int* __restrict__ qlo1, const int* __restrict__ qlo2,
+                                                          const uint32_t* __restrict__ qdesc, float* __restrict__ out, int n_out) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef uint64_t u64_u __attribute__((aligned(1)));
+  const int t0 = blockIdx.y * F;
+  const int nt = min(n_frames - t0, F);                    // block-uniform: the ragged last block of frames does not diverge
+  const uint8_t* img = frames + (int64_t)t0 * src_elems;
+  const int nq = n_out >> 2;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+    const uint32_t d = qdesc[q];
+    if (d >> 31) continue;                                 // project_slow_kernel's quad
+    float* dst = out + (int64_t)t0 * n_out + 4 * q;
+    const int a = qlo1[q], b = qlo2[q];
+    uint64_t wa[F], wb[F];
+#pragma unroll
+    for (int t = 0; t < F; ++t)
+      if (t < nt) {
+        wa[t] = *reinterpret_cast<const u64_u*>(img + (int64_t)t * src_elems + a);
+        wb[t] = *reinterpret_cast<const u64_u*>(img + (int64_t)t * src_elems + b);   // (predicating it on a != b was slower)
+      }
+#pragma unroll
+    for (int t = 0; t < F; ++t)
+      if (t < nt) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t c = d >> (5 * e);
+          const uint64_t w = (c & 8u) ? wb[t] : wa[t];
+          const uint32_t byte = (uint32_t)(w >> (8 * (c & 7u))) & 0xffu;
+          v[e] = (c & 16u) ? (float)byte : 0.0f;           // a cell without a source stays 0
+        }
+        *reinterpret_cast<f32x4*>(dst + (int64_t)t * n_out) = v;
+      }
+  }
+}
+
+// the quads the window plan leaves out (a group mean among the four cells, sources further apart), listed by the host: a
+// thread = one cell of one such quad and F frames, the per-cell arithmetic of project_kernel (same float32 operations, same
+// order).  A kernel of its own so that no wave of project_win_kernel runs both paths.
+template <int F>
+__global__ __launch_bounds__(256) void project_slow_kernel(const uint8_t* __restrict__ frames, int64_t src_elems, int n_frames,
+                                                           const int* __restrict__ slow_q, int n_slow, const int* __restrict__ nn_src,
+                                                           const int* __restrict__ grp_of, const int* __restrict__ grp_off,
+                                                           const int* __restrict__ grp_src, float* __restrict__ out, int n_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * n_slow) return;
+  const int o = 4 * slow_q[i >> 2] + (i & 3), nn = nn_src[o], g = grp_of[o];
+  int k0 = 0, k1 = 0;
+  if (g >= 0) { k0 = grp_off[g]; k1 = grp_off[g + 1]; }
+  const float cnt = (float)(k1 - k0);
+  const int t0 = blockIdx.y * F, nt = min(n_frames - t0, F);
+  const uint8_t* im = frames + (int64_t)t0 * src_elems;
+  float* dst = out + (int64_t)t0 * n_out + o;
+  for (int t = 0; t < nt; ++t, im += src_elems) {
+    float val = 0.0f;
+    if (nn >= 0) val = (float)im[nn];
+    if (g >= 0) {
+      float sacc = 0.0f;
+      for (int k = k0; k < k1; ++k) sacc += (float)im[grp_src[k]];
+      val = sacc / cnt;
+    }
+    dst[(int64_t)t * n_out] = val;                         // uint8 samples: no NaN to fill
+  }
+}
+
+hipError_t launch_project_win(const uint8_t* frames, int64_t src_elems, int n_frames, const int* qlo1, const int* qlo2,
+                              const uint32_t* qdesc, const int* slow_q, int n_slow, const int* nn_src, const int* grp_of,
+                              const int* grp_off, const int* grp_src, float* out, int n_out, hipStream_t s) {
+  if (n_frames <= 0 || n_out <= 0) return hipSuccess;
+  constexpr int F = 8;
+  const unsigned bx = (unsigned)std::min((n_out / 4 + 255) / 256, 4096);
+  hipLaunchKernelGGL((project_win_kernel<F>), dim3(bx, (n_frames + F - 1) / F), dim3(256), 0, s, frames, src_elems, n_frames, qlo1, qlo2,
+                     qdesc, out, n_out);
+  if (n_slow > 0)
+    hipLaunchKernelGGL((project_slow_kernel<F>), dim3((unsigned)((4 * n_slow + 255) / 256), (n_frames + F - 1) / F), dim3(256), 0, s, frames,
+                       src_elems, n_frames, slow_q, n_slow, nn_src, grp_of, grp_off, grp_src, out, n_out);
+  return hipGetLastError();
+}
+
 hipError_t launch_project(const void* frames, int dtype, int64_t src_elems, int n_frames, const int* nn_src,
                           const int* grp_of, const int* grp_off, const int* grp_src, float* out, int n_out,
                           hipStream_t s) {
