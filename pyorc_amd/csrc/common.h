@@ -286,6 +286,10 @@ hipError_t launch_project_win(const uint8_t* frames, int64_t src_elems, int n_fr
 // project_cv: one fixed-point bilinear remap (cv2.remap INTER_LINEAR, BORDER_CONSTANT 0); dtype 0 (uint8) or 1 (float32), output of the same type
 hipError_t launch_remap(const void* frames, int dtype, int64_t src_elems, int Hs, int Ws, int n_frames, const int* mx, const int* my,
                         const uint16_t* mf, void* out, int n_out, hipStream_t s);
+// uint8 frames through the quad plan (two 8-byte source windows per four destination pixels; project.hip)
+hipError_t launch_remap_win(const uint8_t* frames, int64_t src_elems, int Hs, int Ws, int n_frames, const int* qbase, const uint64_t* qdesc,
+                            const int* slow_q, int n_slow, const int* mx, const int* my, const uint16_t* mf, uint8_t* out, int n_out,
+                            hipStream_t s);
 hipError_t launch_pack_int16(const float* in, int64_t n, float scale, int fill, int16_t* out, hipStream_t s);
 // element-wise pre-processing filters (filters.hip)
 hipError_t launch_time_diff(const void* frames, int dtype, int64_t frame_elems, int64_t n_frames, float thres, int use_abs,

@@ -1016,6 +1016,10 @@ struct lspiv_remap {
   int *d_mx1, *d_my1, *d_mx2, *d_my2;      // integer source coordinates of the undistortion map / of the warp map
   uint16_t *d_mf1, *d_mf2;                 // 1/32-pixel fraction index fy * 32 + fx
   void* d_tmp; size_t tmp_cap;             // undistorted frames of one call (grow-only)
+  // quad plans for uint8 frames (project.hip, remap_win_kernel), one per remap; nullptr: not built
+  int *d_qb1, *d_qb2, *d_slow1, *d_slow2;
+  uint64_t *d_qd1, *d_qd2;
+  int n_slow1, n_slow2;
 };
 
 namespace {
@@ -1049,6 +1053,50 @@ int upload_map(const std::vector<int>& mx, const std::vector<int>& my, const std
   return LSPIV_OK;
 }
 int clamp_short(int64_t v) { return (int)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }   // OpenCV keeps the integer part as short
+
+// Quad plan of a remap for uint8 frames: four consecutive destination pixels whose 2 x 2 source neighbourhoods are all
+// interior, share the source row pair and fit 8 bytes (max ix - min ix <= 6) read two 8-byte windows instead of eight 2-byte
+// pairs.  Built when the destination has whole quads and >= 80 % of them qualify; the others are listed for the per-pixel
+// kernel.  LSPIV_PROJECT_ONE_CELL=1 skips it (A/B).
+int build_remap_quads(const std::vector<int>& mx, const std::vector<int>& my, const std::vector<uint16_t>& mf, int64_t Hs, int64_t Ws,
+                      int** d_qb, uint64_t** d_qd, int** d_slow, int* n_slow) {
+  const size_t n = mx.size();
+  if (n % 4 != 0 || Hs * Ws < 16 || getenv("LSPIV_PROJECT_ONE_CELL")) return LSPIV_OK;
+  const size_t nq = n / 4;
+  std::vector<int> qb(nq, 0), slow;
+  std::vector<uint64_t> qd(nq, 0);
+  for (size_t q = 0; q < nq; ++q) {
+    const size_t o = 4 * q;
+    bool ok = true, outside = true;
+    int lo = mx[o], hi = mx[o];
+    for (int k = 0; k < 4; ++k) {
+      const int ix = mx[o + k], iy = my[o + k];
+      ok = ok && ix >= 0 && ix + 1 < Ws && iy >= 0 && iy + 1 < Hs && iy == my[o];
+      outside = outside && !((ix >= -1 && ix < Ws) && (iy >= -1 && iy < Hs));   // no neighbour of the 2 x 2 patch inside
+      lo = std::min(lo, ix); hi = std::max(hi, ix);
+    }
+    if (outside) { qd[q] = (uint64_t)1 << 62; continue; }
+    const int64_t base = ok ? (int64_t)my[o] * Ws + lo : 0;
+    ok = ok && hi - lo <= 6 && base + Ws + 8 <= Hs * Ws;     // both windows end inside the frame
+    if (!ok) { qd[q] = (uint64_t)1 << 63; slow.push_back((int)q); continue; }
+    uint64_t d = 0;
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t fr = mf[o + k], fx = fr & 31u, fy = fr >> 5;
+      d |= (uint64_t)((uint32_t)(mx[o + k] - lo) | (fx << 3) | (fy << 8)) << (16 * k);
+    }
+    qb[q] = (int)base; qd[q] = d;
+  }
+  if (slow.size() * 5 > nq) return LSPIV_OK;                  // fewer than 80 % fit: the per-pixel kernel does everything
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, nq * sizeof(int))); *d_qb = (int*)p;
+  HIP_TRY(hipMalloc(&p, nq * sizeof(uint64_t))); *d_qd = (uint64_t*)p;
+  HIP_TRY(hipMalloc(&p, std::max<size_t>(slow.size(), 1) * sizeof(int))); *d_slow = (int*)p;
+  HIP_TRY(hipMemcpy(*d_qb, qb.data(), nq * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(*d_qd, qd.data(), nq * sizeof(uint64_t), hipMemcpyHostToDevice));
+  if (!slow.empty()) HIP_TRY(hipMemcpy(*d_slow, slow.data(), slow.size() * sizeof(int), hipMemcpyHostToDevice));
+  *n_slow = (int)slow.size();
+  return LSPIV_OK;
+}
 }  // namespace
 
 int lspiv_project_cv_create(int64_t src_h, int64_t src_w, int64_t dst_h, int64_t dst_w, const double* camera_matrix,
@@ -1091,6 +1139,7 @@ int lspiv_project_cv_create(int64_t src_h, int64_t src_w, int64_t dst_h, int64_t
       }
     }
     rc = upload_map(mx, my, mf, &h->d_mx1, &h->d_my1, &h->d_mf1);
+    if (!rc) rc = build_remap_quads(mx, my, mf, src_h, src_w, &h->d_qb1, &h->d_qd1, &h->d_slow1, &h->n_slow1);
     if (rc) { lspiv_project_cv_destroy(h); return rc; }
   }
   {
@@ -1115,6 +1164,7 @@ int lspiv_project_cv_create(int64_t src_h, int64_t src_w, int64_t dst_h, int64_t
         }
       }
     rc = upload_map(mx, my, mf, &h->d_mx2, &h->d_my2, &h->d_mf2);
+    if (!rc) rc = build_remap_quads(mx, my, mf, src_h, src_w, &h->d_qb2, &h->d_qd2, &h->d_slow2, &h->n_slow2);
     if (rc) { lspiv_project_cv_destroy(h); return rc; }
   }
   *handle = h;
@@ -1135,11 +1185,19 @@ int lspiv_project_cv_frames_dev(lspiv_remap* h, const void* d_frames, int dtype,
   if (h->undistort) {
     rc = ensure(&h->d_tmp, &h->tmp_cap, (size_t)T * n_src * elem_size(dtype));
     if (rc) return rc;
-    e = lspiv::launch_remap(d_frames, dtype, n_src, (int)h->src_h, (int)h->src_w, (int)T, h->d_mx1, h->d_my1, h->d_mf1, h->d_tmp, (int)n_src, s);
+    if (dtype == LSPIV_U8 && h->d_qd1)
+      e = lspiv::launch_remap_win((const uint8_t*)d_frames, n_src, (int)h->src_h, (int)h->src_w, (int)T, h->d_qb1, h->d_qd1, h->d_slow1,
+                                  h->n_slow1, h->d_mx1, h->d_my1, h->d_mf1, (uint8_t*)h->d_tmp, (int)n_src, s);
+    else
+      e = lspiv::launch_remap(d_frames, dtype, n_src, (int)h->src_h, (int)h->src_w, (int)T, h->d_mx1, h->d_my1, h->d_mf1, h->d_tmp, (int)n_src, s);
     if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
     src = h->d_tmp;
   }
-  e = lspiv::launch_remap(src, dtype, n_src, (int)h->src_h, (int)h->src_w, (int)T, h->d_mx2, h->d_my2, h->d_mf2, d_out, (int)n_dst, s);
+  if (dtype == LSPIV_U8 && h->d_qd2 && (reinterpret_cast<uintptr_t>(d_out) & 3) == 0)
+    e = lspiv::launch_remap_win((const uint8_t*)src, n_src, (int)h->src_h, (int)h->src_w, (int)T, h->d_qb2, h->d_qd2, h->d_slow2, h->n_slow2,
+                                h->d_mx2, h->d_my2, h->d_mf2, (uint8_t*)d_out, (int)n_dst, s);
+  else
+    e = lspiv::launch_remap(src, dtype, n_src, (int)h->src_h, (int)h->src_w, (int)T, h->d_mx2, h->d_my2, h->d_mf2, d_out, (int)n_dst, s);
   if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
   return LSPIV_OK;
 }
@@ -1167,7 +1225,8 @@ int lspiv_project_cv_frames(lspiv_remap* h, const void* frames, int dtype, int64
 
 int lspiv_project_cv_destroy(lspiv_remap* h) {
   if (!h) return LSPIV_OK;
-  for (void* p : {(void*)h->d_mx1, (void*)h->d_my1, (void*)h->d_mf1, (void*)h->d_mx2, (void*)h->d_my2, (void*)h->d_mf2, h->d_tmp})
+  for (void* p : {(void*)h->d_mx1, (void*)h->d_my1, (void*)h->d_mf1, (void*)h->d_mx2, (void*)h->d_my2, (void*)h->d_mf2, h->d_tmp,
+                  (void*)h->d_qb1, (void*)h->d_qb2, (void*)h->d_qd1, (void*)h->d_qd2, (void*)h->d_slow1, (void*)h->d_slow2})
     if (p) hipFree(p);
   delete h;
   return LSPIV_OK;

@@ -204,10 +204,14 @@ hipError_t launch_project(const void* frames, int dtype, int64_t src_elems, int 
 template <typename T, int F>
 __global__ __launch_bounds__(256) void remap_kernel(const T* __restrict__ frames, int64_t src_elems, int Hs, int Ws, int n_frames,
                                                      const int* __restrict__ mx, const int* __restrict__ my,
-                                                     const uint16_t* __restrict__ mf, T* __restrict__ out, int n_out) {
+                                                     const uint16_t* __restrict__ mf, T* __restrict__ out, int n_out,
+                                                     const int* __restrict__ quads = nullptr, int n_quads = 0) {
   const int t0 = blockIdx.y * F;
   const int nt = min(n_frames - t0, F);
-  for (int o = blockIdx.x * 256 + threadIdx.x; o < n_out; o += gridDim.x * 256) {
+  // `quads`: only the pixels of the listed groups of four (the ones remap_win_kernel leaves out)
+  const int n_work = quads ? 4 * n_quads : n_out;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n_work; i += gridDim.x * 256) {
+    const int o = quads ? 4 * quads[i >> 2] + (i & 3) : i;
     const int ix = mx[o], iy = my[o];
     const int fr = mf[o], fx = fr & 31, fy = fr >> 5;
     const bool x0 = ix >= 0 && ix < Ws, x1 = ix + 1 >= 0 && ix + 1 < Ws, y0 = iy >= 0 && iy < Hs, y1 = iy + 1 >= 0 && iy + 1 < Hs;
@@ -259,6 +263,74 @@ __global__ __launch_bounds__(256) void remap_kernel(const T* __restrict__ frames
       }
     }
   }
+}
+
+// uint8 frames through the quad plan of lspiv_project_cv_create: four consecutive destination pixels whose 2 x 2
+// neighbourhoods are interior, lie in one pair of source rows and within 8 source bytes share TWO 8-byte loads per frame
+// (the one-pixel kernel issues eight 2-byte ones), blend with the same integer weights and leave as one packed dword.
+// qbase: flat source index of (iy, min ix); qdesc: per pixel 16 bits = byte offset (3) | fx (5) | fy (5); bit 62 = all four wholly outside the source
+// (zeros), bit 63 = not in the plan (the one-pixel kernel runs over a list of those).
+template <int F>
+__global__ __launch_bounds__(256) void remap_win_kernel(const uint8_t* __restrict__ frames, int64_t src_elems, int Ws, int n_frames,
+                                                        const int* __restrict__ qbase, const uint64_t* __restrict__ qdesc,
+                                                        uint8_t* __restrict__ out, int n_out) {
+  typedef uint64_t u64_u __attribute__((aligned(1)));
+  const int t0 = blockIdx.y * F;
+  const int nt = min(n_frames - t0, F);
+  const uint8_t* img = frames + (int64_t)t0 * src_elems;
+  const int nq = n_out >> 2;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+    const uint64_t d = qdesc[q];
+    if (d >> 63) continue;
+    if (d >> 62) {                                           // all four pixels wholly outside the source: border value
+      uint32_t* z = reinterpret_cast<uint32_t*>(out + (int64_t)t0 * n_out + 4 * q);
+      for (int t = 0; t < nt; ++t) z[(int64_t)t * (n_out >> 2)] = 0u;
+      continue;
+    }
+    const int base = qbase[q];
+    uint64_t top[F], bot[F];
+#pragma unroll
+    for (int t = 0; t < F; ++t)
+      if (t < nt) {
+        top[t] = *reinterpret_cast<const u64_u*>(img + (int64_t)t * src_elems + base);
+        bot[t] = *reinterpret_cast<const u64_u*>(img + (int64_t)t * src_elems + base + Ws);
+      }
+    int sh[4], w00[4], w01[4], w10[4], w11[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t c = (uint32_t)(d >> (16 * e)) & 0xffffu;
+      const int fx = (c >> 3) & 31, fy = (c >> 8) & 31;
+      sh[e] = 8 * (int)(c & 7u);
+      w00[e] = (32 - fx) * (32 - fy) * 32; w01[e] = fx * (32 - fy) * 32; w10[e] = (32 - fx) * fy * 32; w11[e] = fx * fy * 32;
+    }
+    uint32_t* dst = reinterpret_cast<uint32_t*>(out + (int64_t)t0 * n_out + 4 * q);
+#pragma unroll
+    for (int t = 0; t < F; ++t)
+      if (t < nt) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t tp = (uint32_t)(top[t] >> sh[e]), bt = (uint32_t)(bot[t] >> sh[e]);   // bytes 0, 1 = the two columns
+          const int acc = (int)(tp & 0xffu) * w00[e] + (int)((tp >> 8) & 0xffu) * w01[e] + (int)(bt & 0xffu) * w10[e] +
+                          (int)((bt >> 8) & 0xffu) * w11[e];
+          packed |= (uint32_t)(uint8_t)((acc + (1 << 14)) >> 15) << (8 * e);
+        }
+        dst[(int64_t)t * (n_out >> 2)] = packed;
+      }
+  }
+}
+
+hipError_t launch_remap_win(const uint8_t* frames, int64_t src_elems, int Hs, int Ws, int n_frames, const int* qbase, const uint64_t* qdesc,
+                            const int* slow_q, int n_slow, const int* mx, const int* my, const uint16_t* mf, uint8_t* out, int n_out,
+                            hipStream_t s) {
+  if (n_frames <= 0 || n_out <= 0) return hipSuccess;
+  constexpr int F = 8;
+  const dim3 grid((unsigned)std::min((n_out / 4 + 255) / 256, 4096), (unsigned)((n_frames + F - 1) / F));
+  hipLaunchKernelGGL((remap_win_kernel<F>), grid, dim3(256), 0, s, frames, src_elems, Ws, n_frames, qbase, qdesc, out, n_out);
+  if (n_slow > 0)   // the pixels of the quads the plan leaves out: the one-pixel kernel over the list
+    hipLaunchKernelGGL((remap_kernel<uint8_t, F>), dim3((unsigned)std::min((4 * n_slow + 255) / 256, 4096), (unsigned)((n_frames + F - 1) / F)),
+                       dim3(256), 0, s, frames, src_elems, Hs, Ws, n_frames, mx, my, mf, out, n_out, slow_q, n_slow);
+  return hipGetLastError();
 }
 
 hipError_t launch_remap(const void* frames, int dtype, int64_t src_elems, int Hs, int Ws, int n_frames, const int* mx, const int* my,
