@@ -350,6 +350,20 @@ def test_streamed_chain_cuts_chunks_on_anchors(lib):
     assert CameraToVelocity._chunk_bounds(SimpleNamespace(window_size=(128, 128)), 40, 8) == [0, 5, 10, 15, 20, 25, 30, 35, 40]
 
 
+def test_every_environment_switch_is_documented():
+    """Every LSPIV_* variable the library, the Python package or bench.py reads is listed in INTEGRATION.md."""
+    import glob
+    import re
+
+    names = set()
+    for f in glob.glob(os.path.join(ROOT, "pyorc_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "pyorc_amd", "*.py")) + \
+            [os.path.join(ROOT, "bench.py")]:
+        names |= set(re.findall(r'(?:getenv\(|environ\.get\(|environ\[|setdefault\()"(LSPIV_[A-Z0-9_]+)"', open(f).read()))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = sorted(n for n in names if n not in doc)
+    assert len(names) > 15 and not missing, missing
+
+
 def test_product_has_no_torch_dependency():
     """The multi-GPU path goes through lspiv_comm_* (RCCL dlopen'ed by the C library): nothing under pyorc_amd/ or in
     bench.py imports torch (two HIP runtimes in one process was round 1's hazard)."""
