@@ -534,29 +534,14 @@ __device__ __forceinline__ void lds_row_write(float* row, const float (&c)[N]) {
 // the buffer (ds_write_b32, the lanes of a group hit consecutive banks), then reads buffer row r =
 // tile column r with ds_read_b128 (row stride N+4 dwords: 16-byte aligned, and the 16 lanes of a b128
 // group land on 16 distinct 4-bank slots since (N/4+1) l mod 16 is a bijection).
-// LSPIV_TR_ASM (N = 32): the column scatter as ds_write_b32 with immediate offsets off ONE base register.  Left to the
-// compiler the 32 stores are paired into ds_write2_b32, whose 8-bit offsets reach only 1 KB, so it keeps six extra base
-// addresses in VGPRs for the whole loop -- registers the 4-waves-per-SIMD build of the walking kernel does not have.
-#ifndef LSPIV_X_NOCARRY
-#define LSPIV_X_NOCARRY 0
-#endif
-#ifndef LSPIV_TR_ASM
-#define LSPIV_TR_ASM 0
-#endif
-template <int N, int J>
-__device__ __forceinline__ void lds_scatter_asm(unsigned addr, const float (&x)[N]) {
-  if constexpr (J < N) {
-    asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(addr), "v"(x[J]), "n"(J * Geo<N>::LDS_ROW * 4) : "memory");
-    lds_scatter_asm<N, J + 1>(addr, x);
-  }
-}
+// (The compiler pairs the 32 column stores into ds_write2_b32, whose 8-bit offsets reach only 1 KB, and keeps six extra base
+// addresses in VGPRs for it; an inline-asm scatter with immediate offsets off one base register was measured for the
+// 4-waves-per-SIMD attempts of the walking kernel and dropped with them -- DESIGN.md section 3.1b, git history.)
 template <int N>
 __device__ __forceinline__ void transpose_plane(float* buf, int lg, float (&x)[N]) {
   constexpr int LR = Geo<N>::LDS_ROW;
   float* wcol = buf + lg;
-  if constexpr (LSPIV_TR_ASM && N == 32) {
-    lds_scatter_asm<N, 0>((unsigned)(size_t)wcol, x);
-  } else if (lane_active<N>(lg)) {
+  if (lane_active<N>(lg)) {
 #pragma unroll
     for (int j = 0; j < N; ++j) wcol[j * LR] = x[j];
   }
@@ -943,47 +928,14 @@ __device__ __forceinline__ void prepare_one(const RowRaw<T, N>& raw, float (&x)[
 #define LSPIV_WALK_SB do { if constexpr (N == 32 || N == 64) __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif
 
-// LSPIV_STAGE_F32 (off: measured and dropped): float32 windows fetched coalesced -- N / 4 consecutive lanes read one row, one
-// instruction = LG / (N / 4) whole rows, every cache line used completely and once -- and staged through the job's transpose
-// tile (idle at this point of the iteration) into the lane = row layout, instead of every lane reading its own 4 N-byte
-// row 16 bytes at a time (one cache line per lane and instruction).  Interleaved A/B on one box, 1080p float32 32 x 32, 300
-// pairs: 104.9 k pairs/s staged against 107.5 k unstaged -- the strided loads are not the bottleneck (L2 hits), the 16 extra
-// LDS instructions per frame and 6 spilled registers are; 64 x 64 went from 152 to 248 B/lane of scratch and was not run.
-#ifndef LSPIV_STAGE_F32
-#define LSPIV_STAGE_F32 0
-#endif
+// float32 rows: every lane reads its own 4 N-byte row 16 bytes at a time.  (Fetching the rows coalesced -- N / 4 consecutive
+// lanes per row -- and staging them through the job's transpose tile was measured and dropped: 104.9 k against 107.5 k pairs/s
+// at 1080p 32 x 32, the 16 extra LDS instructions per frame and 6 spilled registers cost more than the strided loads, which
+// hit L2; DESIGN.md section 4, git history.)
 #ifndef LSPIV_F32_EARLY
 #define LSPIV_F32_EARLY 1
 #endif
 template <int N> constexpr bool kF32Early = LSPIV_F32_EARLY && Geo<N>::FULL;
-template <int N> constexpr bool kStageF32 = LSPIV_STAGE_F32 && Geo<N>::FULL && N % 4 == 0 && N >= 16 && N <= 32;
-template <int N>
-__device__ __forceinline__ void fetch_rows_coalesced(const float* win /* window origin in its frame */, int W, int lg, float (&x)[N]) {
-  constexpr int LPR = N / 4;                 // lanes per row, 16 bytes each
-  constexpr int RPI = Geo<N>::LG / LPR;      // rows per instruction
-  const int r0 = lg / LPR, cq = lg - r0 * LPR;
-  const float* src = win + (int64_t)r0 * W + 4 * cq;
-#pragma unroll
-  for (int k = 0; k < N / RPI; ++k) {
-    const f32x4 v = *reinterpret_cast<const f32x4_u*>(src + (int64_t)(k * RPI) * W);
-    x[4 * k] = v[0]; x[4 * k + 1] = v[1]; x[4 * k + 2] = v[2]; x[4 * k + 3] = v[3];
-  }
-}
-// x holds 16-byte pieces of RPI rows per register quad (fetch_rows_coalesced) -> x holds this lane's own row
-template <int N>
-__device__ __forceinline__ void stage_rows(float* buf, int lg, float (&x)[N]) {
-  constexpr int LPR = N / 4, RPI = Geo<N>::LG / LPR, LR = Geo<N>::LDS_ROW;
-  const int r0 = lg / LPR, cq = lg - r0 * LPR;
-  float* dst = buf + r0 * LR + 4 * cq;
-#pragma unroll
-  for (int k = 0; k < N / RPI; ++k) {
-    const f32x4 v = {x[4 * k], x[4 * k + 1], x[4 * k + 2], x[4 * k + 3]};
-    *reinterpret_cast<f32x4*>(dst + k * RPI * LR) = v;
-  }
-  __builtin_amdgcn_wave_barrier();
-  lds_row_read<N>(buf + lg * LR, x);
-  __builtin_amdgcn_wave_barrier();
-}
 
 // what a walking job carries from one iteration to the next
 template <int N>
@@ -1009,25 +961,7 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
   constexpr int H = N / 2;
   bool dead0, dead1, fin0 = true, fin1 = true;
   int nz0 = G::NN, nz1 = G::NN;
-  if constexpr (sizeof(T) == 4 && kStageF32<N>) {
-    constexpr float kHalf = 1.0f / (2.0f * (float)G::NN);
-    const float* win = reinterpret_cast<const float*>(row) - (int64_t)lg * p.W;   // the lane's row pointer minus its row
-    fetch_rows_coalesced<N>(win, p.W, lg, xr);                                    // both frames' loads in flight ...
-    fetch_rows_coalesced<N>(has2 ? win + p.frame_elems : win, p.W, lg, xi);
-    stage_rows<N>(buf, lg, xr);                                                   // ... while the first one is staged
-    const float inv0 = center_clip_f<N, true>(xr, WANT_NZ, p.nz_positive != 0, nz0, fin0);
-    const float g0 = inv0 * kHalf;
-#pragma unroll
-    for (int j = 0; j < N; ++j) xr[j] = __builtin_amdgcn_fmed3f(xr[j] * g0, 0.0f, 1.0f);
-    dead0 = inv0 == 0.0f;
-    LSPIV_WALK_SB;
-    stage_rows<N>(buf, lg, xi);
-    const float inv1 = center_clip_f<N, true>(xi, WANT_NZ, p.nz_positive != 0, nz1, fin1);
-    const float g1 = inv1 * kHalf;
-#pragma unroll
-    for (int j = 0; j < N; ++j) xi[j] = __builtin_amdgcn_fmed3f(xi[j] * g1, 0.0f, 1.0f);
-    dead1 = inv1 == 0.0f;
-  } else if constexpr (sizeof(T) == 4 && kF32Early<N>) {
+  if constexpr (sizeof(T) == 4 && kF32Early<N>) {
     // float32 rows: the loads of BOTH frames are in flight before the first is consumed (they land in xr / xi, the registers
     // they are converted in), so an iteration waits for memory once instead of twice
     constexpr float kHalf = 1.0f / (2.0f * (float)G::NN);
@@ -1069,16 +1003,11 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
     const float mr = bperm_f(partner_byte, xr[kn]);
     const float mi = bperm_f(partner_byte, xi[kn]);
     const float pr = xr[ky] + mr, pi = xi[ky] - mi;     // 2 F_f      (each with its frame's 1 / (2 N^2))
-#if LSPIV_X_NOCARRY   // EXPERIMENT (wrong results): what the kernel would run at if the carry cost no registers
-    const float ar = 0.75f * pr + 0.5f * pi, ai = 0.75f * pi - 0.5f * pr;
-    const float qr = xi[ky] + mi, qi = mr - xr[ky];
-#else
     const float ar = c.fpr[ky] * pr + c.fpi[ky] * pi, ai = c.fpr[ky] * pi - c.fpi[ky] * pr;   // conj(F_prev) P
     // the new carry is formed AFTER the last use of the old one, straight into its place: no copies on the loop back-edge
     c.fpr[ky] = xi[ky] + mi;                            // 2 F_{f+1}
     c.fpi[ky] = mr - xr[ky];
     const float qr = c.fpr[ky], qi = c.fpi[ky];
-#endif
     const float br = pr * qr + pi * qi, bi = pr * qi - pi * qr;                               // conj(P) Q
     xr[ky] = ar - bi;                // (R_a + i R_b)[ky][kx]
     xi[ky] = ai + br;
