@@ -54,10 +54,11 @@ extern "C" {
 #define LSPIV_F32 1
 #define LSPIV_F64 2
 
-/* largest interrogation window side the kernels accept.  2..64: register-resident kernels; above 64 (any parity, square
- * or not, e.g. 96 x 96 and 128 x 128 for 4K footage): the LDS-resident DFT kernel, as long as 2 wy wx floats fit the
- * 160 KB of a CU -- 128 x 128 does, 128 x 160 does not (LSPIV_EUNSUPPORTED). */
-#define LSPIV_MAX_WINDOW 128
+/* largest interrogation window side the kernels accept (ffpiv.cross_corr itself has no upper bound).  2..64:
+ * register-resident kernels; above 64 (any parity, square or not, e.g. 96 x 96 and 128 x 128 for 4K footage): the
+ * LDS-resident DFT kernel, as long as 2 wy wx floats fit the 160 KB of a CU -- 128 x 128 does; anything larger up to this
+ * limit runs the same transforms on slots of HBM scratch: correct, an order of magnitude slower per sample. */
+#define LSPIV_MAX_WINDOW 512
 
 /* ---------------------------------------------------------------- library / device ------- */
 int         lspiv_abi_version(void);
@@ -87,7 +88,8 @@ int         lspiv_get_option(const char* name, int* value);
  * kernels (every other even square window 6..62), 7 / 4 / 5 = odd square windows (and 4x4) 4..7 / 9..15 / 21..31
  * embedded in the 16- / 32- / 64-point FFT kernels, 3 = direct spatial correlation (non-square and odd 17 / 19 / 33..63
  * windows of fewer than 1500 samples), 9 = LDS-resident 2-D transform (any window with a side above 64, and the non-square /
- * odd ones from 1500 samples on); <0 = unsupported.  Host-only. */
+ * odd ones from 1500 samples on), 10 = the same transforms on HBM scratch (windows that outgrow the LDS of a CU: a side
+ * above 128); <0 = unsupported.  Host-only. */
 int         lspiv_kernel_kind(int wy, int wx);
 
 /* ---------------------------------------------------------------- window grid (host) ----- */

@@ -29,7 +29,7 @@
 #include <omp.h>
 #endif
 
-#define MAXW 128
+#define MAXW 512
 #define EPS_PEAK 1e-7
 
 typedef struct { double re, im; } cpx;

@@ -72,6 +72,8 @@ struct PivParams {
   // walking ensemble kernels: per-segment partial sums / counts (zeroed by the caller), merged in segment order
   float* part_sum;         // n_seg * n_win * wy * wx, or nullptr: the single-owner kernels
   float* part_cnt;         // n_seg * n_win
+  float* dft_scratch;      // windows above 128 px: per-block slots of HBM for the two planes (piv_dft_global_kernel), else nullptr
+  size_t dft_slot;         // floats per slot
   uint32_t seg_len, n_seg; // pairs per segment (odd), number of segments
   uint32_t seg_first;      // pairs in segment 0: seg_len, or what is left up to the next anchor when the chunk starts off-anchor
   uint32_t n_pairs;        // T-1
@@ -236,6 +238,10 @@ hipError_t launch_piv_direct(const PivParams& p, int dtype, bool ensemble, hipSt
 // windows above 64 px per side (any shape that fits LDS): packed 2-D DFT in LDS (piv_direct.hip)
 hipError_t launch_piv_dft(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 bool piv_dft_fits(int wy, int wx);
+// windows above 128 px: the DFT passes on per-block slots of HBM scratch (piv_direct.hip); PivParams::dft_scratch / dft_slot
+size_t piv_dft_global_slot_floats(int wy, int wx);
+int piv_dft_global_blocks(uint32_t n_work);
+hipError_t launch_piv_dft_global(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 // square windows 4..16 / 17..31 through the 32- / 64-point transforms
 hipError_t launch_piv_embed16(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 hipError_t launch_piv_embed32(const PivParams& p, int dtype, bool ensemble, hipStream_t s);

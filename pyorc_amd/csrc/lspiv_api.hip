@@ -81,6 +81,7 @@ struct DeviceCtx {
   float* d_out = nullptr;    size_t out_cap = 0;
   float* d_planes = nullptr; size_t planes_cap = 0;
   void* d_scratch = nullptr; size_t scratch_cap = 0;   // temporaries of *_dev entry points (normalize)
+  void* d_dft = nullptr; size_t dft_cap = 0;           // plane slots of the windows above 128 px (grow-only)
   uint8_t* d_keep = nullptr; size_t keep_cap = 0;      // per-window flags of the "stack" signal mode
   void* pinned[2] = {nullptr, nullptr}; size_t pinned_cap = 0;  // H2D staging ring
   hipEvent_t staged[2] = {nullptr, nullptr};
@@ -278,6 +279,21 @@ int dispatch(const lspiv::PivParams& p, int dtype, bool ensemble, hipStream_t s)
     case 2: e = lspiv::launch_piv_fft64(p, dtype, ensemble, s); break;
     case 3: e = lspiv::launch_piv_direct(p, dtype, ensemble, s); break;
     case 9: e = lspiv::launch_piv_dft(p, dtype, ensemble, s); break;
+    case 10: {   // above 128 px: the same passes on slots of HBM scratch owned by the context (one stream at a time, like the
+                 // other context workspaces)
+      DeviceCtx* c;
+      int rc = get_ctx(&c);
+      if (rc) return rc;
+      const size_t slot = lspiv::piv_dft_global_slot_floats(p.wy, p.wx);
+      const int blocks = lspiv::piv_dft_global_blocks(ensemble ? p.n_win : p.n_tiles);
+      rc = ensure(&c->d_dft, &c->dft_cap, slot * (size_t)blocks * sizeof(float));
+      if (rc) return rc;
+      lspiv::PivParams q = p;
+      q.dft_scratch = (float*)c->d_dft;
+      q.dft_slot = slot;
+      e = lspiv::launch_piv_dft_global(q, dtype, ensemble, s);
+      break;
+    }
     default: return fail(LSPIV_EUNSUPPORTED, "no kernel for window %dx%d", p.wy, p.wx);
   }
   if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -415,7 +431,7 @@ int lspiv_get_option(const char* name, int* value) {
 
 int lspiv_kernel_kind(int wy, int wx) {
   if (wy < 2 || wx < 2 || wy > LSPIV_MAX_WINDOW || wx > LSPIV_MAX_WINDOW) return LSPIV_EUNSUPPORTED;
-  if (wy > 64 || wx > 64) return lspiv::piv_dft_fits(wy, wx) ? 9 : LSPIV_EUNSUPPORTED;   // LDS-resident 2-D DFT, any shape
+  if (wy > 64 || wx > 64) return lspiv::piv_dft_fits(wy, wx) ? 9 : 10;   // 2-D DFT of any shape: LDS-resident up to 128 x 128, HBM slots above
   if (wy == 32 && wx == 32) return 1;
   if (wy == 64 && wx == 64) return 2;
   if (wy == 16 && wx == 16) return 6;

@@ -617,12 +617,14 @@ __host__ __device__ inline int fourstep_m(int wy, int wx) {
 
 // one window pair -> clipped, fft-shifted plane in `plane` (n floats, aliases the imaginary plane).  false: NaN plane.
 template <typename T, int M>
-__device__ __forceinline__ bool dft_pair(const PivParams& p, uint32_t pair, uint32_t win, float* smem, const DftGeo& g, float*& plane,
-                                         float*& red) {
+// `data`: the two planes (2 wy pitch floats; LDS, or a slot of HBM scratch for windows that outgrow a CU's LDS), `small`:
+// the twiddle tables and the reduction scratch (LDS)
+__device__ __forceinline__ bool dft_pair(const PivParams& p, uint32_t pair, uint32_t win, float* data, float* small, const DftGeo& g,
+                                         float*& plane, float*& red) {
   const int wy = p.wy, wx = p.wx, P = g.pitch;
-  float* re = smem;
+  float* re = data;
   float* im = re + wy * P;
-  float* twx = im + wy * P;
+  float* twx = small;
   float* twy = twx + 2 * wx;
   red = twy + 2 * wy;
   plane = im;
@@ -717,7 +719,7 @@ __global__ __launch_bounds__(FBLOCK, 4) void piv_dft_kernel(PivParams p) {
   const uint32_t t = blockIdx.x;
   const uint32_t pair = t / p.n_win, win = t - pair * p.n_win;
   float *plane, *red;
-  const bool ok = dft_pair<T, M>(p, pair, win, smem, g, plane, red);
+  const bool ok = dft_pair<T, M>(p, pair, win, smem, smem + 2 * p.wy * g.pitch, g, plane, red);
   float vmax, sum, u, v;
   int imax;
   plane_reduce(plane, g.n, red, vmax, imax, sum);
@@ -743,7 +745,7 @@ __global__ __launch_bounds__(FBLOCK) void piv_dft_ensemble_kernel(PivParams p) {
   float cnt = 0.0f;
   for (uint32_t pair = 0; pair < p.n_pairs; ++pair) {
     float *plane, *red;
-    const bool ok = dft_pair<T, M>(p, pair, win, smem, g, plane, red);
+    const bool ok = dft_pair<T, M>(p, pair, win, smem, smem + 2 * p.wy * g.pitch, g, plane, red);
     float vmax, sum;
     int imax;
     plane_reduce(plane, g.n, red, vmax, imax, sum);
@@ -761,6 +763,91 @@ __global__ __launch_bounds__(FBLOCK) void piv_dft_ensemble_kernel(PivParams p) {
     __syncthreads();
   }
   if (threadIdx.x == 0) p.corr_count[win] += cnt;
+}
+
+// ---- windows above 128 px: the same transforms on a slot of HBM scratch ---------------------------------------------------------
+// Two planes of 129 x 129 complex samples no longer fit the 160 KB of a CU.  ffpiv.cross_corr has no upper bound on the
+// window, so these sizes run the SAME code -- dft_pair on the DFT passes (a composite length as two shorter passes, oversized
+// tile sets in rounds) -- with the planes in a per-block slot of HBM scratch instead of LDS; only the twiddle tables and the
+// reduction scratch stay in LDS.  A persistent grid (one slot per block) walks the (pair, window) tiles.  This is a
+// functional path, not a fast one: every pass goes through L2 / MALL.
+template <typename T>
+__global__ __launch_bounds__(FBLOCK) void piv_dft_global_kernel(PivParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const DftGeo g(p.wy, p.wx);
+  float* data = p.dft_scratch + (size_t)blockIdx.x * p.dft_slot;
+  for (uint32_t t = blockIdx.x; t < p.n_tiles; t += gridDim.x) {
+    const uint32_t pair = t / p.n_win, win = t - pair * p.n_win;
+    float *plane, *red;
+    const bool ok = dft_pair<T, 0>(p, pair, win, data, smem, g, plane, red);
+    float vmax, sum, u, v;
+    int imax;
+    plane_reduce(plane, g.n, red, vmax, imax, sum);
+    subpixel_generic([&](int o) { return plane[o]; }, p.wy, p.wx, imax, p.border_mode, u, v);
+    float cm = vmax, sn = vmax / (sum / (float)g.n);
+    if (!ok) u = v = cm = sn = __builtin_nanf("");
+    if (threadIdx.x == 0) {
+      p.u[t] = u; p.v[t] = v; p.cmax[t] = cm; p.s2n[t] = sn;
+    }
+    if (p.planes) {
+      float* dst = p.planes + (size_t)t * g.n;
+      for (int o = threadIdx.x; o < g.n; o += blockDim.x) dst[o] = ok ? plane[o] : __builtin_nanf("");
+    }
+    __syncthreads();   // the next tile overwrites the slot
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(FBLOCK) void piv_dft_global_ensemble_kernel(PivParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const DftGeo g(p.wy, p.wx);
+  float* data = p.dft_scratch + (size_t)blockIdx.x * p.dft_slot;
+  for (uint32_t win = blockIdx.x; win < p.n_win; win += gridDim.x) {   // a block owns a window and walks the chunk's pairs in order
+    float* dst = p.corr_sum + (size_t)win * g.n;
+    float cnt = 0.0f;
+    for (uint32_t pair = 0; pair < p.n_pairs; ++pair) {
+      float *plane, *red;
+      const bool ok = dft_pair<T, 0>(p, pair, win, data, smem, g, plane, red);
+      float vmax, sum;
+      int imax;
+      plane_reduce(plane, g.n, red, vmax, imax, sum);
+      float cm = vmax, sn = vmax / (sum / (float)g.n);
+      const bool keep = ok && (cm >= p.corr_min) && (sn >= p.s2n_min);
+      cm = keep ? cm : 0.0f;
+      sn = keep ? sn : 0.0f;
+      cnt += (cm > 1e-6f) ? 1.0f : 0.0f;
+      if (threadIdx.x == 0) {
+        p.cmax[(size_t)pair * p.n_win + win] = cm;
+        p.s2n[(size_t)pair * p.n_win + win] = sn;
+      }
+      if (keep)
+        for (int o = threadIdx.x; o < g.n; o += blockDim.x) dst[o] += plane[o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) p.corr_count[win] += cnt;
+  }
+}
+
+size_t piv_dft_global_slot_floats(int wy, int wx) { return (((size_t)2 * wy * (wx | 1)) + 63) & ~(size_t)63; }
+int piv_dft_global_blocks(uint32_t n_work) { return (int)std::min<uint32_t>(n_work, 512u); }   // two slots per CU
+
+hipError_t launch_piv_dft_global(const PivParams& p, int dtype, bool ensemble, hipStream_t s) {
+  if (!p.dft_scratch) return hipErrorInvalidValue;
+  const size_t lds = ((size_t)2 * (p.wx + p.wy) + 24) * sizeof(float);
+  const dim3 grid((unsigned)piv_dft_global_blocks(ensemble ? p.n_win : p.n_tiles));
+#define LSPIV_DFT_G(T)                                                                                       \
+  do {                                                                                                       \
+    if (ensemble) hipLaunchKernelGGL((piv_dft_global_ensemble_kernel<T>), grid, dim3(FBLOCK), lds, s, p);    \
+    else hipLaunchKernelGGL((piv_dft_global_kernel<T>), grid, dim3(FBLOCK), lds, s, p);                      \
+  } while (0)
+  switch (dtype) {
+    case 0: LSPIV_DFT_G(uint8_t); break;
+    case 1: LSPIV_DFT_G(float); break;
+    case 2: LSPIV_DFT_G(double); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef LSPIV_DFT_G
+  return hipGetLastError();
 }
 
 size_t piv_dft_lds_bytes(int wy, int wx) { return DftGeo(wy, wx).lds_floats(wy, wx) * sizeof(float); }

@@ -30,7 +30,7 @@ def rel_err(got, ref, floor=0.05):
     return float(np.nanmax(e)) if np.isfinite(e).any() else 0.0
 
 
-def check_against_oracle(frames, ws, ov, thr=None, min_ok=0.5, min_neighbour=0.02, plane_tol=2e-6):
+def check_against_oracle(frames, ws, ov, thr=None, min_ok=0.5, min_neighbour=0.02, plane_tol=2e-6, uv_tol=TOL):
     import pyorc_amd
 
     u, v, cm, sn, planes = pyorc_amd.piv_pairs(frames, ws, ov, thr, return_planes=True)
@@ -50,8 +50,8 @@ def check_against_oracle(frames, ws, ov, thr=None, min_ok=0.5, min_neighbour=0.0
     assert np.array_equal(np.isnan(planes), np.isnan(po_planes))
     assert np.nanmax(np.abs(planes - po_planes), initial=0.0) < plane_tol
     if ok.any():
-        assert rel_err(u[ok], uo[ok].astype(np.float64)) <= TOL
-        assert rel_err(v[ok], vo[ok].astype(np.float64)) <= TOL
+        assert rel_err(u[ok], uo[ok].astype(np.float64)) <= uv_tol
+        assert rel_err(v[ok], vo[ok].astype(np.float64)) <= uv_tol
     assert ok.mean() >= min_ok, "test input is mostly ill-posed windows"
     return u, v, cm, sn
 
@@ -280,6 +280,41 @@ def test_windows_above_64_vs_oracle(gpu, ws, ov, dtype):
         f[2] = 1.5                                       # a constant frame: both pairs that touch it are dead
         f[:, : ws[0] // 2, : ws[1]] = -0.75              # a constant corner
         check_against_oracle(f, ws, ov, thr=0.25, min_ok=0.0, **kw)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("ws,ov", [((160, 160), (80, 80)), ((256, 256), (128, 192)), ((130, 130), (65, 65)), ((192, 144), (96, 72)),
+                                   ((64, 320), (32, 160)), ((251, 251), (100, 100))])
+def test_windows_above_128_vs_oracle(gpu, ws, ov, dtype):
+    """ffpiv.cross_corr has no upper bound on the window.  Two planes of more than 128 x 128 complex samples do not fit the
+    LDS of a CU; those windows run the same transforms on slots of HBM scratch (kernel kind 10): composite sides in two
+    passes and rounds (160 = 10 x 16, 256 = 16 x 16, 130 = 10 x 13, 192 x 144), a prime side (251) in single passes, a
+    side below 65 next to one above 128 -- planes, NaN masks, corr / s2n and peaks against the oracle, plus ensemble mode."""
+    import pyorc_amd.piv as P
+    from pyorc_amd import _lib
+
+    assert _lib.load().lspiv_kernel_kind(*ws) == 10
+    H, Wd = 2 * ws[0] + 9, 2 * ws[1] + ws[1] // 3 + 5
+    fr = particle_stack(4, H, Wd, seed=ws[0] + 3 * ws[1], density=0.03)
+    # planes agree to 4e-7; the broad peaks of these windows (log-curvature down to 0.2) turn that into up to 6e-6 px, which is
+    # 1.2e-4 of the 0.05-px floor of the relative measure at 256 x 256: the gate on u, v is 2e-4 here
+    kw = dict(plane_tol=2e-6, min_neighbour=0.05, uv_tol=2e-4)
+    if dtype == np.uint8:
+        check_against_oracle(fr, ws, ov, min_ok=0.5, **kw)
+        check_against_oracle(fr, ws, ov, thr=0.12, min_ok=0.0, **kw)
+    else:
+        f = (fr.astype(dtype) - 21.5) * 0.37
+        f[2] = 1.5                                       # a constant frame: both pairs that touch it are dead
+        f[:, : ws[0] // 2, : ws[1]] = -0.75              # a constant corner
+        check_against_oracle(f, ws, ov, thr=0.25, min_ok=0.0, **kw)
+    if dtype == np.uint8 and ws[0] == ws[1]:             # ensemble mode through the same slots
+        ens = P.Ensemble((H, Wd), ws, ov)
+        ens.accumulate(fr, 0.05, 1.0)
+        u, v, cnt = ens.finish(0.0, 3)
+        ens.close()
+        ref = po.get_ffpiv(fr, np.ones(3), ws, ov, 1.0, 1.0, ensemble_corr=True, corr_min=0.05, s2n_min=1.0, count_min=0.0)
+        assert np.array_equal(np.isnan(u[0]), np.isnan(ref["v_x"][0])) and rel_err(u[0], ref["v_x"][0].astype(np.float64)) <= 2e-4
+        assert rel_err(v[0], ref["v_y"][0].astype(np.float64)) <= 2e-4
 
 
 @pytest.mark.parametrize("ws", [96, 128])
@@ -577,7 +612,7 @@ def test_error_mapping(gpu):
     with pytest.raises((ValueError, _lib.LspivError)):
         pyorc_amd.piv_pairs(np.zeros((2, 16, 16), np.uint8))          # frame smaller than window
     with pytest.raises(ValueError) as ei:                                # the reference's exception type for a bad window
-        pyorc_amd.piv_pairs(np.zeros((2, 300, 300), np.uint8), (130, 130), (65, 65))
+        pyorc_amd.piv_pairs(np.zeros((2, 1100, 1100), np.uint8), (514, 514), (257, 257))
     assert ei.value.code == _lib.LSPIV_EUNSUPPORTED and isinstance(ei.value, _lib.LspivError)
     with pytest.raises(_lib.LspivError) as ei:
         pyorc_amd.piv_pairs(np.zeros((2, 64, 64), np.uint8), (32, 32), (32, 16))

@@ -54,12 +54,12 @@ def test_grid_errors_map_to_status_codes(lib):
     nr, nc = C.c_int64(), C.c_int64()
     assert lib.lspiv_grid_shape(100, 100, 32, 32, 32, 16, C.byref(nr), C.byref(nc)) == _lib.LSPIV_EINVAL
     assert b"overlap" in lib.lspiv_last_error()
-    assert lib.lspiv_grid_shape(200, 200, 130, 130, 0, 0, C.byref(nr), C.byref(nc)) == _lib.LSPIV_EUNSUPPORTED
+    assert lib.lspiv_grid_shape(800, 800, 513, 513, 0, 0, C.byref(nr), C.byref(nc)) == _lib.LSPIV_EUNSUPPORTED
     assert lib.lspiv_grid_shape(200, 200, 128, 128, 64, 64, C.byref(nr), C.byref(nc)) == 0 and (nr.value, nc.value) == (2, 2)
     # windows above 64 px run the LDS-resident DFT kernel (any shape whose two planes fit the 160 KB of a CU)
     assert [lib.lspiv_kernel_kind(w, w) for w in (66, 96, 97, 100, 128)] == [9] * 5
     assert lib.lspiv_kernel_kind(128, 96) == 9 and lib.lspiv_kernel_kind(80, 20) == 9
-    assert lib.lspiv_kernel_kind(129, 129) == _lib.LSPIV_EUNSUPPORTED
+    assert lib.lspiv_kernel_kind(513, 513) == _lib.LSPIV_EUNSUPPORTED and lib.lspiv_kernel_kind(129, 129) == 10
     assert lib.lspiv_grid_shape(10, 100, 32, 32, 16, 16, C.byref(nr), C.byref(nc)) == 0 and nr.value == 0
     with pytest.raises(_lib.LspivError):
         window.get_rect_coordinates((100, 100), (32, 32), (40, 16))
@@ -79,7 +79,7 @@ def test_kernel_dispatch_table(lib):
     assert lib.lspiv_kernel_kind(48, 32) == 9 and lib.lspiv_kernel_kind(39, 39) == 9   # from 1500 samples on: DFT passes
     assert lib.lspiv_kernel_kind(41, 41) == 9 and lib.lspiv_kernel_kind(64, 32) == 9 and lib.lspiv_kernel_kind(63, 63) == 9
     assert lib.lspiv_kernel_kind(64, 64) == 2
-    assert lib.lspiv_kernel_kind(128, 128) == 9 and lib.lspiv_kernel_kind(256, 256) == _lib.LSPIV_EUNSUPPORTED   # LDS-resident DFT up to 128
+    assert lib.lspiv_kernel_kind(128, 128) == 9 and lib.lspiv_kernel_kind(256, 256) == 10 and lib.lspiv_kernel_kind(128, 160) == 10   # LDS-resident DFT up to 128 x 128, HBM slots above
 
 
 def test_required_memory_counts_frames_and_results():

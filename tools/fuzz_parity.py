@@ -15,8 +15,9 @@ for case in range(n_cases):
     ws = int(rng.choice([32, 32, 32, 64, 64, 16, 24, 10, 48, 8, 6, 12, 20, 14, 18, 22, 26, 28, 30, 36, 40, 44, 50, 56, 60, 62, 9, 25, 35,
                          72, 80, 96, 100, 112, 128, 66, 97,     # above 64: four-step sizes, a 2 x odd and an odd one (DFT passes)
                          17, 33, 41, 49, 63,                    # odd: embedded below 33, direct up to 39, DFT passes from 41
-                         74, 98, 110, 114, 125, 126]))          # composite lengths in two DFT passes (126, 114: in two rounds)
-    wsy = ws if rng.random() < 0.8 else int(rng.choice([8, 16, 20, 32, 80]))
+                         74, 98, 110, 114, 125, 126,            # composite lengths in two DFT passes (126, 114: in two rounds)
+                         144, 160, 200]))                       # above 128: the same passes on HBM slots
+    wsy = ws if rng.random() < 0.8 else int(rng.choice([8, 16, 20, 32, 80, 136]))
     ov = (int(rng.integers(0, wsy)), int(rng.integers(0, ws)))
     H = int(rng.integers(wsy, wsy * 4 + 7)); W = int(rng.integers(ws, ws * 5 + 9)); T = int(rng.integers(2, 6)) if rng.random() < 0.6 else int(rng.integers(6, 14)) if rng.random() < 0.8 or ws > 40 else int(rng.integers(26, 60))   # sometimes across a 25-pair anchor
     dtype = rng.choice([np.uint8, np.float32, np.float64])
