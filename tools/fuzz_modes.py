@@ -12,7 +12,7 @@ from pyorc_amd.synth import particle_stack
 warnings.simplefilter("ignore")
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-SIZES = [32, 32, 64, 16, 24, 10, 48, 8, 12, 20, 26, 30, 36, 44, 56, 62, 9, 25, 35, 41, 72, 96]
+SIZES = [32, 32, 64, 16, 24, 10, 48, 8, 12, 20, 26, 30, 36, 44, 56, 62, 9, 25, 35, 41, 72, 96, 98, 144]
 
 
 def rel(g, r, floor=0.05):
