@@ -82,8 +82,19 @@ int         lspiv_synchronize(void);                    /* hipDeviceSynchronize 
  *                      the fraction (default; CHANGELOG 0.9.5 "any of the 2 interrogation window in a window pair"), 1 each
  *                      window POSITION over all frames of the chunk ("fraction of non-zero pixels in the window stack");
  *   "signal_positive"  the score counts 0 samples != 0 ("non-zero pixels", default), 1 samples > 0 ("above zero"). */
+/* Float64 rescue pass (round 3): the reference fits EVERY correlation plane in its engine's precision
+ * (pyorc/velocimetry/ffpiv.py:465-471); a float32 plane carries ~1e-7 of noise, which the 3-point log fit amplifies beyond
+ * 1e-4 on ill-conditioned peaks (a neighbour that is exactly zero, a flat ridge, a tie for the maximum).  The kernels flag
+ * those windows and a second kernel re-evaluates them from the frames in float64, overwriting u and v:
+ *   "rescue"           1 (default; environment LSPIV_RESCUE) | 0 float32 results as they are;
+ *   "rescue_kappa"     plane noise the flag model assumes, in 1e-9 of the plane maximum (default 500);
+ *   "rescue_tau"       relative gap between the two largest samples below which the arg-max counts as ambiguous and the whole
+ *                      plane is re-evaluated, in 1e-9 (default 4000). */
 int         lspiv_set_option(const char* name, int value);
 int         lspiv_get_option(const char* name, int* value);
+/* counters of the rescue pass on `stream` (NULL: the library's own stream), after synchronising with it: stats[0..4] =
+ * "fit" / "amb" windows of the last launch, the same two summed over all launches, windows processed by all launches */
+int         lspiv_rescue_stats(void* stream, int64_t* stats);
 /* which kernel a window size dispatches to: 1 = FFT 32x32, 2 = FFT 64x64, 6 = FFT 8x8 / 16x16, 8 = prime-factor FFT
  * kernels (every other even square window 6..62), 7 / 4 / 5 = odd square windows (and 4x4) 4..7 / 9..15 / 21..31
  * embedded in the 16- / 32- / 64-point FFT kernels, 3 = direct spatial correlation (non-square and odd 17 / 19 / 33..63

@@ -14,7 +14,8 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblspiv_hip.so")
+# LSPIV_LIBRARY: another build of the same ABI (A/B measurements of kernel variants, tools/ab_time.py); the default is the in-tree build
+LIB_PATH = os.environ.get("LSPIV_LIBRARY") or os.path.join(_HERE, "liblspiv_hip.so")
 
 LSPIV_OK = 0
 LSPIV_EINVAL = -1
@@ -54,6 +55,7 @@ SIGNATURES = {
     "lspiv_synchronize": (_i32, []),
     "lspiv_set_option": (_i32, [C.c_char_p, _i32]),
     "lspiv_get_option": (_i32, [C.c_char_p, C.POINTER(_i32)]),
+    "lspiv_rescue_stats": (_i32, [_vp, _pi64]),
     "lspiv_kernel_kind": (_i32, [_i32, _i32]),
     "lspiv_grid_shape": (_i32, [_i64, _i64, _i32, _i32, _i32, _i32, _pi64, _pi64]),
     "lspiv_grid_coords": (_i32, [_i64, _i64, _i32, _i32, _i32, _i32, _pi64, _pi64]),
@@ -152,6 +154,8 @@ def load() -> C.CDLL:
         )
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if not hasattr(lib, name) and os.environ.get("LSPIV_LIBRARY"):
+            continue  # an older build loaded for an A/B measurement: it simply lacks the newer entry points
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args

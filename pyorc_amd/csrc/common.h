@@ -42,6 +42,15 @@ struct FastDiv {
   }
 };
 
+// header of the rescue lists in device memory (zeroed once; the rescue kernel's last block resets it after every pass)
+struct RescueHdr {
+  uint32_t n_fit, n_amb;         // records appended by the PIV kernel of this pass (may exceed the capacities: the excess is dropped)
+  uint32_t spare0, spare1;
+  uint32_t done_blocks, pad;
+  uint32_t last_fit, last_amb;   // counts of the last completed pass
+  unsigned long long total_fit, total_amb, total_windows;
+};
+
 // One launch = all interrogation-window pairs of a frame chunk.
 // Replaces, fused: ffpiv.cross_corr + corr_max/s2n reductions + ffpiv.u_v_displacement
 // (pyorc/velocimetry/ffpiv.py:446-474).
@@ -79,6 +88,15 @@ struct PivParams {
   uint32_t n_pairs;        // T-1
   int64_t pair_offset;     // absolute index of the chunk's first pair in the caller's stack: the walking kernels cut
                            // segments at multiples of the anchor length of THAT index, so results do not depend on the chunking
+  // float64 rescue pass (piv_rescue.hip): the kernels' epilogues append the windows whose float32
+  // sub-pixel result cannot be trusted to 1e-4 -- the arg-max is not unique under float32 plane noise ("amb"), or the
+  // log-Gaussian fit amplifies that noise beyond the tolerance ("fit") -- to two device lists; nullptr: off
+  RescueHdr* rescue_hdr;
+  uint4* rescue_fit;       // {result index, (ip << 16) | jp, second candidate or ~0, -}: the five samples of the fit in float64
+  uint32_t* rescue_amb;    // result index: re-evaluate the whole plane in float64
+  uint32_t rescue_cap_fit, rescue_cap_amb;
+  float rescue_k;          // 2 kappa / (ln 2 * 1e-4), kappa = absolute plane noise / plane maximum the flag assumes
+  float rescue_tau;        // relative arg-max gap below which the arg-max counts as not unique
   FastDiv div_ncols;       // window index -> (row, col)
   FastDiv div_jobs;        // fft kernels: job index -> (pair, job in pair), divisor (n_win + 1) / 2
   FastDiv div_nwin;        // one-window-per-job kernels: job index -> (pair, window), divisor n_win
@@ -140,11 +158,29 @@ __device__ __forceinline__ int row_sum_i(int x) {
   x += dpp_i<DPP_MIRROR>(x);
   return x;
 }
-// sum over all 64 lanes (two halves joined by a cross-half permute)
+// The two 32-lane halves of a wave joined with gfx950's v_permlane32_swap: ONE VALU instruction hands every lane l the pair
+// (x[l mod 32], x[32 + l mod 32]) -- where __shfl_xor(x, 32) is a ds_bpermute through the LDS pipe plus an s_waitcnt.  Both
+// halves combine the pair in the same operand order (lower, upper); for +, max and min that gives the bits of the exchange.
+struct HalfPair { float lo, hi; };
+__device__ __forceinline__ HalfPair half_pair_f(float x) {
+  const unsigned b = __builtin_bit_cast(unsigned, x);
+  const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+  return {__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1])};
+}
+__device__ __forceinline__ float cross_half_sum(float x) { const HalfPair h = half_pair_f(x); return h.lo + h.hi; }
+__device__ __forceinline__ float cross_half_max(float x) { const HalfPair h = half_pair_f(x); return fmaxf(h.lo, h.hi); }
+__device__ __forceinline__ int cross_half_sum_i(int x) {
+  const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+  return (int)(r[0] + r[1]);
+}
+__device__ __forceinline__ int cross_half_min_i(int x) {
+  const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+  return min((int)r[0], (int)r[1]);
+}
+// sum over all 64 lanes (two halves joined by the cross-half swap)
 __device__ __forceinline__ float wave_sum(float x) {
   x = half_sum(x);
-  x += __shfl_xor(x, 32, 64);
-  return x;
+  return cross_half_sum(x);
 }
 
 // lexicographic arg-max step: keep (v, idx) unless partner is larger, or equal with smaller idx
@@ -172,6 +208,11 @@ __device__ __forceinline__ float gauss_offset(float lm, float l0, float lp) {
 __device__ __forceinline__ float gauss_offset_fast(float lm, float l0, float lp) {
   float nom = lm - lp;
   float den = 2.0f * lm - 4.0f * l0 + 2.0f * lp;
+  return den != 0.0f ? nom * __builtin_amdgcn_rcpf(den) : 0.0f;
+}
+__device__ __forceinline__ float gauss_offset_fast(float lm, float l0, float lp, float& den) {
+  float nom = lm - lp;
+  den = 2.0f * lm - 4.0f * l0 + 2.0f * lp;
   return den != 0.0f ? nom * __builtin_amdgcn_rcpf(den) : 0.0f;
 }
 // min over the 32 lanes of a half-wave
@@ -217,6 +258,40 @@ __device__ __forceinline__ void border_result(int mode, int dx, int dy, float& u
   v = mode == 0 ? nanv : mode == 1 ? 0.0f : (float)dy;
 }
 
+// ---- which float32 peaks go to the float64 rescue pass ------------------------------------------------------------------
+// A float32 plane carries absolute noise of <= ~3e-7 of its maximum (measured against the float64 oracle on 330 k windows of
+// the benchmark stacks: 4.2e-7 worst).  (i) "amb": the runner-up is within rescue_tau of the maximum -- which sample is
+// the arg-max (and whether it sits on the border => NaN) is then a matter of rounding.  (ii) "fit": the 3-point log-Gaussian
+// offset nom / den moves by about 2 (d_m + d_0 + d_p) / |den| when the logs move by d_x = noise / c_x; with the smaller
+// neighbour c_min that is <= 2 kappa (2 vmax / c_min + 1) / (ln 2 |den|) for logs to base 2, and the window is flagged when
+// this exceeds 1e-4 max(|result|, 0.05 px) -- the parity gate of SURVEY.md section 8d.  Typical cause: a neighbour of the
+// peak that is exactly 0 in exact arithmetic (clipped), where log(c + 1e-7) turns 1e-8 of rounding noise into 1e-3 px.
+// cm_* = min of the two neighbours + eps, den_* in log2 units, res_* the float32 result of that axis.
+struct PeakCond { bool amb, fit; };
+__device__ __forceinline__ PeakCond peak_cond(float vmax, float second, bool border, float cm_v, float den_v, float res_v,
+                                              float cm_u, float den_u, float res_u, float k, float tau) {
+  PeakCond c;
+  const bool live = vmax > 0.0f;   // an all-zero plane is NaN by construction (first arg-max on the border)
+  c.amb = live && second >= vmax * (1.0f - tau);
+  const float a_v = k * fmaf(2.0f, vmax, cm_v), a_u = k * fmaf(2.0f, vmax, cm_u);
+  const bool bad_v = !(a_v <= fmaxf(fabsf(res_v), 0.05f) * fabsf(den_v) * cm_v);   // NaN compares false => flagged
+  const bool bad_u = !(a_u <= fmaxf(fabsf(res_u), 0.05f) * fabsf(den_u) * cm_u);
+  c.fit = live && !border && !c.amb && (bad_v || bad_u);
+  return c;
+}
+// one lane appends the record (g = result index inside this launch); pos2: the only other arg-max candidate of an "amb"
+// window ((ip << 16) | jp), or ~0 -- with exactly two candidates their two float64 sums settle it, no whole plane needed
+__device__ __forceinline__ void rescue_note(RescueHdr* hdr, uint4* fit, uint32_t cap_fit, uint32_t* amb, uint32_t cap_amb,
+                                            uint32_t g, PeakCond c, int ip, int jp, uint32_t pos2 = 0xffffffffu) {
+  if (c.amb && pos2 == 0xffffffffu) {
+    const uint32_t i = atomicAdd(&hdr->n_amb, 1u);
+    if (i < cap_amb) amb[i] = g;
+  } else if (c.amb || c.fit) {
+    const uint32_t i = atomicAdd(&hdr->n_fit, 1u);
+    if (i < cap_fit) fit[i] = make_uint4(g, ((uint32_t)ip << 16) | (uint32_t)jp, pos2, 0u);
+  }
+}
+
 // element -> float conversion of the three frame dtypes
 __device__ __forceinline__ float to_f32(uint8_t x) { return (float)x; }
 __device__ __forceinline__ float to_f32(float x) { return x; }
@@ -246,6 +321,8 @@ hipError_t launch_piv_dft_global(const PivParams& p, int dtype, bool ensemble, h
 hipError_t launch_piv_embed16(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 hipError_t launch_piv_embed32(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 hipError_t launch_piv_embed64(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
+// float64 re-evaluation of the windows the PIV kernel of this pass appended to p.rescue_* (piv_rescue.hip)
+hipError_t launch_piv_rescue(const PivParams& p, int dtype, hipStream_t s);
 hipError_t launch_peaks_from_planes(const float* planes, uint32_t n_planes, int wy, int wx, int border_mode,
                                     float* u, float* v, hipStream_t s);
 // "stack" signal mode: keep[w] = fraction of non-zero (or positive) samples of window position w over ALL frames >= thr

@@ -83,6 +83,10 @@ struct DeviceCtx {
   void* d_scratch = nullptr; size_t scratch_cap = 0;   // temporaries of *_dev entry points (normalize)
   void* d_dft = nullptr; size_t dft_cap = 0;           // plane slots of the windows above 128 px (grow-only)
   uint8_t* d_keep = nullptr; size_t keep_cap = 0;      // per-window flags of the "stack" signal mode
+  // float64 rescue pass: one set of lists per launch stream (a stream orders its own PIV kernel -> rescue kernel pairs;
+  // two streams must not share counters), grow-only
+  struct RescueWs { hipStream_t stream; void* base; size_t cap_bytes; uint32_t cap_fit, cap_amb; };
+  std::vector<RescueWs> rescue;
   void* pinned[2] = {nullptr, nullptr}; size_t pinned_cap = 0;  // H2D staging ring
   hipEvent_t staged[2] = {nullptr, nullptr};
   bool arch_ok = false;
@@ -231,6 +235,46 @@ std::atomic<int> g_opt_border{env_opt("LSPIV_BORDER_PEAK", 0, 2)};        // 0 N
 std::atomic<int> g_opt_signal_mode{env_opt("LSPIV_SIGNAL_MODE", 0, 1)};   // 0 per window pair, 1 per window position over the chunk
 std::atomic<int> g_opt_signal_pos{env_opt("LSPIV_SIGNAL_POSITIVE", 0, 1)}; // 0 samples != 0, 1 samples > 0
 
+// float64 rescue pass (piv_rescue.hip): on by default; LSPIV_RESCUE=0 / lspiv_set_option("rescue", 0) keeps the float32 results.
+// rescue_kappa: the plane noise the flags assume, in 1e-9 of the plane maximum (measured worst case 2.7e-7 in the units of the
+// flag's error model -- tools/calib_rescue.py; default 500 = 5e-7); rescue_tau: relative arg-max gap, in 1e-9, below which the
+// whole plane is re-evaluated (float32 noise between two samples is <= 8.4e-7; default 4000 = 4e-6)
+static int env_opt_def(const char* name, int lo, int hi, int def) {
+  const char* e = getenv(name);
+  if (!e) return def;
+  const int v = atoi(e);
+  return v < lo || v > hi ? def : v;
+}
+std::atomic<int> g_opt_rescue{env_opt_def("LSPIV_RESCUE", 0, 1, 1)};
+std::atomic<int> g_opt_rescue_kappa{env_opt_def("LSPIV_RESCUE_KAPPA", 0, 1000000, 500)};
+std::atomic<int> g_opt_rescue_tau{env_opt_def("LSPIV_RESCUE_TAU", 0, 1000000, 4000)};
+
+// the rescue lists of stream `s`, large enough for a launch of n_tiles windows (a quarter of them "fit", a sixteenth "amb":
+// beyond that the excess keeps its float32 result -- imagery THAT sparse has no usable peaks)
+int rescue_ws(DeviceCtx* c, hipStream_t s, uint32_t n_tiles, lspiv::PivParams* p) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  DeviceCtx::RescueWs* ws = nullptr;
+  for (auto& w : c->rescue) if (w.stream == s) ws = &w;
+  if (!ws) { c->rescue.push_back({s, nullptr, 0, 0, 0}); ws = &c->rescue.back(); }
+  const uint32_t cap_fit = std::max<uint32_t>(4096u, n_tiles / 4u), cap_amb = std::max<uint32_t>(1024u, n_tiles / 16u);
+  const size_t hdr_bytes = 256;   // sizeof(RescueHdr) rounded up, keeps the lists 256-byte aligned
+  static_assert(sizeof(lspiv::RescueHdr) <= 256, "header slot too small");
+  if (cap_fit > ws->cap_fit || cap_amb > ws->cap_amb || !ws->base) {
+    const uint32_t nf = std::max(cap_fit, ws->cap_fit), na = std::max(cap_amb, ws->cap_amb);
+    const size_t bytes = hdr_bytes + (size_t)nf * sizeof(uint4) + (size_t)na * sizeof(uint32_t);
+    if (ws->base) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipFree(ws->base)); ws->base = nullptr; }
+    HIP_TRY(hipMalloc(&ws->base, bytes));
+    HIP_TRY(hipMemsetAsync(ws->base, 0, hdr_bytes, s));   // ordered before the kernels of this stream
+    ws->cap_bytes = bytes; ws->cap_fit = nf; ws->cap_amb = na;
+  }
+  p->rescue_hdr = static_cast<lspiv::RescueHdr*>(ws->base);
+  p->rescue_fit = reinterpret_cast<uint4*>((char*)ws->base + hdr_bytes);
+  p->rescue_amb = reinterpret_cast<uint32_t*>((char*)ws->base + hdr_bytes + (size_t)ws->cap_fit * sizeof(uint4));
+  p->rescue_cap_fit = ws->cap_fit;
+  p->rescue_cap_amb = ws->cap_amb;
+  return LSPIV_OK;
+}
+
 int fill_params(lspiv::PivParams* p, const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, int wy, int wx,
                 int oy, int ox, float signal_threshold, const Grid& g) {
   if (dtype < 0 || dtype > 2) return fail(LSPIV_EINVAL, "dtype %d not in {0:u8, 1:f32, 2:f64}", dtype);
@@ -253,13 +297,35 @@ int fill_params(lspiv::PivParams* p, const void* d_frames, int dtype, int64_t T,
   p->signal_threshold = signal_threshold;
   p->border_mode = g_opt_border.load();
   p->nz_positive = g_opt_signal_pos.load();
+  // flag model of the rescue pass (common.h, peak_cond): k = 2 kappa / (ln 2 * 1e-4)
+  p->rescue_k = (float)(2.0 * g_opt_rescue_kappa.load() * 1e-9 / (0.6931471805599453 * 1e-4));
+  p->rescue_tau = (float)(g_opt_rescue_tau.load() * 1e-9);
   p->div_ncols = lspiv::FastDiv::make((uint32_t)g.n_cols);
   p->div_jobs = lspiv::FastDiv::make((uint32_t)((n_win + 1) / 2));
   p->div_nwin = lspiv::FastDiv::make((uint32_t)n_win);
   return LSPIV_OK;
 }
 
-int dispatch(const lspiv::PivParams& p, int dtype, bool ensemble, hipStream_t s) {
+int dispatch_kernels(const lspiv::PivParams& p, int dtype, bool ensemble, hipStream_t s);
+
+// PIV kernel of the window's family, then -- per-timestep mode, unless switched off -- the float64 rescue pass over the
+// windows that kernel flagged (piv_rescue.hip)
+int dispatch(const lspiv::PivParams& p0, int dtype, bool ensemble, hipStream_t s) {
+  if (ensemble || !g_opt_rescue.load()) return dispatch_kernels(p0, dtype, ensemble, s);
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  lspiv::PivParams p = p0;
+  rc = rescue_ws(c, s, p.n_tiles, &p);
+  if (rc) return rc;
+  rc = dispatch_kernels(p, dtype, false, s);
+  if (rc) return rc;
+  const hipError_t e = lspiv::launch_piv_rescue(p, dtype, s);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "rescue kernel launch failed: %s", hipGetErrorString(e));
+  return LSPIV_OK;
+}
+
+int dispatch_kernels(const lspiv::PivParams& p, int dtype, bool ensemble, hipStream_t s) {
   const int kind = lspiv_kernel_kind(p.wy, p.wx);
   hipError_t e;
   switch (kind) {
@@ -418,6 +484,21 @@ int lspiv_set_option(const char* name, int value) {
     g_opt_signal_pos.store(value);
     return LSPIV_OK;
   }
+  if (strcmp(name, "rescue") == 0) {
+    if (value < 0 || value > 1) return fail(LSPIV_EINVAL, "rescue must be 0 (float32 results as they are) or 1 (float64 rescue pass)");
+    g_opt_rescue.store(value);
+    return LSPIV_OK;
+  }
+  if (strcmp(name, "rescue_kappa") == 0) {
+    if (value < 0 || value > 1000000) return fail(LSPIV_EINVAL, "rescue_kappa must be 0 .. 1000000 (units of 1e-9)");
+    g_opt_rescue_kappa.store(value);
+    return LSPIV_OK;
+  }
+  if (strcmp(name, "rescue_tau") == 0) {
+    if (value < 0 || value > 1000000) return fail(LSPIV_EINVAL, "rescue_tau must be 0 .. 1000000 (units of 1e-9)");
+    g_opt_rescue_tau.store(value);
+    return LSPIV_OK;
+  }
   return fail(LSPIV_EINVAL, "unknown option '%s'", name);
 }
 int lspiv_get_option(const char* name, int* value) {
@@ -426,7 +507,31 @@ int lspiv_get_option(const char* name, int* value) {
   if (strcmp(name, "border_peak") == 0) { *value = g_opt_border.load(); return LSPIV_OK; }
   if (strcmp(name, "signal_mode") == 0) { *value = g_opt_signal_mode.load(); return LSPIV_OK; }
   if (strcmp(name, "signal_positive") == 0) { *value = g_opt_signal_pos.load(); return LSPIV_OK; }
+  if (strcmp(name, "rescue") == 0) { *value = g_opt_rescue.load(); return LSPIV_OK; }
+  if (strcmp(name, "rescue_kappa") == 0) { *value = g_opt_rescue_kappa.load(); return LSPIV_OK; }
+  if (strcmp(name, "rescue_tau") == 0) { *value = g_opt_rescue_tau.load(); return LSPIV_OK; }
   return fail(LSPIV_EINVAL, "unknown option '%s'", name);
+}
+
+int lspiv_rescue_stats(void* stream, int64_t* stats) {
+  if (!stats) return fail(LSPIV_EINVAL, "stats is NULL");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  void* base = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& w : c->rescue) if (w.stream == s) base = w.base;
+  }
+  for (int k = 0; k < 5; ++k) stats[k] = 0;
+  if (!base) return LSPIV_OK;   // no pass has run on this stream
+  lspiv::RescueHdr h;
+  HIP_TRY(hipMemcpyAsync(&h, base, sizeof(h), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  stats[0] = h.last_fit; stats[1] = h.last_amb;
+  stats[2] = (int64_t)h.total_fit; stats[3] = (int64_t)h.total_amb; stats[4] = (int64_t)h.total_windows;
+  return LSPIV_OK;
 }
 
 int lspiv_kernel_kind(int wy, int wx) {

@@ -31,6 +31,11 @@ __device__ __forceinline__ void wave_argmax(float& v, int& idx) {
   argmax_merge(v, idx, pv, pi);
 }
 
+__device__ __forceinline__ float wave_max_f(float x) {
+  x = half_max(x);
+  return fmaxf(x, __shfl_xor(x, 32, 64));
+}
+
 // ---- block-level pieces: 256 threads (4 waves) work on one window pair -----------------------------------------
 constexpr int DBLOCK_MAX = 512;   // block = as many waves as the strips of one window pair need (2..8), one round of strips
 constexpr int DXB = 8;            // lags per thread: one a-sample and one new b-sample feed 8 FMAs
@@ -232,6 +237,38 @@ __device__ __forceinline__ void subpixel_generic(F ld, int wy, int wx, int imax,
       (float)(wx / 2);
 }
 
+// After plane_reduce / subpixel_generic: does this window go to the float64 rescue pass (common.h, peak_cond)?  One more
+// pass over the plane for the runner-up, the fit's own terms again from the five samples; thread 0 appends the record.
+// The block-per-window kernels are not the tuned path: they assume twice the plane noise of the fused FFT kernels.
+__device__ __forceinline__ void block_rescue_note(const PivParams& p, const float* plane, int n, float* red, float vmax, int imax,
+                                                  float u, float v, uint32_t t, bool ok) {
+  if (!p.rescue_hdr) return;   // uniform
+  float m = 0.0f;
+  for (int o = threadIdx.x; o < n; o += blockDim.x) m = fmaxf(m, o != imax ? plane[o] : 0.0f);
+  m = wave_max_f(m);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[8 + (threadIdx.x >> 6)] = m;
+  __syncthreads();
+  float second = red[8];
+  for (int k = 1; k < (int)(blockDim.x >> 6); ++k) second = fmaxf(second, red[8 + k]);
+  __syncthreads();
+  if (threadIdx.x != 0 || !ok) return;
+  const int wy = p.wy, wx = p.wx;
+  const int i = imax / wx, j = imax - i * wx;
+  const bool border = i <= 0 || i >= wy - 1 || j <= 0 || j >= wx - 1;
+  float cm_v = 1.0f, cm_u = 1.0f, den_v = 1.0f, den_u = 1.0f;
+  if (!border) {
+    const float l0 = __builtin_amdgcn_logf(plane[imax] + kEpsPeak);
+    const float cl = plane[imax - wx] + kEpsPeak, cr = plane[imax + wx] + kEpsPeak;
+    const float cd = plane[imax - 1] + kEpsPeak, cu = plane[imax + 1] + kEpsPeak;
+    gauss_offset_fast(__builtin_amdgcn_logf(cl), l0, __builtin_amdgcn_logf(cr), den_v);
+    gauss_offset_fast(__builtin_amdgcn_logf(cd), l0, __builtin_amdgcn_logf(cu), den_u);
+    cm_v = fminf(cl, cr); cm_u = fminf(cd, cu);
+  }
+  const PeakCond pc = peak_cond(vmax, second, border, cm_v, den_v, v, cm_u, den_u, u, 2.0f * p.rescue_k, p.rescue_tau);
+  if (pc.amb || pc.fit) rescue_note(p.rescue_hdr, p.rescue_fit, p.rescue_cap_fit, p.rescue_amb, p.rescue_cap_amb, t, pc, i, j);
+}
+
 // one window pair -> plane in LDS.  Returns false when the plane is NaN (non-finite input / signal threshold).
 template <typename T>
 __device__ __forceinline__ bool direct_pair(const PivParams& p, uint32_t pair, uint32_t win, float* a, float* b2,
@@ -277,6 +314,7 @@ __global__ __launch_bounds__(DBLOCK_MAX) void piv_direct_kernel(PivParams p) {
   int imax;
   plane_reduce(plane, g.n, red, vmax, imax, sum);
   subpixel_generic([&](int o) { return plane[o]; }, p.wy, p.wx, imax, p.border_mode, u, v);
+  block_rescue_note(p, plane, g.n, red, vmax, imax, u, v, t, ok);
   float cm = vmax, sn = vmax / (sum / (float)g.n);
   if (!ok) u = v = cm = sn = __builtin_nanf("");
   if (threadIdx.x == 0) {
@@ -724,6 +762,7 @@ __global__ __launch_bounds__(FBLOCK, 4) void piv_dft_kernel(PivParams p) {
   int imax;
   plane_reduce(plane, g.n, red, vmax, imax, sum);
   subpixel_generic([&](int o) { return plane[o]; }, p.wy, p.wx, imax, p.border_mode, u, v);
+  block_rescue_note(p, plane, g.n, red, vmax, imax, u, v, t, ok);
   float cm = vmax, sn = vmax / (sum / (float)g.n);
   if (!ok) u = v = cm = sn = __builtin_nanf("");
   if (threadIdx.x == 0) {
@@ -784,6 +823,7 @@ __global__ __launch_bounds__(FBLOCK) void piv_dft_global_kernel(PivParams p) {
     int imax;
     plane_reduce(plane, g.n, red, vmax, imax, sum);
     subpixel_generic([&](int o) { return plane[o]; }, p.wy, p.wx, imax, p.border_mode, u, v);
+    block_rescue_note(p, plane, g.n, red, vmax, imax, u, v, t, ok);
     float cm = vmax, sn = vmax / (sum / (float)g.n);
     if (!ok) u = v = cm = sn = __builtin_nanf("");
     if (threadIdx.x == 0) {

@@ -98,19 +98,19 @@ template <int N> __device__ __forceinline__ float group_sum(float x) { return Ge
 template <int N> __device__ __forceinline__ int group_sum_i(int x) {
   if (Geo<N>::LG == 16) return row_sum_i(x);
   x = half_sum_i(x);
-  if (Geo<N>::LG == 64) x += __shfl_xor(x, 32, 64);
+  if (Geo<N>::LG == 64) x = cross_half_sum_i(x);
   return x;
 }
 template <int N> __device__ __forceinline__ float group_max(float x) {
   if (Geo<N>::LG == 16) return row_max(x);
   x = half_max(x);
-  if (Geo<N>::LG == 64) x = fmaxf(x, __shfl_xor(x, 32, 64));
+  if (Geo<N>::LG == 64) x = cross_half_max(x);
   return x;
 }
 template <int N> __device__ __forceinline__ int group_min_i(int x) {
   if (Geo<N>::LG == 16) return row_min_i(x);
   x = half_min_i(x);
-  if (Geo<N>::LG == 64) x = min(x, __shfl_xor(x, 32, 64));
+  if (Geo<N>::LG == 64) x = cross_half_min_i(x);
   return x;
 }
 
@@ -731,9 +731,13 @@ __device__ __forceinline__ float plane_max(const float (&c)[N], float& row_max) 
 // fft-shifted plane (first maximum in row-major order: smallest shifted row holding the maximum, then the
 // smallest shifted column of that row -- one lane per column compares its LDS sample, DPP min-reductions),
 // and fits the 3-point log-Gaussian.  u, v in pixels; NaN when the peak sits on the plane border.
+// note / g: append the window (result index g) to the lists of the float64 rescue pass if its float32 fit cannot be trusted
+// (common.h, peak_cond); decided and written here, so that nothing of it stays live in the callers.
 template <int N>
-__device__ __forceinline__ void find_peak(float* buf, int lg, const float (&c)[N], float vmax, float row_max, int border_mode,
-                                          float& u, float& v) {
+__device__ __forceinline__ void find_peak(float* buf, int lg, const float (&c)[N], float vmax, float row_max, const PivParams& p,
+                                          float& u, float& v, bool note, uint32_t g) {
+  const int border_mode = p.border_mode;
+  int ip, jp;
   constexpr int LR = Geo<N>::LDS_ROW;
   constexpr int M = N - 1, C = N / 2, NONE = 1 << 12;
   const bool active = lane_active<N>(lg);
@@ -741,9 +745,12 @@ __device__ __forceinline__ void find_peak(float* buf, int lg, const float (&c)[N
   if (active) lds_row_write<N>(buf + lg * LR, c);
   __builtin_amdgcn_wave_barrier();
   const int sh = wrap_n<N>(lr + C);                                                  // this lane's shifted row AND column
-  const int ip = group_min_i<N>((active && row_max == vmax) ? sh : NONE);            // first shifted row with the maximum
+  ip = group_min_i<N>((active && row_max == vmax) ? sh : NONE);                      // first shifted row with the maximum
   const int y = wrap_n<N>(ip + C);
-  const int jp = group_min_i<N>((active && buf[y * LR + lr] == vmax) ? sh : NONE);   // first shifted column in that row
+  const float rowv = buf[y * LR + lr];                                               // the peak row, one sample per lane
+  jp = group_min_i<N>((active && rowv == vmax) ? sh : NONE);                         // first shifted column in that row
+  // runner-up = largest sample other than (ip, jp): the other rows' maxima and the rest of the peak row
+  const float second = group_max<N>(active ? fmaxf(sh != ip ? row_max : 0.0f, sh != jp ? rowv : 0.0f) : 0.0f);
   const bool border = (ip == 0 || ip == M || jp == 0 || jp == M);
   const int x = wrap_n<N>(jp + C);
   const int ym = wrap_n<N>(ip + C - 1), yp = wrap_n<N>(ip + C + 1);
@@ -756,8 +763,32 @@ __device__ __forceinline__ void find_peak(float* buf, int lg, const float (&c)[N
   __builtin_amdgcn_wave_barrier();
   // the fit is a ratio of log differences, so any base works: v_log_f32 (log2, 1 ulp) on inputs >= 1e-7
   const float l0 = __builtin_amdgcn_logf(c0);
-  v = (float)ip + gauss_offset_fast(__builtin_amdgcn_logf(cl), l0, __builtin_amdgcn_logf(cr)) - (float)C;
-  u = (float)jp + gauss_offset_fast(__builtin_amdgcn_logf(cd), l0, __builtin_amdgcn_logf(cu)) - (float)C;
+  float den_v, den_u;
+  v = (float)ip + gauss_offset_fast(__builtin_amdgcn_logf(cl), l0, __builtin_amdgcn_logf(cr), den_v) - (float)C;
+  u = (float)jp + gauss_offset_fast(__builtin_amdgcn_logf(cd), l0, __builtin_amdgcn_logf(cu), den_u) - (float)C;
+  const PeakCond pc = peak_cond(vmax, second, border, fminf(cl, cr), den_v, v, fminf(cd, cu), den_u, u, p.rescue_k, p.rescue_tau);
+  if (note) {
+    uint32_t pos2 = 0xffffffffu;
+    if (__builtin_amdgcn_ballot_w64(pc.amb) != 0) {
+      // cold path (a few windows in 100 000): how many samples are within tau of the maximum, and where is the other one?
+      // With exactly two candidates the rescue pass compares their two float64 sums instead of rebuilding the whole plane.
+      const float thr = vmax * (1.0f - p.rescue_tau);
+      const int pos1 = (ip << 16) | jp;
+      int cnt = 0, other = 0x7fffffff;
+#pragma unroll 1
+      for (int yy = 0; yy < N; ++yy) {
+        const bool cand = active && buf[yy * LR + lr] >= thr;   // column lr of un-shifted row yy
+        const int pos = (wrap_n<N>(yy + C) << 16) | sh;
+        cnt += cand ? 1 : 0;
+        other = (cand && pos != pos1) ? min(other, pos) : other;
+      }
+      cnt = group_sum_i<N>(cnt);
+      other = group_min_i<N>(other);
+      if (cnt == 2) pos2 = (uint32_t)other;
+    }
+    if (lg == 0 && (pc.amb || pc.fit))
+      rescue_note(p.rescue_hdr, p.rescue_fit, p.rescue_cap_fit, p.rescue_amb, p.rescue_cap_amb, g, pc, ip, jp, pos2);
+  }
   if (border) border_result(border_mode, jp - C, ip - C, u, v);
 }
 
@@ -857,23 +888,23 @@ __global__ __launch_bounds__(BLOCK, (kWavesPerSimd<T, N>)) void piv_fft_kernel(P
   const float nanv = __builtin_nanf("");
   {
     float row_max, u, v;
+    const uint32_t g = t[0].pair * p.n_win + t[0].win;
     const float vmax = plane_max<N>(xr, row_max);
-    find_peak<N>(buf, lg, xr, vmax, row_max, p.border_mode, u, v);
+    find_peak<N>(buf, lg, xr, vmax, row_max, p, u, v, p.rescue_hdr && t[0].valid && !skip[0], g);
     float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean[0]);
     if (skip[0]) u = v = cm = sn = nanv;
     if (t[0].valid && lg == 0) {
-      const uint32_t g = t[0].pair * p.n_win + t[0].win;
       p.u[g] = u; p.v[g] = v; p.cmax[g] = cm; p.s2n[g] = sn;
     }
   }
   {
     float row_max, u, v;
+    const uint32_t g = t[1].pair * p.n_win + t[1].win;
     const float vmax = plane_max<N>(xi, row_max);
-    find_peak<N>(buf, lg, xi, vmax, row_max, p.border_mode, u, v);
+    find_peak<N>(buf, lg, xi, vmax, row_max, p, u, v, p.rescue_hdr && t[1].valid && !skip[1], g);
     float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean[1]);
     if (skip[1]) u = v = cm = sn = nanv;
     if (t[1].valid && lg == 0) {
-      const uint32_t g = t[1].pair * p.n_win + t[1].win;
       p.u[g] = u; p.v[g] = v; p.cmax[g] = cm; p.s2n[g] = sn;
     }
   }
@@ -1096,25 +1127,25 @@ __global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_kernel
     const bool valid_a = job_valid && f > p0, valid_b = job_valid && has2;
     {
       float row_max, u, v;
+      const uint32_t g = (f - 1) * p.n_win + win;
       const float vmax = plane_max<N>(xr, row_max);
-      find_peak<N>(buf, lg, xr, vmax, row_max, p.border_mode, u, v);
+      find_peak<N>(buf, lg, xr, vmax, row_max, p, u, v, p.rescue_hdr && valid_a && !dead_a && !skip_a, g);
       float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean_a);
       if (dead_a) { u = v = sn = nanv; cm = 0.0f; }   // zero-variance window: an exactly-zero plane (corr 0, s2n 0/0, peak on the border)
       if (skip_a) u = v = cm = sn = nanv;
       if (valid_a && lg == 0) {
-        const uint32_t g = (f - 1) * p.n_win + win;
         p.u[g] = u; p.v[g] = v; p.cmax[g] = cm; p.s2n[g] = sn;
       }
     }
     {
       float row_max, u, v;
+      const uint32_t g = f * p.n_win + win;
       const float vmax = plane_max<N>(xi, row_max);
-      find_peak<N>(buf, lg, xi, vmax, row_max, p.border_mode, u, v);
+      find_peak<N>(buf, lg, xi, vmax, row_max, p, u, v, p.rescue_hdr && valid_b && !dead_b && !skip_b, g);
       float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean_b);
       if (dead_b) { u = v = sn = nanv; cm = 0.0f; }
       if (skip_b) u = v = cm = sn = nanv;
       if (valid_b && lg == 0) {
-        const uint32_t g = f * p.n_win + win;
         p.u[g] = u; p.v[g] = v; p.cmax[g] = cm; p.s2n[g] = sn;
       }
     }
@@ -1129,8 +1160,9 @@ __global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_kernel
 // The plane is parked in LDS un-shifted (row ky at buf[ky * LDS_ROW + kx]); the reference's plane is its fftshift,
 // shifted index = (k + n/2) mod n.  Same first-maximum rule and arithmetic as find_peak, with run-time n.
 template <int N>
-__device__ __forceinline__ void find_peak_embed(float* buf, int lg, const float (&c)[N], int n, int border_mode, float& vmax,
-                                                float& mean, float& u, float& v) {
+__device__ __forceinline__ void find_peak_embed(float* buf, int lg, const float (&c)[N], int n, const PivParams& p, float& vmax,
+                                                float& mean, float& u, float& v, PeakCond& pc, int& ip, int& jp) {
+  const int border_mode = p.border_mode;
   constexpr int LR = Geo<N>::LDS_ROW;
   constexpr int NONE = 1 << 12;
   f32x4* wrow = reinterpret_cast<f32x4*>(buf + lg * LR);
@@ -1151,9 +1183,11 @@ __device__ __forceinline__ void find_peak_embed(float* buf, int lg, const float 
   mean = group_sum<N>(rsum) / (float)(n * n);
   const int C = n / 2, M = n - 1;
   const int sh = lg + C >= n ? lg + C - n : lg + C;                       // this lane's shifted row AND column
-  const int ip = group_min_i<N>((row_in && rmax == vmax) ? sh : NONE);    // first shifted row with the maximum
+  ip = group_min_i<N>((row_in && rmax == vmax) ? sh : NONE);              // first shifted row with the maximum
   const int y = ip - C < 0 ? ip - C + n : ip - C;
-  const int jp = group_min_i<N>((row_in && buf[y * LR + lg] == vmax) ? sh : NONE);   // first shifted column in that row
+  const float rowv = buf[y * LR + lg];                                    // the peak row, one sample per lane
+  jp = group_min_i<N>((row_in && rowv == vmax) ? sh : NONE);              // first shifted column in that row
+  const float second = group_max<N>(row_in ? fmaxf(sh != ip ? rmax : 0.0f, sh != jp ? rowv : 0.0f) : 0.0f);   // runner-up
   const bool border = (ip == 0 || ip == M || jp == 0 || jp == M);
   const int x = jp - C < 0 ? jp - C + n : jp - C;
   const int ym = y == 0 ? M : y - 1, yp = y == M ? 0 : y + 1;
@@ -1164,8 +1198,10 @@ __device__ __forceinline__ void find_peak_embed(float* buf, int lg, const float 
   const float cd = buf[y * LR + xm] + kEpsPeak;
   const float cu = buf[y * LR + xp] + kEpsPeak;
   const float l0 = __builtin_amdgcn_logf(c0);
-  v = (float)ip + gauss_offset_fast(__builtin_amdgcn_logf(cl), l0, __builtin_amdgcn_logf(cr)) - (float)C;
-  u = (float)jp + gauss_offset_fast(__builtin_amdgcn_logf(cd), l0, __builtin_amdgcn_logf(cu)) - (float)C;
+  float den_v, den_u;
+  v = (float)ip + gauss_offset_fast(__builtin_amdgcn_logf(cl), l0, __builtin_amdgcn_logf(cr), den_v) - (float)C;
+  u = (float)jp + gauss_offset_fast(__builtin_amdgcn_logf(cd), l0, __builtin_amdgcn_logf(cu), den_u) - (float)C;
+  pc = peak_cond(vmax, second, border, fminf(cl, cr), den_v, v, fminf(cd, cu), den_u, u, p.rescue_k, p.rescue_tau);
   if (border) border_result(border_mode, jp - C, ip - C, u, v);
 }
 
@@ -1219,12 +1255,16 @@ __global__ __launch_bounds__(BLOCK, 2) void piv_fft_embed_kernel(PivParams p) {
 #pragma unroll
   for (int k = 0; k < (SINGLE ? 1 : 2); ++k) {
     float vmax, mean, u, v;
-    find_peak_embed<N>(buf, lg, k == 0 ? xr : xi, n, p.border_mode, vmax, mean, u, v);
+    PeakCond pc;
+    int ip, jp;
+    find_peak_embed<N>(buf, lg, k == 0 ? xr : xi, n, p, vmax, mean, u, v, pc, ip, jp);
     float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean);
     if (skip[k]) u = v = cm = sn = nanv;
     if (t[k].valid && lg == 0) {
       const uint32_t g = t[k].pair * p.n_win + t[k].win;
       p.u[g] = u; p.v[g] = v; p.cmax[g] = cm; p.s2n[g] = sn;
+      if (p.rescue_hdr && !skip[k] && (pc.amb || pc.fit))
+        rescue_note(p.rescue_hdr, p.rescue_fit, p.rescue_cap_fit, p.rescue_amb, p.rescue_cap_amb, g, pc, ip, jp);
     }
     if constexpr (PLANES) {
       if (t[k].valid) store_plane_embed<N>(p.planes + ((size_t)t[k].pair * p.n_win + t[k].win) * n * n, buf, lg, n, skip[k]);

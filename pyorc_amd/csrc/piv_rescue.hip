@@ -1,0 +1,369 @@
+// Float64 rescue pass of the PIV kernels (gfx950).
+//
+// The fused kernels compute the correlation planes in float32: every sample carries absolute noise of ~1e-7 .. 4e-7 of the
+// plane maximum.  The reference (ffpiv behind pyorc/velocimetry/ffpiv.py:450-471) fits EVERY plane, also those on which the
+// 3-point log-Gaussian fit amplifies such noise beyond the 1e-4 parity gate -- a neighbour of the peak that is exactly zero
+// in exact arithmetic (clipped), a flat ridge, two samples that tie for the maximum.  The kernels' epilogues recognise those
+// windows (common.h, peak_cond) and append them to two device lists; this pass re-evaluates them from the FRAMES in float64
+// and overwrites u and v (and with them the NaN decision of a border peak):
+//   "fit" records  (g, pos, [pos2]): the arg-max is trusted -- or is one of exactly two candidates, settled first by their two
+//                   float64 sums --; the five samples the fit reads are five circular cross-correlation
+//                   sums  c[k] = (1 / n) sum_m a'[m] b'[m + k],  a' = max((a - mean a) / std a, 0)  -- 5 n multiply-adds, one wave;
+//   "amb" records  (g):          the whole plane, n^2 multiply-adds by one block (normalised windows in LDS up to 64 x 64,
+//                   zero samples of a' skipped -- a wave-uniform branch --, from L2 above), then first arg-max in fft-shifted
+//                   row-major order and the same five-sample fit.
+// Same semantics as the float64 CPU restatement the tests check against (mean as x0 + mean(x - x0), population std,
+// clip [0, 1], eps 1e-7, zero denominator -> 0, border -> NaN / option); the summation order differs (direct sums here, FFT
+// there), i.e. agreement to ~1e-13, not bit identity.  Exact float64 ties (e.g. two lags of a sparse integer-valued window
+// with the very same products) stay a matter of rounding in ANY implementation.
+//
+// A fixed grid strides over both lists; its last block moves the counts to the statistics fields and zeroes the counters, so
+// a pass costs one extra launch and no memset.
+#include "common.h"
+
+namespace lspiv {
+
+namespace {
+
+constexpr int RBLOCK = 256;
+constexpr int RESCUE_LDS_SAMPLES = 4096;   // both normalised windows as doubles: 64 KB
+
+__device__ __forceinline__ double wave_sum_d(double x) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+
+// mean / population std of both windows of a pair in float64, by one wave (every lane gets the totals); the two windows go
+// through the same loops and the loops are unrolled so that a batch of independent loads is in flight per wait
+// lane -> its samples e = lane, lane + 64, ...: (y, x) advanced without a division per sample
+struct LaneWalk {
+  int qy, qx, wx;   // 64 = qy * wx + qx
+  __device__ LaneWalk(int wx_) : qy(64 / wx_), qx(64 - (64 / wx_) * wx_), wx(wx_) {}
+  __device__ __forceinline__ void start(int lane, int& y, int& x) const { y = lane / wx; x = lane - y * wx; }
+  __device__ __forceinline__ void next(int& y, int& x) const {
+    y += qy; x += qx;
+    if (x >= wx) { x -= wx; ++y; }
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ void window_stats_wave2(const T* A, const T* B, int W, int wy, int wx, int lane, double& mean_a,
+                                                   double& sd_a, double& mean_b, double& sd_b) {
+  const int n = wy * wx;
+  const LaneWalk lw(wx);
+  const double x0a = (double)A[0], x0b = (double)B[0];
+  double sa = 0.0, sb = 0.0;
+  int y, x;
+  lw.start(lane, y, x);
+#pragma unroll 8
+  for (int e = lane; e < n; e += 64, lw.next(y, x)) {
+    const int64_t off = (int64_t)y * W + x;
+    sa += (double)A[off] - x0a;
+    sb += (double)B[off] - x0b;
+  }
+  mean_a = x0a + wave_sum_d(sa) / n;
+  mean_b = x0b + wave_sum_d(sb) / n;
+  double qa = 0.0, qb = 0.0;
+  lw.start(lane, y, x);
+#pragma unroll 8
+  for (int e = lane; e < n; e += 64, lw.next(y, x)) {
+    const int64_t off = (int64_t)y * W + x;
+    const double da = (double)A[off] - mean_a, db = (double)B[off] - mean_b;
+    qa += da * da;
+    qb += db * db;
+  }
+  sd_a = sqrt(wave_sum_d(qa) / n);
+  sd_b = sqrt(wave_sum_d(qb) / n);
+}
+
+// max((x - mean) / std, 0) with the reciprocal of std formed once per window (1 ulp of float64 from the division)
+__device__ __forceinline__ double norm_clip(double x, double mean, double inv_sd) {
+  const double d = (x - mean) * inv_sd;
+  return d > 0.0 ? d : 0.0;
+}
+
+// un-shifted lag of a shifted plane coordinate
+__device__ __forceinline__ int unshift(int ip, int c, int w) { return ip - c < 0 ? ip - c + w : ip - c; }
+
+// which of two shifted plane positions holds the larger float64 correlation (ties: the smaller row-major index, np.argmax)
+template <typename T>
+__device__ __forceinline__ uint32_t choose_wave(const PivParams& p, const T* A, const T* B, double mean_a, double inv_a, double mean_b,
+                                                double inv_b, uint32_t pos1, uint32_t pos2, int lane) {
+  const int wy = p.wy, wx = p.wx, n = wy * wx, cy = wy / 2, cx = wx / 2;
+  const int ky1 = unshift((int)(pos1 >> 16), cy, wy), kx1 = unshift((int)(pos1 & 0xffffu), cx, wx);
+  const int ky2 = unshift((int)(pos2 >> 16), cy, wy), kx2 = unshift((int)(pos2 & 0xffffu), cx, wx);
+  const LaneWalk lw(wx);
+  double acc1 = 0.0, acc2 = 0.0;
+  int y, x;
+  lw.start(lane, y, x);
+#pragma unroll 4
+  for (int e = lane; e < n; e += 64, lw.next(y, x)) {
+    const double av = norm_clip((double)A[(int64_t)y * p.W + x], mean_a, inv_a);
+    int y1 = y + ky1; y1 = y1 >= wy ? y1 - wy : y1;
+    int x1 = x + kx1; x1 = x1 >= wx ? x1 - wx : x1;
+    int y2 = y + ky2; y2 = y2 >= wy ? y2 - wy : y2;
+    int x2 = x + kx2; x2 = x2 >= wx ? x2 - wx : x2;
+    acc1 += av * norm_clip((double)B[(int64_t)y1 * p.W + x1], mean_b, inv_b);
+    acc2 += av * norm_clip((double)B[(int64_t)y2 * p.W + x2], mean_b, inv_b);
+  }
+  const double c1 = wave_sum_d(acc1), c2 = wave_sum_d(acc2);   // same scale and clip for both: compare the sums
+  const uint32_t o1 = (pos1 >> 16) * (uint32_t)wx + (pos1 & 0xffffu), o2 = (pos2 >> 16) * (uint32_t)wx + (pos2 & 0xffffu);
+  return (c2 > c1 || (c2 == c1 && o2 < o1)) ? pos2 : pos1;
+}
+
+// the five-sample fit at shifted position (ip, jp), all in float64; one wave, lane 0 stores
+template <typename T>
+__device__ __forceinline__ void fit_wave(const PivParams& p, const T* A, const T* B, double mean_a, double inv_a, double mean_b,
+                                         double inv_b, uint32_t g, int ip, int jp, int lane) {
+  const int wy = p.wy, wx = p.wx, n = wy * wx, cy = wy / 2, cx = wx / 2;
+  if (ip <= 0 || ip >= wy - 1 || jp <= 0 || jp >= wx - 1) {   // border peak: no fit (A5)
+    if (lane == 0) {
+      float u, v;
+      border_result(p.border_mode, jp - cx, ip - cy, u, v);
+      p.u[g] = u; p.v[g] = v;
+    }
+    return;
+  }
+  // un-shifted lags of the peak and its four neighbours
+  const int ky0 = unshift(ip, cy, wy), kx0 = unshift(jp, cx, wx);
+  const int kym = ky0 == 0 ? wy - 1 : ky0 - 1, kyp = ky0 == wy - 1 ? 0 : ky0 + 1;
+  const int kxm = kx0 == 0 ? wx - 1 : kx0 - 1, kxp = kx0 == wx - 1 ? 0 : kx0 + 1;
+  const LaneWalk lw(wx);
+  double acc0 = 0.0, accu = 0.0, accd = 0.0, accl = 0.0, accr = 0.0;
+  int y, x;
+  lw.start(lane, y, x);
+#pragma unroll 4
+  for (int e = lane; e < n; e += 64, lw.next(y, x)) {
+    const double av = norm_clip((double)A[(int64_t)y * p.W + x], mean_a, inv_a);
+    int y0 = y + ky0; y0 = y0 >= wy ? y0 - wy : y0;
+    int ym = y + kym; ym = ym >= wy ? ym - wy : ym;
+    int yp = y + kyp; yp = yp >= wy ? yp - wy : yp;
+    int x0 = x + kx0; x0 = x0 >= wx ? x0 - wx : x0;
+    int xm = x + kxm; xm = xm >= wx ? xm - wx : xm;
+    int xp = x + kxp; xp = xp >= wx ? xp - wx : xp;
+    acc0 += av * norm_clip((double)B[(int64_t)y0 * p.W + x0], mean_b, inv_b);
+    accu += av * norm_clip((double)B[(int64_t)ym * p.W + x0], mean_b, inv_b);
+    accd += av * norm_clip((double)B[(int64_t)yp * p.W + x0], mean_b, inv_b);
+    accl += av * norm_clip((double)B[(int64_t)y0 * p.W + xm], mean_b, inv_b);
+    accr += av * norm_clip((double)B[(int64_t)y0 * p.W + xp], mean_b, inv_b);
+  }
+  const double inv_n = 1.0 / (double)n;
+  auto clip01 = [](double c) { return c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c); };
+  const double c0 = clip01(wave_sum_d(acc0) * inv_n), cu = clip01(wave_sum_d(accu) * inv_n), cd = clip01(wave_sum_d(accd) * inv_n);
+  const double cl = clip01(wave_sum_d(accl) * inv_n), cr = clip01(wave_sum_d(accr) * inv_n);
+  if (lane == 0) {
+    const double eps = 1e-7;
+    const double l0 = log(c0 + eps), lu = log(cu + eps), ld = log(cd + eps), ll = log(cl + eps), lr = log(cr + eps);
+    const double den1 = 2 * lu - 4 * l0 + 2 * ld, den2 = 2 * ll - 4 * l0 + 2 * lr;
+    const double di = den1 != 0.0 ? (lu - ld) / den1 : 0.0;
+    const double dj = den2 != 0.0 ? (ll - lr) / den2 : 0.0;
+    p.v[g] = (float)((double)ip + di - (double)cy);
+    p.u[g] = (float)((double)jp + dj - (double)cx);
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ const T* window_base(const PivParams& p, uint32_t g) {
+  const uint32_t pair = g / p.n_win, win = g - pair * p.n_win;
+  const uint32_t wrow = win / (uint32_t)p.n_cols, wcol = win - wrow * (uint32_t)p.n_cols;
+  return static_cast<const T*>(p.frames) + ((int64_t)pair * p.H + (int64_t)wrow * p.sy) * p.W + (int64_t)wcol * p.sx;
+}
+
+// first arg-max merge in shifted row-major order: larger value wins, equal values -> smaller index
+__device__ __forceinline__ void amax_merge_d(double& v, int& idx, double pv, int pidx) {
+  const bool take = (pv > v) || (pv == v && pidx < idx);
+  v = take ? pv : v;
+  idx = take ? pidx : idx;
+}
+
+// ---- "fit" records: one wave each, statically strided over the grid (every lane of a wave holds the same index: no
+// cross-lane hand-over of a work counter, nothing the compiler has to prove uniform -- a dynamic counter handed round with
+// readfirstlane was structurised into a loop that never left its first record) -------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(RBLOCK) void piv_rescue_fit_kernel(PivParams p) {
+  const RescueHdr* hdr = p.rescue_hdr;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wy = p.wy, wx = p.wx;
+  const uint32_t n_fit = min(hdr->n_fit, p.rescue_cap_fit);
+  const uint32_t n_waves = gridDim.x * (RBLOCK / 64);
+  for (uint32_t i = blockIdx.x * (RBLOCK / 64) + (uint32_t)wave; i < n_fit; i += n_waves) {
+    const uint4 rec = p.rescue_fit[i];
+    const uint32_t g = rec.x;
+    const T* A = window_base<T>(p, g);
+    const T* B = A + p.frame_elems;
+    double mean_a, sd_a, mean_b, sd_b;
+    window_stats_wave2<T>(A, B, p.W, wy, wx, lane, mean_a, sd_a, mean_b, sd_b);
+    // (a zero-variance window is NaN already and is never listed)
+    if (sd_a != 0.0 && sd_b != 0.0) {
+      const double inv_a = 1.0 / sd_a, inv_b = 1.0 / sd_b;
+      uint32_t pos = rec.y;
+      if (rec.z != 0xffffffffu) pos = choose_wave<T>(p, A, B, mean_a, inv_a, mean_b, inv_b, rec.y, rec.z, lane);   // two candidates
+      fit_wave<T>(p, A, B, mean_a, inv_a, mean_b, inv_b, g, (int)(pos >> 16), (int)(pos & 0xffffu), lane);
+    }
+  }
+}
+
+// ---- "amb" records: one block each.  Fast path (wx a multiple of 4, both windows fit the LDS budget): the normalised
+// windows sit in LDS as doubles, b with every row doubled (b2[y][x] = b'[y][x mod wx], 2 wx entries) so that a lag never
+// wraps inside a row; a thread owns strips of FOUR consecutive lags kx .. kx + 3 of one ky and slides a 4-sample window of
+// b2 along x: one broadcast read of a' and one read of b2 feed four float64 FMAs (the shape of the direct float32 kernel,
+// piv_direct.hip).  64 x 64: 16.8 M FMAs per record, ~0.2 ms on one CU. ---------------------------------------------------------
+constexpr int AMB_R = 4;
+
+template <typename T>
+__global__ __launch_bounds__(RBLOCK) void piv_rescue_amb_kernel(PivParams p) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  __shared__ double red_v[RBLOCK / 64];
+  __shared__ int red_i[RBLOCK / 64];
+  RescueHdr* hdr = p.rescue_hdr;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wy = p.wy, wx = p.wx, n = wy * wx, cy = wy / 2, cx = wx / 2;
+  const uint32_t n_amb = min(hdr->n_amb, p.rescue_cap_amb);
+  const bool fast = n <= RESCUE_LDS_SAMPLES && (wx % AMB_R) == 0;
+  const int pitch = 2 * wx;
+  double* la = dsm;
+  double* lb2 = dsm + n;
+  for (uint32_t i = blockIdx.x; i < n_amb; i += gridDim.x) {
+    __syncthreads();   // the previous record's LDS windows and reduction slots are free
+    const uint32_t g = p.rescue_amb[i];
+    const T* A = window_base<T>(p, g);
+    const T* B = A + p.frame_elems;
+    double mean_a, sd_a, mean_b, sd_b;
+    window_stats_wave2<T>(A, B, p.W, wy, wx, lane, mean_a, sd_a, mean_b, sd_b);   // every wave computes the same totals
+    const bool dead = sd_a == 0.0 || sd_b == 0.0;   // never listed; kept out of the control flow around the barriers below
+    const double inv_a = dead ? 1.0 : 1.0 / sd_a, inv_b = dead ? 1.0 : 1.0 / sd_b;
+    double best = -1.0;
+    int bi = 0x7fffffff;
+    if (fast) {
+      for (int e = threadIdx.x; e < n; e += RBLOCK) {
+        const int y = e / wx, x = e - y * wx;
+        la[e] = norm_clip((double)A[(int64_t)y * p.W + x], mean_a, inv_a);
+        const double bv = norm_clip((double)B[(int64_t)y * p.W + x], mean_b, inv_b);
+        lb2[y * pitch + x] = bv;
+        lb2[y * pitch + wx + x] = bv;
+      }
+      __syncthreads();
+      const int strips_per_row = wx / AMB_R, strips = wy * strips_per_row;
+      for (int sidx = threadIdx.x; sidx < strips; sidx += RBLOCK) {
+        const int ky = sidx / strips_per_row, kx0 = (sidx - ky * strips_per_row) * AMB_R;
+        double acc[AMB_R];
+#pragma unroll
+        for (int r = 0; r < AMB_R; ++r) acc[r] = 0.0;
+        int yb = ky;
+        for (int y = 0; y < wy; ++y) {
+          const double* ar = la + y * wx;
+          const double* br = lb2 + yb * pitch + kx0;
+          double w[AMB_R];
+#pragma unroll
+          for (int r = 0; r < AMB_R - 1; ++r) w[r] = br[r];
+#pragma unroll 4
+          for (int x = 0; x < wx; ++x) {
+            w[AMB_R - 1] = br[x + AMB_R - 1];
+            const double av = ar[x];
+#pragma unroll
+            for (int r = 0; r < AMB_R; ++r) acc[r] = fma(av, w[r], acc[r]);
+#pragma unroll
+            for (int r = 0; r < AMB_R - 1; ++r) w[r] = w[r + 1];
+          }
+          yb = yb + 1 == wy ? 0 : yb + 1;
+        }
+        // shifted plane index o = ip * wx + jp of lag (ky, kx): ascending kx inside a strip may wrap jp once, so merge by index
+        const int ipo = ky + cy >= wy ? ky + cy - wy : ky + cy;
+#pragma unroll
+        for (int r = 0; r < AMB_R; ++r) {
+          const int kx = kx0 + r;
+          const int jpo = kx + cx >= wx ? kx + cx - wx : kx + cx;
+          double c = acc[r] / (double)n;
+          c = c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);
+          amax_merge_d(best, bi, c, ipo * wx + jpo);
+        }
+      }
+    } else {
+      // any other shape: one lag at a time, samples normalised on the fly from L2 (functional path: windows above 64 px,
+      // widths that are no multiple of 4)
+      for (int o = threadIdx.x; o < n; o += RBLOCK) {
+        const int ipo = o / wx, jpo = o - ipo * wx;
+        const int ky = ipo - cy < 0 ? ipo - cy + wy : ipo - cy, kx = jpo - cx < 0 ? jpo - cx + wx : jpo - cx;
+        double acc = 0.0;
+        int yb = ky;
+        for (int y = 0; y < wy; ++y) {
+          int xb = kx;
+          for (int x = 0; x < wx; ++x) {
+            const double av = norm_clip((double)A[(int64_t)y * p.W + x], mean_a, inv_a);
+            if (av != 0.0) acc += av * norm_clip((double)B[(int64_t)yb * p.W + xb], mean_b, inv_b);
+            xb = xb + 1 == wx ? 0 : xb + 1;
+          }
+          yb = yb + 1 == wy ? 0 : yb + 1;
+        }
+        double c = acc / (double)n;
+        c = c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);
+        amax_merge_d(best, bi, c, o);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) amax_merge_d(best, bi, __shfl_xor(best, o, 64), __shfl_xor(bi, o, 64));
+    if (lane == 0) { red_v[wave] = best; red_i[wave] = bi; }
+    __syncthreads();
+    best = red_v[0]; bi = red_i[0];
+#pragma unroll
+    for (int k = 1; k < RBLOCK / 64; ++k) amax_merge_d(best, bi, red_v[k], red_i[k]);
+    if (wave == 0 && !dead) {
+      const int ip = bi / wx, jp = bi - ip * wx;
+      fit_wave<T>(p, A, B, mean_a, inv_a, mean_b, inv_b, g, ip, jp, lane);
+    }
+  }
+
+  // ---- the last block to finish publishes the counts and clears the counters for the next pass (the fit kernel of this
+  // pass ran before this one on the same stream) -----------------------------------------------------------------------------
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const uint32_t d = atomicAdd(&hdr->done_blocks, 1u);
+    if (d == gridDim.x - 1) {
+      hdr->last_fit = hdr->n_fit;
+      hdr->last_amb = hdr->n_amb;
+      hdr->total_fit += hdr->n_fit;
+      hdr->total_amb += hdr->n_amb;
+      hdr->total_windows += p.n_tiles;
+      hdr->n_fit = 0; hdr->n_amb = 0; hdr->done_blocks = 0;
+      __threadfence();
+    }
+  }
+}
+
+template <typename T>
+hipError_t launch_rescue_t(const PivParams& p, hipStream_t s) {
+  const int n = p.wy * p.wx;
+  const bool fast = n <= RESCUE_LDS_SAMPLES && (p.wx % AMB_R) == 0;
+  const size_t lds = fast ? (size_t)3 * n * sizeof(double) : 0;
+  // fixed grids (the record counts live on the device): empty blocks leave within microseconds
+  const uint32_t fit_blocks = std::min<uint32_t>(4096u, std::max<uint32_t>(64u, p.n_tiles / 512u + 1u));
+  const uint32_t amb_blocks = std::min<uint32_t>(1024u, std::max<uint32_t>(64u, p.n_tiles / 2048u + 1u));
+  hipLaunchKernelGGL(piv_rescue_fit_kernel<T>, dim3(fit_blocks), dim3(RBLOCK), 0, s, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  static bool attr_set = false;   // per instantiation: the request is a constant upper bound (96 KB)
+  if (!attr_set) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&piv_rescue_amb_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(3 * RESCUE_LDS_SAMPLES * sizeof(double)));
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(piv_rescue_amb_kernel<T>, dim3(amb_blocks), dim3(RBLOCK), lds, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_piv_rescue(const PivParams& p, int dtype, hipStream_t s) {
+  if (!p.rescue_hdr) return hipSuccess;
+  switch (dtype) {
+    case 0: return launch_rescue_t<uint8_t>(p, s);
+    case 1: return launch_rescue_t<float>(p, s);
+    case 2: return launch_rescue_t<double>(p, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace lspiv
