@@ -86,3 +86,16 @@ def well_posed(cond, min_gap=1e-5, min_neighbour=0.02, min_curvature=0.05):
     gate on u, v and counted separately; their NaN mask, corr_max and s2n are still gated.
     """
     return (cond[..., 0] >= min_gap) & (cond[..., 1] >= min_neighbour) & (cond[..., 2] >= min_curvature)
+
+
+def exact_tie(cond, corr_max, tol=1e-12):
+    """Windows whose float64 plane maximum is not unique: the runner-up is within ``tol`` (relative) of it, or the whole
+    plane is below ``tol`` (zero in exact arithmetic -- the normalised windows are >= 0 -- so that every sample ties).
+
+    Which of two equal samples is "the" arg-max is decided by the rounding of whatever transform computed them; the
+    oracle's own answer there is not reproducible by any other implementation (ffpiv's FFT included).  Since round 3
+    these are the ONLY windows the 1e-4 gate on u, v sets aside: the library's float64 rescue pass covers the
+    ill-conditioned ones that ``well_posed`` used to exclude."""
+    cm = np.asarray(corr_max)
+    with np.errstate(invalid="ignore"):
+        return ((cond[..., 0] < tol) | (cm < tol)) & (cm > 0)

@@ -161,21 +161,29 @@ __device__ __forceinline__ int row_sum_i(int x) {
 // The two 32-lane halves of a wave joined with gfx950's v_permlane32_swap: ONE VALU instruction hands every lane l the pair
 // (x[l mod 32], x[32 + l mod 32]) -- where __shfl_xor(x, 32) is a ds_bpermute through the LDS pipe plus an s_waitcnt.  Both
 // halves combine the pair in the same operand order (lower, upper); for +, max and min that gives the bits of the exchange.
+// Inline assembly: ROCm 7.2's __builtin_amdgcn_permlane32_swap maps BOTH of its results to the first register (a one-line
+// test kernel stores v1 twice), so the instruction is written out, with the two wait states the compiler itself puts between
+// a VALU write and this read.
+__device__ __forceinline__ void permlane32_swap(unsigned& a, unsigned& b) {   // a[32..63] <-> b[0..31]
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
 struct HalfPair { float lo, hi; };
 __device__ __forceinline__ HalfPair half_pair_f(float x) {
-  const unsigned b = __builtin_bit_cast(unsigned, x);
-  const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
-  return {__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1])};
+  unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+  permlane32_swap(a, b);   // a = lower half's values in both halves, b = upper half's
+  return {__builtin_bit_cast(float, a), __builtin_bit_cast(float, b)};
 }
 __device__ __forceinline__ float cross_half_sum(float x) { const HalfPair h = half_pair_f(x); return h.lo + h.hi; }
 __device__ __forceinline__ float cross_half_max(float x) { const HalfPair h = half_pair_f(x); return fmaxf(h.lo, h.hi); }
 __device__ __forceinline__ int cross_half_sum_i(int x) {
-  const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
-  return (int)(r[0] + r[1]);
+  unsigned a = (unsigned)x, b = a;
+  permlane32_swap(a, b);
+  return (int)(a + b);
 }
 __device__ __forceinline__ int cross_half_min_i(int x) {
-  const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
-  return min((int)r[0], (int)r[1]);
+  unsigned a = (unsigned)x, b = a;
+  permlane32_swap(a, b);
+  return min((int)a, (int)b);
 }
 // sum over all 64 lanes (two halves joined by the cross-half swap)
 __device__ __forceinline__ float wave_sum(float x) {

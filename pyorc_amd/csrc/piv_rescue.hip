@@ -52,29 +52,27 @@ __device__ __forceinline__ void window_stats_wave2(const T* A, const T* B, int W
                                                    double& sd_a, double& mean_b, double& sd_b) {
   const int n = wy * wx;
   const LaneWalk lw(wx);
+  // one pass over shifted samples d = x - x[0]: mean = x0 + S1 / n, variance = (S2 - S1^2 / n) / n.  With the shift the
+  // cancellation costs ~1e-16 (mean - x0)^2 / variance relative -- 1e-13 at worst for 8-bit imagery -- and a constant window
+  // still has exactly zero variance (all d are 0).
   const double x0a = (double)A[0], x0b = (double)B[0];
-  double sa = 0.0, sb = 0.0;
+  double sa = 0.0, sb = 0.0, qa = 0.0, qb = 0.0;
   int y, x;
   lw.start(lane, y, x);
 #pragma unroll 8
   for (int e = lane; e < n; e += 64, lw.next(y, x)) {
     const int64_t off = (int64_t)y * W + x;
-    sa += (double)A[off] - x0a;
-    sb += (double)B[off] - x0b;
+    const double da = (double)A[off] - x0a, db = (double)B[off] - x0b;
+    sa += da; qa = fma(da, da, qa);
+    sb += db; qb = fma(db, db, qb);
   }
-  mean_a = x0a + wave_sum_d(sa) / n;
-  mean_b = x0b + wave_sum_d(sb) / n;
-  double qa = 0.0, qb = 0.0;
-  lw.start(lane, y, x);
-#pragma unroll 8
-  for (int e = lane; e < n; e += 64, lw.next(y, x)) {
-    const int64_t off = (int64_t)y * W + x;
-    const double da = (double)A[off] - mean_a, db = (double)B[off] - mean_b;
-    qa += da * da;
-    qb += db * db;
-  }
-  sd_a = sqrt(wave_sum_d(qa) / n);
-  sd_b = sqrt(wave_sum_d(qb) / n);
+  sa = wave_sum_d(sa); sb = wave_sum_d(sb); qa = wave_sum_d(qa); qb = wave_sum_d(qb);
+  const double inv_n = 1.0 / (double)n;
+  mean_a = x0a + sa * inv_n;
+  mean_b = x0b + sb * inv_n;
+  const double va = (qa - sa * sa * inv_n) * inv_n, vb = (qb - sb * sb * inv_n) * inv_n;
+  sd_a = va > 0.0 ? sqrt(va) : 0.0;
+  sd_b = vb > 0.0 ? sqrt(vb) : 0.0;
 }
 
 // max((x - mean) / std, 0) with the reciprocal of std formed once per window (1 ulp of float64 from the division)
@@ -152,9 +150,11 @@ __device__ __forceinline__ void fit_wave(const PivParams& p, const T* A, const T
   auto clip01 = [](double c) { return c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c); };
   const double c0 = clip01(wave_sum_d(acc0) * inv_n), cu = clip01(wave_sum_d(accu) * inv_n), cd = clip01(wave_sum_d(accd) * inv_n);
   const double cl = clip01(wave_sum_d(accl) * inv_n), cr = clip01(wave_sum_d(accr) * inv_n);
+  // the five logarithms side by side on five lanes instead of one after the other on lane 0
+  const double eps = 1e-7;
+  const double mine = log((lane == 0 ? c0 : lane == 1 ? cu : lane == 2 ? cd : lane == 3 ? cl : cr) + eps);
+  const double l0 = __shfl(mine, 0, 64), lu = __shfl(mine, 1, 64), ld = __shfl(mine, 2, 64), ll = __shfl(mine, 3, 64), lr = __shfl(mine, 4, 64);
   if (lane == 0) {
-    const double eps = 1e-7;
-    const double l0 = log(c0 + eps), lu = log(cu + eps), ld = log(cd + eps), ll = log(cl + eps), lr = log(cr + eps);
     const double den1 = 2 * lu - 4 * l0 + 2 * ld, den2 = 2 * ll - 4 * l0 + 2 * lr;
     const double di = den1 != 0.0 ? (lu - ld) / den1 : 0.0;
     const double dj = den2 != 0.0 ? (ll - lr) / den2 : 0.0;
@@ -206,9 +206,8 @@ __global__ __launch_bounds__(RBLOCK) void piv_rescue_fit_kernel(PivParams p) {
 
 // ---- "amb" records: one block each.  Fast path (wx a multiple of 4, both windows fit the LDS budget): the normalised
 // windows sit in LDS as doubles, b with every row doubled (b2[y][x] = b'[y][x mod wx], 2 wx entries) so that a lag never
-// wraps inside a row; a thread owns strips of FOUR consecutive lags kx .. kx + 3 of one ky and slides a 4-sample window of
-// b2 along x: one broadcast read of a' and one read of b2 feed four float64 FMAs (the shape of the direct float32 kernel,
-// piv_direct.hip).  64 x 64: 16.8 M FMAs per record, ~0.2 ms on one CU. ---------------------------------------------------------
+// wraps inside a row; a thread owns strips of FOUR consecutive lags kx .. kx + 3 of one ky; the rows of a' are compacted to
+// their non-zero samples, so a step is two broadcast reads (sample, its x) and four reads of b2 for four float64 FMAs. ------
 constexpr int AMB_R = 4;
 
 template <typename T>
@@ -224,6 +223,8 @@ __global__ __launch_bounds__(RBLOCK) void piv_rescue_amb_kernel(PivParams p) {
   const int pitch = 2 * wx;
   double* la = dsm;
   double* lb2 = dsm + n;
+  int* lx = reinterpret_cast<int*>(dsm + 3 * n);   // x of the compacted samples, row by row
+  int* lcnt = lx + n;                              // non-zero samples per row
   for (uint32_t i = blockIdx.x; i < n_amb; i += gridDim.x) {
     __syncthreads();   // the previous record's LDS windows and reduction slots are free
     const uint32_t g = p.rescue_amb[i];
@@ -244,6 +245,20 @@ __global__ __launch_bounds__(RBLOCK) void piv_rescue_amb_kernel(PivParams p) {
         lb2[y * pitch + wx + x] = bv;
       }
       __syncthreads();
+      // The clip at zero leaves most samples of a' exactly zero on particle imagery (and nearly all of them in the sparse
+      // windows that end up here): compact each row to its non-zero samples, in place and in x order (one thread per row:
+      // a fixed order, so the sums are reproducible), and let the lag loops walk those only.
+      if ((int)threadIdx.x < wy) {
+        double* ar = la + threadIdx.x * wx;
+        int* xr = lx + threadIdx.x * wx;
+        int k = 0;
+        for (int x = 0; x < wx; ++x) {
+          const double av = ar[x];
+          if (av != 0.0) { ar[k] = av; xr[k] = x; ++k; }
+        }
+        lcnt[threadIdx.x] = k;
+      }
+      __syncthreads();
       const int strips_per_row = wx / AMB_R, strips = wy * strips_per_row;
       for (int sidx = threadIdx.x; sidx < strips; sidx += RBLOCK) {
         const int ky = sidx / strips_per_row, kx0 = (sidx - ky * strips_per_row) * AMB_R;
@@ -252,19 +267,16 @@ __global__ __launch_bounds__(RBLOCK) void piv_rescue_amb_kernel(PivParams p) {
         for (int r = 0; r < AMB_R; ++r) acc[r] = 0.0;
         int yb = ky;
         for (int y = 0; y < wy; ++y) {
-          const double* ar = la + y * wx;
+          const double* ar = la + y * wx;     // the same words for every thread: broadcast reads, uniform trip count
+          const int* xr = lx + y * wx;
           const double* br = lb2 + yb * pitch + kx0;
-          double w[AMB_R];
+          const int cnt = lcnt[y];
+#pragma unroll 2
+          for (int k = 0; k < cnt; ++k) {
+            const double av = ar[k];
+            const double* bq = br + xr[k];
 #pragma unroll
-          for (int r = 0; r < AMB_R - 1; ++r) w[r] = br[r];
-#pragma unroll 4
-          for (int x = 0; x < wx; ++x) {
-            w[AMB_R - 1] = br[x + AMB_R - 1];
-            const double av = ar[x];
-#pragma unroll
-            for (int r = 0; r < AMB_R; ++r) acc[r] = fma(av, w[r], acc[r]);
-#pragma unroll
-            for (int r = 0; r < AMB_R - 1; ++r) w[r] = w[r + 1];
+            for (int r = 0; r < AMB_R; ++r) acc[r] = fma(av, bq[r], acc[r]);
           }
           yb = yb + 1 == wy ? 0 : yb + 1;
         }
@@ -336,7 +348,7 @@ template <typename T>
 hipError_t launch_rescue_t(const PivParams& p, hipStream_t s) {
   const int n = p.wy * p.wx;
   const bool fast = n <= RESCUE_LDS_SAMPLES && (p.wx % AMB_R) == 0;
-  const size_t lds = fast ? (size_t)3 * n * sizeof(double) : 0;
+  const size_t lds = fast ? (size_t)3 * n * sizeof(double) + (size_t)(n + p.wy) * sizeof(int) : 0;
   // fixed grids (the record counts live on the device): empty blocks leave within microseconds
   const uint32_t fit_blocks = std::min<uint32_t>(4096u, std::max<uint32_t>(64u, p.n_tiles / 512u + 1u));
   const uint32_t amb_blocks = std::min<uint32_t>(1024u, std::max<uint32_t>(64u, p.n_tiles / 2048u + 1u));
@@ -346,7 +358,7 @@ hipError_t launch_rescue_t(const PivParams& p, hipStream_t s) {
   static bool attr_set = false;   // per instantiation: the request is a constant upper bound (96 KB)
   if (!attr_set) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&piv_rescue_amb_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(3 * RESCUE_LDS_SAMPLES * sizeof(double)));
+                            (int)(3 * RESCUE_LDS_SAMPLES * sizeof(double) + (RESCUE_LDS_SAMPLES + 512) * sizeof(int)));
     if (e != hipSuccess) return e;
     attr_set = true;
   }

@@ -63,10 +63,10 @@ def check_sample(stack, out, ws, ov, starts):
     for s in starts:
         fr = stack.frames(s, 3)
         uo, vo, cmo, sno, cond = c_oracle.piv_pairs(fr, ws, ov, return_cond=True)
-        ok = c_oracle.well_posed(cond)
+        ok = ~c_oracle.exact_tie(cond, cmo)   # every window but exact float64 ties (rescue pass, round 3)
         g = out[:, s:s + 2]
         for k, r in enumerate((uo, vo, cmo, sno)):
-            assert np.array_equal(np.isnan(g[k]), np.isnan(r)), (s, k)
+            assert np.array_equal(np.isnan(g[k])[ok], np.isnan(r)[ok]), (s, k)
         assert rel_err(g[2], cmo.astype(np.float64)) <= TOL and rel_err(g[3], sno.astype(np.float64)) <= TOL
         assert ok.mean() > 0.9
         assert rel_err(g[0][ok], uo[ok].astype(np.float64)) <= TOL
@@ -167,7 +167,7 @@ def test_config1_ngwerere_geometry(gpu):
     for k in ("v_x", "v_y", "corr", "s2n"):
         assert np.array_equal(ds[k], whole[k], equal_nan=True)                    # any chunksize, same bits
     uo, vo, cmo, sno, cond = c_oracle.piv_pairs(fr, (32, 32), (16, 16), return_cond=True)
-    ok = c_oracle.well_posed(cond)
+    ok = ~c_oracle.exact_tie(cond, cmo)
     assert ok.mean() > 0.9
     assert rel_err(ds["corr"], cmo.astype(np.float64)) <= TOL and rel_err(ds["s2n"], sno.astype(np.float64)) <= TOL
     vx_ref = (uo.astype(np.float64) * 0.01 * 30.0)
@@ -188,7 +188,7 @@ def test_ngwerere_recipe_window_25(gpu):
     ds = F.get_piv(fr, 25, time=t, resolution=0.01)
     assert ds["v_x"].shape == (6, 64, 71)
     uo, vo, cmo, sno, cond = c_oracle.piv_pairs(fr, (24, 24), (12, 12), return_cond=True)
-    ok = c_oracle.well_posed(cond, min_neighbour=0.05)
+    ok = ~c_oracle.exact_tie(cond, cmo)
     assert ok.mean() > 0.8
     assert np.array_equal(np.isnan(ds["corr"]), np.isnan(cmo))
     assert rel_err(ds["corr"], cmo.astype(np.float64)) <= TOL and rel_err(ds["s2n"], sno.astype(np.float64)) <= TOL

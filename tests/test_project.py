@@ -133,7 +133,7 @@ def test_gpu_project_then_piv_equals_oracle_chain(gpu):
     assert np.array_equal(ortho.astype(np.float64), ref_ortho)
     u, v, cm, sn = pyorc_amd.piv_pairs(ortho, (32, 32), (16, 16))
     uo, vo, cmo, sno, cond = c_oracle.piv_pairs(ref_ortho, (32, 32), (16, 16), return_cond=True)
-    ok = c_oracle.well_posed(cond)
+    ok = ~c_oracle.exact_tie(cond, cmo)   # all windows but exact float64 ties (float64 rescue pass)
     assert ok.mean() > 0.5 and np.array_equal(np.isnan(cm), np.isnan(cmo))
     err = lambda g, r: float(np.nanmax(np.abs(g - r) / np.maximum(np.abs(r), 0.05)))
     assert err(cm, cmo) <= 1e-4 and err(u[ok], uo[ok]) <= 1e-4 and err(v[ok], vo[ok]) <= 1e-4

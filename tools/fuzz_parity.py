@@ -31,8 +31,8 @@ for case in range(n_cases):
         fr[rng.integers(T)] = 0                           # an empty frame
     u, v, cm, sn = pyorc_amd.piv_pairs(fr, (wsy, ws), ov, thr)
     uo, vo, cmo, sno, cond = c_oracle.piv_pairs(fr, (wsy, ws), ov, thr, return_cond=True)
-    ok = c_oracle.well_posed(cond, min_neighbour=0.05 if min(ws, wsy) >= 16 else 0.2)
-    uniq = c_oracle.unique_peak(cond) | (cmo == 0) | np.isnan(cmo)
+    ok = ~c_oracle.exact_tie(cond, cmo)   # round 3: every window but exact float64 ties (the float64 rescue pass covers the ill-conditioned ones)
+    uniq = ok
     def err(g, r, m=None):
         with np.errstate(all="ignore"):
             e = np.abs(g - r) / np.maximum(np.abs(r), 0.05)
@@ -47,6 +47,6 @@ for case in range(n_cases):
         np.savez_compressed(os.path.join(os.environ["FUZZ_DUMP"], f"case{case}.npz"), fr=fr, ws=(wsy, ws), ov=ov, thr=-1 if thr is None else thr,
                             u=u, v=v, cm=cm, sn=sn, uo=uo, vo=vo, cmo=cmo, sno=sno)
     print(f"{'FAIL' if fail else 'ok  '} {case:3d} win ({wsy},{ws}) ov {ov} frame ({T},{H},{W}) {np.dtype(dtype).name:7s} thr {thr} "
-          f"well-posed {ok.mean():.2f} errs c {e_c:.1e} s {e_s:.1e} u {e_u:.1e} v {e_v:.1e} nan {nan_bad}", flush=True)
+          f"gated {ok.mean():.3f} errs c {e_c:.1e} s {e_s:.1e} u {e_u:.1e} v {e_v:.1e} nan {nan_bad}", flush=True)
 print(f"{n_cases} cases, {bad} failures, {time.time()-t_start:.1f} s")
 sys.exit(1 if bad else 0)
