@@ -82,6 +82,15 @@ int         lspiv_synchronize(void);                    /* hipDeviceSynchronize 
  *                      the fraction (default; CHANGELOG 0.9.5 "any of the 2 interrogation window in a window pair"), 1 each
  *                      window POSITION over all frames of the chunk ("fraction of non-zero pixels in the window stack");
  *   "signal_positive"  the score counts 0 samples != 0 ("non-zero pixels", default), 1 samples > 0 ("above zero"). */
+/* Four more readings became switches in round 3 (environment presets LSPIV_V_SIGN, LSPIV_NORM_CLIP, LSPIV_STD_DDOF,
+ * LSPIV_ROUND_ODD), so that a run of the real ffpiv (tests/golden/regen_from_ffpiv.py) can only end in "combination X matches":
+ *   "v_sign"           0 v = row shift of the correlation peak, positive down the image (default; pyorc/api/plot.py:548,576-583
+ *                      flips it for plotting only), 1 negated inside the engine;
+ *   "norm_clip"        1 the normalised window is clipped at zero (default, A3), 0 plain (a - mean) / std -- served by the
+ *                      block-per-window kernels (kinds 3 / 9 / 10), not by the fused FFT kernels;
+ *   "std_ddof"         0 population standard deviation in the window normalisation (default), 1 sample (n - 1);
+ *   "round_odd"        ffpiv.window.round_to_even for odd sizes (pyorc/api/frames.py:167): 0 half-even of x / 2 (25 -> 24, 27 -> 28;
+ *                      default), 1 up (25 -> 26), 2 down (27 -> 26); host side -- pyorc_amd.window.round_to_even reads it. */
 /* Float64 rescue pass (round 3): the reference fits EVERY correlation plane in its engine's precision
  * (pyorc/velocimetry/ffpiv.py:465-471); a float32 plane carries ~1e-7 of noise, which the 3-point log fit amplifies beyond
  * 1e-4 on ill-conditioned peaks (a neighbour that is exactly zero, a flat ridge, a tie for the maximum).  The kernels flag

@@ -64,7 +64,16 @@ EPS_PEAK = 1e-7  # [FFPIV-RESTATED] eps added to the plane before the log-Gaussi
 #                    "any of the 2 interrogation window in a window pair"); 1: one score per window POSITION over the whole
 #                    chunk ("fraction of non-zero pixels in the window stack", pyorc/velocimetry/ffpiv.py:93-97)
 #   signal_positive  0: the score counts samples != 0 ("non-zero pixels"); 1: samples > 0 ("intensities above zero")
-SEMANTICS = {"border_peak": 0, "signal_mode": 0, "signal_positive": 0}
+# Round 3 widened the set (VERDICT r02 "what's missing" 2): every other reading the restatement hard-coded is a switch too,
+# so that a future ffpiv run can only end in "combination X matches":
+#   v_sign           0: v = row shift of the peak as it comes out of the plane (positive = down the image rows; inferred from
+#                    pyorc/api/plot.py:548,576-583, which flips v only for plotting); 1: v negated inside the engine
+#   norm_clip        1: negative lobes of the normalised window are removed, clip(x, 0, max) (A3; OpenPIV's normalize_intensity);
+#                    0: no clip, plain (a - mean) / std
+#   std_ddof         0: population standard deviation (numpy's default, A3); 1: sample standard deviation (n - 1)
+#   round_odd        round_to_even for odd window sizes (A8): 0 round-half-even of x / 2 (25 -> 24, 27 -> 28); 1 up to the next
+#                    even number (25 -> 26); 2 down (27 -> 26)
+SEMANTICS = {"border_peak": 0, "signal_mode": 0, "signal_positive": 0, "v_sign": 0, "norm_clip": 1, "std_ddof": 0, "round_odd": 0}
 
 
 class semantics:
@@ -95,6 +104,11 @@ def round_to_even(input_tuple: Sequence[float]) -> Tuple[int, ...]:
     A8 (unverified): direction for odd sizes.  Restated as round-half-even of x/2 times 2
     (25 -> 24, 27 -> 28); irrelevant for the even sizes of every BASELINE config.
     """
+    mode = SEMANTICS["round_odd"]
+    if mode == 1:
+        return tuple(int(np.ceil(float(x) / 2.0) * 2) for x in input_tuple)
+    if mode == 2:
+        return tuple(int(np.floor(float(x) / 2.0) * 2) for x in input_tuple)
     return tuple(int(np.round(float(x) / 2.0) * 2) for x in input_tuple)
 
 
@@ -166,10 +180,10 @@ def normalize_intensity(win: np.ndarray) -> np.ndarray:
     """Per-window normalisation inside ncc (A3): (a-mean)/std (0 if std==0), clipped to >= 0."""
     win = np.asarray(win, dtype=np.float64)
     off = win - win.mean(axis=(-2, -1), keepdims=True)
-    std = off.std(axis=(-2, -1), keepdims=True)
+    std = off.std(axis=(-2, -1), keepdims=True, ddof=SEMANTICS["std_ddof"])
     out = np.divide(off, std, out=np.zeros_like(off), where=(std != 0))
     # clip(x, 0, max(x)): the upper bound never binds, the lower removes negative lobes
-    return np.maximum(out, 0.0)
+    return np.maximum(out, 0.0) if SEMANTICS["norm_clip"] else out
 
 
 def ncc(win_a: np.ndarray, win_b: np.ndarray) -> np.ndarray:
@@ -318,6 +332,8 @@ def u_v_displacement(corr: np.ndarray, n_rows: int, n_cols: int, engine: str = "
     elif SEMANTICS["border_peak"] == 2:    # integer peak
         uf[edge] = (j - cj)[edge]
         vf[edge] = (i - ci)[edge]
+    if SEMANTICS["v_sign"]:
+        vf = -vf
     return uf.reshape(P, n_rows, n_cols), vf.reshape(P, n_rows, n_cols)
 
 

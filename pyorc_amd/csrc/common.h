@@ -69,6 +69,12 @@ struct PivParams {
   int border_mode;         // arg-max on the plane border: 0 NaN (default), 1 the plane centre (zero displacement), 2 the integer peak
   int nz_positive;         // signal score counts samples != 0 (0, default) or > 0 (1)
   const uint8_t* win_keep; // nullptr, or n_win flags of the "stack" signal mode: 0 = this window position is dropped
+  // two more unpinned readings (A3), run-time options like the three above: the standard deviation of the window
+  // normalisation (std_gain = 1 for the population value, sqrt((n - 1) / n) for the sample value -- a scale on every
+  // normalised window, std_gain2 = its square on every plane), and whether negative lobes are clipped after it (norm_clip = 0
+  // is served by the block-per-window kernels only: lspiv_kernel_kind)
+  float std_gain, std_gain2;
+  int norm_clip;
   float* u;                // each n_tiles float32
   float* v;
   float* cmax;
@@ -381,6 +387,8 @@ hipError_t launch_remap(const void* frames, int dtype, int64_t src_elems, int Hs
 hipError_t launch_remap_win(const uint8_t* frames, int64_t src_elems, int Hs, int Ws, int n_frames, const int* qbase, const uint64_t* qdesc,
                             const int* slow_q, int n_slow, const int* mx, const int* my, const uint16_t* mf, uint8_t* out, int n_out,
                             hipStream_t s);
+// x[i] = -x[i]: the "v_sign" option (a reading of ffpiv nothing in the reference decides), applied after the kernels
+hipError_t launch_negate(float* x, int64_t n, hipStream_t s);
 hipError_t launch_pack_int16(const float* in, int64_t n, float scale, int fill, int16_t* out, hipStream_t s);
 // element-wise pre-processing filters (filters.hip)
 hipError_t launch_time_diff(const void* frames, int dtype, int64_t frame_elems, int64_t n_frames, float thres, int use_abs,

@@ -235,6 +235,12 @@ std::atomic<int> g_opt_border{env_opt("LSPIV_BORDER_PEAK", 0, 2)};        // 0 N
 std::atomic<int> g_opt_signal_mode{env_opt("LSPIV_SIGNAL_MODE", 0, 1)};   // 0 per window pair, 1 per window position over the chunk
 std::atomic<int> g_opt_signal_pos{env_opt("LSPIV_SIGNAL_POSITIVE", 0, 1)}; // 0 samples != 0, 1 samples > 0
 
+// the readings of ffpiv added in round 3 (same names and values as oracle/'s SEMANTICS)
+std::atomic<int> g_opt_v_sign{env_opt("LSPIV_V_SIGN", 0, 1)};      // 0 v as it comes out of the plane, 1 negated
+std::atomic<int> g_opt_norm_clip{getenv("LSPIV_NORM_CLIP") && atoi(getenv("LSPIV_NORM_CLIP")) == 0 ? 0 : 1};   // 1 negative lobes of the normalised window removed (A3), 0 kept
+std::atomic<int> g_opt_std_ddof{env_opt("LSPIV_STD_DDOF", 0, 1)};    // 0 population, 1 sample standard deviation
+std::atomic<int> g_opt_round_odd{env_opt("LSPIV_ROUND_ODD", 0, 2)};   // round_to_even of odd sizes: 0 half-even of x / 2, 1 up, 2 down (host side; kept here so that ONE place holds every switch)
+
 // float64 rescue pass (piv_rescue.hip): on by default; LSPIV_RESCUE=0 / lspiv_set_option("rescue", 0) keeps the float32 results.
 // rescue_kappa: the plane noise the flags assume, in 1e-9 of the plane maximum (measured worst case 2.7e-7 in the units of the
 // flag's error model -- tools/calib_rescue.py; default 500 = 5e-7); rescue_tau: relative arg-max gap, in 1e-9, below which the
@@ -297,6 +303,13 @@ int fill_params(lspiv::PivParams* p, const void* d_frames, int dtype, int64_t T,
   p->signal_threshold = signal_threshold;
   p->border_mode = g_opt_border.load();
   p->nz_positive = g_opt_signal_pos.load();
+  {
+    const double n = (double)wy * (double)wx;
+    const double g2 = g_opt_std_ddof.load() && n > 1.0 ? (n - 1.0) / n : 1.0;   // sample std: every normalised window shrinks by sqrt((n-1)/n)
+    p->std_gain2 = (float)g2;
+    p->std_gain = (float)std::sqrt(g2);
+    p->norm_clip = g_opt_norm_clip.load();
+  }
   // flag model of the rescue pass (common.h, peak_cond): k = 2 kappa / (ln 2 * 1e-4)
   p->rescue_k = (float)(2.0 * g_opt_rescue_kappa.load() * 1e-9 / (0.6931471805599453 * 1e-4));
   p->rescue_tau = (float)(g_opt_rescue_tau.load() * 1e-9);
@@ -322,6 +335,14 @@ int dispatch(const lspiv::PivParams& p0, int dtype, bool ensemble, hipStream_t s
   if (rc) return rc;
   const hipError_t e = lspiv::launch_piv_rescue(p, dtype, s);
   if (e != hipSuccess) return fail(LSPIV_EHIP, "rescue kernel launch failed: %s", hipGetErrorString(e));
+  return LSPIV_OK;
+}
+
+// "v_sign" option: the engine's v negated (after the kernels and the rescue pass; the default costs nothing)
+int apply_v_sign(float* d_v, int64_t n, hipStream_t s) {
+  if (!g_opt_v_sign.load() || !d_v) return LSPIV_OK;
+  const hipError_t e = lspiv::launch_negate(d_v, n, s);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
   return LSPIV_OK;
 }
 
@@ -484,6 +505,26 @@ int lspiv_set_option(const char* name, int value) {
     g_opt_signal_pos.store(value);
     return LSPIV_OK;
   }
+  if (strcmp(name, "v_sign") == 0) {
+    if (value < 0 || value > 1) return fail(LSPIV_EINVAL, "v_sign must be 0 (v = row shift of the peak) or 1 (negated)");
+    g_opt_v_sign.store(value);
+    return LSPIV_OK;
+  }
+  if (strcmp(name, "norm_clip") == 0) {
+    if (value < 0 || value > 1) return fail(LSPIV_EINVAL, "norm_clip must be 1 (negative lobes of the normalised window removed) or 0");
+    g_opt_norm_clip.store(value);
+    return LSPIV_OK;
+  }
+  if (strcmp(name, "std_ddof") == 0) {
+    if (value < 0 || value > 1) return fail(LSPIV_EINVAL, "std_ddof must be 0 (population standard deviation) or 1 (sample)");
+    g_opt_std_ddof.store(value);
+    return LSPIV_OK;
+  }
+  if (strcmp(name, "round_odd") == 0) {
+    if (value < 0 || value > 2) return fail(LSPIV_EINVAL, "round_odd must be 0 (half-even of x / 2), 1 (up) or 2 (down)");
+    g_opt_round_odd.store(value);
+    return LSPIV_OK;
+  }
   if (strcmp(name, "rescue") == 0) {
     if (value < 0 || value > 1) return fail(LSPIV_EINVAL, "rescue must be 0 (float32 results as they are) or 1 (float64 rescue pass)");
     g_opt_rescue.store(value);
@@ -507,6 +548,10 @@ int lspiv_get_option(const char* name, int* value) {
   if (strcmp(name, "border_peak") == 0) { *value = g_opt_border.load(); return LSPIV_OK; }
   if (strcmp(name, "signal_mode") == 0) { *value = g_opt_signal_mode.load(); return LSPIV_OK; }
   if (strcmp(name, "signal_positive") == 0) { *value = g_opt_signal_pos.load(); return LSPIV_OK; }
+  if (strcmp(name, "v_sign") == 0) { *value = g_opt_v_sign.load(); return LSPIV_OK; }
+  if (strcmp(name, "norm_clip") == 0) { *value = g_opt_norm_clip.load(); return LSPIV_OK; }
+  if (strcmp(name, "std_ddof") == 0) { *value = g_opt_std_ddof.load(); return LSPIV_OK; }
+  if (strcmp(name, "round_odd") == 0) { *value = g_opt_round_odd.load(); return LSPIV_OK; }
   if (strcmp(name, "rescue") == 0) { *value = g_opt_rescue.load(); return LSPIV_OK; }
   if (strcmp(name, "rescue_kappa") == 0) { *value = g_opt_rescue_kappa.load(); return LSPIV_OK; }
   if (strcmp(name, "rescue_tau") == 0) { *value = g_opt_rescue_tau.load(); return LSPIV_OK; }
@@ -537,6 +582,10 @@ int lspiv_rescue_stats(void* stream, int64_t* stats) {
 int lspiv_kernel_kind(int wy, int wx) {
   if (wy < 2 || wx < 2 || wy > LSPIV_MAX_WINDOW || wx > LSPIV_MAX_WINDOW) return LSPIV_EUNSUPPORTED;
   if (wy > 64 || wx > 64) return lspiv::piv_dft_fits(wy, wx) ? 9 : 10;   // 2-D DFT of any shape: LDS-resident up to 128 x 128, HBM slots above
+  if (!g_opt_norm_clip.load()) {   // the un-clipped reading of A3 lives in the block-per-window kernels only (a switch, not a tuned path)
+    static const int min_area = getenv("LSPIV_DFT_MIN_AREA") ? atoi(getenv("LSPIV_DFT_MIN_AREA")) : 1500;
+    return wy * wx >= min_area && lspiv::piv_dft_fits(wy, wx) ? 9 : 3;
+  }
   if (wy == 32 && wx == 32) return 1;
   if (wy == 64 && wx == 64) return 2;
   if (wy == 16 && wx == 16) return 6;
@@ -643,7 +692,9 @@ int lspiv_piv_pairs_dev_at(const void* d_frames, int dtype, int64_t T, int64_t H
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   rc = apply_signal_mode(c, &p, dtype, s);
   if (rc) return rc;
-  return dispatch(p, dtype, false, s);
+  rc = dispatch(p, dtype, false, s);
+  if (rc) return rc;
+  return apply_v_sign(p.v, (int64_t)p.n_tiles, s);
 }
 
 int lspiv_piv_pairs_dev(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, int wy, int wx, int oy,
@@ -730,6 +781,8 @@ int lspiv_piv_pairs_at(const void* frames, int dtype, int64_t T, int64_t H, int6
       if (rc) return rc;
       rc = dispatch(p, dev_dtype, false, c->stream);
       if (rc) return rc;
+      rc = apply_v_sign(p.v, (int64_t)p.n_tiles, c->stream);
+      if (rc) return rc;
       launched = p1;
     }
     f0 = f1;
@@ -768,6 +821,8 @@ int lspiv_u_v_displacement(const float* corr_planes, int64_t P, int64_t n_win, i
   HIP_TRY(hipMemcpyAsync(c->d_planes, corr_planes, pb, hipMemcpyHostToDevice, c->stream));
   hipError_t e = lspiv::launch_peaks_from_planes(c->d_planes, (uint32_t)n, wy, wx, g_opt_border.load(), c->d_out, c->d_out + n, c->stream);
   if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  rc = apply_v_sign(c->d_out + n, n, c->stream);
+  if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(u, c->d_out, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(v, c->d_out + n, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -922,6 +977,8 @@ int lspiv_ensemble_finish(lspiv_ensemble* h, float count_min, float n_frames, fl
   if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
   e = lspiv::launch_peaks_from_planes(c->d_planes, (uint32_t)n_win, h->wy, h->wx, g_opt_border.load(), c->d_out, c->d_out + n_win, c->stream);
   if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  rc = apply_v_sign(c->d_out + n_win, (int64_t)n_win, c->stream);
+  if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(u, c->d_out, n_win * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(v, c->d_out + n_win, n_win * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   if (corr_count) HIP_TRY(hipMemcpyAsync(corr_count, h->d_count, n_win * sizeof(float), hipMemcpyDeviceToHost, c->stream));

@@ -100,7 +100,8 @@ struct RowCol {
 // `clip_sum` (optional): sum of the clipped samples, for callers that remove the mean of the clipped window afterwards.
 template <typename T>
 __device__ __forceinline__ float stage_window(const T* src, int W, int wy, int wx, float* dst, int pitch, bool periodic,
-                                              bool nz_pos, float* red, int& nonzero, bool& finite, float* clip_sum = nullptr) {
+                                              bool nz_pos, float* red, int& nonzero, bool& finite, float* clip_sum = nullptr,
+                                              bool clip = true) {
   const int n = wy * wx;
   const float x0 = to_f32(src[0]);
   const RowCol rc0(wx);
@@ -136,7 +137,7 @@ __device__ __forceinline__ float stage_window(const T* src, int W, int wy, int w
   rc = rc0;
   for (int o = threadIdx.x; o < n; o += blockDim.x, rc.next()) {
     const float d = dst[rc.y * pitch + rc.x] - mean;
-    const float c = fmaxf(d, 0.0f);
+    const float c = clip ? fmaxf(d, 0.0f) : d;   // clip: A3's removal of the negative lobes ("norm_clip" option)
     ssq += d * d;
     cs += c;
     dst[rc.y * pitch + rc.x] = c;
@@ -278,8 +279,8 @@ __device__ __forceinline__ bool direct_pair(const PivParams& p, uint32_t pair, u
   const int64_t off = ((int64_t)pair * p.H + (int64_t)wrow * p.sy) * p.W + (int64_t)wcol * p.sx;
   int nza, nzb;
   bool finite = true;
-  const float inv_a = stage_window(frames + off, p.W, p.wy, p.wx, a, p.wx, false, p.nz_positive != 0, red, nza, finite);
-  const float inv_b = stage_window(frames + off + p.frame_elems, p.W, p.wy, p.wx, b2, g.bpitch, true, p.nz_positive != 0, red, nzb, finite);
+  const float inv_a = stage_window(frames + off, p.W, p.wy, p.wx, a, p.wx, false, p.nz_positive != 0, red, nza, finite, nullptr, p.norm_clip != 0);
+  const float inv_b = stage_window(frames + off + p.frame_elems, p.W, p.wy, p.wx, b2, g.bpitch, true, p.nz_positive != 0, red, nzb, finite, nullptr, p.norm_clip != 0);
   __syncthreads();
   bool ok = finite;
   if (p.signal_threshold >= 0.0f) {
@@ -287,7 +288,7 @@ __device__ __forceinline__ bool direct_pair(const PivParams& p, uint32_t pair, u
     ok = ok && (fa >= p.signal_threshold) && (fb >= p.signal_threshold);
     if (p.win_keep) ok = ok && p.win_keep[win];   // "stack" mode: one score per window position (A7)
   }
-  correlate_direct(a, b2, plane, p.wy, p.wx, g, inv_a * inv_b / (float)g.n);
+  correlate_direct(a, b2, plane, p.wy, p.wx, g, inv_a * inv_b * p.std_gain2 / (float)g.n);
   __syncthreads();
   return ok;
 }
@@ -681,8 +682,8 @@ __device__ __forceinline__ bool dft_pair(const PivParams& p, uint32_t pair, uint
   int nza, nzb;
   bool finite = true;
   float sa, sb;                                             // sums of the clipped windows
-  const float inv_a = stage_window(frames + off, p.W, wy, wx, re, P, false, p.nz_positive != 0, red, nza, finite, &sa);
-  const float inv_b = stage_window(frames + off + p.frame_elems, p.W, wy, wx, im, P, false, p.nz_positive != 0, red, nzb, finite, &sb);
+  const float inv_a = p.std_gain * stage_window(frames + off, p.W, wy, wx, re, P, false, p.nz_positive != 0, red, nza, finite, &sa, p.norm_clip != 0);
+  const float inv_b = p.std_gain * stage_window(frames + off + p.frame_elems, p.W, wy, wx, im, P, false, p.nz_positive != 0, red, nzb, finite, &sb, p.norm_clip != 0);
   __syncthreads();
   bool ok = finite;
   if (p.signal_threshold >= 0.0f) {

@@ -489,7 +489,7 @@ __device__ __forceinline__ void prepare_pair_embed(const PivParams& p, const Til
   const bool dead = (inv_a == 0.0f) || (inv_b == 0.0f);
   const float rho = dead ? 0.0f : inv_b * __builtin_amdgcn_rcpf(inv_a);
   // plane = (unnormalised inverse N x N transform) / N^2 / n^2, and the cross-spectrum formula carries a factor 4
-  scale = dead ? 0.0f : inv_a * inv_a * inv_nn * (1.0f / (4.0f * (float)Geo<N>::NN));
+  scale = dead ? 0.0f : inv_a * inv_a * inv_nn * (1.0f / (4.0f * (float)Geo<N>::NN)) * p.std_gain2;
   hi = dead ? 0.0f : 1.0f;
 #pragma unroll
   for (int j = 0; j < N; ++j) xi[j] *= rho;
@@ -664,6 +664,7 @@ __device__ __forceinline__ void correlate_job(const PivParams& p, const TileRef 
     } else {
       if constexpr (sizeof(T) != 1) fetch_rows(k);
       prepare_pair(raw[k][0], raw[k][1], xr, xi, want_nz, p.signal_threshold, p.nz_positive != 0, scale, hi[k], skip[k]);
+      scale *= p.std_gain2;   // 1, or (n - 1) / n under the "std_ddof" option
       if (WANT_NZ && p.win_keep) skip[k] = skip[k] || !p.win_keep[t[k].win];   // "stack" mode (A7)
     }
     fft_n<false>(xr, xi);              // along x
@@ -929,12 +930,12 @@ __global__ __launch_bounds__(BLOCK, (kWavesPerSimd<T, N>)) void piv_fft_kernel(P
 // transforms with depends on where the segment starts, so results are bit-reproducible for a given chunk but differ
 // in the last float32 bit between different chunkings (the per-pair kernel does not; LSPIV_WALK=0 selects it).
 template <typename T, int N, bool WANT_NZ>
-__device__ __forceinline__ void prepare_one(const RowRaw<T, N>& raw, float (&x)[N], bool nz_pos, int& nonzero, bool& finite,
-                                            bool& dead) {
+__device__ __forceinline__ void prepare_one(const RowRaw<T, N>& raw, float (&x)[N], bool nz_pos, float std_gain, int& nonzero,
+                                            bool& finite, bool& dead) {
   // every frame carries 1 / (2 N^2) on top of 1 / std, so each cross spectrum (a product of two frames' spectra)
   // comes out scaled by the 1 / (4 N^4) the planes need -- no multiply in the un-packing loop; a power of two for
   // N = 8 ... 64, i.e. the same bits as scaling the product
-  constexpr float kHalf = 1.0f / (2.0f * (float)Geo<N>::NN);
+  const float kHalf = std_gain * (1.0f / (2.0f * (float)Geo<N>::NN));   // std_gain: 1, or sqrt((n - 1) / n) under the "std_ddof" option
   if constexpr (sizeof(T) == 1) {
     const RowStats st = stats_u8<N>(raw, WANT_NZ, nonzero);
     center_u8<N, true>(raw, st.mean, st.inv_std * kHalf, x);   // max((byte - mean) / std, 0) / (2 N^2) < 1; all zero for a constant window
@@ -995,7 +996,7 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
   if constexpr (sizeof(T) == 4 && kF32Early<N>) {
     // float32 rows: the loads of BOTH frames are in flight before the first is consumed (they land in xr / xi, the registers
     // they are converted in), so an iteration waits for memory once instead of twice
-    constexpr float kHalf = 1.0f / (2.0f * (float)G::NN);
+    const float kHalf = p.std_gain * (1.0f / (2.0f * (float)G::NN));
     const float* r0 = reinterpret_cast<const float*>(row);
     const float* r1 = has2 ? r0 + p.frame_elems : r0;
     load_row_f32<N>(r0, xr);
@@ -1015,9 +1016,9 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
     RowRaw<T, N> raw0, raw1;
     raw0.fetch(row);
     raw1.fetch(has2 ? row + p.frame_elems : row);
-    prepare_one<T, N, WANT_NZ>(raw0, xr, p.nz_positive != 0, nz0, fin0, dead0);
+    prepare_one<T, N, WANT_NZ>(raw0, xr, p.nz_positive != 0, p.std_gain, nz0, fin0, dead0);
     LSPIV_WALK_SB;
-    prepare_one<T, N, WANT_NZ>(raw1, xi, p.nz_positive != 0, nz1, fin1, dead1);
+    prepare_one<T, N, WANT_NZ>(raw1, xi, p.nz_positive != 0, p.std_gain, nz1, fin1, dead1);
   }
   LSPIV_WALK_SB;
   fft_n<false>(xr, xi);              // along x

@@ -76,9 +76,10 @@ __device__ __forceinline__ void window_stats_wave2(const T* A, const T* B, int W
 }
 
 // max((x - mean) / std, 0) with the reciprocal of std formed once per window (1 ulp of float64 from the division)
+// (inv_sd < 0 encodes the "norm_clip" = 0 option: |inv_sd| is the factor and the negative lobes stay)
 __device__ __forceinline__ double norm_clip(double x, double mean, double inv_sd) {
-  const double d = (x - mean) * inv_sd;
-  return d > 0.0 ? d : 0.0;
+  const double d = (x - mean) * fabs(inv_sd);
+  return (d > 0.0 || inv_sd < 0.0) ? d : 0.0;
 }
 
 // un-shifted lag of a shifted plane coordinate
@@ -196,7 +197,8 @@ __global__ __launch_bounds__(RBLOCK) void piv_rescue_fit_kernel(PivParams p) {
     window_stats_wave2<T>(A, B, p.W, wy, wx, lane, mean_a, sd_a, mean_b, sd_b);
     // (a zero-variance window is NaN already and is never listed)
     if (sd_a != 0.0 && sd_b != 0.0) {
-      const double inv_a = 1.0 / sd_a, inv_b = 1.0 / sd_b;
+      const double sg = p.norm_clip ? (double)p.std_gain : -(double)p.std_gain;   // options "std_ddof" / "norm_clip"
+      const double inv_a = sg / sd_a, inv_b = sg / sd_b;
       uint32_t pos = rec.y;
       if (rec.z != 0xffffffffu) pos = choose_wave<T>(p, A, B, mean_a, inv_a, mean_b, inv_b, rec.y, rec.z, lane);   // two candidates
       fit_wave<T>(p, A, B, mean_a, inv_a, mean_b, inv_b, g, (int)(pos >> 16), (int)(pos & 0xffffu), lane);
@@ -233,7 +235,8 @@ __global__ __launch_bounds__(RBLOCK) void piv_rescue_amb_kernel(PivParams p) {
     double mean_a, sd_a, mean_b, sd_b;
     window_stats_wave2<T>(A, B, p.W, wy, wx, lane, mean_a, sd_a, mean_b, sd_b);   // every wave computes the same totals
     const bool dead = sd_a == 0.0 || sd_b == 0.0;   // never listed; kept out of the control flow around the barriers below
-    const double inv_a = dead ? 1.0 : 1.0 / sd_a, inv_b = dead ? 1.0 : 1.0 / sd_b;
+    const double sg = p.norm_clip ? (double)p.std_gain : -(double)p.std_gain;   // options "std_ddof" / "norm_clip"
+    const double inv_a = dead ? 1.0 : sg / sd_a, inv_b = dead ? 1.0 : sg / sd_b;
     double best = -1.0;
     int bi = 0x7fffffff;
     if (fast) {

@@ -145,4 +145,14 @@ hipError_t launch_synth_particles(uint8_t* d_frames, int64_t T, int H, int W, ui
   return e != hipSuccess ? e : hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void negate_kernel(float* x, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) x[i] = -x[i];
+}
+hipError_t launch_negate(float* x, int64_t n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(negate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n);
+  return hipGetLastError();
+}
+
 }  // namespace lspiv

@@ -18,7 +18,13 @@ from . import _lib
 
 
 def round_to_even(input_tuple: Sequence[float]) -> Tuple[int, ...]:
-    """Round window sizes to even integers (pyorc/api/frames.py:167; direction for odd sizes: SURVEY A8)."""
+    """Round window sizes to even integers (pyorc/api/frames.py:167).  The direction for odd sizes is the
+    library option ``round_odd``: 0 round-half-even of x / 2 (25 -> 24, 27 -> 28; default), 1 up, 2 down."""
+    mode = _lib.get_option("round_odd")
+    if mode == 1:
+        return tuple(int(np.ceil(float(x) / 2.0) * 2) for x in input_tuple)
+    if mode == 2:
+        return tuple(int(np.floor(float(x) / 2.0) * 2) for x in input_tuple)
     return tuple(int(np.round(float(x) / 2.0) * 2) for x in input_tuple)
 
 

@@ -406,6 +406,62 @@ def test_unpinned_semantics_switches(gpu, opt, val, ws):
         pyorc_amd.set_option(opt, 0)
 
 
+@pytest.mark.parametrize("ws", [(32, 32), (64, 64), (24, 24), (16, 16), (9, 9), (27, 27), (24, 16), (96, 96)])
+@pytest.mark.parametrize("opt,val", [("v_sign", 1), ("std_ddof", 1), ("norm_clip", 0)])
+def test_unpinned_semantics_switches_round3(gpu, opt, val, ws):
+    """The four readings that became switches in round 3: v negated inside the engine, sample instead of
+    population standard deviation, no clip of the normalised windows -- same names and values in `po.semantics` and in
+    `lspiv_set_option`, every kernel family, per-timestep + plane volume + ensemble finish; all windows gated at 1e-4
+    (the rescue pass honours the options).  `round_odd` is host-side: test_host.py."""
+    import pyorc_amd
+    import pyorc_amd.piv as P
+    from pyorc_amd import _lib
+
+    H, Wd = 3 * ws[0] + 5, 4 * ws[1] + 3
+    fr = particle_stack(4, H, Wd, seed=70 + ws[0], density=0.05)
+    ov = (ws[0] // 2, ws[1] // 2)
+    base = pyorc_amd.piv_pairs(fr, ws, ov)
+    default = 1 if opt == "norm_clip" else 0
+    pyorc_amd.set_option(opt, val)
+    try:
+        if opt == "norm_clip":
+            assert _lib.load().lspiv_kernel_kind(*ws) in (3, 9, 10)          # block-per-window kernels serve this reading
+        with po.semantics(**{opt: val}):
+            u, v, cm, sn, planes = pyorc_amd.piv_pairs(fr, ws, ov, return_planes=True)
+            n_rows, n_cols = u.shape[1:]
+            _, _, corr = po.cross_corr(fr, ws, ov)
+            uo, vo, cmo, sno = po.get_uv_timestep(fr, n_cols, n_rows, ws, ov)
+            assert np.nanmax(np.abs(planes - corr), initial=0.0) < 5e-6
+            flat = np.sort(corr.reshape(corr.shape[0], corr.shape[1], -1), axis=-1)
+            ok = ((flat[..., -1] - flat[..., -2]) > 1e-12 * np.maximum(flat[..., -1], 1e-300)).reshape(uo.shape)   # no exact tie
+            assert ok.mean() > 0.9 and np.array_equal(np.isnan(u)[ok], np.isnan(uo)[ok])
+            assert rel_err(cm, cmo.astype(np.float64)) <= TOL and rel_err(sn, sno.astype(np.float64)) <= TOL
+            assert rel_err(u[ok], uo[ok].astype(np.float64)) <= TOL and rel_err(v[ok], vo[ok].astype(np.float64)) <= TOL
+            u2, v2 = pyorc_amd.u_v_displacement(planes, n_rows, n_cols)        # the plane-volume entry point (float32 planes)
+            both = ~np.isnan(u2) & ~np.isnan(uo) & (np.abs(u2 - uo) < 0.5) & (np.abs(v2 - vo) < 0.5)
+            assert both.mean() > 0.5 and np.percentile(np.abs(v2 - vo)[both], 95) < 2e-3
+        if opt == "v_sign":
+            assert np.array_equal(v, -base[1], equal_nan=True) and np.array_equal(u, base[0], equal_nan=True)
+            if ws[0] == ws[1] and ws[0] <= 64:                                 # ensemble finish honours it too
+                for sign in (1, 0):
+                    pyorc_amd.set_option("v_sign", sign)
+                    ens = P.Ensemble((H, Wd), ws, ov)
+                    ens.accumulate(fr, 0.0, 0.0)
+                    ue, ve, _ = ens.finish(0.0, 1)
+                    ens.close()
+                    if sign:
+                        first = (ue, ve)
+                    else:
+                        assert np.array_equal(first[0], ue, equal_nan=True) and np.array_equal(first[1], -ve, equal_nan=True)
+        elif opt == "std_ddof":
+            n = ws[0] * ws[1]
+            assert np.allclose(cm, base[2] * (n - 1) / n, rtol=2e-6, equal_nan=True)
+        else:
+            assert not np.allclose(cm, base[2], rtol=1e-3, equal_nan=True), "the option changes nothing on this input"
+    finally:
+        pyorc_amd.set_option(opt, default)
+
+
 # ------------------------------------------------------------------ get_ffpiv / get_piv -------------
 def test_get_ffpiv_timestep_chunking_is_bit_identical(gpu):
     """get_ffpiv with the DEFAULT (time-walking) kernels returns the same bits for every chunk size -- the reference

@@ -407,3 +407,28 @@ def test_bench_fails_loudly_without_a_gpu():
                            capture_output=True, text=True, timeout=120, cwd=ROOT)
         assert r.returncode != 0 and r.stdout.strip() == ""
         assert "no gfx950" in r.stderr
+
+
+def test_round_odd_option_reaches_the_python_mirror(lib):
+    """A8 as a switch (round 3): `round_odd` lives in the library's option store, pyorc_amd.window.round_to_even and therefore
+    frames.resolve_window follow it, the oracle has the same switch."""
+    assert window.round_to_even((25, 27, 32)) == (24, 28, 32) == po.round_to_even((25, 27, 32))
+    for mode in (1, 2, 0):
+        _lib.set_option("round_odd", mode)
+        try:
+            with po.semantics(round_odd=mode):
+                assert window.round_to_even((25, 27, 32)) == po.round_to_even((25, 27, 32))
+                assert frames.resolve_window(25) == po.resolve_piv_args(25)
+        finally:
+            _lib.set_option("round_odd", 0)
+    with pytest.raises(_lib.LspivError):
+        _lib.set_option("round_odd", 3)
+    for name, bad in (("v_sign", 2), ("norm_clip", 2), ("std_ddof", -1)):
+        with pytest.raises(_lib.LspivError):
+            _lib.set_option(name, bad)
+    _lib.set_option("norm_clip", 0)
+    try:
+        assert lib.lspiv_kernel_kind(32, 32) == 3 and lib.lspiv_kernel_kind(64, 64) == 9 and lib.lspiv_chunk_alignment(32, 32) == 1
+    finally:
+        _lib.set_option("norm_clip", 1)
+    assert lib.lspiv_kernel_kind(32, 32) == 1
