@@ -73,11 +73,13 @@ def kernel_name_for(ws: int, pairs: int) -> str:
 def measured_traffic(kernel_substr: str, pairs: int, H: int, W: int, window_size: int, overlap: int):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_summary.json,
     written by tools/summarize_profile.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this very
-    command).  Only returned when the profiled launch had the same shape and kernel (latest summary wins); otherwise
-    null."""
+    command).  Only returned when the profiled launch had the same shape and kernel AND the summary carries the hash of the
+    kernel sources in this tree (`code_hash`, pyorc_amd._lib.kernel_code_hash): change the kernel without re-profiling
+    and the line says `traffic: null`, not a stale number.  Latest matching summary wins."""
     import glob
 
     best = None
+    code = _lib.kernel_code_hash()
     want = {"pairs": pairs, "H": H, "W": W, "window": window_size, "overlap": overlap}
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
         try:
@@ -85,7 +87,7 @@ def measured_traffic(kernel_substr: str, pairs: int, H: int, W: int, window_size
         except (OSError, ValueError):
             continue
         launch = d.get("launch", {"pairs": 1000, "H": 1080, "W": 1920, "window": 32, "overlap": 16})
-        if launch != want:
+        if launch != want or d.get("code_hash") != code:   # another shape, or profiled on other kernel code: not this kernel's traffic
             continue
         for name, k in d.get("kernels", {}).items():
             if kernel_substr in name and "hbm_traffic_bytes" in k:
@@ -115,6 +117,7 @@ def roofline_block(lib, kernel_ms: float, pairs: int, H: int, W: int, ws: int, o
                       "frac": round(fpp * pairs / (kernel_ms * 1e-3) / 1e12 / FP32_VALU_TFLOPS, 4)},
     }
     tr = measured_traffic(name.split(",")[0] + "," + name.split(",")[1] + ",", pairs, H, W, ws, ov)
+    r["kernel_code_hash"] = _lib.kernel_code_hash()
     if tr:
         r["traffic"] = tr["bytes"]
         r["traffic_source"] = f"profiles/{tr['source']} (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"

@@ -243,3 +243,15 @@ def as_frames(imgs) -> np.ndarray:
         else:
             a = a.astype(np.float64)
     return np.ascontiguousarray(a)
+
+
+def kernel_code_hash() -> str:
+    """sha256 over the sources of the fused PIV kernels (csrc/piv_fft_impl.h, fft_regs.h, common.h, piv_rescue.hip): what a
+    committed profile summary is keyed to (tools/summarize_profile.py writes it, bench.py compares it)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("piv_fft_impl.h", "fft_regs.h", "common.h", "piv_rescue.hip"):
+        with open(os.path.join(_HERE, "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]

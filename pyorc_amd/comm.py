@@ -30,35 +30,75 @@ _TRANSPORTS = {"rccl": RCCL, "shm": SHM}
 _DT = {np.dtype(np.float32): 1, np.dtype(np.float64): 2}
 
 
+def _rendezvous_dir() -> str:
+    """A directory only this user can write: XDG_RUNTIME_DIR, else a 0700 directory of our own under the temp dir."""
+    d = os.environ.get("XDG_RUNTIME_DIR")
+    if d and os.path.isdir(d) and os.access(d, os.W_OK):
+        return d
+    import tempfile
+
+    d = os.path.join(tempfile.gettempdir(), f"lspiv-{os.getuid()}")
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    st = os.lstat(d)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o077) or not os.path.isdir(d) or os.path.islink(d):
+        raise PermissionError(f"{d} is not a private directory of uid {os.getuid()}")
+    return d
+
+
 def default_id_file() -> str:
     f = os.environ.get("LSPIV_COMM_ID_FILE")
     if f:
         return f
-    return os.path.join("/tmp", f"lspiv_comm_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
+    # under torch.distributed.run all ranks share the agent as parent; bench.py passes LSPIV_COMM_ID_FILE to its own ranks
+    return os.path.join(_rendezvous_dir(), f"lspiv_comm_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
+
+
+def _job_nonce() -> bytes:
+    """8 bytes that tell this job's id file from a stale one of a crashed run at the same path: the launcher's start time
+    (TORCHELASTIC_RUN_ID / LSPIV_COMM_NONCE when given, else the parent process's start time from /proc)."""
+    tag = os.environ.get("LSPIV_COMM_NONCE") or os.environ.get("TORCHELASTIC_RUN_ID")
+    if not tag:
+        try:
+            with open(f"/proc/{os.getppid()}/stat", "rb") as fh:
+                tag = fh.read().rsplit(b")", 1)[1].split()[19].decode()   # starttime of the parent, in clock ticks
+        except (OSError, IndexError):
+            tag = str(os.getppid())
+    import hashlib
+
+    return hashlib.sha256(str(tag).encode()).digest()[:8]
 
 
 def exchange_id(rank: int, world: int, transport: int, path: str, timeout: float = 300.0) -> bytes:
-    """Rank 0 creates the communicator id and writes it to ``path`` (atomically); the others wait for the file."""
+    """Rank 0 creates the communicator id and publishes ``nonce + id`` at ``path``: written to a fresh O_EXCL | O_NOFOLLOW
+    file (0600) next to it and renamed over whatever a crashed run may have left there.  The other ranks poll and accept
+    only a file that carries this job's nonce, so a stale id is never handed to ncclCommInitRank."""
     lib = _lib.load()
+    nonce = _job_nonce()
     if rank == 0:
         buf = C.create_string_buffer(ID_BYTES)
         _lib.check(lib.lspiv_comm_unique_id(transport, buf))
         tmp = f"{path}.{os.getpid()}.tmp"
-        with open(tmp, "wb") as fh:
-            fh.write(buf.raw)
+        try:
+            os.unlink(tmp)
+        except OSError:
+            pass
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+        with os.fdopen(fd, "wb") as fh:
+            fh.write(nonce + buf.raw)
         os.replace(tmp, path)
         return buf.raw
     t0 = time.time()
     while True:
         try:
-            with open(path, "rb") as fh:
+            fd = os.open(path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+            with os.fdopen(fd, "rb") as fh:
                 raw = fh.read()
-            if len(raw) == ID_BYTES:
-                return raw
+            if len(raw) == len(nonce) + ID_BYTES and raw[:len(nonce)] == nonce:
+                return raw[len(nonce):]
         except OSError:
             pass
         if time.time() - t0 > timeout:
-            raise TimeoutError(f"rank {rank}: no communicator id at {path} after {timeout:.0f} s")
+            raise TimeoutError(f"rank {rank}: no communicator id of this job at {path} after {timeout:.0f} s")
         time.sleep(0.02)
 
 

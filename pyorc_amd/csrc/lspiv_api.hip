@@ -870,8 +870,7 @@ static int ensemble_launch(lspiv_ensemble* h, DeviceCtx* c, const void* d_frames
   p.corr_count = h->d_count;
   const int kind = lspiv_kernel_kind(h->wy, h->wx);
   const int walk = lspiv::walk_setting();
-  p.pair_offset = h->pairs_done;
-  h->pairs_done += p.n_pairs;
+  p.pair_offset = h->pairs_done;   // advanced only once the launch has been issued (a failed accumulate changes nothing)
   if (kind_walks(kind) && walk != 0) {
     // segments anchored at multiples of the anchor length of the absolute pair index (common.h): the partial sums, and
     // the order they are merged in, are the same for every chunking whose boundaries are multiples of that length
@@ -887,7 +886,10 @@ static int ensemble_launch(lspiv_ensemble* h, DeviceCtx* c, const void* d_frames
   }
   rc = apply_signal_mode(c, &p, dtype, s);
   if (rc) return rc;
-  return dispatch(p, dtype, true, s);
+  rc = dispatch(p, dtype, true, s);
+  if (rc) return rc;
+  h->pairs_done += p.n_pairs;
+  return LSPIV_OK;
 }
 
 int lspiv_ensemble_accumulate_dev(lspiv_ensemble* h, const void* d_frames, int dtype, int64_t T, float corr_min,

@@ -243,9 +243,10 @@ int lspiv_comm_init(int rank, int world, const void* id, int transport, lspiv_co
     if (r != 0) { delete c; return comm_fail(LSPIV_EHIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, g_rccl.GetErrorString(r)); }
     r = g_rccl.CommCount(c->nccl, &c->nccl_ranks);
     if (r != 0 || c->nccl_ranks != world) {
+      const int reported = c->nccl_ranks;   // read before the communicator object goes away
       g_rccl.CommDestroy(c->nccl);
       delete c;
-      return comm_fail(LSPIV_EHIP, "RCCL reports %d ranks, expected %d", c->nccl_ranks, world);
+      return comm_fail(LSPIV_EHIP, "RCCL reports %d ranks, expected %d", reported, world);
     }
   } else if (transport == LSPIV_COMM_SHM) {
     if (memcmp(id, "LSPIVSHM", 8) != 0) { delete c; return comm_fail(LSPIV_EINVAL, "id was not made by lspiv_comm_unique_id(LSPIV_COMM_SHM)"); }

@@ -70,6 +70,8 @@ class CameraToVelocity:
         self.edge_detect = None if edge_detect is None else (2 * int(edge_detect[0]) + 1, 2 * int(edge_detect[1]) + 1)
         self.minmax = None if minmax is None else (float("-inf") if minmax[0] is None else float(minmax[0]),
                                                    float("inf") if minmax[1] is None else float(minmax[1]))
+        if self.minmax and not self.edge_detect:   # checked before any buffer exists
+            raise ValueError("minmax in the chain follows edge_detect (float32 frames); uint8 frames are not thresholded")
         self.n_rows, self.n_cols = window.get_array_shape(self.ortho_shape, self.window_size, self.overlap)
         if self.n_rows < 1 or self.n_cols < 1:
             raise ValueError("ortho frame smaller than the interrogation window")
@@ -154,8 +156,6 @@ class CameraToVelocity:
         d_cam = self._cam.ensure(T * n_cam)
         d_norm = self._norm.ensure(T * n_cam) if self.normalize_samples else None
         d_edge = self._edge.ensure(T * n_cam * 4) if self.edge_detect else None
-        if self.minmax and not self.edge_detect:
-            raise ValueError("minmax in the chain follows edge_detect (float32 frames); uint8 frames are not thresholded")
         d_ortho = self._ortho.ensure(T * n_ortho * 4)
         d_out = self._out.ensure(4 * n_vec * 4)             # chunk k's (4, pairs_k, n_win) block at float offset 4 * p_k * n_win
         d_pk = self._packed.ensure(4 * n_vec * 2) if packed else None
@@ -176,6 +176,21 @@ class CameraToVelocity:
 
         res = np.empty((4, T - 1, self.n_rows, self.n_cols), dtype=np.int16 if packed else np.float32)
         events = []
+        try:
+            self._stream_chunks(lib, a, bounds, packed, res, events, comp, d_cam, d_norm, d_edge, d_ortho, d_out, d_pk,
+                                d_mean if self.normalize_samples else None)
+        finally:
+            # also on a failure half way (e.g. ENOMEM in a later chunk): nothing of this run may still be queued on the
+            # compute stream when the buffers are reused by the next run() or freed by close(), and no event leaks
+            lib.lspiv_stream_synchronize(comp)
+            for ev in events:
+                lib.lspiv_event_destroy(ev)
+        return res[0], res[1], res[2], res[3]
+
+    def _stream_chunks(self, lib, a, bounds, packed, res, events, comp, d_cam, d_norm, d_edge, d_ortho, d_out, d_pk, d_mean):
+        Hc, Wc = self.cam_shape
+        n_cam, n_ortho, n_win = Hc * Wc, self.ortho_shape[0] * self.ortho_shape[1], self.n_rows * self.n_cols
+        at = lambda base, off: C.c_void_p(base.value + off)
 
         def fetch(k):                                       # result block of chunk k -> its rows of `res`
             p0, p1 = bounds[k], bounds[k + 1]
@@ -215,9 +230,6 @@ class CameraToVelocity:
             if k >= 1:
                 fetch(k - 1)
         fetch(len(bounds) - 2)
-        for ev in events:
-            lib.lspiv_event_destroy(ev)
-        return res[0], res[1], res[2], res[3]
 
     def close(self):
         self.projection.close()

@@ -109,6 +109,11 @@ def sharded_ensemble(load_frames: Callable[[int, int], np.ndarray], n_pairs: int
     CHUNKS there (quirk Q3, ffpiv.py:373,280-281).  It is an argument (what the single-process chunk planner yields,
     ``len(velocimetry.plan_chunks(...)[1])``; 1 for a stack that fits one chunk), NOT the number of ranks: which
     windows survive the filter must not depend on how many GPUs shared the work.
+
+    Reproducibility: a rank's partial sum is bit-reproducible (anchored segments, fixed merge order), but the sum over
+    ranks is a floating-point all-reduce and every rank's handle starts its segment anchors at its own pair 0 -- so the
+    sharded mean planes agree with a single-GPU run to float32 rounding (1e-6 of the plane), not bit for bit.  The
+    per-timestep path (``sharded_piv``) IS bit-identical to one GPU.
     """
     ens = make_ensemble()
     f0, f1 = frame_block(n_pairs, comm.rank, comm.world, align)

@@ -112,15 +112,26 @@ def plan_chunks(n_frames: int, req_mem: float, avail_mem: float, chunksize: Opti
     return chunksize, [(a, b) for a, b in slices if b - a >= 2]
 
 
-def aligned_slices(n_frames: int, chunksize: int, align: int, n_win: int = 1):
+def aligned_slices(n_frames: int, chunksize: int, align: int, n_win: int = 1, fits=None):
     """Frame slices ``[(a, b), ...]`` of chunks whose first PAIR index ``a`` is a multiple of ``align``.
 
-    ``chunksize`` (frames per chunk as planned by :func:`plan_chunks`) is rounded down to a multiple of ``align``
-    pairs, at least one; chunk c owns pairs ``[c C, (c+1) C)`` and reads frames ``[c C, (c+1) C]`` -- the halo frame sits
-    at the end of a chunk instead of at its start (ffpiv.py:140), the union of pairs is the same.
+    ``chunksize`` is the number of FRAMES per chunk planned by :func:`plan_chunks` (a memory bound).  A chunk of C pairs
+    reads C + 1 frames -- the halo frame sits at the end of a chunk instead of at its start (ffpiv.py:140), the union of
+    pairs is the same --, so C is ``chunksize - 1`` rounded down to a multiple of ``align``.  When the plan is smaller
+    than one anchor length (the forced ``chunksize = 5`` of the low-memory branch, or a small user value), one anchor
+    length is still used IF ``fits(n_frames_of_chunk)`` says it fits the memory budget (chunk-invariant results are worth
+    more than a plan that was conservative for the reference's 4-15x larger window stack); otherwise the plan is
+    honoured with chunks of ``chunksize - 1`` pairs that start off the anchors: correct, and equal to an aligned run
+    up to the last float32 bit of a chunk's first pairs.
     """
     n_pairs = n_frames - 1
-    C = max(align, (int(chunksize) // align) * align)
+    budget = max(1, int(chunksize) - 1)            # pairs per chunk the plan allows (C + 1 <= chunksize frames)
+    if budget >= align:
+        C = (budget // align) * align
+    elif fits is None or fits(min(align, n_pairs) + 1):
+        C = align
+    else:
+        C = budget
     max_pairs = max(1, MAX_WINDOWS_PER_LAUNCH // max(n_win, 1))
     if C > max_pairs:  # one launch indexes windows with 32 bits: shrink, aligned if possible
         C = max(1, (max_pairs // align) * align) if max_pairs >= align else max_pairs
@@ -175,7 +186,11 @@ def get_ffpiv(
                                      overlap=overlap, search_area_size=search_area_size, dtype=dtype)
     avail_mem = window.available_memory() / memory_factor
     chunksize, ref_slices = plan_chunks(n_frames, req_mem, avail_mem, chunksize, engine, n_win=n_rows * n_cols)
-    slices = aligned_slices(n_frames, chunksize, window.chunk_alignment(window_size), n_win=n_rows * n_cols)
+    def fits(n_chunk_frames: int) -> bool:   # does a chunk of that many frames respect the planner's memory budget?
+        return window.required_memory(n_frames=n_chunk_frames, dim_size=dim_size, window_size=window_size, overlap=overlap,
+                                      search_area_size=search_area_size, dtype=dtype) <= avail_mem
+
+    slices = aligned_slices(n_frames, chunksize, window.chunk_alignment(window_size), n_win=n_rows * n_cols, fits=fits)
     if time is None:
         time = frames["time"] if _is_xr(frames) else np.arange(n_frames)
     dt_arr = np.asarray(_values(dt), dtype=np.float64)

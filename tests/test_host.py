@@ -319,6 +319,15 @@ def test_aligned_chunk_slices_cover_every_pair_once():
         assert max(b - a - 1 for a, b in sl) <= max(align, cs)
     sl = velocimetry.aligned_slices(1001, 1001, 25, n_win=2**29)   # 32-bit window index per launch
     assert all(b - a - 1 <= 3 for a, b in sl)
+    # a chunk never reads more frames than planned when the plan is at least one anchor length ...
+    for cs in (26, 27, 51, 52, 334, 1001):
+        assert max(b - a for a, b in velocimetry.aligned_slices(1001, cs, 25)) <= cs
+    # ... and a plan below one anchor length is honoured when that anchor does not fit the memory budget (the low-memory
+    # branch of the planner): chunks of chunksize - 1 pairs, off the anchors, every pair still exactly once
+    sl = velocimetry.aligned_slices(101, 5, 25, fits=lambda n: False)
+    assert max(b - a for a, b in sl) == 5 and sum(b - a - 1 for a, b in sl) == 100 and sl[0][0] == 0 and sl[-1][1] == 101
+    assert velocimetry.aligned_slices(101, 5, 25, fits=lambda n: True) == velocimetry.aligned_slices(101, 5, 25)
+    assert velocimetry.aligned_slices(101, 5, 25)[0] == (0, 26)
 
 
 def test_shard_blocks_start_on_anchors():
@@ -432,3 +441,30 @@ def test_round_odd_option_reaches_the_python_mirror(lib):
     finally:
         _lib.set_option("norm_clip", 1)
     assert lib.lspiv_kernel_kind(32, 32) == 1
+
+
+def test_roofline_traffic_is_keyed_to_the_kernel_sources(tmp_path, monkeypatch):
+    """bench.py takes `roofline.traffic` from a committed profile summary only if that summary carries
+    the hash of the kernel sources in this tree; a summary of other code (or without a hash, like round 2's) gives null."""
+    import json
+    import bench
+
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    kern = "void lspiv::piv_fft_walk_kernel<unsigned char, 32, false, false>(lspiv::PivParams)"
+    launch = {"pairs": 1000, "H": 1080, "W": 1920, "window": 32, "overlap": 16}
+
+    def write(name, **extra):
+        json.dump({"tag": name, "launch": launch, "kernels": {kern: {"hbm_traffic_bytes": 2.5e9}}, **extra},
+                  open(prof / f"{name}_summary.json", "w"))
+
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    args = ("piv_fft_walk_kernel<unsigned char, 32,", 1000, 1080, 1920, 32, 16)
+    write("old")                                              # no hash: a round-2 summary
+    write("other", code_hash="0123456789abcdef")              # profiled on other kernel code
+    assert bench.measured_traffic(*args) is None
+    write("now", code_hash=_lib.kernel_code_hash())
+    got = bench.measured_traffic(*args)
+    assert got == {"bytes": 2500000000, "source": "now_summary.json"}
+    assert bench.measured_traffic("piv_fft_walk_kernel<unsigned char, 32,", 500, 1080, 1920, 32, 16) is None   # another launch shape
+    assert len(_lib.kernel_code_hash()) == 16

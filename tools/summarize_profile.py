@@ -13,6 +13,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pyorc_amd._lib import kernel_code_hash  # noqa: E402  (the same function bench.py checks a summary against)
+
 src, tag = sys.argv[1], sys.argv[2]
 # optional: the launch shape the profile was taken on (bench.py defaults), so bench.py can match it: pairs H W window overlap
 shape = [int(x) for x in sys.argv[3:8]] if len(sys.argv) >= 8 else [1000, 1080, 1920, 32, 16]
@@ -26,7 +29,10 @@ stats = {}
 for r in csv.DictReader(open(os.path.join(src, "trace_kernel_stats.csv"))):
     if "piv_" in r["Name"]:
         stats[r["Name"]] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"])}
-out = {"tag": tag, "source": src, "launch": dict(zip(("pairs", "H", "W", "window", "overlap"), shape)), "kernels": {}}
+# code_hash: the PIV kernel sources this profile was taken on; bench.py reports `traffic: null` for a summary whose hash is not
+# the tree's (a number measured on other kernel code is not this kernel's traffic)
+out = {"tag": tag, "source": src, "launch": dict(zip(("pairs", "H", "W", "window", "overlap"), shape)), "code_hash": kernel_code_hash(),
+       "kernels": {}}
 for k in kernels:
     c = {n: sum(v) / len(v) for (kk, n), v in acc.items() if kk == k}
     d = {"counters_mean_per_launch": c, "trace": stats.get(k)}
