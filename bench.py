@@ -95,7 +95,7 @@ def measured_traffic(kernel_substr: str, pairs: int, H: int, W: int, window_size
     return best
 
 
-def roofline_block(lib, kernel_ms: float, pairs: int, H: int, W: int, ws: int, ov: int, n_win: int) -> dict:
+def roofline_block(lib, kernel_ms: float, pairs: int, H: int, W: int, ws: int, ov: int, n_win: int, launch_ms=None) -> dict:
     b_alg_pair = 2 * H * W * 1 + 16 * n_win  # both frames read once + 4 f32 per window
     achieved = b_alg_pair * pairs / (kernel_ms * 1e-3) / 1e9
     fpp = flop_per_pair(ws, n_win)
@@ -118,6 +118,8 @@ def roofline_block(lib, kernel_ms: float, pairs: int, H: int, W: int, ws: int, o
     }
     tr = measured_traffic(name.split(",")[0] + "," + name.split(",")[1] + ",", pairs, H, W, ws, ov)
     r["kernel_code_hash"] = _lib.kernel_code_hash()
+    if launch_ms is not None:
+        r["launch_ms_with_rescue_kernels"] = round(launch_ms, 4)
     if tr:
         r["traffic"] = tr["bytes"]
         r["traffic_source"] = f"profiles/{tr['source']} (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"
@@ -153,7 +155,14 @@ def other_config(lib, name: str, d_frames, pairs: int, H: int, W: int, ws: int, 
 
     go()
     _lib.check(lib.lspiv_synchronize())
-    ms = time_launches(lib, go, reps)
+    ms = time_launches(lib, go, reps)                 # the launch as a caller issues it: PIV kernel + rescue kernels
+    st = (C.c_int64 * 5)()
+    _lib.check(lib.lspiv_rescue_stats(None, st))
+    _lib.set_option("rescue", 0)
+    try:
+        kernel_ms = time_launches(lib, go, reps)      # the dominant kernel alone (roofline)
+    finally:
+        _lib.set_option("rescue", 1)
     _lib.check(lib.lspiv_dev_free(d_out))
     return {
         "workload": name,
@@ -161,8 +170,10 @@ def other_config(lib, name: str, d_frames, pairs: int, H: int, W: int, ws: int, 
         "mvectors_per_s": round(pairs * n_win / (ms * 1e-3) / 1e6, 2),
         "windows_per_pair": n_win,
         "kernel": kernel_name_for(ws, pairs),
-        "kernel_ms": round(ms, 4),
-        "roofline": {k: v for k, v in roofline_block(lib, ms, pairs, H, W, ws, ov, n_win).items()
+        "launch_ms": round(ms, 4),
+        "kernel_ms": round(kernel_ms, 4),
+        "rescued_windows_per_launch": {"fit": int(st[0]), "amb": int(st[1])},
+        "roofline": {k: v for k, v in roofline_block(lib, kernel_ms, pairs, H, W, ws, ov, n_win).items()
                      if k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "secondary",
                               "algorithmic_bytes_per_pair")},
     }
@@ -362,7 +373,41 @@ def main():
 
     # ---- live kernel timing with HIP events on the launch stream (roofline leg, N-independent) --
     reps = max(3, min(a.steps, 10))
-    kernel_ms = time_launches(lib, launch_all, reps)
+    launch_ms = time_launches(lib, launch_all, reps)          # PIV kernel + the two rescue kernels: what a step issues
+    # the dominant kernel alone (what roofline.achieved and the rocprofv3 per-kernel average are about): the same launch with
+    # the rescue pass switched off -- the kernel still evaluates its flags, it just appends nothing and no rescue kernel follows
+    _lib.set_option("rescue", 0)
+    try:
+        kernel_ms = time_launches(lib, launch_all, reps)
+    finally:
+        _lib.set_option("rescue", 1)
+    launch_all()                                              # leave d_out as a full launch (with the rescue pass) produces it
+
+    # float64 rescue pass: how many windows of one launch the kernels flagged (the launches above ran on the library's stream)
+    rescue = None
+    if hasattr(lib, "lspiv_rescue_stats"):
+        st = (C.c_int64 * 5)()
+        _lib.check(lib.lspiv_rescue_stats(None, st))
+        rescue = {"enabled": bool(_lib.get_option("rescue")), "fit_windows_per_launch": int(st[0]), "amb_windows_per_launch": int(st[1]),
+                  "share_of_windows": round((st[0] + st[1]) / max(n_tiles, 1), 6),
+                  "note": "windows whose float32 peak fit the kernel flags as ill-conditioned are re-evaluated from the frames in "
+                          "float64 (csrc/piv_rescue.hip); the two rescue kernels run inside the timed region and inside kernel_ms"}
+    gather_ms = None
+    if comm is not None and state["k"] > 0:
+        # one all-gather of a result block on its own, by events on the gather stream (outside the timed region)
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        _lib.check(lib.lspiv_event_create(C.byref(e0)))
+        _lib.check(lib.lspiv_event_create(C.byref(e1)))
+        sync()
+        _lib.check(lib.lspiv_event_record_on(e0, comm_s))
+        comm.allgather_dev(outs[0].value, alls[0].value, 4 * n_tiles, np.float32, comm_s.value)
+        _lib.check(lib.lspiv_event_record_on(e1, comm_s))
+        _lib.check(lib.lspiv_stream_synchronize(comm_s))
+        ms = C.c_float()
+        _lib.check(lib.lspiv_event_elapsed_ms(e0, e1, C.byref(ms)))
+        gather_ms = round(ms.value, 4)
+        _lib.check(lib.lspiv_event_destroy(e0))
+        _lib.check(lib.lspiv_event_destroy(e1))
 
     dist_check = None
     if comm is not None and state["k"] > 0:
@@ -412,12 +457,15 @@ def main():
             "scaling_denominator": "per-GPU work fixed at --pairs: speed-up at N GPUs = value(N) / value(1) of this command "
                                    "(north_star's >= 6.5x at 8 GPUs = 8000 pairs on 8 GPUs vs 1000 pairs on 1)",
         },
-        "roofline": roofline_block(lib, kernel_ms, a.pairs, H, W, a.window, a.overlap, n_win),
+        "roofline": roofline_block(lib, kernel_ms, a.pairs, H, W, a.window, a.overlap, n_win, launch_ms),
     }
+    if rescue is not None:
+        out["config"]["rescue"] = rescue
     if comm is not None:
         out["config"]["comm"] = {"transport": comm.transport, "ranks_reported_by_transport": comm.backend_ranks,
                                  "allgather_matches_single_launch": dist_check,
                                  "allgather_bytes_per_rank_per_step": 4 * n_tiles * 4,
+                                 "allgather_ms_alone": gather_ms,
                                  **({"same_device_plumbing_test": True} if same_device else {})}
     # ---- CPU baseline on a bounded sample of the same stack (rank 0, N = 1 only) --------------
     if world == 1 and a.cpu_pairs != 0:

@@ -28,9 +28,31 @@ namespace {
 constexpr int RBLOCK = 256;
 constexpr int RESCUE_LDS_SAMPLES = 4096;   // both normalised windows as doubles: 64 KB
 
+// float64 sum over the wave, every lane gets the total: the DPP / swizzle / permlane32 steps of the float32 reductions
+// (common.h) on the two halves of the double -- __shfl_xor on a double is two ds_bpermute plus a wait per step
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double x) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = (unsigned)dpp_i<CTRL>((int)(unsigned)b), hi = (unsigned)dpp_i<CTRL>((int)(unsigned)(b >> 32));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double wave_sum_d(double x) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+  x += dpp_d<DPP_XOR1>(x);
+  x += dpp_d<DPP_XOR2>(x);
+  x += dpp_d<DPP_HALF_MIRROR>(x);
+  x += dpp_d<DPP_MIRROR>(x);
+  {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)swz16_i((int)(unsigned)b), hi = (unsigned)swz16_i((int)(unsigned)(b >> 32));
+    x += __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+  }
+  {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+    unsigned lo_a = (unsigned)b, lo_b = lo_a, hi_a = (unsigned)(b >> 32), hi_b = hi_a;
+    permlane32_swap(lo_a, lo_b);
+    permlane32_swap(hi_a, hi_b);
+    x = __builtin_bit_cast(double, ((unsigned long long)hi_a << 32) | lo_a) + __builtin_bit_cast(double, ((unsigned long long)hi_b << 32) | lo_b);
+  }
   return x;
 }
 
@@ -47,9 +69,9 @@ struct LaneWalk {
   }
 };
 
-template <typename T>
+template <typename T, bool STAGE = false>
 __device__ __forceinline__ void window_stats_wave2(const T* A, const T* B, int W, int wy, int wx, int lane, double& mean_a,
-                                                   double& sd_a, double& mean_b, double& sd_b) {
+                                                   double& sd_a, double& mean_b, double& sd_b, T* la = nullptr, T* lb = nullptr) {
   const int n = wy * wx;
   const LaneWalk lw(wx);
   // one pass over shifted samples d = x - x[0]: mean = x0 + S1 / n, variance = (S2 - S1^2 / n) / n.  With the shift the
@@ -62,7 +84,9 @@ __device__ __forceinline__ void window_stats_wave2(const T* A, const T* B, int W
 #pragma unroll 8
   for (int e = lane; e < n; e += 64, lw.next(y, x)) {
     const int64_t off = (int64_t)y * W + x;
-    const double da = (double)A[off] - x0a, db = (double)B[off] - x0b;
+    const T ra = A[off], rb = B[off];
+    if constexpr (STAGE) { la[e] = ra; lb[e] = rb; }   // dense copy of the window (pitch wx) in the wave's LDS slice
+    const double da = (double)ra - x0a, db = (double)rb - x0b;
     sa += da; qa = fma(da, da, qa);
     sb += db; qb = fma(db, db, qb);
   }
@@ -86,8 +110,8 @@ __device__ __forceinline__ double norm_clip(double x, double mean, double inv_sd
 __device__ __forceinline__ int unshift(int ip, int c, int w) { return ip - c < 0 ? ip - c + w : ip - c; }
 
 // which of two shifted plane positions holds the larger float64 correlation (ties: the smaller row-major index, np.argmax)
-template <typename T>
-__device__ __forceinline__ uint32_t choose_wave(const PivParams& p, const T* A, const T* B, double mean_a, double inv_a, double mean_b,
+template <typename PA>
+__device__ __forceinline__ uint32_t choose_wave(const PivParams& p, PA A, PA B, int pitch, double mean_a, double inv_a, double mean_b,
                                                 double inv_b, uint32_t pos1, uint32_t pos2, int lane) {
   const int wy = p.wy, wx = p.wx, n = wy * wx, cy = wy / 2, cx = wx / 2;
   const int ky1 = unshift((int)(pos1 >> 16), cy, wy), kx1 = unshift((int)(pos1 & 0xffffu), cx, wx);
@@ -98,13 +122,13 @@ __device__ __forceinline__ uint32_t choose_wave(const PivParams& p, const T* A, 
   lw.start(lane, y, x);
 #pragma unroll 4
   for (int e = lane; e < n; e += 64, lw.next(y, x)) {
-    const double av = norm_clip((double)A[(int64_t)y * p.W + x], mean_a, inv_a);
+    const double av = norm_clip((double)A[y * pitch + x], mean_a, inv_a);
     int y1 = y + ky1; y1 = y1 >= wy ? y1 - wy : y1;
     int x1 = x + kx1; x1 = x1 >= wx ? x1 - wx : x1;
     int y2 = y + ky2; y2 = y2 >= wy ? y2 - wy : y2;
     int x2 = x + kx2; x2 = x2 >= wx ? x2 - wx : x2;
-    acc1 += av * norm_clip((double)B[(int64_t)y1 * p.W + x1], mean_b, inv_b);
-    acc2 += av * norm_clip((double)B[(int64_t)y2 * p.W + x2], mean_b, inv_b);
+    acc1 += av * norm_clip((double)B[y1 * pitch + x1], mean_b, inv_b);
+    acc2 += av * norm_clip((double)B[y2 * pitch + x2], mean_b, inv_b);
   }
   const double c1 = wave_sum_d(acc1), c2 = wave_sum_d(acc2);   // same scale and clip for both: compare the sums
   const uint32_t o1 = (pos1 >> 16) * (uint32_t)wx + (pos1 & 0xffffu), o2 = (pos2 >> 16) * (uint32_t)wx + (pos2 & 0xffffu);
@@ -112,8 +136,9 @@ __device__ __forceinline__ uint32_t choose_wave(const PivParams& p, const T* A, 
 }
 
 // the five-sample fit at shifted position (ip, jp), all in float64; one wave, lane 0 stores
-template <typename T>
-__device__ __forceinline__ void fit_wave(const PivParams& p, const T* A, const T* B, double mean_a, double inv_a, double mean_b,
+// (A, B: the two windows, in global memory (pitch = frame width) or staged in LDS (pitch = window width))
+template <typename PA>
+__device__ __forceinline__ void fit_wave(const PivParams& p, PA A, PA B, int pitch, double mean_a, double inv_a, double mean_b,
                                          double inv_b, uint32_t g, int ip, int jp, int lane) {
   const int wy = p.wy, wx = p.wx, n = wy * wx, cy = wy / 2, cx = wx / 2;
   if (ip <= 0 || ip >= wy - 1 || jp <= 0 || jp >= wx - 1) {   // border peak: no fit (A5)
@@ -134,18 +159,18 @@ __device__ __forceinline__ void fit_wave(const PivParams& p, const T* A, const T
   lw.start(lane, y, x);
 #pragma unroll 4
   for (int e = lane; e < n; e += 64, lw.next(y, x)) {
-    const double av = norm_clip((double)A[(int64_t)y * p.W + x], mean_a, inv_a);
+    const double av = norm_clip((double)A[y * pitch + x], mean_a, inv_a);
     int y0 = y + ky0; y0 = y0 >= wy ? y0 - wy : y0;
     int ym = y + kym; ym = ym >= wy ? ym - wy : ym;
     int yp = y + kyp; yp = yp >= wy ? yp - wy : yp;
     int x0 = x + kx0; x0 = x0 >= wx ? x0 - wx : x0;
     int xm = x + kxm; xm = xm >= wx ? xm - wx : xm;
     int xp = x + kxp; xp = xp >= wx ? xp - wx : xp;
-    acc0 += av * norm_clip((double)B[(int64_t)y0 * p.W + x0], mean_b, inv_b);
-    accu += av * norm_clip((double)B[(int64_t)ym * p.W + x0], mean_b, inv_b);
-    accd += av * norm_clip((double)B[(int64_t)yp * p.W + x0], mean_b, inv_b);
-    accl += av * norm_clip((double)B[(int64_t)y0 * p.W + xm], mean_b, inv_b);
-    accr += av * norm_clip((double)B[(int64_t)y0 * p.W + xp], mean_b, inv_b);
+    acc0 += av * norm_clip((double)B[y0 * pitch + x0], mean_b, inv_b);
+    accu += av * norm_clip((double)B[ym * pitch + x0], mean_b, inv_b);
+    accd += av * norm_clip((double)B[yp * pitch + x0], mean_b, inv_b);
+    accl += av * norm_clip((double)B[y0 * pitch + xm], mean_b, inv_b);
+    accr += av * norm_clip((double)B[y0 * pitch + xp], mean_b, inv_b);
   }
   const double inv_n = 1.0 / (double)n;
   auto clip01 = [](double c) { return c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c); };
@@ -181,11 +206,22 @@ __device__ __forceinline__ void amax_merge_d(double& v, int& idx, double pv, int
 // ---- "fit" records: one wave each, statically strided over the grid (every lane of a wave holds the same index: no
 // cross-lane hand-over of a work counter, nothing the compiler has to prove uniform -- a dynamic counter handed round with
 // readfirstlane was structurised into a loop that never left its first record) -------------------------------------------
+// Staging: a record's two windows are read ONCE from L2 into the wave's slice of LDS (in the frames' own sample type), the
+// statistics ride on that pass, and the six samples per element of the fit come out of LDS -- read straight from the frames the
+// fit issues 6 n single-sample loads through the texture path, which is what bounded this kernel (140 -> ~50 us per 32 k records).
+// Windows whose two copies exceed the slice (float32 64 x 64 and up) take the direct path.
+constexpr int FIT_LDS_PER_WAVE = 8192;
+
 template <typename T>
 __global__ __launch_bounds__(RBLOCK) void piv_rescue_fit_kernel(PivParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+  typedef const T __attribute__((address_space(3))) * LdsPtr;
   const RescueHdr* hdr = p.rescue_hdr;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wy = p.wy, wx = p.wx;
+  const int wy = p.wy, wx = p.wx, n = wy * wx;
+  const bool staged = (size_t)2 * n * sizeof(T) <= (size_t)FIT_LDS_PER_WAVE;
+  T* la = reinterpret_cast<T*>(fsm + (size_t)wave * FIT_LDS_PER_WAVE);
+  T* lb = la + n;
   const uint32_t n_fit = min(hdr->n_fit, p.rescue_cap_fit);
   const uint32_t n_waves = gridDim.x * (RBLOCK / 64);
   for (uint32_t i = blockIdx.x * (RBLOCK / 64) + (uint32_t)wave; i < n_fit; i += n_waves) {
@@ -194,14 +230,23 @@ __global__ __launch_bounds__(RBLOCK) void piv_rescue_fit_kernel(PivParams p) {
     const T* A = window_base<T>(p, g);
     const T* B = A + p.frame_elems;
     double mean_a, sd_a, mean_b, sd_b;
-    window_stats_wave2<T>(A, B, p.W, wy, wx, lane, mean_a, sd_a, mean_b, sd_b);
+    if (staged) window_stats_wave2<T, true>(A, B, p.W, wy, wx, lane, mean_a, sd_a, mean_b, sd_b, la, lb);
+    else window_stats_wave2<T, false>(A, B, p.W, wy, wx, lane, mean_a, sd_a, mean_b, sd_b, nullptr, nullptr);
     // (a zero-variance window is NaN already and is never listed)
     if (sd_a != 0.0 && sd_b != 0.0) {
       const double sg = p.norm_clip ? (double)p.std_gain : -(double)p.std_gain;   // options "std_ddof" / "norm_clip"
       const double inv_a = sg / sd_a, inv_b = sg / sd_b;
       uint32_t pos = rec.y;
-      if (rec.z != 0xffffffffu) pos = choose_wave<T>(p, A, B, mean_a, inv_a, mean_b, inv_b, rec.y, rec.z, lane);   // two candidates
-      fit_wave<T>(p, A, B, mean_a, inv_a, mean_b, inv_b, g, (int)(pos >> 16), (int)(pos & 0xffffu), lane);
+      if (staged) {
+        __builtin_amdgcn_wave_barrier();   // the wave's own LDS writes above are in order with the reads below; this pins the compiler
+        const LdsPtr SA = (LdsPtr)la, SB = (LdsPtr)lb;
+        if (rec.z != 0xffffffffu) pos = choose_wave(p, SA, SB, wx, mean_a, inv_a, mean_b, inv_b, rec.y, rec.z, lane);   // two candidates
+        fit_wave(p, SA, SB, wx, mean_a, inv_a, mean_b, inv_b, g, (int)(pos >> 16), (int)(pos & 0xffffu), lane);
+        __builtin_amdgcn_wave_barrier();
+      } else {
+        if (rec.z != 0xffffffffu) pos = choose_wave(p, A, B, p.W, mean_a, inv_a, mean_b, inv_b, rec.y, rec.z, lane);
+        fit_wave(p, A, B, p.W, mean_a, inv_a, mean_b, inv_b, g, (int)(pos >> 16), (int)(pos & 0xffffu), lane);
+      }
     }
   }
 }
@@ -325,7 +370,7 @@ __global__ __launch_bounds__(RBLOCK) void piv_rescue_amb_kernel(PivParams p) {
     for (int k = 1; k < RBLOCK / 64; ++k) amax_merge_d(best, bi, red_v[k], red_i[k]);
     if (wave == 0 && !dead) {
       const int ip = bi / wx, jp = bi - ip * wx;
-      fit_wave<T>(p, A, B, mean_a, inv_a, mean_b, inv_b, g, ip, jp, lane);
+      fit_wave(p, A, B, p.W, mean_a, inv_a, mean_b, inv_b, g, ip, jp, lane);
     }
   }
 
@@ -355,7 +400,8 @@ hipError_t launch_rescue_t(const PivParams& p, hipStream_t s) {
   // fixed grids (the record counts live on the device): empty blocks leave within microseconds
   const uint32_t fit_blocks = std::min<uint32_t>(4096u, std::max<uint32_t>(64u, p.n_tiles / 512u + 1u));
   const uint32_t amb_blocks = std::min<uint32_t>(1024u, std::max<uint32_t>(64u, p.n_tiles / 2048u + 1u));
-  hipLaunchKernelGGL(piv_rescue_fit_kernel<T>, dim3(fit_blocks), dim3(RBLOCK), 0, s, p);
+  const size_t fit_lds = (size_t)2 * n * sizeof(T) <= (size_t)FIT_LDS_PER_WAVE ? (size_t)(RBLOCK / 64) * FIT_LDS_PER_WAVE : 0;
+  hipLaunchKernelGGL(piv_rescue_fit_kernel<T>, dim3(fit_blocks), dim3(RBLOCK), fit_lds, s, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   static bool attr_set = false;   // per instantiation: the request is a constant upper bound (96 KB)
