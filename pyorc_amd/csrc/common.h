@@ -186,6 +186,11 @@ __device__ __forceinline__ int cross_half_sum_i(int x) {
   permlane32_swap(a, b);
   return (int)(a + b);
 }
+__device__ __forceinline__ int cross_half_max_i(int x) {
+  unsigned a = (unsigned)x, b = a;
+  permlane32_swap(a, b);
+  return max((int)a, (int)b);
+}
 __device__ __forceinline__ int cross_half_min_i(int x) {
   unsigned a = (unsigned)x, b = a;
   permlane32_swap(a, b);
@@ -247,6 +252,25 @@ __device__ __forceinline__ float half_max(float x) {
   return x;
 }
 
+// max over a half-wave / a DPP row as signed integers: one v_max_i32 with a DPP operand per step.  The float reductions above
+// cost three instructions per step (fmaxf has to quiet signalling NaNs: v_mov_dpp + v_max(x, x) + v_max), so the maxima of
+// NON-NEGATIVE floats -- clipped correlation planes -- are taken on their bit patterns, which order like the values (a NaN
+// ranks above every finite value and survives, as with fmaxf of a quiet NaN in every lane)
+__device__ __forceinline__ int half_max_i(int x) {
+  x = max(x, dpp_i<DPP_XOR1>(x));
+  x = max(x, dpp_i<DPP_XOR2>(x));
+  x = max(x, dpp_i<DPP_HALF_MIRROR>(x));
+  x = max(x, dpp_i<DPP_MIRROR>(x));
+  x = max(x, swz16_i(x));
+  return x;
+}
+__device__ __forceinline__ int row_max_i(int x) {
+  x = max(x, dpp_i<DPP_XOR1>(x));
+  x = max(x, dpp_i<DPP_XOR2>(x));
+  x = max(x, dpp_i<DPP_HALF_MIRROR>(x));
+  x = max(x, dpp_i<DPP_MIRROR>(x));
+  return x;
+}
 __device__ __forceinline__ int row_min_i(int x) {
   x = min(x, dpp_i<DPP_XOR1>(x));
   x = min(x, dpp_i<DPP_XOR2>(x));
@@ -282,14 +306,22 @@ __device__ __forceinline__ void border_result(int mode, int dx, int dy, float& u
 // peak that is exactly 0 in exact arithmetic (clipped), where log(c + 1e-7) turns 1e-8 of rounding noise into 1e-3 px.
 // cm_* = min of the two neighbours + eps, den_* in log2 units, res_* the float32 result of that axis.
 struct PeakCond { bool amb, fit; };
-__device__ __forceinline__ PeakCond peak_cond(float vmax, float second, bool border, float cm_v, float den_v, float res_v,
-                                              float cm_u, float den_u, float res_u, float k, float tau) {
+// min / max of POSITIVE floats on their bit patterns (fminf / fmaxf cost an extra v_max(x, x) per operand to quiet signalling NaNs)
+__device__ __forceinline__ float min_pos(float a, float b) { return __builtin_bit_cast(float, min(__builtin_bit_cast(int, a), __builtin_bit_cast(int, b))); }
+__device__ __forceinline__ float max_abs(float a, float floor_) {   // max(|a|, floor_), floor_ > 0; a NaN stays a NaN
+  return __builtin_bit_cast(float, max(__builtin_bit_cast(int, a) & 0x7fffffff, __builtin_bit_cast(int, floor_)));
+}
+// cl_, cr_ (cd_, cu_): the two neighbours of the peak along v (u), eps already added (> 0)
+// near_tie: some sample other than the arg-max is >= vmax (1 - tau)
+__device__ __forceinline__ PeakCond peak_cond(float vmax, bool near_tie, bool border, float cl_, float cr_, float den_v, float res_v,
+                                              float cd_, float cu_, float den_u, float res_u, float k) {
   PeakCond c;
   const bool live = vmax > 0.0f;   // an all-zero plane is NaN by construction (first arg-max on the border)
-  c.amb = live && second >= vmax * (1.0f - tau);
+  c.amb = live && near_tie;
+  const float cm_v = min_pos(cl_, cr_), cm_u = min_pos(cd_, cu_);
   const float a_v = k * fmaf(2.0f, vmax, cm_v), a_u = k * fmaf(2.0f, vmax, cm_u);
-  const bool bad_v = !(a_v <= fmaxf(fabsf(res_v), 0.05f) * fabsf(den_v) * cm_v);   // NaN compares false => flagged
-  const bool bad_u = !(a_u <= fmaxf(fabsf(res_u), 0.05f) * fabsf(den_u) * cm_u);
+  const bool bad_v = !(a_v <= max_abs(res_v, 0.05f) * fabsf(den_v) * cm_v);   // NaN compares false => flagged
+  const bool bad_u = !(a_u <= max_abs(res_u, 0.05f) * fabsf(den_u) * cm_u);
   c.fit = live && !border && !c.amb && (bad_v || bad_u);
   return c;
 }

@@ -257,16 +257,15 @@ __device__ __forceinline__ void block_rescue_note(const PivParams& p, const floa
   const int wy = p.wy, wx = p.wx;
   const int i = imax / wx, j = imax - i * wx;
   const bool border = i <= 0 || i >= wy - 1 || j <= 0 || j >= wx - 1;
-  float cm_v = 1.0f, cm_u = 1.0f, den_v = 1.0f, den_u = 1.0f;
+  float cl = 1.0f, cr = 1.0f, cd = 1.0f, cu = 1.0f, den_v = 1.0f, den_u = 1.0f;
   if (!border) {
     const float l0 = __builtin_amdgcn_logf(plane[imax] + kEpsPeak);
-    const float cl = plane[imax - wx] + kEpsPeak, cr = plane[imax + wx] + kEpsPeak;
-    const float cd = plane[imax - 1] + kEpsPeak, cu = plane[imax + 1] + kEpsPeak;
+    cl = plane[imax - wx] + kEpsPeak; cr = plane[imax + wx] + kEpsPeak;
+    cd = plane[imax - 1] + kEpsPeak; cu = plane[imax + 1] + kEpsPeak;
     gauss_offset_fast(__builtin_amdgcn_logf(cl), l0, __builtin_amdgcn_logf(cr), den_v);
     gauss_offset_fast(__builtin_amdgcn_logf(cd), l0, __builtin_amdgcn_logf(cu), den_u);
-    cm_v = fminf(cl, cr); cm_u = fminf(cd, cu);
   }
-  const PeakCond pc = peak_cond(vmax, second, border, cm_v, den_v, v, cm_u, den_u, u, 2.0f * p.rescue_k, p.rescue_tau);
+  const PeakCond pc = peak_cond(vmax, second >= vmax * (1.0f - p.rescue_tau), border, cl, cr, den_v, v, cd, cu, den_u, u, 2.0f * p.rescue_k);
   if (pc.amb || pc.fit) rescue_note(p.rescue_hdr, p.rescue_fit, p.rescue_cap_fit, p.rescue_amb, p.rescue_cap_amb, t, pc, i, j);
 }
 

@@ -107,6 +107,21 @@ template <int N> __device__ __forceinline__ float group_max(float x) {
   if (Geo<N>::LG == 64) x = cross_half_max(x);
   return x;
 }
+// maximum of NON-NEGATIVE floats (clipped planes) over the group, on the bit patterns (common.h, half_max_i)
+template <int N> __device__ __forceinline__ float group_max_nonneg(float x) {
+  int b = __builtin_bit_cast(int, x);
+  if (Geo<N>::LG == 16) return __builtin_bit_cast(float, row_max_i(b));
+  b = half_max_i(b);
+  if (Geo<N>::LG == 64) b = cross_half_max_i(b);
+  return __builtin_bit_cast(float, b);
+}
+// "some lane of my group has `cond`": one ballot and scalar / per-lane mask arithmetic instead of a DPP reduction
+template <int N> __device__ __forceinline__ bool group_any(bool cond) {
+  const uint64_t m = __builtin_amdgcn_ballot_w64(cond);
+  if constexpr (Geo<N>::LG == 64) return m != 0;
+  else if constexpr (Geo<N>::LG == 32) return ((threadIdx.x & 32u) ? (uint32_t)(m >> 32) : (uint32_t)m) != 0u;
+  else return ((m >> (threadIdx.x & 48u)) & 0xffffull) != 0ull;
+}
 template <int N> __device__ __forceinline__ int group_min_i(int x) {
   if (Geo<N>::LG == 16) return row_min_i(x);
   x = half_min_i(x);
@@ -725,7 +740,7 @@ __device__ __forceinline__ float plane_max(const float (&c)[N], float& row_max) 
     w = t + (rem ? 1 : 0);
   }
   row_max = m[0];
-  return group_max<N>(row_max);
+  return group_max_nonneg<N>(row_max);   // the planes are clipped to [0, 1]
 }
 
 // Peak of one plane: parks the plane in LDS (row y at buf[y * LDS_ROW + x]), finds np.argmax of the
@@ -750,8 +765,10 @@ __device__ __forceinline__ void find_peak(float* buf, int lg, const float (&c)[N
   const int y = wrap_n<N>(ip + C);
   const float rowv = buf[y * LR + lr];                                               // the peak row, one sample per lane
   jp = group_min_i<N>((active && rowv == vmax) ? sh : NONE);                         // first shifted column in that row
-  // runner-up = largest sample other than (ip, jp): the other rows' maxima and the rest of the peak row
-  const float second = group_max<N>(active ? fmaxf(sh != ip ? row_max : 0.0f, sh != jp ? rowv : 0.0f) : 0.0f);
+  // is any sample other than (ip, jp) within tau of the maximum?  The other rows through their maxima, the rest of the peak
+  // row through this lane's sample of it
+  const float thr = vmax * (1.0f - p.rescue_tau);
+  const bool near_tie = group_any<N>(active && ((row_max >= thr && sh != ip) || (rowv >= thr && sh != jp)));
   const bool border = (ip == 0 || ip == M || jp == 0 || jp == M);
   const int x = wrap_n<N>(jp + C);
   const int ym = wrap_n<N>(ip + C - 1), yp = wrap_n<N>(ip + C + 1);
@@ -767,13 +784,12 @@ __device__ __forceinline__ void find_peak(float* buf, int lg, const float (&c)[N
   float den_v, den_u;
   v = (float)ip + gauss_offset_fast(__builtin_amdgcn_logf(cl), l0, __builtin_amdgcn_logf(cr), den_v) - (float)C;
   u = (float)jp + gauss_offset_fast(__builtin_amdgcn_logf(cd), l0, __builtin_amdgcn_logf(cu), den_u) - (float)C;
-  const PeakCond pc = peak_cond(vmax, second, border, fminf(cl, cr), den_v, v, fminf(cd, cu), den_u, u, p.rescue_k, p.rescue_tau);
+  const PeakCond pc = peak_cond(vmax, near_tie, border, cl, cr, den_v, v, cd, cu, den_u, u, p.rescue_k);
   if (note) {
     uint32_t pos2 = 0xffffffffu;
     if (__builtin_amdgcn_ballot_w64(pc.amb) != 0) {
       // cold path (a few windows in 100 000): how many samples are within tau of the maximum, and where is the other one?
       // With exactly two candidates the rescue pass compares their two float64 sums instead of rebuilding the whole plane.
-      const float thr = vmax * (1.0f - p.rescue_tau);
       const int pos1 = (ip << 16) | jp;
       int cnt = 0, other = 0x7fffffff;
 #pragma unroll 1
@@ -1188,7 +1204,8 @@ __device__ __forceinline__ void find_peak_embed(float* buf, int lg, const float 
   const int y = ip - C < 0 ? ip - C + n : ip - C;
   const float rowv = buf[y * LR + lg];                                    // the peak row, one sample per lane
   jp = group_min_i<N>((row_in && rowv == vmax) ? sh : NONE);              // first shifted column in that row
-  const float second = group_max<N>(row_in ? fmaxf(sh != ip ? rmax : 0.0f, sh != jp ? rowv : 0.0f) : 0.0f);   // runner-up
+  const float thr = vmax * (1.0f - p.rescue_tau);
+  const bool near_tie = group_any<N>(row_in && ((rmax >= thr && sh != ip) || (rowv >= thr && sh != jp)));   // another sample within tau of the maximum
   const bool border = (ip == 0 || ip == M || jp == 0 || jp == M);
   const int x = jp - C < 0 ? jp - C + n : jp - C;
   const int ym = y == 0 ? M : y - 1, yp = y == M ? 0 : y + 1;
@@ -1202,7 +1219,7 @@ __device__ __forceinline__ void find_peak_embed(float* buf, int lg, const float 
   float den_v, den_u;
   v = (float)ip + gauss_offset_fast(__builtin_amdgcn_logf(cl), l0, __builtin_amdgcn_logf(cr), den_v) - (float)C;
   u = (float)jp + gauss_offset_fast(__builtin_amdgcn_logf(cd), l0, __builtin_amdgcn_logf(cu), den_u) - (float)C;
-  pc = peak_cond(vmax, second, border, fminf(cl, cr), den_v, v, fminf(cd, cu), den_u, u, p.rescue_k, p.rescue_tau);
+  pc = peak_cond(vmax, near_tie, border, cl, cr, den_v, v, cd, cu, den_u, u, p.rescue_k);
   if (border) border_result(border_mode, jp - C, ip - C, u, v);
 }
 
