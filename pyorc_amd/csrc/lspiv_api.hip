@@ -645,6 +645,8 @@ int64_t lspiv_required_bytes(int64_t T, int64_t H, int64_t W, int dtype, int wy,
   const int64_t n_tiles = (T - 1) * g.n_rows * g.n_cols;
   int64_t b = T * H * W * (int64_t)elem_size(dtype) + 4 * n_tiles * 4;
   if (with_planes) b += n_tiles * wy * wx * 4;
+  if (g_opt_rescue.load())   // the rescue lists of the launch stream: n_tiles / 4 records of 16 bytes + n_tiles / 16 of 4 (rescue_ws)
+    b += 256 + (int64_t)std::max<int64_t>(4096, n_tiles / 4) * 16 + (int64_t)std::max<int64_t>(1024, n_tiles / 16) * 4;
   return b;
 }
 

@@ -841,3 +841,64 @@ def test_register_ffts_match_numpy(gpu, n):
         scale = np.abs(ref).max(axis=1, keepdims=True)
         assert np.max(np.abs(out - ref) / scale) < 2e-6, (n, inverse)
     assert gpu.lspiv_debug_fft(7, 0, _lib.ptr(z), _lib.ptr(out), 1) == _lib.LSPIV_EUNSUPPORTED
+
+
+# ------------------------------------------------------------------ float64 rescue pass (round 3) ---
+def _rescue_stats(stream=None):
+    from pyorc_amd import _lib
+
+    st = (C.c_int64 * 5)()
+    _lib.check(_lib.load().lspiv_rescue_stats(stream, st))
+    return list(st)
+
+
+def test_rescue_pass_touches_only_the_flagged_windows(gpu):
+    """Rescue on vs off: the unflagged windows keep their bits (the PIV kernel is the same launch), the flagged ones move to
+    the float64 answer; the counters say how many; `rescue = 0` reproduces round 2's float32 results (loosely gated)."""
+    import pyorc_amd
+    from pyorc_amd import _lib
+
+    fr = particle_stack(30, 200, 260, seed=11, density=0.015)      # sparse seeding: plenty of ill-conditioned peaks
+    ws, ov = (32, 32), (16, 16)
+    on = pyorc_amd.piv_pairs(fr, ws, ov)
+    st = _rescue_stats()
+    n_tiles = on[0].size
+    assert st[0] + st[1] > 0 and st[0] + st[1] < 0.2 * n_tiles
+    _lib.set_option("rescue", 0)
+    try:
+        off = pyorc_amd.piv_pairs(fr, ws, ov)
+    finally:
+        _lib.set_option("rescue", 1)
+    assert np.array_equal(on[2], off[2], equal_nan=True) and np.array_equal(on[3], off[3], equal_nan=True)   # corr, s2n untouched
+    moved = ~((on[0] == off[0]) | (np.isnan(on[0]) & np.isnan(off[0]))) | ~((on[1] == off[1]) | (np.isnan(on[1]) & np.isnan(off[1])))
+    assert 0 < moved.sum() <= st[0] + st[1]
+    uo, vo, cmo, sno, cond = c_oracle.piv_pairs(fr, ws, ov, return_cond=True)
+    ok = ~c_oracle.exact_tie(cond, cmo)
+    assert rel_err(on[0][ok], uo[ok].astype(np.float64)) <= TOL and rel_err(on[1][ok], vo[ok].astype(np.float64)) <= TOL
+    assert max(rel_err(off[0][ok], uo[ok].astype(np.float64)), rel_err(off[1][ok], vo[ok].astype(np.float64))) > TOL   # what the pass is for
+    good = ok & c_oracle.well_posed(cond)
+    assert rel_err(off[0][good], uo[good].astype(np.float64)) <= TOL                                       # round 2's gate still holds without it
+
+
+def test_rescue_list_overflow_keeps_float32_results(gpu):
+    """More flagged windows than the lists hold (a quarter of the launch): the excess keeps its float32 result, nothing
+    crashes, the counters report the demand, and the next launch starts from clean counters."""
+    import pyorc_amd
+
+    rng = np.random.default_rng(3)
+    T, H, W = 41, 528, 528                                          # 40 pairs x 32 x 32 windows = 40 960 > 4 x 4 096
+    fr = np.zeros((T, H, W), np.uint8)
+    ys, xs = np.meshgrid(np.arange(8, H, 16), np.arange(8, W, 16), indexing="ij")
+    for t in range(T):                                              # one single-pixel speckle per window cell, drifting: every peak
+        fr[t, (ys + t // 4) % H, (xs + t // 3) % W] = rng.integers(100, 255, ys.shape)   # sits on an exactly-zero neighbourhood
+    u, v, cm, sn = pyorc_amd.piv_pairs(fr, (32, 32), (16, 16))
+    st = _rescue_stats()
+    n_tiles = u.size
+    assert n_tiles == 40 * 32 * 32 and st[0] + st[1] > n_tiles // 4           # demand above the capacity of the fit list
+    assert np.isfinite(cm).all() and (np.isfinite(u) | np.isnan(u)).all()
+    small = particle_stack(3, 96, 128, seed=5)
+    a = pyorc_amd.piv_pairs(small, (32, 32), (16, 16))
+    st2 = _rescue_stats()
+    assert st2[0] + st2[1] <= a[0].size and st2[4] == st[4] + a[0].size        # counters were reset by the previous pass
+    b = pyorc_amd.piv_pairs(small, (32, 32), (16, 16))
+    assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(a, b))     # and the results are reproducible

@@ -83,10 +83,18 @@ def test_kernel_dispatch_table(lib):
 
 
 def test_required_memory_counts_frames_and_results():
+    def rescue_lists(n_tiles):   # the float64 rescue pass's lists on the launch stream (round 3)
+        return 256 + max(4096, n_tiles // 4) * 16 + max(1024, n_tiles // 16) * 4
+
     b = window.required_memory(1001, (1080, 1920), (32, 32), (16, 16), dtype=np.uint8)
-    assert b == 1001 * 1080 * 1920 + 4 * 4 * 1000 * 66 * 119
+    assert b == 1001 * 1080 * 1920 + 4 * 4 * 1000 * 66 * 119 + rescue_lists(1000 * 66 * 119)
     bp = window.required_memory(3, (64, 64), (32, 32), (16, 16), dtype=np.float32, with_planes=True)
-    assert bp == 3 * 64 * 64 * 4 + 16 * 2 * 9 + 2 * 9 * 1024 * 4
+    assert bp == 3 * 64 * 64 * 4 + 16 * 2 * 9 + 2 * 9 * 1024 * 4 + rescue_lists(18)
+    _lib.set_option("rescue", 0)
+    try:
+        assert window.required_memory(3, (64, 64), (32, 32), (16, 16), dtype=np.float32) == 3 * 64 * 64 * 4 + 16 * 2 * 9
+    finally:
+        _lib.set_option("rescue", 1)
 
 
 def test_no_gpu_means_loud_failure_not_fallback(lib):
