@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define LSPIV_ABI_VERSION 2
+#define LSPIV_ABI_VERSION 3   /* 3: lspiv_rescue_stats, the rescue / v_sign / norm_clip / std_ddof / round_odd options (round 3; additions only) */
 
 /* status codes (mapped by the Python shim onto the reference's exception types) */
 #define LSPIV_OK            0

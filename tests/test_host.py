@@ -28,7 +28,7 @@ def test_library_exports_every_header_symbol(lib):
         assert hasattr(lib, s), f"{s} declared in include/lspiv.h but not exported by liblspiv_hip.so"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes prototype in pyorc_amd/_lib.py"
     assert sorted(_lib.SIGNATURES) == syms
-    assert lib.lspiv_abi_version() == 2
+    assert lib.lspiv_abi_version() == 3
     assert b"gfx950" in lib.lspiv_version()
 
 
