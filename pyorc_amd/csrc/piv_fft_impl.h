@@ -749,9 +749,17 @@ __device__ __forceinline__ float plane_max(const float (&c)[N], float& row_max) 
 // and fits the 3-point log-Gaussian.  u, v in pixels; NaN when the peak sits on the plane border.
 // note / g: append the window (result index g) to the lists of the float64 rescue pass if its float32 fit cannot be trusted
 // (common.h, peak_cond); decided and written here, so that nothing of it stays live in the callers.
+// first shifted row holding the plane maximum (register-only: DPP reductions, no LDS), so that a caller with two planes can
+// start the second plane's search while the first plane's LDS round trips are in flight
+template <int N>
+__device__ __forceinline__ int peak_row(int lg, float vmax, float row_max) {
+  constexpr int C = N / 2, NONE = 1 << 12;
+  const int sh = wrap_n<N>(row_of<N>(lg) + C);
+  return group_min_i<N>((lane_active<N>(lg) && row_max == vmax) ? sh : NONE);
+}
 template <int N>
 __device__ __forceinline__ void find_peak(float* buf, int lg, const float (&c)[N], float vmax, float row_max, const PivParams& p,
-                                          float& u, float& v, bool note, uint32_t g) {
+                                          float& u, float& v, bool note, uint32_t g, int ip_known = -1) {
   const int border_mode = p.border_mode;
   int ip, jp;
   constexpr int LR = Geo<N>::LDS_ROW;
@@ -761,7 +769,7 @@ __device__ __forceinline__ void find_peak(float* buf, int lg, const float (&c)[N
   if (active) lds_row_write<N>(buf + lg * LR, c);
   __builtin_amdgcn_wave_barrier();
   const int sh = wrap_n<N>(lr + C);                                                  // this lane's shifted row AND column
-  ip = group_min_i<N>((active && row_max == vmax) ? sh : NONE);                      // first shifted row with the maximum
+  ip = ip_known >= 0 ? ip_known : peak_row<N>(lg, vmax, row_max);                    // first shifted row with the maximum
   const int y = wrap_n<N>(ip + C);
   const float rowv = buf[y * LR + lr];                                               // the peak row, one sample per lane
   jp = group_min_i<N>((active && rowv == vmax) ? sh : NONE);                         // first shifted column in that row
@@ -1142,6 +1150,10 @@ __global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_kernel
                                   dead_a, dead_b);
     if (WANT_NZ && win_dropped) skip_a = skip_b = true;
     const bool valid_a = job_valid && f > p0, valid_b = job_valid && has2;
+    // plane b's maximum and peak row first: register-only work the scheduler can slot into the LDS waits of plane a's fit
+    float row_max_b;
+    const float vmax_b = plane_max<N>(xi, row_max_b);
+    const int ip_b = peak_row<N>(lg, vmax_b, row_max_b);
     {
       float row_max, u, v;
       const uint32_t g = (f - 1) * p.n_win + win;
@@ -1155,10 +1167,10 @@ __global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_kernel
       }
     }
     {
-      float row_max, u, v;
+      float u, v;
       const uint32_t g = f * p.n_win + win;
-      const float vmax = plane_max<N>(xi, row_max);
-      find_peak<N>(buf, lg, xi, vmax, row_max, p, u, v, p.rescue_hdr && valid_b && !dead_b && !skip_b, g);
+      const float vmax = vmax_b, row_max = row_max_b;
+      find_peak<N>(buf, lg, xi, vmax, row_max, p, u, v, p.rescue_hdr && valid_b && !dead_b && !skip_b, g, ip_b);
       float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean_b);
       if (dead_b) { u = v = sn = nanv; cm = 0.0f; }
       if (skip_b) u = v = cm = sn = nanv;
