@@ -817,6 +817,87 @@ __device__ __forceinline__ void find_peak(float* buf, int lg, const float (&c)[N
   if (border) border_result(border_mode, jp - C, ip - C, u, v);
 }
 
+// ---- the two planes of a walking iteration side by side (64 x 64) ----------------------------------------------------
+// find_peak does one plane at a time through ONE parked copy in LDS: plane b cannot start before plane a has read its samples,
+// and each plane's chain (park -> row search -> LDS read -> column search -> LDS reads -> logs) is latency, not work.  Here
+// plane a parks whole in the job's tile as before, plane b parks only the THREE rows its fit reads (the peak's row and its two
+// neighbours, written by the lanes that own them once the peak row is known -- 3 * LDS_ROW floats per job of extra LDS), and
+// both fits are straight-line code in one block, so the scheduler overlaps the two chains.
+// Measured on one box (1000 pairs, interleaved): 64 x 64 -- 2 waves per SIMD, nobody else to fill a wave's LDS waits -- gains
+// 1.8 % (30.8 -> 30.2 ms); 32 x 32 at 3 waves loses 1.3 % to the extra parked rows (6.92 -> 7.03 ms) and keeps the
+// one-plane-at-a-time fit with plane b's maximum and peak row hoisted.
+template <int N> constexpr bool kTwoPlaneEpilogue = N == 64;
+template <int N>
+struct PeakFit {
+  float u, v;
+  PeakCond pc;
+  int ip, jp;
+  float thr;
+};
+template <int N>
+__device__ __forceinline__ void park_three_rows(float* mini, int lg, const float (&c)[N], int ip) {
+  constexpr int LR = Geo<N>::LDS_ROW, C = N / 2;
+  const int lr = row_of<N>(lg);
+  const int y = wrap_n<N>(ip + C), ym = wrap_n<N>(ip + C - 1), yp = wrap_n<N>(ip + C + 1);
+  const int slot = lr == ym ? 0 : lr == y ? 1 : lr == yp ? 2 : -1;   // (N >= 3: the three rows are distinct)
+  if (lane_active<N>(lg) && slot >= 0) lds_row_write<N>(mini + slot * LR, c);
+}
+// rows: base + r0 / r1 / r2 = the rows above / of / below the peak (whole plane: un-shifted row indices; three-row park: 0, 1, 2)
+template <int N, bool MINI>
+__device__ __forceinline__ PeakFit<N> peak_fit(const float* base, int lg, float vmax, float row_max, int ip, const PivParams& p) {
+  constexpr int LR = Geo<N>::LDS_ROW;
+  constexpr int M = N - 1, C = N / 2, NONE = 1 << 12;
+  const bool active = lane_active<N>(lg);
+  const int lr = row_of<N>(lg);
+  const int sh = wrap_n<N>(lr + C);
+  const int r1 = MINI ? 1 : wrap_n<N>(ip + C), r0 = MINI ? 0 : wrap_n<N>(ip + C - 1), r2 = MINI ? 2 : wrap_n<N>(ip + C + 1);
+  PeakFit<N> o;
+  o.ip = ip;
+  const float rowv = base[r1 * LR + lr];                                             // the peak row, one sample per lane
+  o.jp = group_min_i<N>((active && rowv == vmax) ? sh : NONE);                       // first shifted column in that row
+  o.thr = vmax * (1.0f - p.rescue_tau);
+  const bool near_tie = group_any<N>(active && ((row_max >= o.thr && sh != ip) || (rowv >= o.thr && sh != o.jp)));
+  const bool border = (ip == 0 || ip == M || o.jp == 0 || o.jp == M);
+  const int x = wrap_n<N>(o.jp + C), xm = wrap_n<N>(o.jp + C - 1), xp = wrap_n<N>(o.jp + C + 1);
+  const float c0 = vmax + kEpsPeak;
+  const float cl = base[r0 * LR + x] + kEpsPeak;
+  const float cr = base[r2 * LR + x] + kEpsPeak;
+  const float cd = base[r1 * LR + xm] + kEpsPeak;
+  const float cu = base[r1 * LR + xp] + kEpsPeak;
+  const float l0 = __builtin_amdgcn_logf(c0);
+  float den_v, den_u;
+  o.v = (float)ip + gauss_offset_fast(__builtin_amdgcn_logf(cl), l0, __builtin_amdgcn_logf(cr), den_v) - (float)C;
+  o.u = (float)o.jp + gauss_offset_fast(__builtin_amdgcn_logf(cd), l0, __builtin_amdgcn_logf(cu), den_u) - (float)C;
+  o.pc = peak_cond(vmax, near_tie, border, cl, cr, den_v, o.v, cd, cu, den_u, o.u, p.rescue_k);
+  if (border) border_result(p.border_mode, o.jp - C, ip - C, o.u, o.v);
+  return o;
+}
+// the rescue record of one plane; `buf` holds the WHOLE plane (cold path: count the candidates within tau of the maximum)
+template <int N>
+__device__ __forceinline__ void peak_note(const float* buf, int lg, const PeakFit<N>& o, const PivParams& p, uint32_t g) {
+  constexpr int LR = Geo<N>::LDS_ROW, C = N / 2;
+  const bool active = lane_active<N>(lg);
+  const int lr = row_of<N>(lg);
+  const int sh = wrap_n<N>(lr + C);
+  uint32_t pos2 = 0xffffffffu;
+  if (__builtin_amdgcn_ballot_w64(o.pc.amb) != 0) {
+    const int pos1 = (o.ip << 16) | o.jp;
+    int cnt = 0, other = 0x7fffffff;
+#pragma unroll 1
+    for (int yy = 0; yy < N; ++yy) {
+      const bool cand = active && buf[yy * LR + lr] >= o.thr;   // column lr of un-shifted row yy
+      const int pos = (wrap_n<N>(yy + C) << 16) | sh;
+      cnt += cand ? 1 : 0;
+      other = (cand && pos != pos1) ? min(other, pos) : other;
+    }
+    cnt = group_sum_i<N>(cnt);
+    other = group_min_i<N>(other);
+    if (cnt == 2) pos2 = (uint32_t)other;
+  }
+  if (lg == 0 && (o.pc.amb || o.pc.fit))
+    rescue_note(p.rescue_hdr, p.rescue_fit, p.rescue_cap_fit, p.rescue_amb, p.rescue_cap_amb, g, o.pc, o.ip, o.jp, pos2);
+}
+
 template <int N>
 __device__ __forceinline__ void store_plane_rows(float* dst, int lg, const float (&c)[N], bool nan_plane, bool zero_plane = false) {
   // shifted row i' = (y + N/2) % N receives columns x = N/2..N-1, 0..N/2-1
@@ -1116,6 +1197,7 @@ __global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_kernel
   const int grp = lane / G::LG;
   const int lg = lane & (G::LG - 1);
   float* buf = smem + (wave * G::GROUPS + grp) * G::LDS_JOB;
+  float* mini = smem + WAVES_PER_BLOCK * G::GROUPS * G::LDS_JOB + (wave * G::GROUPS + grp) * 3 * G::LDS_ROW;   // plane b's three rows (64 x 64)
   const int partner_byte = partner_byte_of<N>(lane, lg);
   const int lane0_byte = lane0_byte_of<N>();
 
@@ -1150,32 +1232,72 @@ __global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_kernel
                                   dead_a, dead_b);
     if (WANT_NZ && win_dropped) skip_a = skip_b = true;
     const bool valid_a = job_valid && f > p0, valid_b = job_valid && has2;
-    // plane b's maximum and peak row first: register-only work the scheduler can slot into the LDS waits of plane a's fit
-    float row_max_b;
-    const float vmax_b = plane_max<N>(xi, row_max_b);
-    const int ip_b = peak_row<N>(lg, vmax_b, row_max_b);
-    {
-      float row_max, u, v;
-      const uint32_t g = (f - 1) * p.n_win + win;
-      const float vmax = plane_max<N>(xr, row_max);
-      find_peak<N>(buf, lg, xr, vmax, row_max, p, u, v, p.rescue_hdr && valid_a && !dead_a && !skip_a, g);
-      float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean_a);
-      if (dead_a) { u = v = sn = nanv; cm = 0.0f; }   // zero-variance window: an exactly-zero plane (corr 0, s2n 0/0, peak on the border)
-      if (skip_a) u = v = cm = sn = nanv;
-      if (valid_a && lg == 0) {
-        p.u[g] = u; p.v[g] = v; p.cmax[g] = cm; p.s2n[g] = sn;
+    if constexpr (kTwoPlaneEpilogue<N>) {
+      // both planes side by side (PeakFit above): maxima and peak rows from registers, plane a parked whole in the tile, plane b's
+      // three rows in the job's slice of the extra LDS, then two independent straight-line fits
+      float row_max_a, row_max_b;
+      const float vmax_a = plane_max<N>(xr, row_max_a);
+      const float vmax_b = plane_max<N>(xi, row_max_b);
+      const int ip_a = peak_row<N>(lg, vmax_a, row_max_a);
+      const int ip_b = peak_row<N>(lg, vmax_b, row_max_b);
+      if (lane_active<N>(lg)) lds_row_write<N>(buf + lg * G::LDS_ROW, xr);
+      park_three_rows<N>(mini, lg, xi, ip_b);
+      __builtin_amdgcn_wave_barrier();
+      const PeakFit<N> fa = peak_fit<N, false>(buf, lg, vmax_a, row_max_a, ip_a, p);
+      const PeakFit<N> fb = peak_fit<N, true>(mini, lg, vmax_b, row_max_b, ip_b, p);
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t g_a = (f - 1) * p.n_win + win, g_b = f * p.n_win + win;
+      if (p.rescue_hdr) {   // uniform
+        const bool note_a = valid_a && !dead_a && !skip_a, note_b = valid_b && !dead_b && !skip_b;
+        if (note_a) peak_note<N>(buf, lg, fa, p, g_a);
+        if (__builtin_amdgcn_ballot_w64(note_b && (fb.pc.amb || fb.pc.fit)) != 0) {   // rare: plane b's cold path wants the whole plane in LDS
+          __builtin_amdgcn_wave_barrier();
+          if (lane_active<N>(lg)) lds_row_write<N>(buf + lg * G::LDS_ROW, xi);
+          __builtin_amdgcn_wave_barrier();
+          if (note_b) peak_note<N>(buf, lg, fb, p, g_b);
+        }
       }
-    }
-    {
-      float u, v;
-      const uint32_t g = f * p.n_win + win;
-      const float vmax = vmax_b, row_max = row_max_b;
-      find_peak<N>(buf, lg, xi, vmax, row_max, p, u, v, p.rescue_hdr && valid_b && !dead_b && !skip_b, g, ip_b);
-      float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean_b);
-      if (dead_b) { u = v = sn = nanv; cm = 0.0f; }
-      if (skip_b) u = v = cm = sn = nanv;
-      if (valid_b && lg == 0) {
-        p.u[g] = u; p.v[g] = v; p.cmax[g] = cm; p.s2n[g] = sn;
+      {
+        float u = fa.u, v = fa.v, cm = vmax_a, sn = vmax_a * __builtin_amdgcn_rcpf(mean_a);
+        if (dead_a) { u = v = sn = nanv; cm = 0.0f; }   // zero-variance window: an exactly-zero plane (corr 0, s2n 0/0, peak on the border)
+        if (skip_a) u = v = cm = sn = nanv;
+        if (valid_a && lg == 0) { p.u[g_a] = u; p.v[g_a] = v; p.cmax[g_a] = cm; p.s2n[g_a] = sn; }
+      }
+      {
+        float u = fb.u, v = fb.v, cm = vmax_b, sn = vmax_b * __builtin_amdgcn_rcpf(mean_b);
+        if (dead_b) { u = v = sn = nanv; cm = 0.0f; }
+        if (skip_b) u = v = cm = sn = nanv;
+        if (valid_b && lg == 0) { p.u[g_b] = u; p.v[g_b] = v; p.cmax[g_b] = cm; p.s2n[g_b] = sn; }
+      }
+      __builtin_amdgcn_wave_barrier();   // the parked samples are read before the next iteration's transposes reuse the tile
+    } else {
+      // plane b's maximum and peak row first: register-only work the scheduler can slot into the LDS waits of plane a's fit
+      float row_max_b;
+      const float vmax_b = plane_max<N>(xi, row_max_b);
+      const int ip_b = peak_row<N>(lg, vmax_b, row_max_b);
+      {
+        float row_max, u, v;
+        const uint32_t g = (f - 1) * p.n_win + win;
+        const float vmax = plane_max<N>(xr, row_max);
+        find_peak<N>(buf, lg, xr, vmax, row_max, p, u, v, p.rescue_hdr && valid_a && !dead_a && !skip_a, g);
+        float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean_a);
+        if (dead_a) { u = v = sn = nanv; cm = 0.0f; }   // zero-variance window: an exactly-zero plane (corr 0, s2n 0/0, peak on the border)
+        if (skip_a) u = v = cm = sn = nanv;
+        if (valid_a && lg == 0) {
+          p.u[g] = u; p.v[g] = v; p.cmax[g] = cm; p.s2n[g] = sn;
+        }
+      }
+      {
+        float u, v;
+        const uint32_t g = f * p.n_win + win;
+        const float vmax = vmax_b, row_max = row_max_b;
+        find_peak<N>(buf, lg, xi, vmax, row_max, p, u, v, p.rescue_hdr && valid_b && !dead_b && !skip_b, g, ip_b);
+        float cm = vmax, sn = vmax * __builtin_amdgcn_rcpf(mean_b);
+        if (dead_b) { u = v = sn = nanv; cm = 0.0f; }
+        if (skip_b) u = v = cm = sn = nanv;
+        if (valid_b && lg == 0) {
+          p.u[g] = u; p.v[g] = v; p.cmax[g] = cm; p.s2n[g] = sn;
+        }
       }
     }
     if constexpr (PLANES) {
@@ -1601,10 +1723,11 @@ static hipError_t launch_t(const PivParams& p, bool ensemble, hipStream_t s) {
     q.seg_len = w.seg_len; q.seg_first = w.seg_first; q.n_seg = w.n_seg;
     const uint64_t wjobs = (uint64_t)w.n_seg * p.n_win;
     const uint32_t wblocks = (uint32_t)((wjobs + jobs_per_block - 1) / jobs_per_block);
+    constexpr size_t walk_lds = G::LDS_BYTES + (kTwoPlaneEpilogue<N> ? (size_t)WAVES_PER_BLOCK * G::GROUPS * 3 * G::LDS_ROW * 4 : 0);   // + plane b's three rows
     if (p.planes)
-      hipLaunchKernelGGL((piv_fft_walk_kernel<T, N, true, WANT_NZ>), dim3(wblocks), dim3(BLOCK), G::LDS_BYTES, s, q);
+      hipLaunchKernelGGL((piv_fft_walk_kernel<T, N, true, WANT_NZ>), dim3(wblocks), dim3(BLOCK), walk_lds, s, q);
     else
-      hipLaunchKernelGGL((piv_fft_walk_kernel<T, N, false, WANT_NZ>), dim3(wblocks), dim3(BLOCK), G::LDS_BYTES, s, q);
+      hipLaunchKernelGGL((piv_fft_walk_kernel<T, N, false, WANT_NZ>), dim3(wblocks), dim3(BLOCK), walk_lds, s, q);
     return hipGetLastError();
   }
   const uint32_t jobs = p.n_pairs * ((p.n_win + 1) / 2);
