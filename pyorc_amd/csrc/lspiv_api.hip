@@ -2001,7 +2001,23 @@ int lspiv_stream_create(void** stream) {
   *stream = s;
   return LSPIV_OK;
 }
-int lspiv_stream_destroy(void* stream) { if (stream) HIP_TRY(hipStreamDestroy((hipStream_t)stream)); return LSPIV_OK; }
+int lspiv_stream_destroy(void* stream) {
+  if (!stream) return LSPIV_OK;
+  // the rescue lists of that stream go with it (a later stream may get the same handle value)
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (DeviceCtx* c : g_ctx) {
+    if (!c) continue;
+    for (size_t k = 0; k < c->rescue.size(); ++k) {
+      if (c->rescue[k].stream != (hipStream_t)stream) continue;
+      (void)hipStreamSynchronize((hipStream_t)stream);
+      if (c->rescue[k].base) (void)hipFree(c->rescue[k].base);
+      c->rescue.erase(c->rescue.begin() + (long)k);
+      break;
+    }
+  }
+  HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+  return LSPIV_OK;
+}
 int lspiv_stream_synchronize(void* stream) {
   DeviceCtx* c;
   int rc = get_ctx(&c);

@@ -404,13 +404,10 @@ hipError_t launch_rescue_t(const PivParams& p, hipStream_t s) {
   hipLaunchKernelGGL(piv_rescue_fit_kernel<T>, dim3(fit_blocks), dim3(RBLOCK), fit_lds, s, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  static bool attr_set = false;   // per instantiation: the request is a constant upper bound (96 KB)
-  if (!attr_set) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&piv_rescue_amb_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(3 * RESCUE_LDS_SAMPLES * sizeof(double) + (RESCUE_LDS_SAMPLES + 512) * sizeof(int)));
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  // (per launch: the attribute belongs to the current device, and a process may drive several)
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&piv_rescue_amb_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)(3 * RESCUE_LDS_SAMPLES * sizeof(double) + (RESCUE_LDS_SAMPLES + 512) * sizeof(int)));
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(piv_rescue_amb_kernel<T>, dim3(amb_blocks), dim3(RBLOCK), lds, s, p);
   return hipGetLastError();
 }
