@@ -55,14 +55,16 @@ def default_id_file() -> str:
 
 def _job_nonce() -> bytes:
     """8 bytes that tell this job's id file from a stale one of a crashed run at the same path: the launcher's start time
-    (TORCHELASTIC_RUN_ID / LSPIV_COMM_NONCE when given, else the parent process's start time from /proc)."""
-    tag = os.environ.get("LSPIV_COMM_NONCE") or os.environ.get("TORCHELASTIC_RUN_ID")
+    (LSPIV_COMM_NONCE when given, else TORCHELASTIC_RUN_ID together with the parent process's start time from /proc)."""
+    tag = os.environ.get("LSPIV_COMM_NONCE")
     if not tag:
+        # torch.distributed.run's default run id is the constant "none": the parent's start time always goes in
         try:
             with open(f"/proc/{os.getppid()}/stat", "rb") as fh:
-                tag = fh.read().rsplit(b")", 1)[1].split()[19].decode()   # starttime of the parent, in clock ticks
+                born = fh.read().rsplit(b")", 1)[1].split()[19].decode()   # starttime of the parent, in clock ticks
         except (OSError, IndexError):
-            tag = str(os.getppid())
+            born = str(os.getppid())
+        tag = f"{os.environ.get('TORCHELASTIC_RUN_ID', '')}:{born}"
     import hashlib
 
     return hashlib.sha256(str(tag).encode()).digest()[:8]
