@@ -227,6 +227,35 @@ def camera_to_velocity_rates(cam: np.ndarray, ws, ov) -> dict:
         r = fn()
         out[key] = round((T - 1) / (time.perf_counter() - t0), 1)
     chain.close()
+    # what the two kinds of plan cost once the (normalised) camera stack is in HBM: project + get_piv, results left in HBM.
+    # Group means make float32 ortho frames (float32 PIV kernels); a nearest-neighbour-only plan (reducer other than "mean")
+    # keeps uint8 frames uint8 (Projection.project_frames, keep_uint8) and the PIV runs its uint8 kernels
+    from pyorc_amd import _lib, window
+    lib = _lib.load()
+    d_norm = filters.normalize(DeviceFrames.from_host(cam), 15)
+    pn = Projection((H, W), (H, W), maps[0], maps[1])
+    nr, nc = window.get_array_shape((H, W), ws, ov)
+    d_res = DeviceFrames.empty((4 * (T - 1), nr, nc), np.float32)
+    res = {}
+    for key, plan, u8 in (("group_means_float32", p, False), ("nearest_only_uint8", pn, True)):
+        d_ortho = DeviceFrames.empty((T, H, W), np.uint8 if u8 else np.float32)
+
+        def fn():
+            plan.project_frames_dev(d_norm.ptr, np.uint8, T, d_ortho.ptr, keep_uint8=u8)
+            _lib.check(lib.lspiv_piv_pairs_dev(d_ortho.c_ptr, 0 if u8 else 1, T, H, W, ws[0], ws[1], ov[0], ov[1], -1.0,
+                                               d_res.c_ptr, None, None))
+        fn()
+        _lib.check(lib.lspiv_synchronize())
+        t0 = time.perf_counter()
+        for _ in range(3):
+            fn()
+        _lib.check(lib.lspiv_synchronize())
+        res[key] = round(3 * (T - 1) / (time.perf_counter() - t0), 1)
+        del d_ortho
+    del d_res
+    out["hbm_resident_project_then_piv"] = res
+    pn.close()
+    del d_norm
     p.close()
     out["note"] = (f"{T - 1} pairs of {H}x{W} uint8 camera frames in pageable host memory -> normalize(15) -> orthoprojection "
                    f"(synthetic homography, group means) -> get_piv {ws[0]}x{ws[1]}; PCIe-inclusive, never `value`")

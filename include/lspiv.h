@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define LSPIV_ABI_VERSION 3   /* 3: lspiv_rescue_stats, the rescue / v_sign / norm_clip / std_ddof / round_odd options (round 3; additions only) */
+#define LSPIV_ABI_VERSION 3   /* 3: lspiv_rescue_stats, lspiv_project_frames_u8[_dev], the rescue / v_sign / norm_clip / std_ddof / round_odd options (round 3; additions only) */
 
 /* status codes (mapped by the Python shim onto the reference's exception types) */
 #define LSPIV_OK            0
@@ -211,6 +211,12 @@ int lspiv_projection_create(int64_t src_h, int64_t src_w, int64_t dst_h, int64_t
 int lspiv_project_frames(lspiv_projection* handle, const void* frames, int dtype, int64_t T, float* out);
 int lspiv_project_frames_dev(lspiv_projection* handle, const void* d_frames, int dtype, int64_t T, float* d_out,
                              void* stream);
+/* A plan without group means (G = 0, Frames.project with a reducer other than "mean": pyorc/project.py:196-199) gives every
+ * cell a source byte or 0, so a uint8 stack may stay uint8: (T, dst_h, dst_w) uint8 holding the values lspiv_project_frames
+ * returns as float32 -- a quarter of the bytes, and get_piv runs its uint8 kernels on them.  LSPIV_EINVAL for a plan
+ * with group means.                                                                                            */
+int lspiv_project_frames_u8(lspiv_projection* handle, const uint8_t* frames, int64_t T, uint8_t* out);
+int lspiv_project_frames_u8_dev(lspiv_projection* handle, const uint8_t* d_frames, int64_t T, uint8_t* d_out, void* stream);
 int lspiv_projection_destroy(lspiv_projection* handle);
 
 /* N1, method "cv" -- replaces pyorc.project.project_cv (pyorc/project.py:56-120): cv2.undistort(img, camera_matrix,

@@ -77,6 +77,8 @@ SIGNATURES = {
     "lspiv_projection_create": (_i32, [_i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, C.POINTER(_vp)]),
     "lspiv_project_frames": (_i32, [_vp, _vp, _i32, _i64, _vp]),
     "lspiv_project_frames_dev": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp]),
+    "lspiv_project_frames_u8": (_i32, [_vp, _vp, _i64, _vp]),
+    "lspiv_project_frames_u8_dev": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "lspiv_projection_destroy": (_i32, [_vp]),
     "lspiv_project_cv_create": (_i32, [_i64, _i64, _i64, _i64, _vp, _vp, _i32, _vp, C.POINTER(_vp)]),
     "lspiv_project_cv_frames": (_i32, [_vp, _vp, _i32, _i64, _vp]),

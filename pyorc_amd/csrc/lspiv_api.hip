@@ -20,6 +20,11 @@
 
 #include "common.h"
 
+namespace lspiv {   // project.hip
+hipError_t launch_project_u8(const uint8_t* frames, int64_t src_elems, int n_frames, const int* qlo1, const int* qlo2,
+                             const uint32_t* qdesc, const int* nn_src, uint8_t* out, int n_out, hipStream_t s);
+}
+
 namespace {
 
 thread_local std::string g_err;
@@ -408,6 +413,7 @@ struct lspiv_projection {
   int *d_qlo1 = nullptr, *d_qlo2 = nullptr;   // quad-window plan for uint8 frames (project.hip), nullptr: not built
   uint32_t* d_qdesc = nullptr;
   int* d_slow_q = nullptr; int n_slow = 0;    // the quads that plan leaves to the per-cell kernel
+  int64_t n_groups = 0;                       // 0: nearest neighbour only -- uint8 frames may stay uint8 (lspiv_project_frames_u8)
 };
 
 struct lspiv_ensemble {
@@ -1072,6 +1078,7 @@ int lspiv_projection_create(int64_t src_h, int64_t src_w, int64_t dst_h, int64_t
   }
   lspiv_projection* h = new lspiv_projection();
   h->src_h = src_h; h->src_w = src_w; h->dst_h = dst_h; h->dst_w = dst_w;
+  h->n_groups = G;
   h->d_nn = h->d_grp_of = h->d_grp_off = h->d_grp_src = nullptr;
   HIP_TRY(hipGetDevice(&h->device));
   auto up = [&](int** d, const std::vector<int>& v) -> hipError_t {
@@ -1171,6 +1178,42 @@ int lspiv_project_frames(lspiv_projection* h, const void* frames, int dtype, int
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(c->d_frames, frames, ib, hipMemcpyHostToDevice, c->stream));
   rc = lspiv_project_frames_dev(h, c->d_frames, dtype, T, c->d_planes, c->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out, c->d_planes, ob, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
+
+int lspiv_project_frames_u8_dev(lspiv_projection* h, const uint8_t* d_frames, int64_t T, uint8_t* d_out, void* stream) {
+  if (!h || !d_frames || !d_out) return fail(LSPIV_EINVAL, "NULL argument");
+  if (h->n_groups != 0)
+    return fail(LSPIV_EINVAL, "the plan averages %lld cells (reducer \"mean\"): their values are no bytes, use lspiv_project_frames",
+                (long long)h->n_groups);
+  if (T < 0 || T >= (int64_t)1 << 28) return fail(LSPIV_ESHAPE, "bad frame count");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  hipError_t e = lspiv::launch_project_u8(d_frames, h->src_h * h->src_w, (int)T, h->d_qlo1, h->d_qlo2, h->d_qdesc, h->d_nn, d_out,
+                                          (int)(h->dst_h * h->dst_w), s);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return LSPIV_OK;
+}
+
+int lspiv_project_frames_u8(lspiv_projection* h, const uint8_t* frames, int64_t T, uint8_t* out) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  if (!h || !frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
+  if (T <= 0) return LSPIV_OK;
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  const size_t ib = (size_t)T * h->src_h * h->src_w, ob = (size_t)T * h->dst_h * h->dst_w;
+  rc = ensure(&c->d_frames, &c->frames_cap, ib);
+  if (rc) return rc;
+  rc = ensure(&c->d_planes, &c->planes_cap, ob);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_frames, frames, ib, hipMemcpyHostToDevice, c->stream));
+  rc = lspiv_project_frames_u8_dev(h, (const uint8_t*)c->d_frames, T, (uint8_t*)c->d_planes, c->stream);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(out, c->d_planes, ob, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));

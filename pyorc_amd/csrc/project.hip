@@ -181,6 +181,95 @@ hipError_t launch_project_win(const uint8_t* frames, int64_t src_elems, int n_fr
   return hipGetLastError();
 }
 
+// Nearest-neighbour-only plans (Frames.project with a reducer other than "mean", pyorc/project.py:196-199) on uint8 frames:
+// every cell is a source byte or 0, so the stack may stay uint8 -- a quarter of the float32 bytes to write here and for the
+// PIV kernels to read, and get_piv runs its uint8 kernels on the same values.  Quads of the window plan as above (one
+// 32-bit store per quad and frame); the quads that plan leaves out gather their four bytes one by one.
+template <int F>
+__global__ __launch_bounds__(256) void project_win_u8_kernel(const uint8_t* __restrict__ frames, int64_t src_elems, int n_frames,
+                                                             const int* __restrict__ qlo1, const int* __restrict__ qlo2,
+                                                             const uint32_t* __restrict__ qdesc, const int* __restrict__ nn_src,
+                                                             uint8_t* __restrict__ out, int n_out) {
+  typedef uint64_t u64_u __attribute__((aligned(1)));
+  const int t0 = blockIdx.y * F;
+  const int nt = min(n_frames - t0, F);
+  const uint8_t* img = frames + (int64_t)t0 * src_elems;
+  const int nq = n_out >> 2;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+    const uint32_t d = qdesc[q];
+    uint32_t* dst = reinterpret_cast<uint32_t*>(out + (int64_t)t0 * n_out) + q;   // n_out % 4 == 0, `out` 4-byte aligned
+    if (d >> 31) {
+      int nn[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) nn[e] = nn_src[4 * q + e];
+      for (int t = 0; t < nt; ++t) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (nn[e] >= 0) v |= (uint32_t)img[(int64_t)t * src_elems + nn[e]] << (8 * e);
+        dst[(int64_t)t * nq] = v;
+      }
+      continue;
+    }
+    const int a = qlo1[q], b = qlo2[q];
+    uint64_t wa[F], wb[F];
+#pragma unroll
+    for (int t = 0; t < F; ++t)
+      if (t < nt) {
+        wa[t] = *reinterpret_cast<const u64_u*>(img + (int64_t)t * src_elems + a);
+        wb[t] = *reinterpret_cast<const u64_u*>(img + (int64_t)t * src_elems + b);
+      }
+#pragma unroll
+    for (int t = 0; t < F; ++t)
+      if (t < nt) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t c = d >> (5 * e);
+          const uint64_t w = (c & 8u) ? wb[t] : wa[t];
+          const uint32_t byte = (uint32_t)(w >> (8 * (c & 7u))) & 0xffu;
+          v |= ((c & 16u) ? byte : 0u) << (8 * e);
+        }
+        dst[(int64_t)t * nq] = v;
+      }
+  }
+}
+
+// the same without a window plan (odd grids, scattered sources): thread = cell, F frames
+template <int F>
+__global__ __launch_bounds__(256) void project_cell_u8_kernel(const uint8_t* __restrict__ frames, int64_t src_elems, int n_frames,
+                                                              const int* __restrict__ nn_src, uint8_t* __restrict__ out, int n_out) {
+  const int t0 = blockIdx.y * F;
+  const int nt = min(n_frames - t0, F);
+  const uint8_t* img = frames + (int64_t)t0 * src_elems;
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += gridDim.x * blockDim.x) {
+    const int nn = nn_src[o];
+    uint8_t* dst = out + (int64_t)t0 * n_out + o;
+    uint8_t val[F];
+#pragma unroll
+    for (int t = 0; t < F; ++t) val[t] = (t < nt && nn >= 0) ? img[(int64_t)t * src_elems + nn] : (uint8_t)0;
+#pragma unroll
+    for (int t = 0; t < F; ++t)
+      if (t < nt) dst[(int64_t)t * n_out] = val[t];
+  }
+}
+
+hipError_t launch_project_u8(const uint8_t* frames, int64_t src_elems, int n_frames, const int* qlo1, const int* qlo2,
+                             const uint32_t* qdesc, const int* nn_src, uint8_t* out, int n_out, hipStream_t s) {
+  if (n_frames <= 0 || n_out <= 0) return hipSuccess;
+  constexpr int F = 8;
+  if (qdesc && n_out % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0) {
+    const unsigned bx = (unsigned)std::min((n_out / 4 + 255) / 256, 4096);
+    hipLaunchKernelGGL((project_win_u8_kernel<F>), dim3(bx, (n_frames + F - 1) / F), dim3(256), 0, s, frames, src_elems, n_frames, qlo1,
+                       qlo2, qdesc, nn_src, out, n_out);
+  } else {
+    const unsigned bx = (unsigned)std::min((n_out + 255) / 256, 4096);
+    hipLaunchKernelGGL((project_cell_u8_kernel<F>), dim3(bx, (n_frames + F - 1) / F), dim3(256), 0, s, frames, src_elems, n_frames, nn_src,
+                       out, n_out);
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_project(const void* frames, int dtype, int64_t src_elems, int n_frames, const int* nn_src,
                           const int* grp_of, const int* grp_off, const int* grp_src, float* out, int n_out,
                           hipStream_t s) {

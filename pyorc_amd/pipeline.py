@@ -7,7 +7,7 @@ x4..x8 the bytes of the camera stack) -> ``get_piv()`` (window stack x3.9, corre
 block in HBM and calls only ``*_dev`` entry points of the C ABI:
 
     H2D uint8 frames -> lspiv_normalize_dev -> lspiv_edge_detect_dev -> lspiv_minmax_dev   (each optional)
-                     -> lspiv_project_frames_dev -> lspiv_piv_pairs_dev
+                     -> lspiv_project_frames_dev (lspiv_project_frames_u8_dev: nearest-neighbour-only plan, uint8 in) -> lspiv_piv_pairs_dev
                      -> lspiv_pack_int16_dev (optional) -> D2H (16 B or 8 B per vector)
 
 Every stage is the same kernel the stand-alone mirrors (``filters``, ``project``, ``piv``) call, so the chain is
@@ -76,6 +76,9 @@ class CameraToVelocity:
         if self.n_rows < 1 or self.n_cols < 1:
             raise ValueError("ortho frame smaller than the interrogation window")
         self.projection = Projection(self.cam_shape, self.ortho_shape, idx_img, idx_ortho, src_idx, uidx, norm_idx)
+        # a nearest-neighbour-only plan fed with uint8 frames (no edge filter before it): the ortho stack stays uint8 and the
+        # PIV runs its uint8 kernels on the same values (Projection.project_frames, keep_uint8)
+        self.ortho_uint8 = self.projection.nearest_only and self.edge_detect is None
         self._cam, self._norm, self._edge, self._ortho, self._out, self._packed, self._mean = (_DevBuf() for _ in range(7))
         self._comp = None                                   # compute stream of the streamed run
 
@@ -122,10 +125,11 @@ class CameraToVelocity:
             if src_dtype is np.uint8:
                 raise ValueError("minmax in the chain follows edge_detect (float32 frames); uint8 frames are not thresholded")
             _lib.check(lib.lspiv_minmax_dev(src, T * n_cam, self.minmax[0], self.minmax[1], src, None))   # in place
-        d_ortho = self._ortho.ensure(T * n_ortho * 4)
-        self.projection.project_frames_dev(src.value, src_dtype, T, d_ortho.value)
+        osz = 1 if self.ortho_uint8 else 4
+        d_ortho = self._ortho.ensure(T * n_ortho * osz)
+        self.projection.project_frames_dev(src.value, src_dtype, T, d_ortho.value, keep_uint8=self.ortho_uint8)
         d_out = self._out.ensure(4 * n_vec * 4)
-        _lib.check(lib.lspiv_piv_pairs_dev(d_ortho, 1, T, self.ortho_shape[0], self.ortho_shape[1], self.window_size[0],
+        _lib.check(lib.lspiv_piv_pairs_dev(d_ortho, 0 if self.ortho_uint8 else 1, T, self.ortho_shape[0], self.ortho_shape[1], self.window_size[0],
                                            self.window_size[1], self.overlap[0], self.overlap[1], self.signal_threshold,
                                            d_out, None, None))
         shape = (4, T - 1, self.n_rows, self.n_cols)
@@ -156,7 +160,7 @@ class CameraToVelocity:
         d_cam = self._cam.ensure(T * n_cam)
         d_norm = self._norm.ensure(T * n_cam) if self.normalize_samples else None
         d_edge = self._edge.ensure(T * n_cam * 4) if self.edge_detect else None
-        d_ortho = self._ortho.ensure(T * n_ortho * 4)
+        d_ortho = self._ortho.ensure(T * n_ortho * (1 if self.ortho_uint8 else 4))
         d_out = self._out.ensure(4 * n_vec * 4)             # chunk k's (4, pairs_k, n_win) block at float offset 4 * p_k * n_win
         d_pk = self._packed.ensure(4 * n_vec * 2) if packed else None
         if self._comp is None:
@@ -216,9 +220,11 @@ class CameraToVelocity:
                 src, src_dtype, esz = dst, np.float32, 4
                 if self.minmax:
                     _lib.check(lib.lspiv_minmax_dev(src, n_new * n_cam, self.minmax[0], self.minmax[1], src, comp))
-            self.projection.project_frames_dev(src.value, src_dtype, n_new, d_ortho.value + f0 * n_ortho * 4, comp.value)
+            osz = 1 if self.ortho_uint8 else 4
+            self.projection.project_frames_dev(src.value, src_dtype, n_new, d_ortho.value + f0 * n_ortho * osz, comp.value,
+                                               keep_uint8=self.ortho_uint8)
             blk_out = at(d_out, 4 * p0 * n_win * 4)
-            _lib.check(lib.lspiv_piv_pairs_dev_at(at(d_ortho, p0 * n_ortho * 4), 1, p1 - p0 + 1, self.ortho_shape[0],
+            _lib.check(lib.lspiv_piv_pairs_dev_at(at(d_ortho, p0 * n_ortho * osz), 0 if self.ortho_uint8 else 1, p1 - p0 + 1, self.ortho_shape[0],
                                                   self.ortho_shape[1], self.window_size[0], self.window_size[1], self.overlap[0],
                                                   self.overlap[1], self.signal_threshold, p0, blk_out, None, comp))
             if packed:

@@ -43,31 +43,56 @@ class Projection:
             si, ni, ui = _i64(src_idx), _i64(norm_idx), _i64(uidx)
             if si.shape != ni.shape:
                 raise ValueError("src_idx and norm_idx must have the same length")
+        self.nearest_only = ui.size == 0   # no averaged cells: uint8 frames may stay uint8 (project_frames, keep_uint8)
         self._h = C.c_void_p()
         _lib.check(lib.lspiv_projection_create(self.src_shape[0], self.src_shape[1], self.dst_shape[0], self.dst_shape[1],
                                                _lib.ptr(ii), _lib.ptr(io), ii.size, _lib.ptr(si), _lib.ptr(ni), si.size,
                                                _lib.ptr(ui), ui.size, C.byref(self._h)))
 
-    def project_frames(self, frames) -> np.ndarray:
+    def project_frames(self, frames, keep_uint8: Optional[bool] = None) -> np.ndarray:
         """(T, Hc, Wc) or (Hc, Wc) camera frames -> (T, Ho, Wo) float32 (``project_numpy`` + ``fillna(0)``).
-        A ``DeviceFrames`` stack is projected in HBM and a ``DeviceFrames`` comes back."""
-        if is_device(frames):
+        A ``DeviceFrames`` stack is projected in HBM and a ``DeviceFrames`` comes back.
+
+        ``keep_uint8``: a nearest-neighbour-only plan (``reducer`` other than "mean", pyorc/project.py:196-199) gives every
+        cell a source byte or 0, so a uint8 stack can stay uint8 -- the same values in a quarter of the bytes, and
+        ``get_piv`` then runs its uint8 kernels.  Default: on for ``DeviceFrames`` (the stack stays in HBM for the next
+        stage), off for host arrays (the reference hands out floats); ``ValueError`` when asked for on a plan with
+        group means or on float frames."""
+        dev = is_device(frames)
+        dt = frames.dtype if dev else np.asarray(frames).dtype
+        can = self.nearest_only and np.dtype(dt) == np.uint8
+        if keep_uint8 and not can:
+            raise ValueError("keep_uint8 needs uint8 frames and a plan without group means (reducer other than 'mean')")
+        u8 = can and (dev if keep_uint8 is None else bool(keep_uint8))
+        if dev:
             if frames.shape[1:] != self.src_shape:
                 raise ValueError(f"frames are {frames.shape[1:]}, projection expects {self.src_shape}")
-            out = DeviceFrames.empty((frames.shape[0],) + self.dst_shape, np.float32)
-            self.project_frames_dev(frames.ptr, frames.dtype, frames.shape[0], out.ptr)
+            out = DeviceFrames.empty((frames.shape[0],) + self.dst_shape, np.uint8 if u8 else np.float32)
+            self.project_frames_dev(frames.ptr, frames.dtype, frames.shape[0], out.ptr, keep_uint8=u8)
             return out
         a = np.asarray(frames)
         single = a.ndim == 2
         a = _lib.as_frames(a[None] if single else a)
         if a.shape[1:] != self.src_shape:
             raise ValueError(f"frames are {a.shape[1:]}, projection expects {self.src_shape}")
+        if u8:
+            out = np.empty((a.shape[0],) + self.dst_shape, dtype=np.uint8)
+            _lib.check(_lib.load().lspiv_project_frames_u8(self._h, _lib.ptr(a), a.shape[0], _lib.ptr(out)))
+            return out[0] if single else out
         out = np.empty((a.shape[0],) + self.dst_shape, dtype=np.float32)
         _lib.check(_lib.load().lspiv_project_frames(self._h, _lib.ptr(a), _lib.DTYPE_CODES[a.dtype], a.shape[0], _lib.ptr(out)))
         return out[0] if single else out
 
-    def project_frames_dev(self, d_frames: int, dtype, T: int, d_out: int, stream: Optional[int] = None) -> None:
-        """Device pointers in, device pointer out (see bench / tools/project_bench.py)."""
+    def project_frames_dev(self, d_frames: int, dtype, T: int, d_out: int, stream: Optional[int] = None,
+                           keep_uint8: bool = False) -> None:
+        """Device pointers in, device pointer out (see bench / tools/project_bench.py); ``keep_uint8``: ``d_out`` is a uint8
+        stack (uint8 frames, nearest-neighbour-only plan)."""
+        if keep_uint8:
+            if np.dtype(dtype) != np.uint8:
+                raise ValueError("keep_uint8 needs uint8 frames")
+            _lib.check(_lib.load().lspiv_project_frames_u8_dev(self._h, C.c_void_p(d_frames), T, C.c_void_p(d_out),
+                                                               C.c_void_p(stream) if stream else None))
+            return
         _lib.check(_lib.load().lspiv_project_frames_dev(self._h, C.c_void_p(d_frames), _lib.DTYPE_CODES[np.dtype(dtype)], T,
                                                         C.c_void_p(d_out), C.c_void_p(stream) if stream else None))
 

@@ -140,6 +140,81 @@ def test_gpu_project_then_piv_equals_oracle_chain(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dst", [(160, 224), (161, 223)])   # whole quads (window plan) | odd grid (one cell per thread)
+def test_gpu_nearest_only_projection_keeps_uint8(gpu, dst):
+    """A plan without group means (reducer other than "mean", pyorc/project.py:196-199) on uint8 frames: the stack may stay
+    uint8 -- the values of the float32 result, the oracle's values, for host arrays and HBM-resident stacks; refused for a
+    plan that averages or for float frames; get_piv on it passes the oracle gate on every window."""
+    import pyorc_amd
+    from oracle import c_oracle
+    from pyorc_amd.device import DeviceFrames
+    from pyorc_amd.project import Projection
+
+    src = (300, 420)
+    idx_img, mask, src_idx, uidx, norm_idx = projection_maps(src, dst, tilt=0.2, seed=9)
+    cam = particle_stack(11, src[0], src[1], seed=4, density=0.03)            # 11 frames: one full block of 8 and a ragged one
+    assert cam.dtype == np.uint8
+    p = Projection(src, dst, idx_img, mask)
+    assert p.nearest_only
+    ref = pro.project_frames(cam, dst, idx_img, mask)
+    f32 = p.project_frames(cam)
+    u8 = p.project_frames(cam, keep_uint8=True)
+    assert f32.dtype == np.float32 and u8.dtype == np.uint8 and u8.shape == ref.shape
+    assert np.array_equal(u8.astype(np.float64), ref) and np.array_equal(f32.astype(np.float64), ref)
+    assert np.array_equal(p.project_frames(cam[3], keep_uint8=True), u8[3])
+    d = p.project_frames(DeviceFrames.from_host(cam))                           # HBM-resident: uint8 by default
+    assert d.dtype == np.uint8 and np.array_equal(d.to_host(), u8)
+    assert p.project_frames(DeviceFrames.from_host(cam), keep_uint8=False).dtype == np.float32
+    sub = p.project_frames(DeviceFrames.from_host(cam)[1:4])                    # a time slice (view) of the stack
+    assert np.array_equal(sub.to_host(), u8[1:4])
+    with pytest.raises(ValueError):
+        p.project_frames(cam.astype(np.float32), keep_uint8=True)
+    # the PIV on the uint8 ortho stack: the oracle's gate on every window, and the same results (to the gate) as from float32
+    u, v, cm, sn = pyorc_amd.piv_pairs(d, (32, 32), (16, 16))
+    uo, vo, cmo, sno, cond = c_oracle.piv_pairs(ref, (32, 32), (16, 16), return_cond=True)
+    ok = ~c_oracle.exact_tie(cond, cmo)
+    err = lambda g, r: float(np.nanmax(np.abs(g - r) / np.maximum(np.abs(r), 0.05)))
+    assert ok.mean() > 0.5 and np.array_equal(np.isnan(cm), np.isnan(cmo)) and np.array_equal(np.isnan(u)[ok], np.isnan(uo)[ok])
+    assert err(cm, cmo) <= 1e-4 and err(sn, sno) <= 1e-4 and err(u[ok], uo[ok]) <= 1e-4 and err(v[ok], vo[ok]) <= 1e-4
+    p.close()
+    q = Projection(src, dst, idx_img, mask, src_idx, uidx, norm_idx)            # group means: no bytes
+    assert not q.nearest_only and q.project_frames(DeviceFrames.from_host(cam)).dtype == np.float32
+    with pytest.raises(ValueError):
+        q.project_frames(cam, keep_uint8=True)
+    out = np.empty((cam.shape[0],) + dst, np.uint8)
+    assert _lib.load().lspiv_project_frames_u8(q._h, _lib.ptr(cam), cam.shape[0], _lib.ptr(out)) != 0    # the C ABI refuses too
+    q.close()
+
+
+@pytest.mark.gpu
+def test_gpu_chain_with_nearest_only_plan_runs_the_uint8_kernels(gpu):
+    """CameraToVelocity on a nearest-neighbour-only plan: uint8 ortho stack, uint8 PIV kernels -- bit for bit the stand-alone
+    stages, one piece and streamed; with the edge filter in front (float frames) the stack is float32 as before."""
+    import pyorc_amd
+    from pyorc_amd import filters
+    from pyorc_amd.pipeline import CameraToVelocity
+    from pyorc_amd.project import Projection
+
+    src, dst = (120, 160), (96, 128)
+    cam = (particle_stack(83, src[0], src[1], seed=28, density=0.04) * 0.6 + 50).astype(np.uint8)
+    idx_img, mask = projection_maps(src, dst, tilt=0.2, seed=6)[:2]
+    p = Projection(src, dst, idx_img, mask)
+    ref = pyorc_amd.piv_pairs(p.project_frames(filters.normalize(cam, 15), keep_uint8=True), (32, 32), (16, 16))
+    with CameraToVelocity(src, dst, idx_img, mask, normalize_samples=15) as chain:
+        assert chain.ortho_uint8
+        for streamed in (False, True):
+            for a, b in zip(ref, chain.run(cam, streamed=streamed, n_chunks=3)):
+                assert np.array_equal(a, b, equal_nan=True)
+    staged = filters.edge_detect(filters.normalize(cam, 15), 1, 2)
+    ref = pyorc_amd.piv_pairs(p.project_frames(staged), (32, 32), (16, 16))
+    with CameraToVelocity(src, dst, idx_img, mask, normalize_samples=15, edge_detect=(1, 2)) as chain:
+        assert not chain.ortho_uint8
+        for a, b in zip(ref, chain.run(cam)):
+            assert np.array_equal(a, b, equal_nan=True)
+    p.close()
+
+
+@pytest.mark.gpu
 def test_gpu_pack_int16_bit_exact(gpu):
     from pyorc_amd.project import pack_int16
 

@@ -46,3 +46,14 @@ cam = np.empty((4,) + src, np.uint8); _lib.check(lib.lspiv_memcpy_d2h(_lib.ptr(c
 got = np.empty((4,) + dst, np.float32); _lib.check(lib.lspiv_memcpy_d2h(_lib.ptr(got), d_ortho, got.nbytes))
 t0 = time.perf_counter(); ref = pro.project_frames(cam, dst, idx_img, mask, src_idx, uidx, norm_idx); t_cpu = (time.perf_counter() - t0) / 4
 print(f"bit-exact vs oracle on 4 frames: {np.array_equal(got.astype(np.float64), ref)}; numpy oracle {1/t_cpu:.1f} frames/s (1 core)")
+# a nearest-neighbour-only plan (reducer other than "mean"): float32 ortho stack vs the uint8-staying one
+pn = Projection(src, dst, idx_img, mask)
+def projn(): pn.project_frames_dev(d_cam.value, np.uint8, T, d_ortho.value)
+def proj8(): pn.project_frames_dev(d_cam.value, np.uint8, T, d_ortho.value, keep_uint8=True)
+def piv8(): _lib.check(lib.lspiv_piv_pairs_dev(d_ortho, 0, T, dst[0], dst[1], 32, 32, 16, 16, -1.0, d_out, None, None))
+tn, tcn = timed(projn), timed(lambda: (projn(), piv()), 3)
+t8, tc8 = timed(proj8), timed(lambda: (proj8(), piv8()), 3)
+print(f"nearest-only plan, float32 ortho: project {tn*1e3:.2f} ms ({T/tn:.0f} frames/s), project+piv {(T-1)/tcn:.0f} pairs/s")
+print(f"nearest-only plan, uint8 ortho:   project {t8*1e3:.2f} ms ({T/t8:.0f} frames/s, {T*(n_src+n_dst)/t8/1e9:.0f} GB/s algorithmic), project+piv {(T-1)/tc8:.0f} pairs/s")
+got8 = np.empty((4,) + dst, np.uint8); _lib.check(lib.lspiv_memcpy_d2h(_lib.ptr(got8), d_ortho, got8.nbytes))
+print(f"uint8 ortho equals the oracle on 4 frames: {np.array_equal(got8.astype(np.float64), pro.project_frames(cam, dst, idx_img, mask))}")
