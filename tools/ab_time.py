@@ -3,7 +3,7 @@
 
     [LSPIV_LIBRARY=other.so] [LSPIV_RESCUE=0] python tools/ab_time.py --window 32 --overlap 16 --pairs 1000 [--dtype f32] [--tag name]
 
-Prints one line: tag, ms per launch (mean of --reps after one warm-up), pairs/s, rescue counters when the build has them.
+Prints one line: tag, ms per launch (mean of --reps after --warm untimed launches), pairs/s, rescue counters when the build has them.
 Interleave builds in a shell loop for A/B claims (box-to-box spread is +-3 %).
 """
 import argparse
@@ -24,6 +24,7 @@ ap.add_argument("--overlap", type=int, default=16)
 ap.add_argument("--pairs", type=int, default=1000)
 ap.add_argument("--dtype", default="u8")
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--warm", type=int, default=6, help="untimed launches first: the first ~5 after an idle gap run slow (tools/clock_ramp.py)")
 ap.add_argument("--seed", type=int, default=20260927 + 2)
 ap.add_argument("--tag", default="")
 a = ap.parse_args()
@@ -50,7 +51,8 @@ def go():
     _lib.check(lib.lspiv_piv_pairs_dev(d_in, code, T, H, W, a.window, a.window, a.overlap, a.overlap, -1.0, d_o, None, None))
 
 
-go()
+for _ in range(max(1, a.warm)):
+    go()
 _lib.check(lib.lspiv_synchronize())
 ev0, ev1 = C.c_void_p(), C.c_void_p()
 _lib.check(lib.lspiv_event_create(C.byref(ev0)))
