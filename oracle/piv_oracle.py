@@ -287,13 +287,16 @@ def peak_position(plane: np.ndarray) -> Tuple[float, float]:
     return i + di, j + dj
 
 
-def u_v_displacement(corr: np.ndarray, n_rows: int, n_cols: int, engine: str = "numpy"):
+def u_v_displacement(corr: np.ndarray, n_rows: int, n_cols: int, engine: str = "numpy", eps: float = None):
     """ffpiv.u_v_displacement restated (call sites pyorc/velocimetry/ffpiv.py:324, 471).
 
     corr (P, n_win, wy, wx) -> u, v (P, n_rows, n_cols) in pixels: u = column shift,
     v = row shift, relative to the plane centre floor(w/2); no sign flip
-    (pyorc/api/plot.py:548,576-583).
+    (pyorc/api/plot.py:548,576-583).  ``eps``: what is added to the plane before the logarithms (default EPS_PEAK = 1e-7,
+    the constant the kernels use too; the keyword exists for tests/golden/regen_from_ffpiv.py, which finds out from a
+    real ffpiv's planes and displacements which value it uses).
     """
+    eps = EPS_PEAK if eps is None else float(eps)
     corr = np.asarray(corr)
     if corr.ndim == 3:
         corr = corr[None]
@@ -310,11 +313,11 @@ def u_v_displacement(corr: np.ndarray, n_rows: int, n_cols: int, engine: str = "
     r = np.nonzero(ok)[0]
     pl = corr.reshape(P * n_win, wy, wx)
     ii, jj = i[r], j[r]
-    c = pl[r, ii, jj] + EPS_PEAK
-    cl = pl[r, ii - 1, jj] + EPS_PEAK
-    cr = pl[r, ii + 1, jj] + EPS_PEAK
-    cd = pl[r, ii, jj - 1] + EPS_PEAK
-    cu = pl[r, ii, jj + 1] + EPS_PEAK
+    c = pl[r, ii, jj] + eps
+    cl = pl[r, ii - 1, jj] + eps
+    cr = pl[r, ii + 1, jj] + eps
+    cd = pl[r, ii, jj - 1] + eps
+    cu = pl[r, ii, jj + 1] + eps
     with np.errstate(all="ignore"):
         lc, lcl, lcr, lcd, lcu = np.log(c), np.log(cl), np.log(cr), np.log(cd), np.log(cu)
         nom1, den1 = lcl - lcr, 2 * lcl - 4 * lc + 2 * lcr

@@ -303,9 +303,11 @@ def test_regen_from_ffpiv_scores_every_switch(monkeypatch, capsys):
         with po.semantics(**secret):
             return po.cross_corr(imgs, window_size, overlap, signal_threshold=signal_threshold)
 
+    secret_eps = [None]
+
     def u_v_displacement(corr, n_rows, n_cols, engine="numba"):
         with po.semantics(**secret):
-            return po.u_v_displacement(np.asarray(corr, np.float64), n_rows, n_cols)
+            return po.u_v_displacement(np.asarray(corr, np.float64), n_rows, n_cols, eps=secret_eps[0])
 
     def rte(t):
         with po.semantics(round_odd=1):
@@ -322,6 +324,14 @@ def test_regen_from_ffpiv_scores_every_switch(monkeypatch, capsys):
     # u_v_displacement sees float32 planes (as pyorc hands them over), the oracle float64: the match is to 1e-4, not bits
     assert "best reading: border_peak=2, signal_mode=0, signal_positive=1, v_sign=1, norm_clip=1, std_ddof=1" in out, out
     assert "round_to_even(25): ffpiv (26, 26)" in out and "matching round_odd values [1]" in out
+    # the stages on their own: the peak fit on the stand-in's planes names the eps in use, the planes agree
+    assert "best eps: 1e-07  (= the constant in use)" in out and "A3 / A4 planes" in out, out
+    # ... and a stand-in that adds another eps before the logarithms is found out, with the reading still named
+    secret_eps[0] = 1e-9
+    mod.main([])
+    out = capsys.readouterr().out
+    assert "best eps: 1e-09  -> change EPS_PEAK" in out and "do NOT reproduce" in out, out
+    assert "best reading: border_peak=2, signal_mode=0, signal_positive=1, v_sign=1, norm_clip=1, std_ddof=1" in out, out
 
 
 def test_regen_from_ffpiv_script_reports_missing_ffpiv():
