@@ -1061,6 +1061,30 @@ __device__ __forceinline__ void prepare_one(const RowRaw<T, N>& raw, float (&x)[
 // inverse transform either way): 50 -> 44 spilled registers and +2.8 %, +3.7 % together with the barriers inside fft64
 // (LSPIV_FFT64_SB; interleaved A/B on one box, 1080p 64 x 64 @ 75 %: 28.7 k -> 29.8 k pairs/s).  The other sizes were
 // measured without and are left alone.
+// VALU arbitration priority per phase of a walking iteration (s_setprio; the arbiter serves priority first, then age).  The
+// register FFTs are long runs of independent VALU work; the epilogue (reductions, LDS round trips, logarithms), the loads +
+// row conversion at the top of the next iteration, the transposes and the un-packing are short dependent chains that wait for
+// LDS or memory between a few instructions.  With everything at priority 0 a wave in such a chain queues behind its
+// neighbours' FFT streams for every one of those instructions; at priority 1 it gets them issued at once, is back in its
+// next FFT sooner, and the SIMD has two FFT streams to pair more often.  Measured (interleaved builds, two boxes, 1000 pairs,
+// rescue off): 32 x 32 6.34 -> 5.95-6.06 ms (-4.5 ... -6 %), 64 x 64 18.0 -> 16.9-17.1 ms (-5.9 %).  Which phases: epilogue +
+// conversion alone bring the same on one box and 1.3 % less on the other; transposes alone or un-packing alone are SLOWER
+// than no priorities (6.52 / 6.44 ms); conversion left at 0 costs 1.5 %; levels 2 / 3 change nothing (docs/history.md).
+// T / U / E / P = priority of transposes / un-packing / epilogue / loads + conversion; the FFTs run at 0.
+#ifndef LSPIV_PRIO_T
+#define LSPIV_PRIO_T 1
+#endif
+#ifndef LSPIV_PRIO_U
+#define LSPIV_PRIO_U 1
+#endif
+#ifndef LSPIV_PRIO_E
+#define LSPIV_PRIO_E 1
+#endif
+#ifndef LSPIV_PRIO_P
+#define LSPIV_PRIO_P LSPIV_PRIO_E   // loads + row conversion at the top of an iteration
+#endif
+#define LSPIV_PRIO_ANY (LSPIV_PRIO_T || LSPIV_PRIO_U || LSPIV_PRIO_E || LSPIV_PRIO_P)
+#define LSPIV_SETPRIO(x) do { if constexpr (LSPIV_PRIO_ANY) __builtin_amdgcn_s_setprio(x); } while (0)
 #ifndef LSPIV_WALK_SB
 #define LSPIV_WALK_SB do { if constexpr (N == 32 || N == 64) __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif
@@ -1098,6 +1122,7 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
   constexpr int H = N / 2;
   bool dead0, dead1, fin0 = true, fin1 = true;
   int nz0 = G::NN, nz1 = G::NN;
+  if constexpr (LSPIV_PRIO_P != LSPIV_PRIO_E) LSPIV_SETPRIO(LSPIV_PRIO_P);
   if constexpr (sizeof(T) == 4 && kF32Early<N>) {
     // float32 rows: the loads of BOTH frames are in flight before the first is consumed (they land in xr / xi, the registers
     // they are converted in), so an iteration waits for memory once instead of twice
@@ -1126,12 +1151,16 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
     prepare_one<T, N, WANT_NZ>(raw1, xi, p.nz_positive != 0, p.std_gain, nz1, fin1, dead1);
   }
   LSPIV_WALK_SB;
+  LSPIV_SETPRIO(0);
   fft_n<false>(xr, xi);              // along x
   LSPIV_WALK_SB;
+  LSPIV_SETPRIO(LSPIV_PRIO_T);
   transpose2<N>(buf, lg, xr, xi);    // lane = kx, regs = y
   LSPIV_WALK_SB;
+  LSPIV_SETPRIO(0);
   fft_n<false>(xr, xi);              // along y -> Z[ky][kx]
   LSPIV_WALK_SB;
+  LSPIV_SETPRIO(LSPIV_PRIO_U);
   // un-pack the two spectra, form both cross spectra and pack them for the shared inverse, one ky at a time (a
   // step only touches registers ky and N - ky of this lane and of the mirrored lane, so it can run in place)
 #pragma unroll
@@ -1156,10 +1185,13 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
   mean_a = bperm_f(lane0_byte, xr[0]);   // plane means = DC bins
   mean_b = bperm_f(lane0_byte, xi[0]);
   __builtin_amdgcn_sched_barrier(0);
+  LSPIV_SETPRIO(0);
   fft_n<true>(xr, xi);                 // along ky
   LSPIV_WALK_SB;
+  LSPIV_SETPRIO(LSPIV_PRIO_T);
   transpose2<N>(buf, lg, xr, xi);      // lane = y, regs = kx
   LSPIV_WALK_SB;
+  LSPIV_SETPRIO(0);
   dead_a = c.prev_dead || dead0;
   dead_b = dead0 || dead1;
   if constexpr (kClampInFft<N>) {
@@ -1178,6 +1210,7 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
       xi[j] = __builtin_amdgcn_fmed3f(xi[j], 0.0f, hi_b);
     }
   }
+  LSPIV_SETPRIO(LSPIV_PRIO_E);         // epilogue, and the next iteration's loads + row conversion
   skip_a = !(c.prev_finite && fin0);
   skip_b = !(fin0 && fin1);
   if (WANT_NZ) {
