@@ -80,6 +80,8 @@ def measured_traffic(kernel_substr: str, pairs: int, H: int, W: int, window_size
 
     best = None
     code = _lib.kernel_code_hash()
+    if _lib.binary_provenance()["binary_kernel_hash"] != code:   # the loaded binary was not built from these kernel sources (LSPIV_ALLOW_STALE / LSPIV_LIBRARY)
+        return None
     want = {"pairs": pairs, "H": H, "W": W, "window": window_size, "overlap": overlap}
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
         try:
@@ -489,6 +491,7 @@ def main():
         },
         "roofline": roofline_block(lib, kernel_ms, a.pairs, H, W, a.window, a.overlap, n_win, launch_ms),
     }
+    out["config"]["binary"] = _lib.binary_provenance(lib)   # hashes compiled into the loaded .so next to the tree's
     if rescue is not None:
         out["config"]["rescue"] = rescue
     if comm is not None:

@@ -37,7 +37,9 @@
 extern "C" {
 #endif
 
-#define LSPIV_ABI_VERSION 3   /* 3: lspiv_rescue_stats, lspiv_project_frames_u8[_dev], the rescue / v_sign / norm_clip / std_ddof / round_odd options (round 3; additions only) */
+#define LSPIV_ABI_VERSION 4   /* 4 (round 4, additions only): lspiv_build_info, the ensemble rescue (lspiv_ensemble_set_retain / _stats / _state_dev /
+                               * _export_f64 / _import_f64), lspiv_stream_release; 3: lspiv_rescue_stats, lspiv_project_frames_u8[_dev], the
+                               * rescue / v_sign / norm_clip / std_ddof / round_odd options */
 
 /* status codes (mapped by the Python shim onto the reference's exception types) */
 #define LSPIV_OK            0
@@ -62,7 +64,15 @@ extern "C" {
 
 /* ---------------------------------------------------------------- library / device ------- */
 int         lspiv_abi_version(void);
-const char* lspiv_version(void);
+const char* lspiv_version(void);                        /* "lspiv-hip <version> (gfx950) src <source hash>" */
+/* Provenance of the loaded binary (csrc/Makefile compiles both in): LSPIV_BUILD_KERNEL_HASH = first 16 hex digits of the
+ * sha256 over csrc/{piv_fft_impl.h, fft_regs.h, common.h, piv_rescue.hip} (the fused PIV kernels; the committed profile
+ * summaries are keyed to it), LSPIV_BUILD_SOURCE_HASH = the same over every csrc/*.hip, csrc/*.h (sorted by name) and this
+ * header.  pyorc_amd._lib.load() recomputes the second from the tree and refuses a stale binary.  "unknown": not built by
+ * csrc/Makefile; "": unknown selector. */
+#define LSPIV_BUILD_KERNEL_HASH 0
+#define LSPIV_BUILD_SOURCE_HASH 1
+const char* lspiv_build_info(int what);
 const char* lspiv_last_error(void);
 int         lspiv_device_count(int* n);                 /* 0 devices is LSPIV_OK with *n = 0 */
 int         lspiv_set_device(int device);               /* per calling thread               */

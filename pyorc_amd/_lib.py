@@ -32,6 +32,11 @@ class LspivLibraryMissing(ImportError):
     """liblspiv_hip.so has not been built (run ``python -c 'import __graft_entry__ as g; g.build()'``)."""
 
 
+class LspivLibraryStale(ImportError):
+    """liblspiv_hip.so was built from other sources than the ones in this tree (``make -C pyorc_amd/csrc`` rebuilds it;
+    ``LSPIV_ALLOW_STALE=1`` loads it anyway -- every measurement then says so, see ``binary_provenance``)."""
+
+
 class LspivError(RuntimeError):
     """A C-ABI call returned a negative status."""
 
@@ -47,6 +52,7 @@ _pi64 = C.POINTER(C.c_int64)
 SIGNATURES = {
     "lspiv_abi_version": (_i32, []),
     "lspiv_version": (C.c_char_p, []),
+    "lspiv_build_info": (C.c_char_p, [_i32]),
     "lspiv_last_error": (C.c_char_p, []),
     "lspiv_device_count": (_i32, [C.POINTER(_i32)]),
     "lspiv_set_device": (_i32, [_i32]),
@@ -161,8 +167,50 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    # the binary must come from THIS tree (the .so is a build artefact outside the history): csrc/Makefile compiles the hash
+    # of every library source into it.  A build loaded on purpose through LSPIV_LIBRARY (A/B measurements) is exempt.
+    if not os.environ.get("LSPIV_LIBRARY") and not os.environ.get("LSPIV_ALLOW_STALE"):
+        prov = binary_provenance(lib)
+        if not prov["binary_hash_matches"]:
+            raise LspivLibraryStale(
+                f"{LIB_PATH} was built from sources with hash {prov['binary_source_hash']}, the tree has {prov['tree_source_hash']}: "
+                "rebuild (`make -C pyorc_amd/csrc`), or set LSPIV_ALLOW_STALE=1 to load it anyway")
     _lib = lib
     return lib
+
+
+KERNEL_SOURCES = ("piv_fft_impl.h", "fft_regs.h", "common.h", "piv_rescue.hip")
+
+
+def _hash_files(paths) -> str:
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in paths:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def source_hash(csrc_dir: Optional[str] = None, header: Optional[str] = None) -> str:
+    """sha256 (16 hex digits) over every source of the library: csrc/*.hip and csrc/*.h sorted by name, then include/lspiv.h --
+    what csrc/Makefile compiles into the binary as LSPIV_BUILD_SOURCE_HASH."""
+    d = csrc_dir or os.path.join(_HERE, "csrc")
+    names = sorted(n for n in os.listdir(d) if n.endswith(".hip") or n.endswith(".h"))
+    return _hash_files([os.path.join(d, n) for n in names] + [header or os.path.join(os.path.dirname(_HERE), "include", "lspiv.h")])
+
+
+def binary_provenance(lib: Optional[C.CDLL] = None, csrc_dir: Optional[str] = None) -> dict:
+    """The hashes the loaded binary carries next to the ones of the tree (bench.py prints this)."""
+    lib = lib if lib is not None else load()
+    if hasattr(lib, "lspiv_build_info"):
+        lib.lspiv_build_info.restype, lib.lspiv_build_info.argtypes = C.c_char_p, [_i32]
+        bk, bs = lib.lspiv_build_info(0).decode(), lib.lspiv_build_info(1).decode()
+    else:
+        bk = bs = "absent"   # a build from before round 4
+    tk, ts = kernel_code_hash(csrc_dir), source_hash(csrc_dir)
+    return {"binary_kernel_hash": bk, "tree_kernel_hash": tk, "binary_source_hash": bs, "tree_source_hash": ts,
+            "binary_hash_matches": bk == tk and bs == ts}
 
 
 class LspivValueError(LspivError, ValueError):
@@ -247,13 +295,9 @@ def as_frames(imgs) -> np.ndarray:
     return np.ascontiguousarray(a)
 
 
-def kernel_code_hash() -> str:
+def kernel_code_hash(csrc_dir: Optional[str] = None) -> str:
     """sha256 over the sources of the fused PIV kernels (csrc/piv_fft_impl.h, fft_regs.h, common.h, piv_rescue.hip): what a
-    committed profile summary is keyed to (tools/summarize_profile.py writes it, bench.py compares it)."""
-    import hashlib
-
-    h = hashlib.sha256()
-    for name in ("piv_fft_impl.h", "fft_regs.h", "common.h", "piv_rescue.hip"):
-        with open(os.path.join(_HERE, "csrc", name), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
+    committed profile summary is keyed to (tools/summarize_profile.py writes it, bench.py compares it) and what the binary
+    carries as LSPIV_BUILD_KERNEL_HASH."""
+    d = csrc_dir or os.path.join(_HERE, "csrc")
+    return _hash_files([os.path.join(d, n) for n in KERNEL_SOURCES])

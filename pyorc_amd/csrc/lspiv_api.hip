@@ -464,7 +464,20 @@ int lspiv::walk_setting() {
 extern "C" {
 
 int lspiv_abi_version(void) { return LSPIV_ABI_VERSION; }
-const char* lspiv_version(void) { return "lspiv-hip 0.1.0 (gfx950)"; }
+#ifndef LSPIV_KERNEL_HASH
+#define LSPIV_KERNEL_HASH "unknown"   // built without csrc/Makefile
+#endif
+#ifndef LSPIV_SOURCE_HASH
+#define LSPIV_SOURCE_HASH "unknown"
+#endif
+const char* lspiv_version(void) { return "lspiv-hip 0.2.0 (gfx950) src " LSPIV_SOURCE_HASH; }
+const char* lspiv_build_info(int what) {
+  switch (what) {
+    case LSPIV_BUILD_KERNEL_HASH: return LSPIV_KERNEL_HASH;
+    case LSPIV_BUILD_SOURCE_HASH: return LSPIV_SOURCE_HASH;
+    default: return "";
+  }
+}
 const char* lspiv_last_error(void) { return g_err.c_str(); }
 
 int lspiv_device_count(int* n) {

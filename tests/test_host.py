@@ -28,7 +28,7 @@ def test_library_exports_every_header_symbol(lib):
         assert hasattr(lib, s), f"{s} declared in include/lspiv.h but not exported by liblspiv_hip.so"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes prototype in pyorc_amd/_lib.py"
     assert sorted(_lib.SIGNATURES) == syms
-    assert lib.lspiv_abi_version() == 3
+    assert lib.lspiv_abi_version() == 4
     assert b"gfx950" in lib.lspiv_version()
 
 
@@ -476,3 +476,33 @@ def test_roofline_traffic_is_keyed_to_the_kernel_sources(tmp_path, monkeypatch):
     assert got == {"bytes": 2500000000, "source": "now_summary.json"}
     assert bench.measured_traffic("piv_fft_walk_kernel<unsigned char, 32,", 500, 1080, 1920, 32, 16) is None   # another launch shape
     assert len(_lib.kernel_code_hash()) == 16
+
+
+def test_loaded_binary_is_tied_to_the_tree(lib, tmp_path, monkeypatch):
+    """csrc/Makefile compiles the hash of every library source (and of the four kernel sources the profile
+    summaries are keyed to) into the binary; _lib.load() recomputes them from the tree and refuses a binary built from other
+    sources.  Here: the in-tree build matches; a copy of the sources with one edited header does not, load() raises
+    LspivLibraryStale for it, and LSPIV_ALLOW_STALE=1 loads it anyway (bench.py then prints binary_hash_matches: false)."""
+    import shutil
+
+    prov = _lib.binary_provenance(lib)
+    assert prov["binary_hash_matches"] and prov["binary_kernel_hash"] == _lib.kernel_code_hash() and len(prov["binary_source_hash"]) == 16
+    assert prov["binary_source_hash"].encode() in lib.lspiv_version()
+    assert lib.lspiv_build_info(0).decode() == prov["binary_kernel_hash"] and lib.lspiv_build_info(7) == b""
+    copy = tmp_path / "csrc"
+    shutil.copytree(os.path.join(ROOT, "pyorc_amd", "csrc"), copy, ignore=shutil.ignore_patterns("*.o"))
+    with open(copy / "common.h", "a") as fh:
+        fh.write("// edited after the build\n")
+    stale = _lib.binary_provenance(lib, csrc_dir=str(copy))
+    assert not stale["binary_hash_matches"]
+    assert stale["tree_kernel_hash"] != prov["tree_kernel_hash"] and stale["tree_source_hash"] != prov["tree_source_hash"]
+    # load() itself: same binary, edited tree
+    real = _lib.source_hash
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "source_hash", lambda csrc_dir=None, header=None: real(str(copy)))
+    monkeypatch.delenv("LSPIV_LIBRARY", raising=False)
+    monkeypatch.delenv("LSPIV_ALLOW_STALE", raising=False)
+    with pytest.raises(_lib.LspivLibraryStale, match="rebuild"):
+        _lib.load()
+    monkeypatch.setenv("LSPIV_ALLOW_STALE", "1")
+    assert _lib.load().lspiv_abi_version() == 4
