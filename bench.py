@@ -55,6 +55,10 @@ def parse():
     ap.add_argument("--cpu-pairs", type=int, default=-1, help="pairs of the CPU-baseline sample (-1: auto, 0: skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the other-configs and host-fed legs (N = 1)")
     ap.add_argument("--seed", type=int, default=20260927 + 2)
+    ap.add_argument("--strong", action="store_true",
+                    help="N > 1: cut a FIXED total of --strong-pairs over the N ranks (north_star's 'strong scaling', literally) "
+                         "instead of --pairs per rank (the default, 'weak')")
+    ap.add_argument("--strong-pairs", type=int, default=8000, help="total frame pairs of --strong (BASELINE.json configs[4]: 8000)")
     return ap.parse_args()
 
 
@@ -327,63 +331,58 @@ def main():
 
         comm = Comm(rank, world)
 
-    H, W, T = a.height, a.width, a.pairs + 1
+    H, W = a.height, a.width
     ws, ov = (a.window, a.window), (a.overlap, a.overlap)
     n_rows, n_cols = window.get_array_shape((H, W), ws, ov)
     n_win = n_rows * n_cols
-    n_tiles = a.pairs * n_win
 
-    # ---- device-resident synthetic stack + result block(s) ----------------------------------
+    # ---- which pairs this rank owns ----------------------------------------------------------
+    # N = 1 without a communicator: one launch over --pairs pairs.  With a communicator the step IS the library's sharded path
+    # (pyorc_amd.shard.ShardedPivDev: this rank's block of the time axis resident in HBM, kernels anchored at their absolute pair
+    # index, the packed result block all-gathered one step behind the kernels) -- weak: every rank owns --pairs pairs of a
+    # world x --pairs stack (blocks cut at multiples of --pairs); --strong: --strong-pairs pairs in total, cut on the walking
+    # kernels' anchors (shard.pair_block).
+    plan = None
+    if use_comm:
+        from pyorc_amd import shard
+
+        total_pairs = a.strong_pairs if a.strong else a.pairs * world
+        plan = shard.ShardedPivDev(comm, total_pairs, (H, W), ws, ov, align=None if a.strong else a.pairs, record_timings=True)
+        my_pairs, pair_offset = plan.p_local, plan.a
+    else:
+        total_pairs = my_pairs = a.pairs
+        pair_offset = 0
+    T = my_pairs + 1
+    n_tiles = my_pairs * n_win
+
+    # ---- device-resident synthetic stack + result block ---------------------------------------
     def dev_alloc(nbytes):
         p = C.c_void_p()
-        _lib.check(lib.lspiv_dev_malloc(C.byref(p), nbytes))
+        _lib.check(lib.lspiv_dev_malloc(C.byref(p), max(int(nbytes), 256)))
         return p
 
-    d_frames = dev_alloc(T * H * W)
-    outs = [dev_alloc(4 * n_tiles * 4) for _ in range(2 if use_comm else 1)]
-    alls = [dev_alloc(world * 4 * n_tiles * 4) for _ in range(2)] if use_comm else []
-    d_out = outs[0]
+    from pyorc_amd.device import DeviceFrames
+
+    frames = DeviceFrames.empty((T, H, W), np.uint8)
+    d_frames = frames.c_ptr
+    d_out = dev_alloc(4 * n_tiles * 4)
     _lib.check(lib.lspiv_synth_particles_dev(d_frames, T, H, W, a.seed + rank, 0.02))
-    _lib.check(lib.lspiv_synchronize())  # the generator ran on the library's stream; the steps may use another one
+    _lib.check(lib.lspiv_synchronize())  # the generator ran on the library's stream; the steps use other ones
 
     def launch_all(out=None, stream=None):
-        _lib.check(lib.lspiv_piv_pairs_dev(d_frames, 0, T, H, W, ws[0], ws[1], ov[0], ov[1], -1.0, out or d_out, None, stream))
+        if my_pairs:
+            _lib.check(lib.lspiv_piv_pairs_dev_at(d_frames, 0, T, H, W, ws[0], ws[1], ov[0], ov[1], -1.0, pair_offset, out or d_out, None, stream))
 
-    state = {"k": 0}
-    if not use_comm:
+    if plan is None:
         step = launch_all
 
         def drain():
             pass
     else:
-        # Software pipeline over steps: step k's kernel (all 1000 pairs, one launch) runs on `comp` while step k-1's
-        # result block is all-gathered over RCCL on `comm_s`.  Two result buffers; before a buffer is overwritten (two
-        # steps later) the compute stream waits for its gather.  Every gather issued inside the timed region completes
-        # inside it (drain() before the closing synchronize), so K steps = K kernels + K all-gathers.
-        comp, comm_s = C.c_void_p(), C.c_void_p()
-        _lib.check(lib.lspiv_stream_create(C.byref(comp)))
-        _lib.check(lib.lspiv_stream_create(C.byref(comm_s)))
-        ev_done = [C.c_void_p(), C.c_void_p()]      # kernel of buffer b finished
-        ev_gathered = [C.c_void_p(), C.c_void_p()]  # gather of buffer b finished
-        for e in ev_done + ev_gathered:
-            _lib.check(lib.lspiv_event_create(C.byref(e)))
-        gathered_once = [False, False]
-
         def step():
-            b = state["k"] & 1
-            if gathered_once[b]:
-                _lib.check(lib.lspiv_stream_wait_event(comp, ev_gathered[b]))   # gather k-2 has read outs[b]
-            launch_all(outs[b], comp)
-            _lib.check(lib.lspiv_event_record_on(ev_done[b], comp))
-            _lib.check(lib.lspiv_stream_wait_event(comm_s, ev_done[b]))
-            comm.allgather_dev(outs[b].value, alls[b].value, 4 * n_tiles, np.float32, comm_s.value)
-            _lib.check(lib.lspiv_event_record_on(ev_gathered[b], comm_s))
-            gathered_once[b] = True
-            state["k"] += 1
+            plan.step(frames)
 
-        def drain():
-            _lib.check(lib.lspiv_stream_synchronize(comp))
-            _lib.check(lib.lspiv_stream_synchronize(comm_s))
+        drain = plan.drain
 
     def sync():
         _lib.check(lib.lspiv_synchronize())
@@ -395,6 +394,8 @@ def main():
     for _ in range(a.warmup):
         step()
     drain(); sync(); barrier(); sync()
+    if plan is not None:
+        plan.timings()          # drop the warm-up steps' marks
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
@@ -402,6 +403,7 @@ def main():
     dt = time.perf_counter() - t0
     if comm is not None:
         dt = float(comm.allreduce(np.array([dt], dtype=np.float64), 1)[0])   # MAX over ranks
+    step_marks = plan.timings() if plan is not None else None
 
     # ---- live kernel timing with HIP events on the launch stream (roofline leg, N-independent) --
     reps = max(3, min(a.steps, 10))
@@ -425,16 +427,16 @@ def main():
                   "note": "windows whose float32 peak fit the kernel flags as ill-conditioned are re-evaluated from the frames in "
                           "float64 (csrc/piv_rescue.hip); the two rescue kernels run inside the timed region and inside kernel_ms"}
     gather_ms = None
-    if comm is not None and state["k"] > 0:
+    if plan is not None and plan.k > 0:
         # one all-gather of a result block on its own, by events on the gather stream (outside the timed region)
         e0, e1 = C.c_void_p(), C.c_void_p()
         _lib.check(lib.lspiv_event_create(C.byref(e0)))
         _lib.check(lib.lspiv_event_create(C.byref(e1)))
         sync()
-        _lib.check(lib.lspiv_event_record_on(e0, comm_s))
-        comm.allgather_dev(outs[0].value, alls[0].value, 4 * n_tiles, np.float32, comm_s.value)
-        _lib.check(lib.lspiv_event_record_on(e1, comm_s))
-        _lib.check(lib.lspiv_stream_synchronize(comm_s))
+        _lib.check(lib.lspiv_event_record_on(e0, plan.comm_s))
+        comm.allgather_dev(plan.send[0].ptr, plan.recv[0].ptr, plan.count, np.float32, plan.comm_s.value)
+        _lib.check(lib.lspiv_event_record_on(e1, plan.comm_s))
+        _lib.check(lib.lspiv_stream_synchronize(plan.comm_s))
         ms = C.c_float()
         _lib.check(lib.lspiv_event_elapsed_ms(e0, e1, C.byref(ms)))
         gather_ms = round(ms.value, 4)
@@ -442,16 +444,15 @@ def main():
         _lib.check(lib.lspiv_event_destroy(e1))
 
     dist_check = None
-    if comm is not None and state["k"] > 0:
-        # this rank's slice of the all-gathered block must equal its own single-launch result bit for bit;
-        # cheap, outside the timed region (launch_all in the kernel-timing loop wrote the same stack into d_out)
-        sync()
-        last = alls[(state["k"] - 1) & 1]
-        mine = np.empty(4 * n_tiles, dtype=np.uint32)
-        whole = np.empty(4 * n_tiles, dtype=np.uint32)
-        _lib.check(lib.lspiv_memcpy_d2h(_lib.ptr(mine), C.c_void_p(last.value + rank * 4 * n_tiles * 4), mine.nbytes))
-        _lib.check(lib.lspiv_memcpy_d2h(_lib.ptr(whole), d_out, whole.nbytes))
-        ok = np.array([1.0 if np.array_equal(mine, whole) else 0.0], dtype=np.float32)
+    if plan is not None and plan.k > 0:
+        # this rank's slice of the all-gathered block must equal its own single-launch result bit for bit; cheap, outside the
+        # timed region (launch_all above wrote the same pairs, at the same absolute pair index, into d_out)
+        plan.step(frames)
+        whole = np.empty((4, my_pairs, n_rows, n_cols), dtype=np.float32)
+        if my_pairs:
+            _lib.check(lib.lspiv_memcpy_d2h(_lib.ptr(whole), d_out, whole.nbytes))
+        mine = plan.gathered_host()[:, plan.a:plan.b]
+        ok = np.array([1.0 if np.array_equal(mine.view(np.uint32), whole.view(np.uint32)) else 0.0], dtype=np.float32)
         dist_check = bool(comm.allreduce(ok, 0)[0] == world)   # true on every rank
     if rank != 0:
         if comm is not None:
@@ -459,7 +460,7 @@ def main():
             comm.close()
         return
 
-    pairs_per_s = world * a.pairs * a.steps / dt
+    pairs_per_s = total_pairs * a.steps / dt
     is_c2 = (a.window, a.overlap, H, W) == (32, 16, 1080, 1920)
     out = {
         # BASELINE.json's metric; a non-default --window / --overlap / --height / --width run says what it measured
@@ -472,22 +473,26 @@ def main():
         "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if (a.strong and world > 1) else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"synthetic {H}x{W} uint8 particle stack, {a.pairs} frame-pairs per GPU, "
+            "workload": f"synthetic {H}x{W} uint8 particle stack, "
+                        + (f"{total_pairs} frame-pairs in total cut over {world} GPUs, " if (a.strong and world > 1) else f"{a.pairs} frame-pairs per GPU, ") +
                         f"{a.window}x{a.window} windows @ overlap {a.overlap} ("
                         + ("BASELINE.json configs[1]" if is_c2 and a.pairs == 1000 else "a variation of BASELINE.json configs[1]")
                         + ("; configs[4] sharding" if world > 1 else "") + ")",
             "frame_dtype": "u8",
             "windows_per_pair": n_win,
             "mvectors_per_s": round(pairs_per_s * n_win / 1e6, 3),
-            "parallelism": (f"time-block shard x{world}, {comm.transport.upper()} all-gather of the (4,t,y,x) result block "
-                            f"through the C ABI (no torch)") if comm is not None else "single GPU",
-            "scaling_denominator": "per-GPU work fixed at --pairs: speed-up at N GPUs = value(N) / value(1) of this command "
-                                   "(north_star's >= 6.5x at 8 GPUs = 8000 pairs on 8 GPUs vs 1000 pairs on 1)",
+            "parallelism": (f"time-block shard x{world} (pyorc_amd.shard.ShardedPivDev), {comm.transport.upper()} all-gather of the "
+                            f"(4,t,y,x) result block through the C ABI (no torch)") if comm is not None else "single GPU",
+            "scaling_denominator": ("--strong: the total is fixed at --strong-pairs; speed-up at N GPUs = value(N) / value(1) of `bench.py "
+                                    "--strong --gpus N`" if a.strong else
+                                    "per-GPU work fixed at --pairs: speed-up at N GPUs = value(N) / value(1) of this command "
+                                    "(north_star's >= 6.5x at 8 GPUs = 8000 pairs on 8 GPUs vs 1000 pairs on 1); `--strong` cuts a "
+                                    "fixed 8000-pair total over the ranks instead"),
         },
         "roofline": roofline_block(lib, kernel_ms, a.pairs, H, W, a.window, a.overlap, n_win, launch_ms),
     }
@@ -495,11 +500,28 @@ def main():
     if rescue is not None:
         out["config"]["rescue"] = rescue
     if comm is not None:
-        out["config"]["comm"] = {"transport": comm.transport, "ranks_reported_by_transport": comm.backend_ranks,
-                                 "allgather_matches_single_launch": dist_check,
-                                 "allgather_bytes_per_rank_per_step": 4 * n_tiles * 4,
-                                 "allgather_ms_alone": gather_ms,
-                                 **({"same_device_plumbing_test": True} if same_device else {})}
+        km = step_marks["kernel_ms"][-a.steps:] if step_marks else []
+        gm = step_marks["gather_ms"][-a.steps:] if step_marks else []
+        lag = step_marks["gather_end_after_kernel_end_ms"][-a.steps:] if step_marks else []
+        mean = lambda x: round(float(np.mean(x)), 4) if len(x) else None   # noqa: E731
+        out["config"]["comm"] = {
+            "transport": comm.transport, "ranks_reported_by_transport": comm.backend_ranks,
+            "path": "pyorc_amd.shard.ShardedPivDev (the library's device-resident sharded path; bench.py only times it)",
+            "mode": "strong" if a.strong else "weak", "pairs_total": total_pairs, "pairs_rank0": my_pairs,
+            "allgather_matches_single_launch": dist_check,
+            "allgather_bytes_per_rank_per_step": 4 * plan.p_max * n_win * 4,
+            "allgather_bytes_received_per_rank_per_step": (world - 1) * 4 * plan.p_max * n_win * 4,
+            "survey_8e_bytes_per_rank": "SURVEY.md section 8e: 1000 pairs x 7854 vectors x 16 B = 125.7 MB per rank and step at the C5 shape",
+            "allgather_ms_alone": gather_ms,
+            # rank 0, by HIP events per timed step: this rank's kernels (PIV + rescue) while the previous step's gather is in
+            # flight on the other stream, that gather itself, and what of the step is not covered by the kernels
+            "kernel_ms_while_gather_in_flight": mean(km), "gather_ms_overlapped": mean(gm),
+            "gather_end_after_kernel_end_ms": mean(lag),
+            "exposed_comm_ms": round(dt / a.steps * 1e3 - float(np.mean(km)), 4) if len(km) else None,
+            "kernel_ms_alone": round(launch_ms, 4),
+            "rccl_env": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "LSPIV_RCCL_MAX_NCHANNELS", "NCCL_ALGO", "NCCL_PROTO")
+                         if os.environ.get(k) is not None},
+            **({"same_device_plumbing_test": True} if same_device else {})}
     # ---- CPU baseline on a bounded sample of the same stack (rank 0, N = 1 only) --------------
     if world == 1 and a.cpu_pairs != 0:
         from oracle import cpu_baseline as cb   # test infrastructure: baseline / parity leg only
@@ -520,8 +542,10 @@ def main():
                                d_frames, a.pairs, H, W, 64, 48)]
         sample = np.empty((min(a.pairs, 200) + 1, H, W), dtype=np.uint8)
         _lib.check(lib.lspiv_memcpy_d2h(_lib.ptr(sample), d_frames, sample.nbytes))
-        _lib.check(lib.lspiv_dev_free(d_frames))
-        d_frames = None
+        frames = d_frames = None                      # the 1080p stack goes back (DeviceFrames' caching allocator) ...
+        from pyorc_amd.device import release_pool
+
+        release_pool()                                # ... and from there to the driver, before the 8.3 GB 4K stack is made
         H4, W4 = 2160, 3840
         d4 = dev_alloc((a.pairs + 1) * H4 * W4)
         _lib.check(lib.lspiv_synth_particles_dev(d4, a.pairs + 1, H4, W4, a.seed + 2, 0.02))

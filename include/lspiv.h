@@ -37,9 +37,9 @@
 extern "C" {
 #endif
 
-#define LSPIV_ABI_VERSION 4   /* 4 (round 4, additions only): lspiv_build_info, the ensemble rescue (lspiv_ensemble_set_retain / _stats / _state_dev /
-                               * _export_f64 / _import_f64), lspiv_stream_release; 3: lspiv_rescue_stats, lspiv_project_frames_u8[_dev], the
-                               * rescue / v_sign / norm_clip / std_ddof / round_odd options */
+#define LSPIV_ABI_VERSION 4   /* 4 (round 4, additions only): lspiv_build_info, the float64 rescue of the ensemble's final fit
+                               * (lspiv_ensemble_set_retain / _stats / _flag / _partials / _finish_partials), lspiv_stream_release; 3: lspiv_rescue_stats,
+                               * lspiv_project_frames_u8[_dev], the rescue / v_sign / norm_clip / std_ddof / round_odd options */
 
 /* status codes (mapped by the Python shim onto the reference's exception types) */
 #define LSPIV_OK            0
@@ -67,7 +67,7 @@ int         lspiv_abi_version(void);
 const char* lspiv_version(void);                        /* "lspiv-hip <version> (gfx950) src <source hash>" */
 /* Provenance of the loaded binary (csrc/Makefile compiles both in): LSPIV_BUILD_KERNEL_HASH = first 16 hex digits of the
  * sha256 over csrc/{piv_fft_impl.h, fft_regs.h, common.h, piv_rescue.hip} (the fused PIV kernels; the committed profile
- * summaries are keyed to it), LSPIV_BUILD_SOURCE_HASH = the same over every csrc/*.hip, csrc/*.h (sorted by name) and this
+ * summaries are keyed to it), LSPIV_BUILD_SOURCE_HASH = the same over every .hip and .h file of csrc/ (sorted by name) and this
  * header.  pyorc_amd._lib.load() recomputes the second from the tree and refuses a stale binary.  "unknown": not built by
  * csrc/Makefile; "": unknown selector. */
 #define LSPIV_BUILD_KERNEL_HASH 0
@@ -200,6 +200,41 @@ int lspiv_ensemble_finish(lspiv_ensemble* handle, float count_min, float n_frame
 /* running state out of / into HBM: corr_sum (n_win*wy*wx, fft-shifted planes) and corr_count (n_win).  Multi-GPU
  * ensemble = every rank accumulates its own time block, the states are summed (one all-reduce) and
  * imported on the rank that calls lspiv_ensemble_finish.  `add` != 0 adds to the current state instead of replacing. */
+/* Float64 rescue of the FINAL fit (round 4).  lspiv_ensemble_finish fits the mean plane; where that float32 fit is
+ * ill-conditioned (same flag model as the per-pair "rescue" option: a neighbour of the peak near zero, a flat ridge, samples tying
+ * for the maximum -- rare, and mostly in ensembles of a few pairs) the samples the fit reads are re-evaluated in float64 from the
+ * FRAMES, over the pairs that were added to the sum, and u, v are overwritten.  The frames therefore have to be reachable at
+ * finish:
+ *   - lspiv_ensemble_accumulate (host frames) keeps its upload buffers in HBM until finish / destroy, as long as they fit
+ *     LSPIV_ENSEMBLE_RETAIN_BYTES (default: a quarter of the device memory); beyond that the float32 fits stay;
+ *   - lspiv_ensemble_accumulate_dev keeps nothing by default (LSPIV_RETAIN_NONE: float32 fits, as in round 3);
+ *     LSPIV_RETAIN_COPY makes the handle copy every chunk (same budget), LSPIV_RETAIN_BORROW only records the caller's pointer --
+ *     the caller then guarantees that every chunk handed to accumulate_dev stays valid and unchanged until finish;
+ *   - a state brought in with lspiv_ensemble_import holds pairs whose frames this handle never saw: lspiv_ensemble_finish keeps the
+ *     float32 fits then (the staged finish below is the multi-GPU way).
+ * Set the mode before the first accumulate call.  lspiv_ensemble_stats after finish: stats[0..5] = windows flagged, windows
+ * re-evaluated, windows left with their float32 fit (no frames / more than four arg-max candidates / list limit), chunks kept,
+ * bytes kept, 1 if every chunk could be kept. */
+#define LSPIV_RETAIN_NONE   0
+#define LSPIV_RETAIN_COPY   1
+#define LSPIV_RETAIN_BORROW 2
+int lspiv_ensemble_set_retain(lspiv_ensemble* handle, int mode);
+int lspiv_ensemble_stats(lspiv_ensemble* handle, int64_t* stats);
+/* The same rescue when the sum is spread over several handles (multi-GPU: every rank accumulated its own time block, the
+ * states were all-reduced and imported -- replaced, `add` = 0 -- on every rank, so all hold the same sums).  lspiv_ensemble_finish
+ * in three stages:
+ *   lspiv_ensemble_flag            mean planes, float32 fits, the flagged windows sorted by index: the same *n_records and the
+ *                                  same list on every rank;
+ *   lspiv_ensemble_partials        this handle's float64 sums over ITS retained chunks, partials[n_records][LSPIV_ENS_PARTIAL_DOUBLES];
+ *                                  *complete = 0 (and zeros) if some chunk of this handle could not be kept -- the ranks then agree
+ *                                  (one more all-reduce) to call plain lspiv_ensemble_finish instead;
+ *   [the caller sums `partials` over the ranks: one float64 all-reduce]
+ *   lspiv_ensemble_finish_partials the fits of the flagged windows from the totals, then the outputs of lspiv_ensemble_finish. */
+#define LSPIV_ENS_PARTIAL_DOUBLES 20
+int lspiv_ensemble_flag(lspiv_ensemble* handle, float count_min, float n_frames, int64_t* n_records);
+int lspiv_ensemble_partials(lspiv_ensemble* handle, double* partials, int* complete);
+int lspiv_ensemble_finish_partials(lspiv_ensemble* handle, const double* partials, float* u, float* v, float* corr_count,
+                                   float* corr_mean);
 int lspiv_ensemble_export(lspiv_ensemble* handle, float* corr_sum, float* corr_count);
 int lspiv_ensemble_import(lspiv_ensemble* handle, const float* corr_sum, const float* corr_count, int add);
 int lspiv_ensemble_destroy(lspiv_ensemble* handle);
@@ -390,6 +425,9 @@ int lspiv_event_destroy(void* ev);
  * entry point takes such a handle; events recorded on one stream can be waited for on another. */
 int lspiv_stream_create(void** stream);
 int lspiv_stream_destroy(void* stream);
+/* a stream the CALLER created (hipStreamCreate) and passed to "_dev" entry points: free what the library keeps for it (the
+ * rescue lists and their counters); NULL = the library's own stream.  lspiv_stream_destroy does this for its own streams. */
+int lspiv_stream_release(void* stream);
 int lspiv_stream_synchronize(void* stream);             /* NULL = the library's launch stream */
 int lspiv_event_record_on(void* ev, void* stream);      /* NULL = the library's launch stream */
 int lspiv_stream_wait_event(void* stream, void* ev);    /* NULL = the library's launch stream */

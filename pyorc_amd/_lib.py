@@ -77,6 +77,11 @@ SIGNATURES = {
     "lspiv_ensemble_accumulate": (_i32, [_vp, _vp, _i32, _i64, _f32, _f32, _f32, _vp, _vp]),
     "lspiv_ensemble_accumulate_dev": (_i32, [_vp, _vp, _i32, _i64, _f32, _f32, _f32, _vp, _vp]),
     "lspiv_ensemble_finish": (_i32, [_vp, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "lspiv_ensemble_set_retain": (_i32, [_vp, _i32]),
+    "lspiv_ensemble_stats": (_i32, [_vp, _pi64]),
+    "lspiv_ensemble_flag": (_i32, [_vp, _f32, _f32, _pi64]),
+    "lspiv_ensemble_partials": (_i32, [_vp, _vp, C.POINTER(_i32)]),
+    "lspiv_ensemble_finish_partials": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "lspiv_ensemble_export": (_i32, [_vp, _vp, _vp]),
     "lspiv_ensemble_import": (_i32, [_vp, _vp, _vp, _i32]),
     "lspiv_ensemble_destroy": (_i32, [_vp]),
@@ -130,6 +135,7 @@ SIGNATURES = {
     "lspiv_event_destroy": (_i32, [_vp]),
     "lspiv_stream_create": (_i32, [C.POINTER(_vp)]),
     "lspiv_stream_destroy": (_i32, [_vp]),
+    "lspiv_stream_release": (_i32, [_vp]),
     "lspiv_stream_synchronize": (_i32, [_vp]),
     "lspiv_event_record_on": (_i32, [_vp, _vp]),
     "lspiv_stream_wait_event": (_i32, [_vp, _vp]),

@@ -113,6 +113,12 @@ class Comm:
         if transport not in _TRANSPORTS:
             raise ValueError(f"transport {transport!r} not in {sorted(_TRANSPORTS)}")
         self.rank, self.world, self.transport = int(rank), int(world), transport
+        if transport == "rccl":
+            # The gather runs on RCCL's own kernels NEXT TO the PIV kernel, which saturates the VALUs of every CU it gets: cap
+            # the channels (one workgroup each) RCCL may take unless the user decided otherwise.  16 channels move the
+            # 126 MB / rank result block of a 1000-pair step well inside the step's 6 ms on xGMI and leave > 90 % of the CUs to
+            # the PIV kernel.  Read by RCCL at ncclCommInitRank, i.e. below.
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("LSPIV_RCCL_MAX_NCHANNELS", "16"))
         self._lib = _lib.load()
         self._h = C.c_void_p()
         path = id_file or default_id_file()

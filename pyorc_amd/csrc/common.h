@@ -108,6 +108,31 @@ struct PivParams {
   FastDiv div_nwin;        // one-window-per-job kernels: job index -> (pair, window), divisor n_win
 };
 
+// ---- float64 rescue of the ENSEMBLE's final fit (piv_rescue.hip) ---------------------------------
+// lspiv_ensemble_finish fits the MEAN plane; where that float32 fit is ill-conditioned (same flag model as above) the five
+// samples it reads are re-evaluated in float64 from the retained frames: c[k] = (1 / count) sum over the KEPT pairs of
+// clip01((1 / n) sum_m a'[m] b'[m + k]).  A record lists the window and up to four candidates of the arg-max (the samples of
+// the float32 mean plane within tau of its maximum, ascending row-major index): each gets its five float64 sums, the largest
+// centre wins.  Partial sums per (record, block of pairs) are merged in block order: deterministic, no atomics on results.
+constexpr int kEnsMaxCand = 4;
+constexpr int kEnsPairBlock = 16;       // pairs per partial sum
+struct EnsRescueRec {
+  uint32_t w;                 // window
+  uint32_t ncand;             // 1 .. kEnsMaxCand; 0: more candidates than that -- the float32 result stays
+  uint32_t pos[kEnsMaxCand];  // (ip << 16) | jp in the fft-shifted plane
+  uint32_t pad[2];
+};
+struct EnsRescueHdr { uint32_t n_rec, n_skipped, pad[2]; };
+struct EnsRescueArgs {
+  const EnsRescueRec* recs;
+  uint32_t n_rec;
+  const float* cmax;          // this chunk's masked per-pair corr_max, (n_pairs, n_win): > 0 <=> the pair was added to the sum
+  uint32_t n_pairs;           // pairs of this chunk
+  uint32_t blk0, n_blk;       // this chunk's first pair-block in `partial`, pair-blocks over all retained chunks
+  double* partial;            // (n_rec, n_blk, kEnsMaxCand, 5)
+  const float* count;         // (n_win) pairs in the sum
+};
+
 // ---- wave64 cross-lane helpers -----------------------------------------------------------------
 // DPP row operations act inside rows of 16 lanes; ds_swizzle(SWAP,16) joins the two rows of a
 // 32-lane half, ds_swizzle cannot cross the 32-lane boundary (which is what we want: the two
@@ -369,6 +394,15 @@ hipError_t launch_piv_embed32(const PivParams& p, int dtype, bool ensemble, hipS
 hipError_t launch_piv_embed64(const PivParams& p, int dtype, bool ensemble, hipStream_t s);
 // float64 re-evaluation of the windows the PIV kernel of this pass appended to p.rescue_* (piv_rescue.hip)
 hipError_t launch_piv_rescue(const PivParams& p, int dtype, hipStream_t s);
+// ensemble mode: flag the windows of the float32 mean planes (u, v = their float32 fits) whose fit cannot be trusted; partial
+// float64 sums of one retained chunk (p: geometry + options + the chunk's frames); merge + fit, overwriting u, v
+hipError_t launch_ens_flag(const float* mean, uint32_t n_win, int wy, int wx, const float* u, const float* v, float k, float tau,
+                           EnsRescueHdr* hdr, EnsRescueRec* recs, uint32_t cap, hipStream_t s);
+hipError_t launch_ens_partial(const PivParams& p, int dtype, const EnsRescueArgs& a, hipStream_t s);
+// totals (n_rec, kEnsMaxCand * 5) = the partial sums of one handle merged in pair-block order
+hipError_t launch_ens_merge(const EnsRescueArgs& a, double* totals, hipStream_t s);
+// fit of the flagged windows from totals over ALL pairs of the sum (p: wy, wx, border_mode; a: recs, n_rec, count)
+hipError_t launch_ens_final(const PivParams& p, const EnsRescueArgs& a, const double* totals, float* u, float* v, hipStream_t s);
 hipError_t launch_peaks_from_planes(const float* planes, uint32_t n_planes, int wy, int wx, int border_mode,
                                     float* u, float* v, hipStream_t s);
 // "stack" signal mode: keep[w] = fraction of non-zero (or positive) samples of window position w over ALL frames >= thr

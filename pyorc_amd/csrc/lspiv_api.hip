@@ -273,9 +273,19 @@ int rescue_ws(DeviceCtx* c, hipStream_t s, uint32_t n_tiles, lspiv::PivParams* p
   if (cap_fit > ws->cap_fit || cap_amb > ws->cap_amb || !ws->base) {
     const uint32_t nf = std::max(cap_fit, ws->cap_fit), na = std::max(cap_amb, ws->cap_amb);
     const size_t bytes = hdr_bytes + (size_t)nf * sizeof(uint4) + (size_t)na * sizeof(uint32_t);
-    if (ws->base) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipFree(ws->base)); ws->base = nullptr; }
-    HIP_TRY(hipMalloc(&ws->base, bytes));
-    HIP_TRY(hipMemsetAsync(ws->base, 0, hdr_bytes, s));   // ordered before the kernels of this stream
+    void* grown = nullptr;
+    HIP_TRY(hipMalloc(&grown, bytes));
+    if (ws->base) {
+      // the header moves along: its per-pass counters are zero between passes (the rescue kernel's last block resets them) and
+      // the totals of lspiv_rescue_stats ("summed over all launches") survive the regrow
+      hipError_t e = hipStreamSynchronize(s);
+      if (e == hipSuccess) e = hipMemcpy(grown, ws->base, hdr_bytes, hipMemcpyDeviceToDevice);
+      if (e != hipSuccess) { (void)hipFree(grown); return fail(LSPIV_EHIP, "rescue lists: %s", hipGetErrorString(e)); }
+      HIP_TRY(hipFree(ws->base));
+    } else {
+      HIP_TRY(hipMemsetAsync(grown, 0, hdr_bytes, s));   // ordered before the kernels of this stream
+    }
+    ws->base = grown;
     ws->cap_bytes = bytes; ws->cap_fit = nf; ws->cap_amb = na;
   }
   p->rescue_hdr = static_cast<lspiv::RescueHdr*>(ws->base);
@@ -328,12 +338,18 @@ int dispatch_kernels(const lspiv::PivParams& p, int dtype, bool ensemble, hipStr
 
 // PIV kernel of the window's family, then -- per-timestep mode, unless switched off -- the float64 rescue pass over the
 // windows that kernel flagged (piv_rescue.hip)
+// The PIV kernel and the two rescue kernels of ONE launch share the stream's lists and counters: they are issued under one
+// lock, so that two host threads launching on the same stream (NULL -> the library's stream) cannot interleave as PIV 1,
+// PIV 2, rescue 1 -- rescue 1 would then consume launch 2's records with launch 1's parameters.  Launches are asynchronous:
+// the lock is held for microseconds.  (The rescue kernels skip a record whose index is outside their launch all the same.)
+std::mutex g_dispatch_mu;
 int dispatch(const lspiv::PivParams& p0, int dtype, bool ensemble, hipStream_t s) {
   if (ensemble || !g_opt_rescue.load()) return dispatch_kernels(p0, dtype, ensemble, s);
   DeviceCtx* c;
   int rc = get_ctx(&c);
   if (rc) return rc;
   lspiv::PivParams p = p0;
+  std::lock_guard<std::mutex> launch_lock(g_dispatch_mu);
   rc = rescue_ws(c, s, p.n_tiles, &p);
   if (rc) return rc;
   rc = dispatch_kernels(p, dtype, false, s);
@@ -426,7 +442,54 @@ struct lspiv_ensemble {
   float* d_part;   // walking kernels: per-segment partial sums + counts (grow-only workspace)
   size_t part_cap;
   int64_t pairs_done;   // pairs accumulated so far = absolute index of the next chunk's first pair (segment anchoring)
+  // float64 rescue of the final fit (piv_rescue.hip, ens_*): the chunks' frames and masked corr_max stay reachable until
+  // lspiv_ensemble_finish -- owned copies (host entry point: the upload buffer itself; "_dev": a device copy, LSPIV_RETAIN_COPY)
+  // or the caller's pointer (LSPIV_RETAIN_BORROW)
+  struct Kept { void* d_frames; bool owned; int dtype; int64_t T; float* d_cmax; };
+  std::vector<Kept> kept;
+  int retain_mode;          // "_dev" entry point: LSPIV_RETAIN_*; the host entry point always keeps its upload buffers
+  size_t kept_bytes;
+  bool retain_complete;     // false: some chunk could not be kept (budget, mode NONE, imported state) -> float32 fits stay
+  void* d_rescue; size_t rescue_cap;     // EnsRescueHdr (256 B) + records
+  double* d_partial; size_t partial_cap;
+  double* d_totals; size_t totals_cap;   // (n_rec, kEnsMaxCand * 5): the partial sums merged over this handle's pair-blocks
+  int64_t last_flagged, last_rescued, last_skipped;
+  bool foreign;             // the sums were replaced by lspiv_ensemble_import: they hold other handles' pairs as well
+  uint32_t n_rec;           // records of the last lspiv_ensemble_flag (sorted by window), 0 if none
+  float flag_min_count;     // count_min * n_frames of that call
 };
+
+// HBM the retained chunks of one ensemble may occupy: LSPIV_ENSEMBLE_RETAIN_BYTES, default a quarter of the device
+static size_t ensemble_retain_budget() {
+  if (const char* e = getenv("LSPIV_ENSEMBLE_RETAIN_BYTES")) return (size_t)atoll(e);
+  size_t f = 0, t = 0;
+  if (hipMemGetInfo(&f, &t) != hipSuccess) { (void)hipGetLastError(); return (size_t)16 << 30; }
+  return t / 4;
+}
+static void ensemble_drop_kept(lspiv_ensemble* h) {
+  for (auto& k : h->kept) {
+    if (k.owned && k.d_frames) (void)hipFree(k.d_frames);
+    if (k.d_cmax) (void)hipFree(k.d_cmax);
+  }
+  h->kept.clear();
+  h->kept_bytes = 0;
+}
+// keep the masked corr_max of a chunk (the kernels' keep decisions) next to its frames; on any failure the ensemble simply
+// stops being rescuable (retain_complete = false), the accumulation itself is not affected
+static void ensemble_keep(lspiv_ensemble* h, void* d_frames, bool owned, int dtype, int64_t T, const float* d_cmax, hipStream_t s) {
+  const size_t n_tiles = (size_t)(T - 1) * h->g.n_rows * h->g.n_cols;
+  void* cm = nullptr;
+  if (hipMalloc(&cm, n_tiles * sizeof(float)) != hipSuccess ||
+      hipMemcpyAsync(cm, d_cmax, n_tiles * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+    (void)hipGetLastError();
+    if (cm) (void)hipFree(cm);
+    if (owned) (void)hipFree(d_frames);
+    h->retain_complete = false;
+    return;
+  }
+  h->kept.push_back({d_frames, owned, dtype, T, (float*)cm});
+  h->kept_bytes += n_tiles * sizeof(float);
+}
 
 static std::atomic<int> g_opt_walk{-1};   // lspiv_set_option("walk", v); -1: not set, fall back to the environment
 // "stack" signal mode: one pass over the chunk's frames leaves a keep flag per window position; the PIV kernels then run
@@ -862,6 +925,10 @@ int lspiv_ensemble_begin(int64_t H, int64_t W, int wy, int wx, int oy, int ox, l
   lspiv_ensemble* h = new lspiv_ensemble();
   h->H = H; h->W = W; h->wy = wy; h->wx = wx; h->oy = oy; h->ox = ox; h->g = g;
   h->d_sum = nullptr; h->d_count = nullptr; h->d_part = nullptr; h->part_cap = 0; h->pairs_done = 0;
+  h->retain_mode = LSPIV_RETAIN_NONE; h->kept_bytes = 0; h->retain_complete = true;
+  h->d_rescue = nullptr; h->rescue_cap = 0; h->d_partial = nullptr; h->partial_cap = 0;
+  h->last_flagged = h->last_rescued = h->last_skipped = 0;
+  h->d_totals = nullptr; h->totals_cap = 0; h->foreign = false; h->n_rec = 0; h->flag_min_count = 0.0f;
   HIP_TRY(hipGetDevice(&h->device));
   const size_t n_win = (size_t)g.n_rows * g.n_cols;
   void* p = nullptr;
@@ -921,8 +988,30 @@ int lspiv_ensemble_accumulate_dev(lspiv_ensemble* h, const void* d_frames, int d
   int rc = get_ctx(&c);
   if (rc) return rc;
   const size_t n_tiles = (size_t)(T - 1) * h->g.n_rows * h->g.n_cols;
-  return ensemble_launch(h, c, d_frames, dtype, T, corr_min, s2n_min, signal_threshold, d_corr_s2n, d_corr_s2n + n_tiles,
-                         stream ? (hipStream_t)stream : c->stream);
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  rc = ensemble_launch(h, c, d_frames, dtype, T, corr_min, s2n_min, signal_threshold, d_corr_s2n, d_corr_s2n + n_tiles, s);
+  if (rc) return rc;
+  // retention for the float64 rescue of the final fit (lspiv_ensemble_set_retain)
+  if (h->retain_mode == LSPIV_RETAIN_NONE || !h->retain_complete || !g_opt_rescue.load()) { h->retain_complete = false; return LSPIV_OK; }
+  if (h->retain_mode == LSPIV_RETAIN_BORROW) {
+    ensemble_keep(h, const_cast<void*>(d_frames), false, dtype, T, d_corr_s2n, s);
+    return LSPIV_OK;
+  }
+  const size_t fbytes = (size_t)T * h->H * h->W * elem_size(dtype);
+  void* copy = nullptr;
+  if (h->kept_bytes + fbytes > ensemble_retain_budget() || hipMalloc(&copy, fbytes) != hipSuccess) {
+    (void)hipGetLastError();
+    h->retain_complete = false;
+    return LSPIV_OK;
+  }
+  if (hipMemcpyAsync(copy, d_frames, fbytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+    (void)hipGetLastError(); (void)hipFree(copy);
+    h->retain_complete = false;
+    return LSPIV_OK;
+  }
+  h->kept_bytes += fbytes;
+  ensemble_keep(h, copy, true, dtype, T, d_corr_s2n, s);
+  return LSPIV_OK;
 }
 
 int lspiv_ensemble_accumulate(lspiv_ensemble* h, const void* frames, int dtype, int64_t T, float corr_min,
@@ -942,8 +1031,19 @@ int lspiv_ensemble_accumulate(lspiv_ensemble* h, const void* frames, int dtype, 
   const int dev_dtype = dtype == LSPIV_F64 ? LSPIV_F32 : dtype;
   const size_t frame_elems = (size_t)h->H * h->W;
   const size_t frame_bytes = frame_elems * elem_size(dev_dtype), src_frame_bytes = frame_elems * elem_size(dtype);
-  rc = ensure(&c->d_frames, &c->frames_cap, (size_t)T * frame_bytes);
-  if (rc) return rc;
+  // the chunk is uploaded into a buffer of its own that stays with the handle until finish (float64 rescue of the final fit),
+  // as long as the retained chunks fit their budget; beyond it, into the shared workspace as before (float32 fits stay)
+  void* own = nullptr;
+  if (g_opt_rescue.load() && h->retain_complete && h->kept_bytes + (size_t)T * frame_bytes <= ensemble_retain_budget()) {
+    if (hipMalloc(&own, (size_t)T * frame_bytes) != hipSuccess) { (void)hipGetLastError(); own = nullptr; }
+  }
+  if (!own) {
+    h->retain_complete = false;
+    rc = ensure(&c->d_frames, &c->frames_cap, (size_t)T * frame_bytes);
+    if (rc) return rc;
+  }
+  char* const d_chunk = own ? (char*)own : (char*)c->d_frames;
+  struct OwnGuard { void* p; ~OwnGuard() { if (p) (void)hipFree(p); } } own_guard{own};   // released on every error path below
   rc = stage_ring(c, frame_bytes);
   if (rc) return rc;
   const int64_t fpb = std::max<int64_t>(1, (int64_t)(c->pinned_cap / frame_bytes));
@@ -960,7 +1060,7 @@ int lspiv_ensemble_accumulate(lspiv_ensemble* h, const void* frames, int dtype, 
         staged_narrow((float*)c->pinned[slot], (const double*)((const char*)frames + (size_t)f0 * src_frame_bytes), (size_t)(f1 - f0) * frame_elems);
       else
         staged_copy(c->pinned[slot], (const char*)frames + (size_t)f0 * src_frame_bytes, nb);
-      HIP_TRY(hipMemcpyAsync((char*)c->d_frames + (size_t)f0 * frame_bytes, c->pinned[slot], nb, hipMemcpyHostToDevice, c->copy_stream));
+      HIP_TRY(hipMemcpyAsync(d_chunk + (size_t)f0 * frame_bytes, c->pinned[slot], nb, hipMemcpyHostToDevice, c->copy_stream));
       HIP_TRY(hipEventRecord(c->staged[slot], c->copy_stream));
       HIP_TRY(hipStreamWaitEvent(c->stream, c->staged[slot], 0));
       // pairs [0, f1 - 1) are resident; accumulate up to the last segment anchor below that (everything at the end)
@@ -968,7 +1068,7 @@ int lspiv_ensemble_accumulate(lspiv_ensemble* h, const void* frames, int dtype, 
       if (f1 < T) p1 = (g_opt_signal_mode.load() == 1 && signal_threshold >= 0.0f) ? 0 : ((base_offset + p1) / align) * align - base_offset;
       const int64_t p0 = launched;
       if (p1 > p0) {
-        rc = ensemble_launch(h, c, (const char*)c->d_frames + (size_t)p0 * frame_bytes, dev_dtype, p1 - p0 + 1, corr_min, s2n_min,
+        rc = ensemble_launch(h, c, d_chunk + (size_t)p0 * frame_bytes, dev_dtype, p1 - p0 + 1, corr_min, s2n_min,
                              signal_threshold, c->d_out + p0 * n_win, c->d_out + n_tiles + p0 * n_win, c->stream);
         if (rc) return rc;
         launched = p1;
@@ -976,9 +1076,190 @@ int lspiv_ensemble_accumulate(lspiv_ensemble* h, const void* frames, int dtype, 
       f0 = f1;
     }
   }
+  if (own) {
+    own_guard.p = nullptr;          // the handle owns it from here
+    h->kept_bytes += (size_t)T * frame_bytes;
+    ensemble_keep(h, own, true, dev_dtype, T, c->d_out, c->stream);
+  }
   HIP_TRY(hipMemcpyAsync(corr_max, c->d_out, n_tiles * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(s2n, c->d_out + n_tiles, n_tiles * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
+
+// ---- float64 rescue of the final fit, in stages (piv_rescue.hip, ens_*) ---------------------------------------------------
+// mean planes (count filter) -> c->d_planes, their float32 fits -> c->d_out [u | v]
+static int ensemble_mean_fit(lspiv_ensemble* h, DeviceCtx* c, float min_count) {
+  const size_t n_win = (size_t)h->g.n_rows * h->g.n_cols;
+  int rc = ensure(&c->d_planes, &c->planes_cap, n_win * h->wy * h->wx * sizeof(float));
+  if (rc) return rc;
+  rc = ensure(&c->d_out, &c->out_cap, 2 * n_win * sizeof(float));
+  if (rc) return rc;
+  hipError_t e = lspiv::launch_ensemble_mean(h->d_sum, h->d_count, min_count, (uint32_t)n_win, h->wy * h->wx, c->d_planes, c->stream);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  e = lspiv::launch_peaks_from_planes(c->d_planes, (uint32_t)n_win, h->wy, h->wx, g_opt_border.load(), c->d_out, c->d_out + n_win, c->stream);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return LSPIV_OK;
+}
+static lspiv::EnsRescueRec* ensemble_recs(lspiv_ensemble* h) { return reinterpret_cast<lspiv::EnsRescueRec*>((char*)h->d_rescue + 256); }
+
+// flag the windows whose float32 fit (c->d_out, of the mean planes in c->d_planes) cannot be trusted to 1e-4; the records end
+// up sorted by window index -- the same list on every handle that holds the same state (multi-GPU: after the all-reduce)
+static int ensemble_flag(lspiv_ensemble* h, DeviceCtx* c) {
+  h->last_flagged = h->last_rescued = h->last_skipped = 0;
+  h->n_rec = 0;
+  const uint32_t n_win = (uint32_t)(h->g.n_rows * h->g.n_cols);
+  const size_t hdr_bytes = 256;
+  int rc = ensure(&h->d_rescue, &h->rescue_cap, hdr_bytes + (size_t)n_win * sizeof(lspiv::EnsRescueRec));
+  if (rc) return rc;
+  lspiv::EnsRescueHdr* d_hdr = static_cast<lspiv::EnsRescueHdr*>(h->d_rescue);
+  HIP_TRY(hipMemsetAsync(d_hdr, 0, hdr_bytes, c->stream));
+  const float k = (float)(2.0 * g_opt_rescue_kappa.load() * 1e-9 / (0.6931471805599453 * 1e-4));
+  hipError_t e = lspiv::launch_ens_flag(c->d_planes, n_win, h->wy, h->wx, c->d_out, c->d_out + n_win, k, (float)(g_opt_rescue_tau.load() * 1e-9),
+                                        d_hdr, ensemble_recs(h), n_win, c->stream);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  lspiv::EnsRescueHdr hdr;
+  HIP_TRY(hipMemcpyAsync(&hdr, d_hdr, sizeof(hdr), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  h->last_flagged = hdr.n_rec;
+  h->last_skipped = hdr.n_skipped;
+  const uint32_t n_rec = std::min<uint32_t>(hdr.n_rec, n_win);
+  if (n_rec > 1) {   // the kernel appends in whatever order its waves finish: sort (a few records, once per video)
+    std::vector<lspiv::EnsRescueRec> recs(n_rec);
+    HIP_TRY(hipMemcpy(recs.data(), ensemble_recs(h), n_rec * sizeof(lspiv::EnsRescueRec), hipMemcpyDeviceToHost));
+    std::sort(recs.begin(), recs.end(), [](const lspiv::EnsRescueRec& a, const lspiv::EnsRescueRec& b) { return a.w < b.w; });
+    HIP_TRY(hipMemcpy(ensemble_recs(h), recs.data(), n_rec * sizeof(lspiv::EnsRescueRec), hipMemcpyHostToDevice));
+  }
+  h->n_rec = n_rec;
+  return LSPIV_OK;
+}
+
+// this handle's share of the float64 sums: over the pairs of its retained chunks, merged in pair-block order -> h->d_totals
+// (n_rec, kEnsMaxCand * 5).  *complete = false (and zeros) when some chunk of this handle could not be kept.
+static int ensemble_partials(lspiv_ensemble* h, DeviceCtx* c, bool* complete) {
+  const size_t row = (size_t)lspiv::kEnsMaxCand * 5 * sizeof(double);
+  int rc = ensure(&h->d_totals, &h->totals_cap, std::max<size_t>(1, h->n_rec) * row);
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(h->d_totals, 0, std::max<size_t>(1, h->n_rec) * row, c->stream));
+  *complete = h->retain_complete;
+  if (h->n_rec == 0 || !h->retain_complete || h->kept.empty()) return LSPIV_OK;
+  uint32_t n_blk = 0;
+  for (const auto& kp : h->kept) n_blk += (uint32_t)((kp.T - 1 + lspiv::kEnsPairBlock - 1) / lspiv::kEnsPairBlock);
+  const size_t per_rec = (size_t)n_blk * row;
+  if ((size_t)h->n_rec * per_rec > ((size_t)4 << 30)) { *complete = false; return LSPIV_OK; }   // (thousands of flagged windows x thousands of pair-blocks)
+  rc = ensure(&h->d_partial, &h->partial_cap, (size_t)h->n_rec * per_rec);
+  if (rc) return rc;
+  lspiv::EnsRescueArgs a;
+  memset(&a, 0, sizeof(a));
+  a.recs = ensemble_recs(h); a.n_rec = h->n_rec; a.n_blk = n_blk; a.partial = h->d_partial; a.count = h->d_count;
+  lspiv::PivParams p;
+  uint32_t blk0 = 0;
+  for (const auto& kp : h->kept) {
+    rc = fill_params(&p, kp.d_frames, kp.dtype, kp.T, h->H, h->W, h->wy, h->wx, h->oy, h->ox, -1.0f, h->g);
+    if (rc) return rc;
+    a.cmax = kp.d_cmax; a.n_pairs = (uint32_t)(kp.T - 1); a.blk0 = blk0;
+    hipError_t e = lspiv::launch_ens_partial(p, kp.dtype, a, c->stream);
+    if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+    blk0 += (a.n_pairs + lspiv::kEnsPairBlock - 1) / lspiv::kEnsPairBlock;
+  }
+  hipError_t e = lspiv::launch_ens_merge(a, h->d_totals, c->stream);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return LSPIV_OK;
+}
+
+// the fit of the flagged windows from the float64 totals (all pairs of the sum), overwriting c->d_out [u | v]
+static int ensemble_final(lspiv_ensemble* h, DeviceCtx* c, const double* d_totals) {
+  if (h->n_rec == 0) return LSPIV_OK;
+  const size_t n_win = (size_t)h->g.n_rows * h->g.n_cols;
+  lspiv::PivParams p;
+  memset(&p, 0, sizeof(p));
+  p.wy = h->wy; p.wx = h->wx; p.border_mode = g_opt_border.load();
+  lspiv::EnsRescueArgs a;
+  memset(&a, 0, sizeof(a));
+  a.recs = ensemble_recs(h); a.n_rec = h->n_rec; a.count = h->d_count;
+  hipError_t e = lspiv::launch_ens_final(p, a, d_totals, c->d_out, c->d_out + n_win, c->stream);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  h->last_rescued = (int64_t)h->n_rec - h->last_skipped;
+  return LSPIV_OK;
+}
+
+// results of c->d_out / c->d_planes / the count to the caller ("v_sign" applied first)
+static int ensemble_deliver(lspiv_ensemble* h, DeviceCtx* c, float* u, float* v, float* corr_count, float* corr_mean) {
+  const size_t n_win = (size_t)h->g.n_rows * h->g.n_cols;
+  int rc = apply_v_sign(c->d_out + n_win, (int64_t)n_win, c->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(u, c->d_out, n_win * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(v, c->d_out + n_win, n_win * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (corr_count) HIP_TRY(hipMemcpyAsync(corr_count, h->d_count, n_win * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (corr_mean) HIP_TRY(hipMemcpyAsync(corr_mean, c->d_planes, n_win * h->wy * h->wx * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
+
+int lspiv_ensemble_flag(lspiv_ensemble* h, float count_min, float n_frames, int64_t* n_records) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  if (!h || !n_records) return fail(LSPIV_EINVAL, "NULL argument");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  h->flag_min_count = count_min * n_frames;
+  h->n_rec = 0;
+  *n_records = 0;
+  if (!g_opt_rescue.load()) return LSPIV_OK;
+  rc = ensemble_mean_fit(h, c, h->flag_min_count);
+  if (rc) return rc;
+  rc = ensemble_flag(h, c);
+  if (rc) return rc;
+  *n_records = h->n_rec;
+  return LSPIV_OK;
+}
+
+int lspiv_ensemble_partials(lspiv_ensemble* h, double* partials, int* complete) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  if (!h || !complete || (h->n_rec && !partials)) return fail(LSPIV_EINVAL, "NULL argument");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  bool ok = false;
+  rc = ensemble_partials(h, c, &ok);
+  if (rc) return rc;
+  *complete = ok ? 1 : 0;
+  if (h->n_rec)
+    HIP_TRY(hipMemcpyAsync(partials, h->d_totals, (size_t)h->n_rec * LSPIV_ENS_PARTIAL_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
+}
+
+int lspiv_ensemble_finish_partials(lspiv_ensemble* h, const double* partials, float* u, float* v, float* corr_count, float* corr_mean) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  if (!h || !u || !v || (h->n_rec && !partials)) return fail(LSPIV_EINVAL, "NULL argument");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  rc = ensemble_mean_fit(h, c, h->flag_min_count);   // the shared workspaces may have been used since lspiv_ensemble_flag
+  if (rc) return rc;
+  if (h->n_rec) {
+    const size_t bytes = (size_t)h->n_rec * LSPIV_ENS_PARTIAL_DOUBLES * sizeof(double);
+    rc = ensure(&h->d_totals, &h->totals_cap, bytes);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h->d_totals, partials, bytes, hipMemcpyHostToDevice, c->stream));
+    rc = ensemble_final(h, c, h->d_totals);
+    if (rc) return rc;
+  }
+  return ensemble_deliver(h, c, u, v, corr_count, corr_mean);
+}
+
+int lspiv_ensemble_set_retain(lspiv_ensemble* h, int mode) {
+  if (!h) return fail(LSPIV_EINVAL, "NULL argument");
+  if (mode < LSPIV_RETAIN_NONE || mode > LSPIV_RETAIN_BORROW) return fail(LSPIV_EINVAL, "retain mode %d not in {0, 1, 2}", mode);
+  h->retain_mode = mode;
+  return LSPIV_OK;
+}
+
+int lspiv_ensemble_stats(lspiv_ensemble* h, int64_t* stats) {
+  if (!h || !stats) return fail(LSPIV_EINVAL, "NULL argument");
+  stats[0] = h->last_flagged; stats[1] = h->last_rescued; stats[2] = h->last_skipped;
+  stats[3] = (int64_t)h->kept.size(); stats[4] = (int64_t)h->kept_bytes; stats[5] = h->retain_complete ? 1 : 0;
   return LSPIV_OK;
 }
 
@@ -989,25 +1270,25 @@ int lspiv_ensemble_finish(lspiv_ensemble* h, float count_min, float n_frames, fl
   DeviceCtx* c;
   int rc = get_ctx(&c);
   if (rc) return rc;
-  const size_t n_win = (size_t)h->g.n_rows * h->g.n_cols;
-  const size_t pb = n_win * h->wy * h->wx * sizeof(float);
-  rc = ensure(&c->d_planes, &c->planes_cap, pb);
+  h->flag_min_count = count_min * n_frames;
+  h->n_rec = 0;
+  rc = ensemble_mean_fit(h, c, h->flag_min_count);
   if (rc) return rc;
-  rc = ensure(&c->d_out, &c->out_cap, 2 * n_win * sizeof(float));
-  if (rc) return rc;
-  hipError_t e = lspiv::launch_ensemble_mean(h->d_sum, h->d_count, count_min * n_frames, (uint32_t)n_win,
-                                             h->wy * h->wx, c->d_planes, c->stream);
-  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
-  e = lspiv::launch_peaks_from_planes(c->d_planes, (uint32_t)n_win, h->wy, h->wx, g_opt_border.load(), c->d_out, c->d_out + n_win, c->stream);
-  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
-  rc = apply_v_sign(c->d_out + n_win, (int64_t)n_win, c->stream);
-  if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(u, c->d_out, n_win * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(v, c->d_out + n_win, n_win * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  if (corr_count) HIP_TRY(hipMemcpyAsync(corr_count, h->d_count, n_win * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  if (corr_mean) HIP_TRY(hipMemcpyAsync(corr_mean, c->d_planes, pb, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return LSPIV_OK;
+  if (g_opt_rescue.load()) {
+    // float64 rescue of the ill-conditioned fits (include/lspiv.h): needs the frames of EVERY pair in the sum -- a state that
+    // was imported holds other handles' pairs (the multi-GPU path runs the three stages itself and all-reduces the partials)
+    rc = ensemble_flag(h, c);
+    if (rc) return rc;
+    bool complete = false;
+    if (h->n_rec && !h->foreign) {
+      rc = ensemble_partials(h, c, &complete);
+      if (rc) return rc;
+    }
+    if (h->n_rec && complete) rc = ensemble_final(h, c, h->d_totals);
+    else h->last_skipped = h->last_flagged;
+    if (rc) return rc;
+  }
+  return ensemble_deliver(h, c, u, v, corr_count, corr_mean);
 }
 
 int lspiv_ensemble_export(lspiv_ensemble* h, float* corr_sum, float* corr_count) {
@@ -1028,6 +1309,11 @@ int lspiv_ensemble_import(lspiv_ensemble* h, const float* corr_sum, const float*
   int rc = get_ctx(&c);
   if (rc) return rc;
   const size_t n_win = (size_t)h->g.n_rows * h->g.n_cols, np = n_win * h->wy * h->wx;
+  // the sums now hold pairs whose frames this handle never saw.  Replaced by a total over several handles (multi-GPU: the
+  // all-reduced state): the staged finish (lspiv_ensemble_flag / _partials / _finish_partials) still reaches every pair, each handle
+  // through its own retained chunks.  Added to: this handle's chunks no longer tell which pairs are in the sum -- float32 fits.
+  if (add) h->retain_complete = false;
+  else h->foreign = true;
   if (!add) {
     HIP_TRY(hipMemcpyAsync(h->d_sum, corr_sum, np * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(h->d_count, corr_count, n_win * sizeof(float), hipMemcpyHostToDevice, c->stream));
@@ -1048,6 +1334,10 @@ int lspiv_ensemble_destroy(lspiv_ensemble* h) {
   if (h->d_sum) hipFree(h->d_sum);
   if (h->d_count) hipFree(h->d_count);
   if (h->d_part) hipFree(h->d_part);
+  ensemble_drop_kept(h);
+  if (h->d_rescue) hipFree(h->d_rescue);
+  if (h->d_partial) hipFree(h->d_partial);
+  if (h->d_totals) hipFree(h->d_totals);
   delete h;
   return LSPIV_OK;
 }
@@ -2072,6 +2362,24 @@ int lspiv_stream_destroy(void* stream) {
     }
   }
   HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+  return LSPIV_OK;
+}
+int lspiv_stream_release(void* stream) {
+  // a stream the caller created itself (hipStreamCreate) and handed to "_dev" entry points: drop what the library keeps for it
+  // (the rescue lists) -- lspiv_stream_destroy does the same for streams of lspiv_stream_create
+  std::lock_guard<std::mutex> launch_lock(g_dispatch_mu);
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (DeviceCtx* c : g_ctx) {
+    if (!c) continue;
+    const hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    for (size_t k = 0; k < c->rescue.size(); ++k) {
+      if (c->rescue[k].stream != s) continue;
+      (void)hipStreamSynchronize(s);
+      if (c->rescue[k].base) (void)hipFree(c->rescue[k].base);
+      c->rescue.erase(c->rescue.begin() + (long)k);
+      break;
+    }
+  }
   return LSPIV_OK;
 }
 int lspiv_stream_synchronize(void* stream) {

@@ -244,14 +244,25 @@ __device__ __forceinline__ void subpixel_generic(F ld, int wy, int wx, int imax,
 __device__ __forceinline__ void block_rescue_note(const PivParams& p, const float* plane, int n, float* red, float vmax, int imax,
                                                   float u, float v, uint32_t t, bool ok) {
   if (!p.rescue_hdr) return;   // uniform
-  float m = 0.0f;
-  for (int o = threadIdx.x; o < n; o += blockDim.x) m = fmaxf(m, o != imax ? plane[o] : 0.0f);
-  m = wave_max_f(m);
+  // candidates of the arg-max besides imax: samples within tau of the maximum -- how many, and the first of them (row-major).
+  // Exactly one other candidate: the rescue pass settles the two by their float64 sums (a "fit" record with pos2), no whole plane.
+  const float thr = vmax * (1.0f - p.rescue_tau);
+  int cnt = 0, other = 0x7fffffff;
+  for (int o = threadIdx.x; o < n; o += blockDim.x) {
+    const bool cand = o != imax && plane[o] >= thr;
+    cnt += cand ? 1 : 0;
+    other = cand ? min(other, o) : other;
+  }
+  cnt = half_sum_i(cnt);
+  cnt += __shfl_xor(cnt, 32, 64);
+  other = half_min_i(other);
+  other = min(other, __shfl_xor(other, 32, 64));
+  int* redi = reinterpret_cast<int*>(red);
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[8 + (threadIdx.x >> 6)] = m;
+  if ((threadIdx.x & 63) == 0) { redi[8 + (threadIdx.x >> 6)] = cnt; redi[16 + (threadIdx.x >> 6)] = other; }
   __syncthreads();
-  float second = red[8];
-  for (int k = 1; k < (int)(blockDim.x >> 6); ++k) second = fmaxf(second, red[8 + k]);
+  cnt = redi[8]; other = redi[16];
+  for (int k = 1; k < (int)(blockDim.x >> 6); ++k) { cnt += redi[8 + k]; other = min(other, redi[16 + k]); }
   __syncthreads();
   if (threadIdx.x != 0 || !ok) return;
   const int wy = p.wy, wx = p.wx;
@@ -265,8 +276,9 @@ __device__ __forceinline__ void block_rescue_note(const PivParams& p, const floa
     gauss_offset_fast(__builtin_amdgcn_logf(cl), l0, __builtin_amdgcn_logf(cr), den_v);
     gauss_offset_fast(__builtin_amdgcn_logf(cd), l0, __builtin_amdgcn_logf(cu), den_u);
   }
-  const PeakCond pc = peak_cond(vmax, second >= vmax * (1.0f - p.rescue_tau), border, cl, cr, den_v, v, cd, cu, den_u, u, 2.0f * p.rescue_k);
-  if (pc.amb || pc.fit) rescue_note(p.rescue_hdr, p.rescue_fit, p.rescue_cap_fit, p.rescue_amb, p.rescue_cap_amb, t, pc, i, j);
+  const PeakCond pc = peak_cond(vmax, cnt > 0, border, cl, cr, den_v, v, cd, cu, den_u, u, 2.0f * p.rescue_k);
+  const uint32_t pos2 = cnt == 1 ? (((uint32_t)(other / wx) << 16) | (uint32_t)(other - (other / wx) * wx)) : 0xffffffffu;
+  if (pc.amb || pc.fit) rescue_note(p.rescue_hdr, p.rescue_fit, p.rescue_cap_fit, p.rescue_amb, p.rescue_cap_amb, t, pc, i, j, pos2);
 }
 
 // one window pair -> plane in LDS.  Returns false when the plane is NaN (non-finite input / signal threshold).

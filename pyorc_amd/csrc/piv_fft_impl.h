@@ -1649,8 +1649,11 @@ __global__ __launch_bounds__(BLOCK, (kWavesPerSimd<T, N>)) void piv_fft_ensemble
 #define LSPIV_ENS_REGACC 1
 #endif
 template <int N> constexpr bool kEnsRegAcc = LSPIV_ENS_REGACC && N <= 32;
+#ifndef LSPIV_WALK_ENS_WAVES_32
+#define LSPIV_WALK_ENS_WAVES_32 2
+#endif
 template <typename T, int N>
-constexpr int kWalkEnsWaves = (kEnsRegAcc<N> && N == 32 && sizeof(T) < 8) ? 2 : kWalkWaves<T, N>;
+constexpr int kWalkEnsWaves = (kEnsRegAcc<N> && N == 32 && sizeof(T) < 8) ? LSPIV_WALK_ENS_WAVES_32 : kWalkWaves<T, N>;
 
 template <typename T, int N, bool WANT_NZ>
 __global__ __launch_bounds__(BLOCK, (kWalkEnsWaves<T, N>)) void piv_fft_walk_ensemble_kernel(PivParams p) {

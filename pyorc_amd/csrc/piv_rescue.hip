@@ -27,6 +27,7 @@ namespace {
 
 constexpr int RBLOCK = 256;
 constexpr int RESCUE_LDS_SAMPLES = 4096;   // both normalised windows as doubles: 64 KB
+constexpr int RESCUE_GENERIC_MAX = 16384;  // whole-plane re-evaluation of windows that do not fit LDS: up to 128 x 128 samples
 
 // float64 sum over the wave, every lane gets the total: the DPP / swizzle / permlane32 steps of the float32 reductions
 // (common.h) on the two halves of the double -- __shfl_xor on a double is two ds_bpermute plus a wait per step
@@ -135,20 +136,14 @@ __device__ __forceinline__ uint32_t choose_wave(const PivParams& p, PA A, PA B, 
   return (c2 > c1 || (c2 == c1 && o2 < o1)) ? pos2 : pos1;
 }
 
-// the five-sample fit at shifted position (ip, jp), all in float64; one wave, lane 0 stores
+// the five circular cross-correlation sums around shifted position (ip, jp), (1 / n) sum_m a'[m] b'[m + k] clipped to [0, 1],
+// k = the peak and its four neighbours, all in float64; every lane gets the five values
 // (A, B: the two windows, in global memory (pitch = frame width) or staged in LDS (pitch = window width))
+struct Lag5 { double c0, cu, cd, cl, cr; };   // centre, row above, row below, column left, column right
 template <typename PA>
-__device__ __forceinline__ void fit_wave(const PivParams& p, PA A, PA B, int pitch, double mean_a, double inv_a, double mean_b,
-                                         double inv_b, uint32_t g, int ip, int jp, int lane) {
+__device__ __forceinline__ Lag5 lag5_wave(const PivParams& p, PA A, PA B, int pitch, double mean_a, double inv_a, double mean_b,
+                                          double inv_b, int ip, int jp, int lane) {
   const int wy = p.wy, wx = p.wx, n = wy * wx, cy = wy / 2, cx = wx / 2;
-  if (ip <= 0 || ip >= wy - 1 || jp <= 0 || jp >= wx - 1) {   // border peak: no fit (A5)
-    if (lane == 0) {
-      float u, v;
-      border_result(p.border_mode, jp - cx, ip - cy, u, v);
-      p.u[g] = u; p.v[g] = v;
-    }
-    return;
-  }
   // un-shifted lags of the peak and its four neighbours
   const int ky0 = unshift(ip, cy, wy), kx0 = unshift(jp, cx, wx);
   const int kym = ky0 == 0 ? wy - 1 : ky0 - 1, kyp = ky0 == wy - 1 ? 0 : ky0 + 1;
@@ -174,11 +169,39 @@ __device__ __forceinline__ void fit_wave(const PivParams& p, PA A, PA B, int pit
   }
   const double inv_n = 1.0 / (double)n;
   auto clip01 = [](double c) { return c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c); };
-  const double c0 = clip01(wave_sum_d(acc0) * inv_n), cu = clip01(wave_sum_d(accu) * inv_n), cd = clip01(wave_sum_d(accd) * inv_n);
-  const double cl = clip01(wave_sum_d(accl) * inv_n), cr = clip01(wave_sum_d(accr) * inv_n);
+  Lag5 o;
+  o.c0 = clip01(wave_sum_d(acc0) * inv_n); o.cu = clip01(wave_sum_d(accu) * inv_n); o.cd = clip01(wave_sum_d(accd) * inv_n);
+  o.cl = clip01(wave_sum_d(accl) * inv_n); o.cr = clip01(wave_sum_d(accr) * inv_n);
+  return o;
+}
+// 3-point log-Gaussian fit of five float64 samples around shifted position (ip, jp) (eps 1e-7, zero denominator -> 0)
+__device__ __forceinline__ void fit5_d(const Lag5& c, int ip, int jp, int cy, int cx, float& u, float& v) {
+  const double eps = 1e-7;
+  const double l0 = log(c.c0 + eps), lu = log(c.cu + eps), ld = log(c.cd + eps), ll = log(c.cl + eps), lr = log(c.cr + eps);
+  const double den1 = 2 * lu - 4 * l0 + 2 * ld, den2 = 2 * ll - 4 * l0 + 2 * lr;
+  const double di = den1 != 0.0 ? (lu - ld) / den1 : 0.0;
+  const double dj = den2 != 0.0 ? (ll - lr) / den2 : 0.0;
+  v = (float)((double)ip + di - (double)cy);
+  u = (float)((double)jp + dj - (double)cx);
+}
+
+// the five-sample fit at shifted position (ip, jp), all in float64; one wave, lane 0 stores
+template <typename PA>
+__device__ __forceinline__ void fit_wave(const PivParams& p, PA A, PA B, int pitch, double mean_a, double inv_a, double mean_b,
+                                         double inv_b, uint32_t g, int ip, int jp, int lane) {
+  const int wy = p.wy, wx = p.wx, cy = wy / 2, cx = wx / 2;
+  if (ip <= 0 || ip >= wy - 1 || jp <= 0 || jp >= wx - 1) {   // border peak: no fit (A5)
+    if (lane == 0) {
+      float u, v;
+      border_result(p.border_mode, jp - cx, ip - cy, u, v);
+      p.u[g] = u; p.v[g] = v;
+    }
+    return;
+  }
+  const Lag5 c = lag5_wave(p, A, B, pitch, mean_a, inv_a, mean_b, inv_b, ip, jp, lane);
   // the five logarithms side by side on five lanes instead of one after the other on lane 0
   const double eps = 1e-7;
-  const double mine = log((lane == 0 ? c0 : lane == 1 ? cu : lane == 2 ? cd : lane == 3 ? cl : cr) + eps);
+  const double mine = log((lane == 0 ? c.c0 : lane == 1 ? c.cu : lane == 2 ? c.cd : lane == 3 ? c.cl : c.cr) + eps);
   const double l0 = __shfl(mine, 0, 64), lu = __shfl(mine, 1, 64), ld = __shfl(mine, 2, 64), ll = __shfl(mine, 3, 64), lr = __shfl(mine, 4, 64);
   if (lane == 0) {
     const double den1 = 2 * lu - 4 * l0 + 2 * ld, den2 = 2 * ll - 4 * l0 + 2 * lr;
@@ -227,6 +250,7 @@ __global__ __launch_bounds__(RBLOCK) void piv_rescue_fit_kernel(PivParams p) {
   for (uint32_t i = blockIdx.x * (RBLOCK / 64) + (uint32_t)wave; i < n_fit; i += n_waves) {
     const uint4 rec = p.rescue_fit[i];
     const uint32_t g = rec.x;
+    if (g >= p.n_tiles) continue;   // a record of another launch (two host threads interleaving on one stream): never write out of bounds
     const T* A = window_base<T>(p, g);
     const T* B = A + p.frame_elems;
     double mean_a, sd_a, mean_b, sd_b;
@@ -274,7 +298,8 @@ __global__ __launch_bounds__(RBLOCK) void piv_rescue_amb_kernel(PivParams p) {
   int* lcnt = lx + n;                              // non-zero samples per row
   for (uint32_t i = blockIdx.x; i < n_amb; i += gridDim.x) {
     __syncthreads();   // the previous record's LDS windows and reduction slots are free
-    const uint32_t g = p.rescue_amb[i];
+    const uint32_t g = min(p.rescue_amb[i], p.n_tiles - 1);   // (clamped, not skipped: the barriers below stay uniform)
+    const bool g_ok = p.rescue_amb[i] < p.n_tiles;
     const T* A = window_base<T>(p, g);
     const T* B = A + p.frame_elems;
     double mean_a, sd_a, mean_b, sd_b;
@@ -296,15 +321,15 @@ __global__ __launch_bounds__(RBLOCK) void piv_rescue_amb_kernel(PivParams p) {
       // The clip at zero leaves most samples of a' exactly zero on particle imagery (and nearly all of them in the sparse
       // windows that end up here): compact each row to its non-zero samples, in place and in x order (one thread per row:
       // a fixed order, so the sums are reproducible), and let the lag loops walk those only.
-      if ((int)threadIdx.x < wy) {
-        double* ar = la + threadIdx.x * wx;
-        int* xr = lx + threadIdx.x * wx;
+      for (int r = threadIdx.x; r < wy; r += RBLOCK) {   // (tall narrow windows have more rows than the block has threads: 512 x 8)
+        double* ar = la + r * wx;
+        int* xr = lx + r * wx;
         int k = 0;
         for (int x = 0; x < wx; ++x) {
           const double av = ar[x];
           if (av != 0.0) { ar[k] = av; xr[k] = x; ++k; }
         }
-        lcnt[threadIdx.x] = k;
+        lcnt[r] = k;
       }
       __syncthreads();
       const int strips_per_row = wx / AMB_R, strips = wy * strips_per_row;
@@ -339,9 +364,10 @@ __global__ __launch_bounds__(RBLOCK) void piv_rescue_amb_kernel(PivParams p) {
           amax_merge_d(best, bi, c, ipo * wx + jpo);
         }
       }
-    } else {
+    } else if (n <= RESCUE_GENERIC_MAX) {
       // any other shape: one lag at a time, samples normalised on the fly from L2 (functional path: windows above 64 px,
-      // widths that are no multiple of 4)
+      // widths that are no multiple of 4).  n^2 multiply-adds by ONE block: bounded at 128 x 128 samples (2.7e8, milliseconds);
+      // a three-way near-tie of the maximum in a larger window keeps its float32 result (include/lspiv.h, "rescue")
       for (int o = threadIdx.x; o < n; o += RBLOCK) {
         const int ipo = o / wx, jpo = o - ipo * wx;
         const int ky = ipo - cy < 0 ? ipo - cy + wy : ipo - cy, kx = jpo - cx < 0 ? jpo - cx + wx : jpo - cx;
@@ -368,7 +394,7 @@ __global__ __launch_bounds__(RBLOCK) void piv_rescue_amb_kernel(PivParams p) {
     best = red_v[0]; bi = red_i[0];
 #pragma unroll
     for (int k = 1; k < RBLOCK / 64; ++k) amax_merge_d(best, bi, red_v[k], red_i[k]);
-    if (wave == 0 && !dead) {
+    if (wave == 0 && !dead && g_ok && (fast || n <= RESCUE_GENERIC_MAX)) {
       const int ip = bi / wx, jp = bi - ip * wx;
       fit_wave(p, A, B, p.W, mean_a, inv_a, mean_b, inv_b, g, ip, jp, lane);
     }
@@ -392,6 +418,178 @@ __global__ __launch_bounds__(RBLOCK) void piv_rescue_amb_kernel(PivParams p) {
   }
 }
 
+// ======== ensemble mode: the final fit of the MEAN plane (lspiv_ensemble_finish) =========================================
+// (i) flag: one wave per window on the float32 mean plane.  Candidates of the arg-max = samples within tau of the maximum; the
+// fit's conditioning by the same model as the per-pair epilogues (peak_cond) with twice the noise allowance (a mean of float32
+// planes summed in float32).  A NaN plane (count filter) or an all-zero one is NaN by construction and never listed.
+__device__ __forceinline__ void wave_argmax_first(float& v, int& idx) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const float pv = __shfl_xor(v, o, 64);
+    const int pi = __shfl_xor(idx, o, 64);
+    const bool take = (pv > v) || (pv == v && pi < idx);
+    v = take ? pv : v;
+    idx = take ? pi : idx;
+  }
+}
+__device__ __forceinline__ int wave_min_i(int x) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) x = min(x, __shfl_xor(x, o, 64));
+  return x;
+}
+__device__ __forceinline__ int wave_sum_i(int x) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+
+__global__ __launch_bounds__(RBLOCK) void ens_flag_kernel(const float* mean, uint32_t n_win, int wy, int wx, const float* u, const float* v,
+                                                          float k, float tau, EnsRescueHdr* hdr, EnsRescueRec* recs, uint32_t cap) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t w = blockIdx.x * (RBLOCK / 64) + (threadIdx.x >> 6);
+  if (w >= n_win) return;   // whole waves
+  const int n = wy * wx;
+  const float* pl = mean + (size_t)w * n;
+  float best = -1.0f;
+  int bi = 0x7fffffff;
+  bool bad = false;
+  for (int o = lane; o < n; o += 64) {
+    const float x = pl[o];
+    bad = bad || !(x == x);
+    if (x > best) { best = x; bi = o; }
+  }
+  if (__builtin_amdgcn_ballot_w64(bad) != 0) return;
+  wave_argmax_first(best, bi);
+  if (!(best > 0.0f)) return;
+  const float thr = best * (1.0f - tau);
+  int cnt = 0;
+  for (int o = lane; o < n; o += 64) cnt += pl[o] >= thr ? 1 : 0;
+  cnt = wave_sum_i(cnt);
+  const int i = bi / wx, j = bi - i * wx;
+  const bool border = i <= 0 || i >= wy - 1 || j <= 0 || j >= wx - 1;
+  bool fit = false;
+  if (cnt == 1 && !border) {
+    const float cl = pl[bi - wx] + kEpsPeak, cr = pl[bi + wx] + kEpsPeak, cd = pl[bi - 1] + kEpsPeak, cu = pl[bi + 1] + kEpsPeak;
+    const float l0 = __builtin_amdgcn_logf(best + kEpsPeak);
+    float den_v, den_u;
+    gauss_offset_fast(__builtin_amdgcn_logf(cl), l0, __builtin_amdgcn_logf(cr), den_v);
+    gauss_offset_fast(__builtin_amdgcn_logf(cd), l0, __builtin_amdgcn_logf(cu), den_u);
+    // the results the fit was flagged for are relative to the plane centre, like the per-pair epilogues'
+    fit = peak_cond(best, false, false, cl, cr, den_v, v[w], cd, cu, den_u, u[w], 2.0f * k).fit;
+  }
+  if (cnt < 2 && !fit) return;
+  EnsRescueRec r;
+  r.w = w; r.ncand = cnt <= kEnsMaxCand ? (uint32_t)cnt : 0u;
+  r.pad[0] = r.pad[1] = 0;
+  int prev = -1;
+#pragma unroll
+  for (int c = 0; c < kEnsMaxCand; ++c) {
+    int m = 0x7fffffff;
+    if (c < cnt && cnt <= kEnsMaxCand) {
+      for (int o = lane; o < n; o += 64) m = (pl[o] >= thr && o > prev) ? min(m, o) : m;
+      m = wave_min_i(m);
+      prev = m;
+    }
+    r.pos[c] = m == 0x7fffffff ? 0xffffffffu : (((uint32_t)(m / wx) << 16) | (uint32_t)(m - (m / wx) * wx));
+  }
+  if (lane == 0) {
+    if (r.ncand == 0) atomicAdd(&hdr->n_skipped, 1u);
+    const uint32_t slot = atomicAdd(&hdr->n_rec, 1u);
+    if (slot < cap) recs[slot] = r;
+  }
+}
+
+// (ii) partial sums: one wave per (record, block of kEnsPairBlock pairs of this chunk).  For every pair of the block that was
+// ADDED to the sum (its masked corr_max is > 0: the decision the float32 kernel took and returned), the two windows are staged
+// once, their float64 statistics taken, and for every candidate the five clipped lag sums are added up in pair order.
+template <typename T>
+__global__ __launch_bounds__(RBLOCK) void ens_partial_kernel(PivParams p, EnsRescueArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+  typedef const T __attribute__((address_space(3))) * LdsPtr;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wy = p.wy, wx = p.wx, n = wy * wx;
+  const bool staged = (size_t)2 * n * sizeof(T) <= (size_t)FIT_LDS_PER_WAVE;
+  T* la = reinterpret_cast<T*>(fsm + (size_t)wave * FIT_LDS_PER_WAVE);
+  T* lb = la + n;
+  const uint32_t chunk_blks = (a.n_pairs + kEnsPairBlock - 1) / kEnsPairBlock;
+  const uint32_t items = a.n_rec * chunk_blks, n_waves = gridDim.x * (RBLOCK / 64);
+  for (uint32_t it = blockIdx.x * (RBLOCK / 64) + (uint32_t)wave; it < items; it += n_waves) {
+    const uint32_t ri = it / chunk_blks, blk = it - ri * chunk_blks;
+    const EnsRescueRec rec = a.recs[ri];
+    double acc[kEnsMaxCand][5];
+#pragma unroll
+    for (int c = 0; c < kEnsMaxCand; ++c)
+#pragma unroll
+      for (int q = 0; q < 5; ++q) acc[c][q] = 0.0;
+    const uint32_t pa = blk * kEnsPairBlock, pb = min(pa + (uint32_t)kEnsPairBlock, a.n_pairs);
+    for (uint32_t pair = pa; pair < pb && rec.ncand != 0; ++pair) {
+      if (!(a.cmax[(size_t)pair * p.n_win + rec.w] > 0.0f)) continue;   // not in the sum (uniform over the wave)
+      const T* A = window_base<T>(p, pair * p.n_win + rec.w);
+      const T* B = A + p.frame_elems;
+      double mean_a, sd_a, mean_b, sd_b;
+      if (staged) window_stats_wave2<T, true>(A, B, p.W, wy, wx, lane, mean_a, sd_a, mean_b, sd_b, la, lb);
+      else window_stats_wave2<T, false>(A, B, p.W, wy, wx, lane, mean_a, sd_a, mean_b, sd_b, nullptr, nullptr);
+      if (sd_a == 0.0 || sd_b == 0.0) continue;   // (a zero-variance window has corr_max 0 and is never kept)
+      const double sg = p.norm_clip ? (double)p.std_gain : -(double)p.std_gain;
+      const double inv_a = sg / sd_a, inv_b = sg / sd_b;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int c = 0; c < kEnsMaxCand; ++c) {
+        if (c >= (int)rec.ncand) break;
+        const int ip = (int)(rec.pos[c] >> 16), jp = (int)(rec.pos[c] & 0xffffu);
+        const Lag5 l = staged ? lag5_wave(p, (LdsPtr)la, (LdsPtr)lb, wx, mean_a, inv_a, mean_b, inv_b, ip, jp, lane)
+                              : lag5_wave(p, A, B, p.W, mean_a, inv_a, mean_b, inv_b, ip, jp, lane);
+        acc[c][0] += l.c0; acc[c][1] += l.cu; acc[c][2] += l.cd; acc[c][3] += l.cl; acc[c][4] += l.cr;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) {
+      double* dst = a.partial + ((size_t)ri * a.n_blk + a.blk0 + blk) * (kEnsMaxCand * 5);
+#pragma unroll
+      for (int c = 0; c < kEnsMaxCand; ++c)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) dst[c * 5 + q] = acc[c][q];
+    }
+  }
+}
+
+// (iii) merge a handle's partial sums in pair-block order (one thread per (record, candidate, sample): a fixed order)
+__global__ __launch_bounds__(RBLOCK) void ens_merge_kernel(EnsRescueArgs a, double* totals) {
+  constexpr int ROW = kEnsMaxCand * 5;
+  const uint32_t i = blockIdx.x * RBLOCK + threadIdx.x;
+  if (i >= a.n_rec * ROW) return;
+  const uint32_t ri = i / ROW, q = i - ri * ROW;
+  const double* src = a.partial + (size_t)ri * a.n_blk * ROW + q;
+  double sum = 0.0;
+  for (uint32_t b = 0; b < a.n_blk; ++b) sum += src[(size_t)b * ROW];
+  totals[i] = sum;
+}
+
+// (iv) totals over ALL pairs of the sum (one handle's, or the all-reduced ones of several): divide by the count, pick the
+// candidate with the largest centre (ties: the smaller row-major index -- candidates are listed in that order), fit in float64
+__global__ __launch_bounds__(RBLOCK) void ens_final_kernel(PivParams p, EnsRescueArgs a, const double* totals, float* u, float* v) {
+  constexpr int ROW = kEnsMaxCand * 5;
+  const uint32_t ri = blockIdx.x * RBLOCK + threadIdx.x;
+  if (ri >= a.n_rec) return;
+  const EnsRescueRec rec = a.recs[ri];
+  if (rec.ncand == 0) return;
+  const double cnt = (double)a.count[rec.w];
+  if (!(cnt > 0.0)) return;
+  const int cy = p.wy / 2, cx = p.wx / 2;
+  int best = -1;
+  Lag5 bl = {0, 0, 0, 0, 0};
+  for (int c = 0; c < (int)rec.ncand; ++c) {
+    const double* t = totals + (size_t)ri * ROW + c * 5;
+    const Lag5 l = {t[0] / cnt, t[1] / cnt, t[2] / cnt, t[3] / cnt, t[4] / cnt};
+    if (best < 0 || l.c0 > bl.c0) { best = c; bl = l; }
+  }
+  const int ip = (int)(rec.pos[best] >> 16), jp = (int)(rec.pos[best] & 0xffffu);
+  float uu, vv;
+  if (ip <= 0 || ip >= p.wy - 1 || jp <= 0 || jp >= p.wx - 1) border_result(p.border_mode, jp - cx, ip - cy, uu, vv);
+  else fit5_d(bl, ip, jp, cy, cx, uu, vv);
+  u[rec.w] = uu; v[rec.w] = vv;
+}
+
 template <typename T>
 hipError_t launch_rescue_t(const PivParams& p, hipStream_t s) {
   const int n = p.wy * p.wx;
@@ -413,6 +611,44 @@ hipError_t launch_rescue_t(const PivParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+hipError_t launch_ens_flag(const float* mean, uint32_t n_win, int wy, int wx, const float* u, const float* v, float k, float tau,
+                           EnsRescueHdr* hdr, EnsRescueRec* recs, uint32_t cap, hipStream_t s) {
+  if (n_win == 0) return hipSuccess;
+  hipLaunchKernelGGL(ens_flag_kernel, dim3((n_win + RBLOCK / 64 - 1) / (RBLOCK / 64)), dim3(RBLOCK), 0, s, mean, n_win, wy, wx, u, v, k, tau,
+                     hdr, recs, cap);
+  return hipGetLastError();
+}
+
+hipError_t launch_ens_partial(const PivParams& p, int dtype, const EnsRescueArgs& a, hipStream_t s) {
+  const uint32_t chunk_blks = (a.n_pairs + kEnsPairBlock - 1) / kEnsPairBlock;
+  const uint64_t items = (uint64_t)a.n_rec * chunk_blks;
+  if (items == 0) return hipSuccess;
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + RBLOCK / 64 - 1) / (RBLOCK / 64), 65536);
+  const int n = p.wy * p.wx;
+  const size_t es = dtype == 0 ? 1 : dtype == 1 ? 4 : 8;
+  const size_t lds = (size_t)2 * n * es <= (size_t)FIT_LDS_PER_WAVE ? (size_t)(RBLOCK / 64) * FIT_LDS_PER_WAVE : 0;
+  switch (dtype) {
+    case 0: hipLaunchKernelGGL(ens_partial_kernel<uint8_t>, dim3(blocks), dim3(RBLOCK), lds, s, p, a); break;
+    case 1: hipLaunchKernelGGL(ens_partial_kernel<float>, dim3(blocks), dim3(RBLOCK), lds, s, p, a); break;
+    case 2: hipLaunchKernelGGL(ens_partial_kernel<double>, dim3(blocks), dim3(RBLOCK), lds, s, p, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_ens_merge(const EnsRescueArgs& a, double* totals, hipStream_t s) {
+  if (a.n_rec == 0) return hipSuccess;
+  const uint32_t n = a.n_rec * kEnsMaxCand * 5;
+  hipLaunchKernelGGL(ens_merge_kernel, dim3((n + RBLOCK - 1) / RBLOCK), dim3(RBLOCK), 0, s, a, totals);
+  return hipGetLastError();
+}
+
+hipError_t launch_ens_final(const PivParams& p, const EnsRescueArgs& a, const double* totals, float* u, float* v, hipStream_t s) {
+  if (a.n_rec == 0) return hipSuccess;
+  hipLaunchKernelGGL(ens_final_kernel, dim3((a.n_rec + RBLOCK - 1) / RBLOCK), dim3(RBLOCK), 0, s, p, a, totals, u, v);
+  return hipGetLastError();
+}
 
 hipError_t launch_piv_rescue(const PivParams& p, int dtype, hipStream_t s) {
   if (!p.rescue_hdr) return hipSuccess;

@@ -128,6 +128,22 @@ class Ensemble:
         self.n_rows, self.n_cols = window.get_array_shape(dim_size, window_size, overlap)
         _lib.check(lib.lspiv_ensemble_begin(dim_size[0], dim_size[1], window_size[0], window_size[1],
                                             overlap[0], overlap[1], C.byref(self._h)))
+        self._held = []   # DeviceFrames chunks the handle borrows until finish (float64 rescue of the final fit)
+
+    RETAIN_NONE, RETAIN_COPY, RETAIN_BORROW = 0, 1, 2
+
+    def set_retain(self, mode: int) -> None:
+        """How ``accumulate_dev`` keeps the chunks for the float64 rescue of the final fit (include/lspiv.h,
+        ``lspiv_ensemble_set_retain``): 0 nothing (float32 fits), 1 the handle copies them, 2 it borrows the caller's pointers."""
+        _lib.check(_lib.load().lspiv_ensemble_set_retain(self._h, int(mode)))
+
+    def stats(self) -> dict:
+        """Counters of the last ``finish``: windows flagged / re-evaluated in float64 / left with their float32 fit, chunks and
+        bytes kept, and whether every chunk could be kept."""
+        st = (C.c_int64 * 6)()
+        _lib.check(_lib.load().lspiv_ensemble_stats(self._h, st))
+        return {"flagged": int(st[0]), "rescued": int(st[1]), "float32_kept": int(st[2]), "chunks_kept": int(st[3]),
+                "bytes_kept": int(st[4]), "retain_complete": bool(st[5])}
 
     def accumulate(self, imgs, corr_min: float, s2n_min: float, signal_threshold: Optional[float] = None):
         """Add one frame chunk; returns masked per-pair (corr_max, s2n), each (T-1, n_win) float32."""
@@ -140,6 +156,10 @@ class Ensemble:
             from .device import DeviceFrames
 
             d = DeviceFrames.empty((2, P, n_win), np.float32)
+            # an HBM-resident stack stays alive as long as this object holds it: the handle borrows the pointer (no copy) and
+            # the final fit can go back to the frames
+            self.set_retain(self.RETAIN_BORROW)
+            self._held.append(a)
             self.accumulate_dev(a.ptr, a.dtype, a.shape[0], corr_min, s2n_min, d.ptr, signal_threshold)
             res = d.to_host()
             return np.ascontiguousarray(res[0]), np.ascontiguousarray(res[1])
@@ -169,6 +189,37 @@ class Ensemble:
                                                      _lib.ptr(mean) if mean is not None else None))
         return (u, v, cnt, mean) if return_mean else (u, v, cnt)
 
+    # ---- the finish in three stages, for a sum spread over several handles (include/lspiv.h; pyorc_amd.shard.sharded_ensemble) ----
+    PARTIAL_DOUBLES = 20
+
+    def flag(self, count_min: float, n_frames: float) -> int:
+        """Mean planes + float32 fits + the windows whose fit needs float64: how many (the same on every rank holding the same state)."""
+        n = C.c_int64(0)
+        _lib.check(_lib.load().lspiv_ensemble_flag(self._h, float(count_min), float(n_frames), C.byref(n)))
+        self._n_rec = int(n.value)
+        return self._n_rec
+
+    def partials(self):
+        """(partials (n_records, 20) float64 over THIS handle's retained chunks, complete: bool)."""
+        part = np.zeros((getattr(self, "_n_rec", 0), self.PARTIAL_DOUBLES), dtype=np.float64)
+        ok = C.c_int(0)
+        _lib.check(_lib.load().lspiv_ensemble_partials(self._h, _lib.ptr(part) if part.size else None, C.byref(ok)))
+        return part, bool(ok.value)
+
+    def finish_partials(self, partials, return_mean: bool = False):
+        """``finish`` with the flagged windows fitted from ``partials`` summed over all handles that share the state."""
+        n_win = self.n_rows * self.n_cols
+        part = np.ascontiguousarray(partials, dtype=np.float64)
+        if part.shape != (getattr(self, "_n_rec", 0), self.PARTIAL_DOUBLES):
+            raise ValueError(f"partials shape {part.shape} != ({getattr(self, '_n_rec', 0)}, {self.PARTIAL_DOUBLES})")
+        u = np.empty((1, self.n_rows, self.n_cols), dtype=np.float32)
+        v = np.empty((1, self.n_rows, self.n_cols), dtype=np.float32)
+        cnt = np.empty(n_win, dtype=np.float32)
+        mean = np.empty((1, n_win) + self.window_size, dtype=np.float32) if return_mean else None
+        _lib.check(_lib.load().lspiv_ensemble_finish_partials(self._h, _lib.ptr(part) if part.size else None, _lib.ptr(u), _lib.ptr(v),
+                                                              _lib.ptr(cnt), _lib.ptr(mean) if mean is not None else None))
+        return (u, v, cnt, mean) if return_mean else (u, v, cnt)
+
     def export_state(self):
         """(corr_sum (n_win, wy, wx) float32 in fft-shifted layout, corr_count (n_win,) float32) from HBM."""
         n_win = self.n_rows * self.n_cols
@@ -190,6 +241,7 @@ class Ensemble:
         if self._h:
             _lib.load().lspiv_ensemble_destroy(self._h)
             self._h = C.c_void_p()
+            self._held = []   # borrowed stacks are released with the handle, not before (finish may be called again)
 
     def __del__(self):
         try:

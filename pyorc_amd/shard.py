@@ -113,7 +113,8 @@ def sharded_ensemble(load_frames: Callable[[int, int], np.ndarray], n_pairs: int
     Reproducibility: a rank's partial sum is bit-reproducible (anchored segments, fixed merge order), but the sum over
     ranks is a floating-point all-reduce and every rank's handle starts its segment anchors at its own pair 0 -- so the
     sharded mean planes agree with a single-GPU run to float32 rounding (1e-6 of the plane), not bit for bit.  The
-    per-timestep path (``sharded_piv``) IS bit-identical to one GPU.
+    per-timestep path (``sharded_piv``) IS bit-identical to one GPU.  Windows whose final fit is ill-conditioned are
+    re-evaluated in float64 from the frames on every rank's block (round 4), like on one GPU.
     """
     ens = make_ensemble()
     f0, f1 = frame_block(n_pairs, comm.rank, comm.world, align)
@@ -125,8 +126,167 @@ def sharded_ensemble(load_frames: Callable[[int, int], np.ndarray], n_pairs: int
     s = comm.allreduce(s, SUM)
     k = comm.allreduce(k, SUM)
     ens.import_state(s, k)
-    u, v, cnt = ens.finish(count_min, n_chunks)
+    # every rank now holds the same sums.  The float64 rescue of the ill-conditioned fits needs the frames of every pair: each
+    # rank contributes the float64 sums over ITS retained block for the (identical, sorted) list of flagged windows -- one more
+    # float64 all-reduce of a few hundred bytes (include/lspiv.h, lspiv_ensemble_flag / _partials / _finish_partials)
+    if hasattr(ens, "flag"):
+        n_rec = ens.flag(count_min, n_chunks)
+        part, ok = ens.partials()
+        all_ok = float(comm.allreduce(np.array([1.0 if ok else 0.0], dtype=np.float64), SUM)[0]) == comm.world
+        if all_ok:
+            if n_rec:
+                part = comm.allreduce(part, SUM)
+            u, v, cnt = ens.finish_partials(part)
+        else:      # some rank could not keep its frames: float32 fits everywhere (the ranks agree)
+            u, v, cnt = ens.finish(count_min, n_chunks)
+    else:
+        u, v, cnt = ens.finish(count_min, n_chunks)
     n_win = k.size
     local = np.stack([cm, sn]).astype(np.float32)[:, :, None, :] if cm is not None else np.empty((2, 0, 1, n_win), np.float32)
     per_pair = gather_blocks(local, n_pairs, comm, align)  # (2, n_pairs, 1, n_win)
     return u, v, cnt, per_pair[0, :, 0], per_pair[1, :, 0]
+
+
+class ShardedPivDev:
+    """The sharded per-timestep path with everything resident in HBM: what ``sharded_piv`` does with host arrays, for a
+    rank whose time block already sits on its GPU (``DeviceFrames``) -- and what ``bench.py --gpus N`` times.
+
+    A plan for repeated use: two packed result blocks and two gather buffers per rank, a compute stream and a gather
+    stream.  ``step(block)`` launches the PIV kernels of this rank's pairs (anchored at their absolute index, so the gathered
+    bits equal one launch over the whole stack) and queues the all-gather of the packed ``[u | v | corr | s2n]`` block behind
+    it on the gather stream; the NEXT step's kernels overlap with that gather (a buffer is reused two steps later, after its
+    gather).  ``drain()`` waits for both streams; ``gathered_host()`` returns the last step's (4, n_pairs, n_rows, n_cols).
+    Blocks of unequal length are padded to the longest in the exchange only (the all-gather moves equal counts).
+    """
+
+    def __init__(self, comm, n_pairs: int, frame_shape, window_size, overlap, signal_threshold=None, align: Optional[int] = None,
+                 record_timings: bool = False):
+        import ctypes as C
+
+        from . import _lib, window
+        from .device import DeviceFrames
+
+        self._C, self._lib_mod, self.lib = C, _lib, _lib.load()
+        self.comm, self.n_pairs = comm, int(n_pairs)
+        self.window_size, self.overlap = tuple(window_size), tuple(overlap)
+        self.H, self.W = int(frame_shape[0]), int(frame_shape[1])
+        self.align = window.chunk_alignment(self.window_size) if align is None else int(align)
+        self.sizes = block_sizes(self.n_pairs, comm.world, self.align)
+        self.a, self.b = pair_block(self.n_pairs, comm.rank, comm.world, self.align)
+        self.p_local, self.p_max = self.b - self.a, max(self.sizes)
+        self.n_rows, self.n_cols = window.get_array_shape((self.H, self.W), self.window_size, self.overlap)
+        self.n_win = self.n_rows * self.n_cols
+        self.thr = -1.0 if signal_threshold is None else float(signal_threshold)
+        self.count = 4 * self.p_max * self.n_win                     # floats every rank sends
+        self.send = [DeviceFrames.empty((4, self.p_max, self.n_win), np.float32) for _ in range(2)]
+        self.recv = [DeviceFrames.empty((comm.world * 4, self.p_max, self.n_win), np.float32) for _ in range(2)]
+        self.comp, self.comm_s = C.c_void_p(), C.c_void_p()
+        _lib.check(self.lib.lspiv_stream_create(C.byref(self.comp)))
+        _lib.check(self.lib.lspiv_stream_create(C.byref(self.comm_s)))
+        self.ev_done = [self._event() for _ in range(2)]             # kernels of buffer b finished
+        self.ev_gathered = [self._event() for _ in range(2)]         # gather of buffer b finished
+        self._gathered_once = [False, False]
+        self.k = 0
+        self.record = bool(record_timings)
+        self._marks = []                                             # per step: (kernel start, kernel stop, gather start, gather stop)
+
+    def _event(self):
+        e = self._C.c_void_p()
+        self._lib_mod.check(self.lib.lspiv_event_create(self._C.byref(e)))
+        return e
+
+    def frame_block(self) -> Tuple[int, int]:
+        """[start, stop) of the frames this rank needs (its pairs + the halo frame)."""
+        return (self.a, self.b + 1) if self.b > self.a else (self.a, self.a)
+
+    def step(self, block) -> None:
+        """``block``: DeviceFrames with frames ``frame_block()`` of the stack (this rank's pairs + one halo frame)."""
+        C, _lib, lib = self._C, self._lib_mod, self.lib
+        if self.p_local and tuple(block.shape) != (self.p_local + 1, self.H, self.W):
+            raise ValueError(f"rank {self.comm.rank} expects a block of shape {(self.p_local + 1, self.H, self.W)}, got {block.shape}")
+        b = self.k & 1
+        if self._gathered_once[b]:
+            _lib.check(lib.lspiv_stream_wait_event(self.comp, self.ev_gathered[b]))      # gather k-2 has read send[b]
+        marks = [self._event() for _ in range(4)] if self.record else None
+        if marks:
+            _lib.check(lib.lspiv_event_record_on(marks[0], self.comp))
+        if self.p_local:
+            _lib.check(lib.lspiv_piv_pairs_dev_at(block.c_ptr, block.dtype_code, self.p_local + 1, self.H, self.W, self.window_size[0],
+                                                  self.window_size[1], self.overlap[0], self.overlap[1], self.thr, self.a,
+                                                  self.send[b].c_ptr, None, self.comp))
+        if marks:
+            _lib.check(lib.lspiv_event_record_on(marks[1], self.comp))
+        _lib.check(lib.lspiv_event_record_on(self.ev_done[b], self.comp))
+        _lib.check(lib.lspiv_stream_wait_event(self.comm_s, self.ev_done[b]))
+        if marks:
+            _lib.check(lib.lspiv_event_record_on(marks[2], self.comm_s))
+        self.comm.allgather_dev(self.send[b].ptr, self.recv[b].ptr, self.count, np.float32, self.comm_s.value)
+        if marks:
+            _lib.check(lib.lspiv_event_record_on(marks[3], self.comm_s))
+            self._marks.append(marks)
+        _lib.check(lib.lspiv_event_record_on(self.ev_gathered[b], self.comm_s))
+        self._gathered_once[b] = True
+        self.k += 1
+
+    def drain(self) -> None:
+        self._lib_mod.check(self.lib.lspiv_stream_synchronize(self.comp))
+        self._lib_mod.check(self.lib.lspiv_stream_synchronize(self.comm_s))
+
+    def timings(self, reset: bool = True) -> dict:
+        """Per recorded step, by HIP events (after ``drain``): kernel ms (PIV + rescue kernels of this rank's block -- while the
+        previous step's gather is in flight), gather ms, and how long after its kernels a step's gather ended."""
+        C, _lib, lib = self._C, self._lib_mod, self.lib
+        self.drain()
+
+        def ms(e0, e1):
+            v = C.c_float()
+            _lib.check(lib.lspiv_event_elapsed_ms(e0, e1, C.byref(v)))
+            return v.value
+
+        out = {"kernel_ms": [ms(m[0], m[1]) for m in self._marks], "gather_ms": [ms(m[2], m[3]) for m in self._marks],
+               "gather_end_after_kernel_end_ms": [ms(m[1], m[3]) for m in self._marks]}
+        if reset:
+            for m in self._marks:
+                for e in m:
+                    lib.lspiv_event_destroy(e)
+            self._marks = []
+        return out
+
+    def gathered_host(self) -> np.ndarray:
+        """The last step's results of ALL ranks, (4, n_pairs, n_rows, n_cols) float32 (after ``drain``)."""
+        if self.k == 0:
+            raise RuntimeError("no step has run")
+        self.drain()
+        raw = self.recv[(self.k - 1) & 1].to_host().reshape(self.comm.world, 4 * self.p_max * self.n_win)
+        parts = [raw[r][: 4 * self.sizes[r] * self.n_win].reshape(4, self.sizes[r], self.n_rows, self.n_cols) for r in range(self.comm.world)]
+        return np.concatenate(parts, axis=1)
+
+    def local_host(self) -> np.ndarray:
+        """This rank's own packed block of the last step, (4, p_local, n_rows, n_cols)."""
+        self.drain()
+        raw = self.send[(self.k - 1) & 1].to_host().reshape(-1)
+        return raw[: 4 * self.p_local * self.n_win].reshape(4, self.p_local, self.n_rows, self.n_cols)
+
+    def close(self) -> None:
+        if self.comp:
+            self.drain()
+            for e in self.ev_done + self.ev_gathered + [e for m in self._marks for e in m]:
+                self.lib.lspiv_event_destroy(e)
+            self.lib.lspiv_stream_destroy(self.comp)
+            self.lib.lspiv_stream_destroy(self.comm_s)
+            self.comp = self.comm_s = None
+            self.send = self.recv = []
+
+
+def sharded_piv_dev(block, n_pairs: int, window_size, overlap, comm, signal_threshold=None, align: Optional[int] = None) -> np.ndarray:
+    """One sharded pass with the rank's frames already in HBM: ``block`` = DeviceFrames of this rank's ``frame_block`` (its
+    pairs + the halo frame; ``None`` for a rank without pairs).  Returns (4, n_pairs, n_rows, n_cols) on every rank --
+    bit-identical to ``piv.piv_pairs`` over the whole stack on one GPU."""
+    if block is None:
+        raise ValueError("sharded_piv_dev needs this rank's DeviceFrames block (ranks without pairs pass an empty (0, H, W) stack)")
+    plan = ShardedPivDev(comm, n_pairs, block.shape[1:], window_size, overlap, signal_threshold, align)
+    try:
+        plan.step(block)
+        return plan.gathered_host()
+    finally:
+        plan.close()

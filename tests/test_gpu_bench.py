@@ -47,6 +47,24 @@ def test_bench_launches_its_own_ranks_and_gathers_over_the_native_comm(gpu):
     assert comm["transport"] == "shm" and comm["ranks_reported_by_transport"] == 2
     assert comm["allgather_matches_single_launch"] is True and comm["same_device_plumbing_test"] is True
     assert comm["allgather_bytes_per_rank_per_step"] == 4 * 4 * 60 * d["config"]["windows_per_pair"]
+    # round 4: the step is the library's own sharded path, and the line diagnoses itself
+    assert "ShardedPivDev" in comm["path"] and comm["mode"] == "weak" and comm["pairs_total"] == 120 and comm["pairs_rank0"] == 60
+    for key in ("kernel_ms_while_gather_in_flight", "gather_ms_overlapped", "exposed_comm_ms", "gather_end_after_kernel_end_ms",
+                "allgather_ms_alone", "kernel_ms_alone", "allgather_bytes_received_per_rank_per_step", "rccl_env"):
+        assert key in comm, key
+    assert comm["kernel_ms_while_gather_in_flight"] > 0 and comm["gather_ms_overlapped"] > 0
+    assert abs(comm["exposed_comm_ms"] - (d["ms_per_step"] - comm["kernel_ms_while_gather_in_flight"])) < 1e-3
+    assert d["config"]["binary"]["binary_hash_matches"] is True
+
+
+@pytest.mark.gpu
+def test_bench_strong_mode_cuts_a_fixed_total(gpu):
+    """`--strong`: a fixed total (here 150 pairs) cut over the ranks on the walking kernels' anchors (75 + 75), value = total / time."""
+    d = run_bench(SMALL + ["--gpus", "2", "--strong", "--strong-pairs", "150"], {"LSPIV_BENCH_SAME_DEVICE": "1"})
+    comm = d["config"]["comm"]
+    assert d["scaling"] == "strong" and comm["mode"] == "strong" and comm["pairs_total"] == 150 and comm["pairs_rank0"] == 75
+    assert comm["allgather_matches_single_launch"] is True
+    assert abs(d["value"] - 150 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
 
 
 @pytest.mark.gpu
@@ -57,3 +75,4 @@ def test_bench_over_rccl_with_one_rank(gpu):
     comm = d["config"]["comm"]
     assert comm["transport"] == "rccl" and comm["ranks_reported_by_transport"] == 1
     assert comm["allgather_matches_single_launch"] is True
+    assert comm["rccl_env"].get("NCCL_MAX_NCHANNELS") == "16"       # the default cap on RCCL's CU take is in force and recorded

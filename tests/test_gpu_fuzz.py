@@ -30,6 +30,19 @@ def test_fuzz_callers(gpu, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [103, 106, 107, 113])
+def test_fuzz_ensemble_every_window(gpu, seed):
+    """Ensemble mode only, 80 cases per seed, gate: EVERY window of every case within 1e-4 (round 4: the float64 rescue of the
+    final fit).  These four seeds each held a case the float32 fit missed -- an 8 x 8 ensemble of two kept pairs, windows on
+    the edge of a constant patch whose exact answer is zero displacement."""
+    env = dict(os.environ, FUZZ_MODE="ensemble")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_modes.py"), str(seed), "80"],
+                         capture_output=True, text=True, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "80 cases, 0 failures" in out.stdout
+
+
+@pytest.mark.gpu
 def test_fuzz_rows(gpu):
     """tools/fuzz_rows.py: filters, both projections, masks and int16 packing against their oracles over random shapes
     (odd widths, single frames, tiny frames), dtypes and parameters."""

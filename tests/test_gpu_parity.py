@@ -626,33 +626,79 @@ def test_pipelined_upload_equals_single_batch(gpu, monkeypatch):
 
 def test_ensemble_state_export_import_merges_time_blocks(gpu):
     """Multi-GPU ensemble = per-rank accumulate + summed state: two half-stack ensembles merged through
-    export_state / import_state must equal one ensemble over the whole stack."""
+    export_state / import_state must equal one ensemble over the whole stack (float32 fits: the rescue of the final fit is
+    switched off here, the staged finish that keeps it across handles is tested below)."""
     import pyorc_amd.piv as P
+    from pyorc_amd import _lib
 
     fr = particle_stack(11, 96, 128, seed=51)
     kw = dict(corr_min=0.1, s2n_min=1.5)
-    whole = P.Ensemble(fr.shape[1:], (32, 32), (16, 16))
-    cm_w, sn_w = whole.accumulate(fr, **kw)
-    a = P.Ensemble(fr.shape[1:], (32, 32), (16, 16))
-    b = P.Ensemble(fr.shape[1:], (32, 32), (16, 16))
-    cm_a, _ = a.accumulate(fr[:6], **kw)      # pairs 0..4
-    cm_b, _ = b.accumulate(fr[5:], **kw)      # pairs 5..9 (one halo frame)
-    # a plane shares its inverse FFT with the neighbouring pair OF ITS CHUNK: same values up to float32 rounding
-    assert np.allclose(np.concatenate([cm_a, cm_b]), cm_w, rtol=2e-6, atol=1e-7)
-    sa, ka = a.export_state()
-    sb, kb = b.export_state()
-    sw, kw_ = whole.export_state()
-    assert np.array_equal(ka + kb, kw_) and np.abs((sa + sb) - sw).max() < 1e-5
-    a.import_state(sb, kb, add=True)
-    u1, v1, c1 = a.finish(0.2, 1)
-    u0, v0, c0 = whole.finish(0.2, 1)
-    assert np.array_equal(c1, c0) and np.array_equal(np.isnan(u1), np.isnan(u0))
-    assert np.nanmax(np.abs(u1 - u0)) < 1e-4 and np.nanmax(np.abs(v1 - v0)) < 1e-4
-    b.import_state(sw, kw_)                   # replace
-    u2, v2, _ = b.finish(0.2, 1)
-    assert np.array_equal(u2, u0, equal_nan=True) and np.array_equal(v2, v0, equal_nan=True)
+    _lib.set_option("rescue", 0)
+    try:
+        whole = P.Ensemble(fr.shape[1:], (32, 32), (16, 16))
+        cm_w, sn_w = whole.accumulate(fr, **kw)
+        a = P.Ensemble(fr.shape[1:], (32, 32), (16, 16))
+        b = P.Ensemble(fr.shape[1:], (32, 32), (16, 16))
+        cm_a, _ = a.accumulate(fr[:6], **kw)      # pairs 0..4
+        cm_b, _ = b.accumulate(fr[5:], **kw)      # pairs 5..9 (one halo frame)
+        # a plane shares its inverse FFT with the neighbouring pair OF ITS CHUNK: same values up to float32 rounding
+        assert np.allclose(np.concatenate([cm_a, cm_b]), cm_w, rtol=2e-6, atol=1e-7)
+        sa, ka = a.export_state()
+        sb, kb = b.export_state()
+        sw, kw_ = whole.export_state()
+        assert np.array_equal(ka + kb, kw_) and np.abs((sa + sb) - sw).max() < 1e-5
+        a.import_state(sb, kb, add=True)
+        u1, v1, c1 = a.finish(0.2, 1)
+        u0, v0, c0 = whole.finish(0.2, 1)
+        assert np.array_equal(c1, c0) and np.array_equal(np.isnan(u1), np.isnan(u0))
+        assert np.nanmax(np.abs(u1 - u0)) < 1e-4 and np.nanmax(np.abs(v1 - v0)) < 1e-4
+        b.import_state(sw, kw_)                   # replace
+        u2, v2, _ = b.finish(0.2, 1)
+        assert np.array_equal(u2, u0, equal_nan=True) and np.array_equal(v2, v0, equal_nan=True)
+        with pytest.raises(ValueError):
+            b.import_state(sw[:3], kw_)
+        for e in (whole, a, b):
+            e.close()
+    finally:
+        _lib.set_option("rescue", 1)
+
+
+def test_ensemble_staged_finish_over_two_handles(gpu):
+    """The multi-GPU finish (include/lspiv.h: lspiv_ensemble_flag / _partials / _finish_partials): two handles hold one half of
+    the pairs each and, after the exchange, the same total state; each contributes the float64 sums over ITS frames for the same
+    sorted list of flagged windows; with the summed partials both arrive at the answer of one handle over all frames."""
+    import pyorc_amd.piv as P
+
+    T, H, W = 9, 200, 264
+    fr = _speckle_and_particles(T, H, W, 12)
+    ws, ov = (32, 32), (16, 16)
+    kw = dict(corr_min=0.1, s2n_min=1.5)
+    whole = P.Ensemble((H, W), ws, ov)
+    whole.accumulate(fr, **kw)
+    u0, v0, _ = whole.finish(0.2, 1)
+    st0 = whole.stats()
+    assert st0["rescued"] > 0
+    a, b = P.Ensemble((H, W), ws, ov), P.Ensemble((H, W), ws, ov)
+    a.accumulate(fr[:5], **kw)
+    b.accumulate(fr[4:], **kw)
+    (sa, ka), (sb, kb) = a.export_state(), b.export_state()
+    for e in (a, b):
+        e.import_state(sa + sb, ka + kb)
+    na, nb = a.flag(0.2, 1), b.flag(0.2, 1)
+    assert na == nb == st0["flagged"] > 0
+    (pa, oka), (pb, okb) = a.partials(), b.partials()
+    assert oka and okb and pa.shape == (na, 20) and np.any(pa != 0) and np.any(pb != 0)
+    ua, va, _ = a.finish_partials(pa + pb)
+    ub, vb, _ = b.finish_partials(pa + pb)
+    assert np.array_equal(ua, ub, equal_nan=True) and np.array_equal(va, vb, equal_nan=True)
+    assert np.array_equal(np.isnan(ua), np.isnan(u0))
+    ref = po.get_ffpiv(fr, np.ones(T - 1), ws, ov, 1.0, 1.0, ensemble_corr=True, count_min=0.2, **kw)
+    for got in ((ua, va), (u0, v0)):
+        assert rel_err(got[0][0], ref["v_x"][0].astype(np.float64)) <= TOL and rel_err(got[1][0], ref["v_y"][0].astype(np.float64)) <= TOL
+    uf, vf, _ = a.finish(0.2, 1)                  # plain finish on a shared state: float32 fits, and it says so
+    assert a.stats()["rescued"] == 0 and a.stats()["float32_kept"] == na
     with pytest.raises(ValueError):
-        b.import_state(sw[:3], kw_)
+        a.finish_partials(pa[:-1])
     for e in (whole, a, b):
         e.close()
 
@@ -902,3 +948,132 @@ def test_rescue_list_overflow_keeps_float32_results(gpu):
     assert st2[0] + st2[1] <= a[0].size and st2[4] == st[4] + a[0].size        # counters were reset by the previous pass
     b = pyorc_amd.piv_pairs(small, (32, 32), (16, 16))
     assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(a, b))     # and the results are reproducible
+
+
+def test_rescue_of_a_many_way_tie_in_a_tall_window(gpu):
+    """the whole-plane ("amb") path of the rescue pass with more window rows than its block has threads (512 x 8:
+    wy > 256).  Frames whose columns alternate give FOUR exactly equal maxima per plane (lags kx = 0, 2, 4, 6 of the true row
+    shift): a 4-way near-tie in float32 -> an amb record -> the float64 plane -> its first maximum in row-major order, which sits
+    in shifted column 0, on the border.  With the "integer peak" reading of border peaks the answer is exact: u = -4, v = +3."""
+    import pyorc_amd
+    from pyorc_amd import _lib
+
+    rng = np.random.default_rng(5)
+    H, W = 520, 24
+    r = rng.integers(20, 200, H + 8).astype(np.float32)
+    col = np.where(np.arange(W) % 2 == 0, 0.2, 1.0).astype(np.float32)
+    fr = np.stack([r[t * 3: t * 3 + H, None] * col[None, :] for t in range(3)]).astype(np.float32)   # rows move by 3 per frame
+    assert _lib.load().lspiv_kernel_kind(512, 8) == 9
+    _lib.set_option("border_peak", 2)
+    try:
+        u, v, cm, sn = pyorc_amd.piv_pairs(fr, (512, 8), (0, 0))
+        st = _rescue_stats()
+    finally:
+        _lib.set_option("border_peak", 0)
+    assert u.shape == (2, 1, 3) and st[1] >= 1, st                 # whole-plane records were processed
+    assert np.array_equal(u, np.full_like(u, -4.0)) and np.array_equal(np.abs(v), np.full_like(v, 3.0)), (u, v)
+    assert np.all(cm > 0.5)
+
+
+def _speckle_and_particles(T, H, W, seed):
+    """Left part: one single-pixel speckle per 16 x 16 cell drifting one pixel per frame -- every correlation peak sits on
+    exactly-zero neighbours, the worst case of the float32 fit; right part: an ordinary sparse particle image."""
+    rng = np.random.default_rng(seed)
+    fr = particle_stack(T, H, W, seed=seed, density=0.012)
+    half = (W // 32) * 16
+    fr[:, :, :half] = 0
+    ys, xs = np.meshgrid(np.arange(8, H, 16), np.arange(8, half - 8, 16), indexing="ij")
+    amp = rng.integers(100, 255, ys.shape)
+    for t in range(T):
+        fr[t, ys, xs + t] = amp
+    return fr
+
+
+def test_ensemble_rescue_of_the_final_fit(gpu, monkeypatch):
+    """Round 4: lspiv_ensemble_finish re-evaluates the ill-conditioned fits of the MEAN planes in float64 from the retained frames
+    (csrc/piv_rescue.hip, ens_*): every window within 1e-4 of the oracle; the host entry point keeps its upload buffers, the
+    device entry point copies / borrows on request, and without frames (mode NONE, budget, imported state) the float32 fits stay."""
+    import pyorc_amd.piv as P
+    from pyorc_amd import DeviceFrames, _lib
+
+    T, H, W = 5, 200, 264
+    fr = _speckle_and_particles(T, H, W, 11)
+    ws, ov = (32, 32), (16, 16)
+    kw = dict(corr_min=0.1, s2n_min=1.5)
+    ref = po.get_ffpiv(fr, np.ones(T - 1), ws, ov, 1.0, 1.0, ensemble_corr=True, count_min=0.0, **kw)
+    uo, vo = ref["v_x"][0].astype(np.float64), ref["v_y"][0].astype(np.float64)
+
+    def finish(ens):
+        u, v, cnt = ens.finish(0.0, 1)
+        st = ens.stats()
+        ens.close()
+        return u[0], v[0], st
+
+    def check(u, v):
+        assert np.array_equal(np.isnan(u), np.isnan(uo)) and np.array_equal(np.isnan(v), np.isnan(vo))
+        return max(rel_err(u, uo), rel_err(v, vo))
+
+    ens = P.Ensemble((H, W), ws, ov)                                 # host frames, one chunk
+    ens.accumulate(fr, kw["corr_min"], kw["s2n_min"])
+    u1, v1, st = finish(ens)
+    assert st["flagged"] > 0 and st["rescued"] == st["flagged"] - st["float32_kept"] > 0 and st["retain_complete"] and st["chunks_kept"] == 1, st
+    assert check(u1, v1) <= TOL
+    ens = P.Ensemble((H, W), ws, ov)                                 # two chunks with their halo frame
+    ens.accumulate(fr[:3], kw["corr_min"], kw["s2n_min"])
+    ens.accumulate(fr[2:], kw["corr_min"], kw["s2n_min"])
+    u2, v2, st2 = finish(ens)
+    assert st2["chunks_kept"] == 2 and st2["rescued"] > 0 and check(u2, v2) <= TOL
+    _lib.set_option("rescue", 0)                                     # what the pass is for
+    try:
+        ens = P.Ensemble((H, W), ws, ov)
+        ens.accumulate(fr, kw["corr_min"], kw["s2n_min"])
+        u0, v0, st0 = finish(ens)
+    finally:
+        _lib.set_option("rescue", 1)
+    assert st0["flagged"] == 0 and st0["chunks_kept"] == 0 and check(u0, v0) > TOL
+    d = DeviceFrames.from_host(fr)                                   # HBM-resident stack: borrowed, no copy
+    ens = P.Ensemble((H, W), ws, ov)
+    ens.accumulate(d, kw["corr_min"], kw["s2n_min"])
+    u3, v3, st3 = finish(ens)
+    assert np.array_equal(u3, u1, equal_nan=True) and np.array_equal(v3, v1, equal_nan=True) and st3["rescued"] == st["rescued"]
+    d_cs = DeviceFrames.empty((2, T - 1, u1.size), np.float32)
+    for mode, rescued in ((P.Ensemble.RETAIN_COPY, True), (P.Ensemble.RETAIN_NONE, False)):
+        ens = P.Ensemble((H, W), ws, ov)
+        ens.set_retain(mode)
+        ens.accumulate_dev(d.ptr, d.dtype, T, kw["corr_min"], kw["s2n_min"], d_cs.ptr)
+        u4, v4, st4 = finish(ens)
+        if rescued:
+            assert np.array_equal(u4, u1, equal_nan=True) and np.array_equal(v4, v1, equal_nan=True) and st4["bytes_kept"] >= fr.nbytes
+        else:
+            assert st4["flagged"] == st["flagged"] and st4["rescued"] == 0 and st4["float32_kept"] == st4["flagged"] and not st4["retain_complete"]
+            assert np.array_equal(u4, u0, equal_nan=True) and np.array_equal(v4, v0, equal_nan=True)
+    monkeypatch.setenv("LSPIV_ENSEMBLE_RETAIN_BYTES", "1000")        # budget too small for the chunk: float32 fits, nothing breaks
+    ens = P.Ensemble((H, W), ws, ov)
+    ens.accumulate(fr, kw["corr_min"], kw["s2n_min"])
+    u5, v5, st5 = finish(ens)
+    assert not st5["retain_complete"] and st5["rescued"] == 0 and np.array_equal(u5, u0, equal_nan=True)
+    monkeypatch.delenv("LSPIV_ENSEMBLE_RETAIN_BYTES")
+    ens = P.Ensemble((H, W), ws, ov)                                 # an imported state has no frames behind it
+    ens.accumulate(fr, kw["corr_min"], kw["s2n_min"])
+    s, k = ens.export_state()
+    ens.import_state(s, k)
+    u6, v6, st6 = finish(ens)
+    assert st6["rescued"] == 0 and np.array_equal(u6, u0, equal_nan=True)
+
+
+@pytest.mark.parametrize("ws,dtype", [(64, np.uint8), (64, np.float32), (24, np.float64), (9, np.uint8), (40, np.float32), (96, np.uint8)])
+def test_ensemble_rescue_other_kernels(gpu, ws, dtype):
+    """The same through get_piv for the other kernel families and sample types (64 x 64 float32 windows do not fit the rescue
+    kernel's LDS slice and are read from L2; odd and > 64 px windows come from the embedded / DFT kernels)."""
+    from pyorc_amd import frames as F
+
+    fr = _speckle_and_particles(4, 4 * ws + 8, 6 * ws + 8, 100 + ws)
+    if dtype != np.uint8:
+        fr = fr.astype(dtype) * 0.5 - 3.0      # (the empty background stays exactly constant)
+    ws_e = int(np.round(ws / 2.0) * 2)
+    ov_e = int(round(ws) / 2)
+    got = F.get_piv(fr, ws, ensemble_corr=True, corr_min=0.1, s2n_min=1.5, count_min=0.0)
+    ref = po.get_ffpiv(fr, np.ones(3), (ws_e, ws_e), (ov_e, ov_e), 1.0, 1.0, ensemble_corr=True, corr_min=0.1, s2n_min=1.5, count_min=0.0)
+    for k in ("v_x", "v_y", "corr", "s2n"):
+        assert np.array_equal(np.isnan(got[k]), np.isnan(ref[k])), k
+    assert rel_err(got["v_x"], ref["v_x"].astype(np.float64)) <= TOL and rel_err(got["v_y"], ref["v_y"].astype(np.float64)) <= TOL

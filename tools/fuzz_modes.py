@@ -28,6 +28,8 @@ for case in range(n_cases):
     ws_e = int(np.round(ws / 2.0) * 2)     # get_piv rounds to even like pyorc (25 -> 24, 35 -> 36)
     ov_e = int(round(ws) / 2)               # ... and takes the default overlap from the size as given (frames.py:169-171)
     mode = str(rng.choice(["timestep", "ensemble", "planes"]))
+    if os.environ.get("FUZZ_MODE"):          # e.g. FUZZ_MODE=ensemble: every case in that mode (the random stream stays the same)
+        mode = os.environ["FUZZ_MODE"]
     T = int(rng.integers(3, 9)) if ws > 40 or rng.random() < 0.5 else int(rng.integers(20, 70))
     H = int(rng.integers(2 * ws, 4 * ws + 9)); W = int(rng.integers(2 * ws, 5 * ws + 9))
     dtype = rng.choice([np.uint8, np.float32, np.float64])
