@@ -1077,3 +1077,35 @@ def test_ensemble_rescue_other_kernels(gpu, ws, dtype):
     for k in ("v_x", "v_y", "corr", "s2n"):
         assert np.array_equal(np.isnan(got[k]), np.isnan(ref[k])), k
     assert rel_err(got["v_x"], ref["v_x"].astype(np.float64)) <= TOL and rel_err(got["v_y"], ref["v_y"].astype(np.float64)) <= TOL
+
+
+def test_two_host_threads_on_one_stream(gpu):
+    """the PIV kernel and its rescue kernels share the stream's lists -- two host threads launching on the same
+    (library) stream must not interleave them.  Different stacks and grid sizes from two threads, against the serial answers."""
+    import threading
+
+    import pyorc_amd
+    from pyorc_amd import DeviceFrames
+
+    stacks = [DeviceFrames.from_host(particle_stack(9, 200, 260, seed=61, density=0.012)),
+              DeviceFrames.from_host(particle_stack(4, 96, 128, seed=62, density=0.012))]
+    serial = [pyorc_amd.piv_pairs(s, (32, 32), (16, 16)) for s in stacks]
+    errors = []
+
+    def work(k):
+        try:
+            for _ in range(25):
+                got = pyorc_amd.piv_pairs(stacks[k], (32, 32), (16, 16))
+                for a, b in zip(serial[k], got):
+                    if not np.array_equal(a, b, equal_nan=True):
+                        errors.append(k)
+                        return
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
