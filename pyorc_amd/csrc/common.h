@@ -92,6 +92,8 @@ struct PivParams {
   uint32_t seg_len, n_seg; // pairs per segment (odd), number of segments
   uint32_t seg_first;      // pairs in segment 0: seg_len, or what is left up to the next anchor when the chunk starts off-anchor
   uint32_t n_pairs;        // T-1
+  uint32_t strip_w;        // walking kernels: 0 = a segment's jobs run over the window grid row by row; w > 0 = in column strips of w
+                           // windows, every strip top to bottom (the vertically overlapping windows of a band share a round of jobs)
   int64_t pair_offset;     // absolute index of the chunk's first pair in the caller's stack: the walking kernels cut
                            // segments at multiples of the anchor length of THAT index, so results do not depend on the chunking
   // float64 rescue pass (piv_rescue.hip): the kernels' epilogues append the windows whose float32
@@ -434,8 +436,10 @@ inline WalkSegments walk_segments(uint32_t n_pairs, int64_t pair_offset, uint32_
 }
 // concurrent lane groups of a kernel that runs `waves_per_simd` waves with `groups` jobs per wave (CU count queried once)
 uint32_t job_slots(int waves_per_simd, int groups);
+// lane_major_n: 0 = the partial sums are fft-shifted row-major planes like corr_sum; N = the N x N slots of the 64 x 64 walking
+// ensemble kernel, element (row y, column x) at slot[(x / 4) * 4 N + y * 4 + x % 4], un-shifted (piv_fft_impl.h, slot_accumulate)
 hipError_t launch_ensemble_merge(const float* part_sum, const float* part_cnt, uint32_t n_seg, uint32_t n_win, int plane_elems,
-                                 float* corr_sum, float* corr_count, hipStream_t s);
+                                 float* corr_sum, float* corr_count, hipStream_t s, int lane_major_n = 0);
 hipError_t launch_ensemble_mean(const float* sum, const float* count, float min_count, uint32_t n_win,
                                 int plane_elems, float* mean, hipStream_t s);
 // orthoprojection gather (project.hip) and int16 result packing

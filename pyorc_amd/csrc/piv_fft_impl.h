@@ -1098,6 +1098,106 @@ __device__ __forceinline__ void prepare_one(const RowRaw<T, N>& raw, float (&x)[
 #endif
 template <int N> constexpr bool kF32Early = LSPIV_F32_EARLY && Geo<N>::FULL;
 
+// ---- 64 x 64 walking ENSEMBLE kernel: the job's partial sum through the idle transpose tile ----------------------------------
+// One job per wave, 256 VGPRs (no room for an accumulator), no LDS to spare next to the tile: the partial sum lives in the job's
+// 16 KB HBM slot.  Round 3 read-modified-wrote it in the plane's row-major layout -- every lane its own 256-byte row, 16 bytes at a
+// time: 64 different lines per load and per store instruction, waves waiting for the loads 56 % of the time, 51.5 ms per 1000
+// pairs against the per-timestep kernel's 28 (profiles/r04a_ens64).  Now:
+//   * the slot is stored in the order the lanes hold it: element (row y = lane, column x = register j) at
+//     slot[(j / 4) * 256 + lane * 4 + j % 4] -- a wave instruction moves 1 KB of consecutive bytes;
+//   * after the last transpose of an iteration the tile is idle until the next iteration's first one: the slot is fetched
+//     into it by 16 global_load_lds_dwordx4 (asynchronous, no registers) while the last FFT stage and the plane maxima run;
+//   * then: wait for it, 16 ds_read_b128, acc = (acc + plane a) + plane b -- the very additions of the round-3 kernel, so the
+//     sums keep their bits --, 16 global_store_dwordx4.  The first iteration of a job stores without reading (slots are
+//     never zeroed).  ensemble_merge_kernel un-permutes when it adds the segments' slots to corr_sum.
+// (No-return float atomics into lane-major slots were measured first: 44.6 ms -- the L2 atomic units take ~3.5 TB/s, 61 GB of
+// adds per 1000 pairs do not hide behind the arithmetic; at 32 x 32 the same scheme LOSES to the register accumulator, 11.6
+// against 7.0 ms.  docs/history.md, round 4.)
+#ifndef LSPIV_ENS_LDS_RMW
+#define LSPIV_ENS_LDS_RMW 1
+#endif
+template <int N> constexpr bool kEnsLdsRmw = LSPIV_ENS_LDS_RMW && N == 64;
+typedef float __attribute__((address_space(1))) * GlobalF32;
+typedef float __attribute__((address_space(3))) * LdsF32;
+__device__ __forceinline__ GlobalF32 uniform_global_ptr(const float* p) {   // visibly wave-uniform: scalar base + lane offset addressing
+  const uint64_t a = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return (GlobalF32)(((uint64_t)hi << 32) | lo);
+}
+template <int N>
+__device__ __forceinline__ void slot_prefetch_lds(GlobalF32 slot, float* buf) {   // slot: wave-uniform (uniform_global_ptr)
+  static_assert(N == 64 && Geo<N>::GROUPS == 1 && Geo<N>::LDS_JOB >= N * N, "one job per wave, the tile holds a plane");
+  const int lane = threadIdx.x & 63;
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the transpose's own reads of the tile have returned
+  // four scalar bases 4 KB apart, four immediate offsets each (the immediate moves the global AND the LDS address): one 32-bit
+  // lane offset, no vector address pairs
+#pragma unroll
+  for (int qq = 0; qq < N / 16; ++qq) {
+    const GlobalF32 src = slot + qq * 1024 + lane * 4;
+    const LdsF32 dst = (LdsF32)(buf + qq * 1024);
+    __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
+    __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 0);
+    __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 0);
+  }
+}
+// acc <- (acc + m0 c0) + m1 c1, m in {0, 1} (exact products: the additions of the masked planes in pair order); `init`: the
+// slot holds nothing yet (no prefetch was issued)
+template <int N>
+__device__ __forceinline__ void slot_accumulate(GlobalF32 slot, const float* buf, const float (&c0)[N], bool keep0, const float (&c1)[N],
+                                                bool keep1, bool init_) {
+  const int lane = threadIdx.x & 63;
+  const bool init = __builtin_amdgcn_readfirstlane((int)init_) != 0;   // one job per wave: uniform, and the compiler may know it
+  const bool any = __builtin_amdgcn_readfirstlane((int)(keep0 || keep1)) != 0;
+  if (!init) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the slot has landed in the tile -- and nothing of it arrives later
+  if (!init && !any) return;
+  const float m0 = keep0 ? 1.0f : 0.0f, m1 = keep1 ? 1.0f : 0.0f;
+  const float* lsrc = buf + lane * 4;
+  if (init) {
+#pragma unroll
+    for (int qq = 0; qq < N / 16; ++qq) {
+      const GlobalF32 dst = slot + qq * 1024 + lane * 4;   // scalar base bumped by 4 KB, the lane's 32-bit offset, immediates below
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int q = 4 * qq + k;
+        f32x4 a;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = fmaf(c1[4 * q + e], m1, c0[4 * q + e] * m0);
+        *reinterpret_cast<f32x4 __attribute__((address_space(1)))*>(dst + k * 256) = a;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int qq = 0; qq < N / 16; ++qq) {
+      const GlobalF32 dst = slot + qq * 1024 + lane * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int q = 4 * qq + k;
+        f32x4 a = *reinterpret_cast<const f32x4*>(lsrc + q * 256);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = fmaf(c1[4 * q + e], m1, fmaf(c0[4 * q + e], m0, a[e]));
+        *reinterpret_cast<f32x4 __attribute__((address_space(1)))*>(dst + k * 256) = a;
+        if (k & 1) __builtin_amdgcn_sched_barrier(0);   // at most two tile reads (8 registers) in flight: all 16 hoisted up front cost 64 registers and spilled the carry
+      }
+    }
+  }
+}
+
+// Order of a segment's jobs over the window grid.  Row-major (strip_w = 0), or column strips of strip_w windows, each strip top
+// to bottom: the jobs that are resident together then span MORE window rows and fewer columns.  64 x 64 @ 75 % overlap: a
+// window row shares 48 of its 64 image rows with the next one, and 256 resident jobs per XCD are 2.2 rows of a 1080p grid -- the
+// other three rows that need a band come rounds later, when the band has left the 4 MB L2 (5.7 GB fetched for a 2.1 GB stack,
+// profiles/r03_c3); with strips of 32 windows a round is 8 rows deep.
+__device__ __forceinline__ uint32_t strip_order(uint32_t idx, uint32_t strip_w, uint32_t n_rows, uint32_t n_cols) {
+  if (strip_w == 0 || strip_w >= n_cols) return idx;
+  const uint32_t n_strips = (n_cols + strip_w - 1) / strip_w, per = strip_w * n_rows;
+  const uint32_t sidx = min(idx / per, n_strips - 1);
+  const uint32_t rem = idx - sidx * per;
+  const uint32_t w = sidx == n_strips - 1 ? n_cols - sidx * strip_w : strip_w;
+  const uint32_t row = rem / w;
+  return row * n_cols + sidx * strip_w + (rem - row * w);
+}
+
 // what a walking job carries from one iteration to the next
 template <int N>
 struct WalkCarry {
@@ -1117,7 +1217,7 @@ template <typename T, int N, bool WANT_NZ>
 __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row, bool has2, float* buf, int lg,
                                                int partner_byte, int lane0_byte, WalkCarry<N>& c, float (&xr)[N],
                                                float (&xi)[N], float& mean_a, float& mean_b, bool& skip_a, bool& skip_b,
-                                               bool& dead_a, bool& dead_b) {
+                                               bool& dead_a, bool& dead_b, GlobalF32 acc_slot = nullptr) {
   using G = Geo<N>;
   constexpr int H = N / 2;
   bool dead0, dead1, fin0 = true, fin1 = true;
@@ -1190,6 +1290,11 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
   LSPIV_WALK_SB;
   LSPIV_SETPRIO(LSPIV_PRIO_T);
   transpose2<N>(buf, lg, xr, xi);      // lane = y, regs = kx
+  if constexpr (kEnsLdsRmw<N>) {
+    // 64 x 64 ensemble kernel: the job's tile is free from here to the next iteration's first transpose -- the running partial
+    // sum of the job starts its way from HBM into it now (asynchronously, no registers) and is there when the planes are final
+    if (acc_slot) slot_prefetch_lds<N>(acc_slot, buf);
+  }
   LSPIV_WALK_SB;
   LSPIV_SETPRIO(0);
   dead_a = c.prev_dead || dead0;
@@ -1244,7 +1349,7 @@ __global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_kernel
   const bool job_valid = job < n_seg * p.n_win;
   job = job_valid ? job : n_seg * p.n_win - 1;
   const uint32_t seg = p.div_nwin.div(job);
-  const uint32_t win = job - seg * p.n_win;
+  const uint32_t win = strip_order(job - seg * p.n_win, p.strip_w, (uint32_t)p.n_rows, (uint32_t)p.n_cols);
   // segments are anchored at absolute pair indices (common.h, kWalkAnchor): segment 0 ends at the first anchor
   const uint32_t p0 = seg == 0 ? 0u : p.seg_first + (seg - 1) * seg_len;
   const uint32_t p1 = min(seg == 0 ? p.seg_first : p0 + seg_len, p.n_pairs);   // pairs [p0, p1) = frames p0 .. p1
@@ -1674,7 +1779,7 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsWaves<T, N>)) void piv_fft_walk_ens
   const bool job_valid = job < p.n_seg * p.n_win;
   job = job_valid ? job : p.n_seg * p.n_win - 1;
   const uint32_t seg = p.div_nwin.div(job);
-  const uint32_t win = job - seg * p.n_win;
+  const uint32_t win = strip_order(job - seg * p.n_win, p.strip_w, (uint32_t)p.n_rows, (uint32_t)p.n_cols);
   const uint32_t p0 = seg == 0 ? 0u : p.seg_first + (seg - 1) * p.seg_len;
   const uint32_t p1 = min(seg == 0 ? p.seg_first : p0 + p.seg_len, p.n_pairs);
   const uint32_t wrow = p.div_ncols.div(win);
@@ -1682,6 +1787,7 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsWaves<T, N>)) void piv_fft_walk_ens
   const T* row = static_cast<const T*>(p.frames) + ((int64_t)p0 * p.H + (int64_t)(wrow * p.sy + row_of<N>(lg))) * p.W +
                  (int64_t)wcol * p.sx;
   float* part = p.part_sum + (size_t)job * G::NN;
+  const GlobalF32 part_u = kEnsLdsRmw<N> ? uniform_global_ptr(part) : nullptr;   // one job per wave: the slot pointer lives in SGPRs
   const bool win_dropped = WANT_NZ && p.win_keep && !p.win_keep[win];
   float cnt = 0.0f;
   float acc[kEnsRegAcc<N> ? N : 1];
@@ -1697,13 +1803,18 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsWaves<T, N>)) void piv_fft_walk_ens
     float xr[N], xi[N], mean[2];
     bool skip[2], keep[2], dead[2];
     walk_iteration<T, N, WANT_NZ>(p, row, has2, buf, lg, partner_byte, lane0_byte, carry, xr, xi, mean[0], mean[1], skip[0], skip[1],
-                                  dead[0], dead[1]);
+                                  dead[0], dead[1], (kEnsLdsRmw<N> && !first) ? part_u : nullptr);
     if (WANT_NZ && win_dropped) skip[0] = skip[1] = true;
     const bool valid[2] = {job_valid && f > p0, job_valid && has2};
+    float vmaxs[2];
+    {
+      float row_max;
+      vmaxs[0] = plane_max<N>(xr, row_max);
+      vmaxs[1] = plane_max<N>(xi, row_max);
+    }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      float row_max;
-      const float vmax = plane_max<N>(k == 0 ? xr : xi, row_max);
+      const float vmax = vmaxs[k];
       float cm = dead[k] ? 0.0f : vmax, sn = dead[k] ? __builtin_nanf("") : vmax * __builtin_amdgcn_rcpf(mean[k]);   // dead: zero plane
       keep[k] = valid[k] && !skip[k] && (cm >= p.corr_min) && (sn >= p.s2n_min);  // NaN s2n compares false
       cm = keep[k] ? cm : 0.0f;
@@ -1721,6 +1832,10 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsWaves<T, N>)) void piv_fft_walk_ens
         acc[j] += keep[0] ? xr[j] : 0.0f;   // pair f-1 first, then f: the reference's summation order
         acc[j] += keep[1] ? xi[j] : 0.0f;
       }
+    } else if constexpr (kEnsLdsRmw<N>) {
+      if (job_valid) slot_accumulate<N>(part_u, buf, xr, keep[0], xi, keep[1], first);
+      else __builtin_amdgcn_s_waitcnt(0x0F70);   // (a job past the end stores nothing, but its prefetch still has to land before the tile is reused)
+      first = false;
     } else {
       if (first || keep[0] || keep[1]) accumulate_planes<N>(part, lg, xr, keep[0], xi, keep[1], first);
       first = false;
@@ -1732,17 +1847,27 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsWaves<T, N>)) void piv_fft_walk_ens
   if (job_valid && lg == 0) p.part_cnt[job] = cnt;
 }
 
+// strip width of the walking kernels' job order (strip_order): 32 windows for 64 x 64, row-major for the other sizes;
+// LSPIV_STRIP_W overrides it for every size (0 = row-major; measurements)
+template <int N>
+static uint32_t walk_strip_width() {
+  static const int env = getenv("LSPIV_STRIP_W") ? atoi(getenv("LSPIV_STRIP_W")) : -1;
+  return env >= 0 ? (uint32_t)env : (N == 64 ? 32u : 0u);
+}
+
 template <typename T, int N, bool WANT_NZ>
 static hipError_t launch_t(const PivParams& p, bool ensemble, hipStream_t s) {
   using G = Geo<N>;
   constexpr uint32_t jobs_per_block = WAVES_PER_BLOCK * G::GROUPS;
   if (ensemble && p.part_sum) {   // walking ensemble kernel + ordered merge of the per-segment partial sums
     const uint64_t wjobs = (uint64_t)p.n_seg * p.n_win;
+    PivParams q = p;
+    q.strip_w = walk_strip_width<N>();
     hipLaunchKernelGGL((piv_fft_walk_ensemble_kernel<T, N, WANT_NZ>), dim3((uint32_t)((wjobs + jobs_per_block - 1) / jobs_per_block)),
-                       dim3(BLOCK), G::LDS_BYTES, s, p);
+                       dim3(BLOCK), G::LDS_BYTES, s, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_ensemble_merge(p.part_sum, p.part_cnt, p.n_seg, p.n_win, G::NN, p.corr_sum, p.corr_count, s);
+    return launch_ensemble_merge(p.part_sum, p.part_cnt, p.n_seg, p.n_win, G::NN, p.corr_sum, p.corr_count, s, kEnsLdsRmw<N> ? N : 0);
   }
   if (ensemble) {
     const uint32_t jobs = p.n_win;
@@ -1757,6 +1882,7 @@ static hipError_t launch_t(const PivParams& p, bool ensemble, hipStream_t s) {
     PivParams q = p;
     const WalkSegments w = walk_segments(p.n_pairs, p.pair_offset, walk > 1 ? (uint32_t)walk : kWalkAnchor);
     q.seg_len = w.seg_len; q.seg_first = w.seg_first; q.n_seg = w.n_seg;
+    q.strip_w = walk_strip_width<N>();
     const uint64_t wjobs = (uint64_t)w.n_seg * p.n_win;
     const uint32_t wblocks = (uint32_t)((wjobs + jobs_per_block - 1) / jobs_per_block);
     constexpr size_t walk_lds = G::LDS_BYTES + (kTwoPlaneEpilogue<N> ? (size_t)WAVES_PER_BLOCK * G::GROUPS * 3 * G::LDS_ROW * 4 : 0);   // + plane b's three rows

@@ -18,14 +18,26 @@ __global__ void ensemble_mean_kernel(const float* sum, const float* count, float
 }
 
 // walking ensemble kernels: corr_sum += part[0] + part[1] + ... in segment (= time) order, counts likewise
+// LANE_MAJOR (64 x 64): the slots hold element (row y, column x) at (x / 4) * 4 N + y * 4 + x % 4 (piv_fft_impl.h, slot_accumulate);
+// a thread owns one slot element (coalesced reads of every segment's slot) and writes it to the fft-shifted row-major position
+// of corr_sum once
+template <bool LANE_MAJOR>
 __global__ __launch_bounds__(256) void ensemble_merge_kernel(const float* __restrict__ part_sum, const float* __restrict__ part_cnt,
-                                                             uint32_t n_seg, int64_t n_elems, uint32_t n_win,
+                                                             uint32_t n_seg, int64_t n_elems, uint32_t n_win, int n,
                                                              float* __restrict__ corr_sum, float* __restrict__ corr_count) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n_elems) {
-    float acc = corr_sum[i];
+    int64_t o = i;
+    if (LANE_MAJOR) {
+      const int nn = n * n;
+      const int64_t win = i / nn;
+      const int e = (int)(i - win * nn), q = e / (4 * n), r = e - q * 4 * n, y = r >> 2, x = 4 * q + (r & 3), h = n / 2;   // slot[(x / 4) * 4 n + y * 4 + x % 4]
+      const int ip = y + h >= n ? y + h - n : y + h, jp = x + h >= n ? x + h - n : x + h;
+      o = win * nn + ip * n + jp;
+    }
+    float acc = corr_sum[o];
     for (uint32_t sg = 0; sg < n_seg; ++sg) acc += part_sum[(int64_t)sg * n_elems + i];
-    corr_sum[i] = acc;
+    corr_sum[o] = acc;
   }
   if (i < n_win) {
     float c = corr_count[i];
@@ -35,11 +47,14 @@ __global__ __launch_bounds__(256) void ensemble_merge_kernel(const float* __rest
 }
 
 hipError_t launch_ensemble_merge(const float* part_sum, const float* part_cnt, uint32_t n_seg, uint32_t n_win, int plane_elems,
-                                 float* corr_sum, float* corr_count, hipStream_t s) {
+                                 float* corr_sum, float* corr_count, hipStream_t s, int lane_major_n) {
   const int64_t n_elems = (int64_t)n_win * plane_elems;
   if (n_elems == 0) return hipSuccess;
-  hipLaunchKernelGGL(ensemble_merge_kernel, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, s, part_sum, part_cnt, n_seg,
-                     n_elems, n_win, corr_sum, corr_count);
+  const dim3 grid((unsigned)((n_elems + 255) / 256));
+  if (lane_major_n)
+    hipLaunchKernelGGL(ensemble_merge_kernel<true>, grid, dim3(256), 0, s, part_sum, part_cnt, n_seg, n_elems, n_win, lane_major_n, corr_sum, corr_count);
+  else
+    hipLaunchKernelGGL(ensemble_merge_kernel<false>, grid, dim3(256), 0, s, part_sum, part_cnt, n_seg, n_elems, n_win, 0, corr_sum, corr_count);
   return hipGetLastError();
 }
 
