@@ -67,7 +67,7 @@ int         lspiv_abi_version(void);
 const char* lspiv_version(void);                        /* "lspiv-hip <version> (gfx950) src <source hash>" */
 /* Provenance of the loaded binary (csrc/Makefile compiles both in): LSPIV_BUILD_KERNEL_HASH = first 16 hex digits of the
  * sha256 over csrc/{piv_fft_impl.h, fft_regs.h, common.h, piv_rescue.hip} (the fused PIV kernels; the committed profile
- * summaries are keyed to it), LSPIV_BUILD_SOURCE_HASH = the same over every .hip and .h file of csrc/ (sorted by name) and this
+ * summaries are keyed to it), LSPIV_BUILD_SOURCE_HASH = the same over every .hip, .h and .cpp file of csrc/ (sorted by name) and this
  * header.  pyorc_amd._lib.load() recomputes the second from the tree and refuses a stale binary.  "unknown": not built by
  * csrc/Makefile; "": unknown selector. */
 #define LSPIV_BUILD_KERNEL_HASH 0
@@ -108,7 +108,15 @@ int         lspiv_synchronize(void);                    /* hipDeviceSynchronize 
  *   "rescue"           1 (default; environment LSPIV_RESCUE) | 0 float32 results as they are;
  *   "rescue_kappa"     plane noise the flag model assumes, in 1e-9 of the plane maximum (default 500);
  *   "rescue_tau"       relative gap between the two largest samples below which the arg-max counts as ambiguous and the whole
- *                      plane is re-evaluated, in 1e-9 (default 4000). */
+ *                      plane is re-evaluated, in 1e-9 (default 4000).
+ * float64 HOST stacks are narrowed to float32 while they are staged (the kernels compute in float32).  A frame that rides on a
+ * DC offset far above its contrast would lose the low bits of its texture in that conversion, where the reference normalises
+ * every window in float64; the per-window normalisation does not see a constant added to a frame, so:
+ *   "narrow_offset"    smallest magnitude of a frame's DC offset (the mean of 4096 strided samples, rounded to an integer: a
+ *                      function of the frame alone) that is subtracted while narrowing; default 1024 (never triggers on 8-bit-like
+ *                      imagery, whose results stay bit-identical to a float32 copy of the stack), -1 never; environment
+ *                      LSPIV_NARROW_OFFSET.  lspiv_piv_pairs / lspiv_ensemble_accumulate only, and only without a signal
+ *                      threshold (which counts samples != 0).  float64 stacks already in HBM ("_dev") are converted as they are. */
 int         lspiv_set_option(const char* name, int value);
 int         lspiv_get_option(const char* name, int* value);
 /* counters of the rescue pass on `stream` (NULL: the library's own stream), after synchronising with it: stats[0..4] =
@@ -436,6 +444,10 @@ int lspiv_stream_wait_event(void* stream, void* ev);    /* NULL = the library's 
  * bench utility, not on the PIV path): N_p = density*H*W Gaussian particles (sigma 1.2 px)
  * advected by u = 3 + 2 sin(2 pi y/H), v = 1.5 cos(2 pi x/W) px/frame.  d_frames (T,H,W) uint8. */
 int lspiv_synth_particles_dev(void* d_frames, int64_t T, int64_t H, int64_t W, uint64_t seed, float density);
+/* test hook, host only: the float64 -> float32 conversion the host entry points apply while staging (csrc/host_stage.cpp), with
+ * the DC-offset rule of the "narrow_offset" option at threshold min_abs (-1: plain conversion); offsets (nullable) receives the
+ * offset taken off every frame; returns the number of staging threads. */
+int lspiv_debug_narrow(const double* frames, int64_t frame_elems, int64_t n_frames, int min_abs, float* out, double* offsets);
 
 /* Test hook: `count` independent length-n complex FFTs with the kernels' own register transforms (fft_regs.h), numpy
  * conventions (forward exp(-2 pi i jk/n), inverse exp(+...), both unnormalised); in / out: host arrays of count*n

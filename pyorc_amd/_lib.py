@@ -150,6 +150,7 @@ SIGNATURES = {
     "lspiv_comm_destroy": (_i32, [_vp]),
     "lspiv_synth_particles_dev": (_i32, [_vp, _i64, _i64, _i64, C.c_uint64, _f32]),
     "lspiv_debug_fft": (_i32, [_i32, _i32, _vp, _vp, _i64]),
+    "lspiv_debug_narrow": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp]),
     "lspiv_debug_segments": (_i32, [_i64, _i64, _i32, _pi64, _pi64]),
 }
 
@@ -199,10 +200,10 @@ def _hash_files(paths) -> str:
 
 
 def source_hash(csrc_dir: Optional[str] = None, header: Optional[str] = None) -> str:
-    """sha256 (16 hex digits) over every source of the library: csrc/*.hip and csrc/*.h sorted by name, then include/lspiv.h --
+    """sha256 (16 hex digits) over every source of the library: csrc/*.hip, *.h and *.cpp sorted by name, then include/lspiv.h --
     what csrc/Makefile compiles into the binary as LSPIV_BUILD_SOURCE_HASH."""
     d = csrc_dir or os.path.join(_HERE, "csrc")
-    names = sorted(n for n in os.listdir(d) if n.endswith(".hip") or n.endswith(".h"))
+    names = sorted(n for n in os.listdir(d) if n.endswith((".hip", ".h", ".cpp")))
     return _hash_files([os.path.join(d, n) for n in names] + [header or os.path.join(os.path.dirname(_HERE), "include", "lspiv.h")])
 
 

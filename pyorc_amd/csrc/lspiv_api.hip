@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "common.h"
+#include "host_stage.h"
 
 namespace lspiv {   // project.hip
 hipError_t launch_project_u8(const uint8_t* frames, int64_t src_elems, int n_frames, const int* qlo1, const int* qlo2,
@@ -130,47 +131,12 @@ static bool is_pinned(const void* p) {
   return a.type == hipMemoryTypeHost;
 }
 
-// host threads of the staging copies: LSPIV_STAGE_THREADS, default 8 (float64 stacks are narrowed while staged and read
-// 2 x the PCIe rate from host memory: 4 threads 3.98 k pairs/s, 8 threads 4.49 k at 1080p), at most half the cores
-static int stage_threads() {
-  if (const char* e = getenv("LSPIV_STAGE_THREADS")) return std::max(1, atoi(e));
-  const unsigned hw = std::thread::hardware_concurrency();
-  return (int)std::max(1u, std::min(8u, hw ? hw / 2 : 4u));
-}
-
-// pageable -> pinned copy on a few host threads (one core moves ~10 GB/s, PCIe Gen5 x16 takes ~55)
-void staged_copy(void* dst, const void* src, size_t bytes) {
-  static const int nthreads = stage_threads();
-  if (nthreads <= 1 || bytes < ((size_t)4 << 20)) {
-    memcpy(dst, src, bytes);
-    return;
-  }
-  std::vector<std::thread> th;
-  const size_t part = ((bytes / nthreads) + 4095) & ~(size_t)4095;
-  for (int i = 1; i < nthreads; ++i) {
-    const size_t off = std::min(bytes, part * i), len = std::min(bytes, part * (i + 1)) - off;
-    if (len) th.emplace_back([=] { memcpy((char*)dst + off, (const char*)src + off, len); });
-  }
-  memcpy(dst, src, std::min(bytes, part));
-  for (auto& t : th) t.join();
-}
-
-// float64 frames (what pyorc's project_numpy hands over) are narrowed to float32 while they are staged:
-// the kernels convert every sample to float32 first thing anyway (same IEEE round-to-nearest conversion on both
-// sides, so the results are bit-identical), and the PCIe transfer -- the bound of the host entry points -- halves.
-void staged_narrow(float* dst, const double* src, size_t n) {
-  static const int nthreads = stage_threads();
-  auto work = [=](size_t a, size_t b) { for (size_t i = a; i < b; ++i) dst[i] = (float)src[i]; };
-  if (nthreads <= 1 || n < ((size_t)1 << 19)) { work(0, n); return; }
-  std::vector<std::thread> th;
-  const size_t part = ((n / nthreads) + 1023) & ~(size_t)1023;
-  for (int i = 1; i < nthreads; ++i) {
-    const size_t a = std::min(n, part * i), b = std::min(n, part * (i + 1));
-    if (b > a) th.emplace_back(work, a, b);
-  }
-  work(0, std::min(n, part));
-  for (auto& t : th) t.join();
-}
+// the staging copies run on persistent host threads (host_stage.cpp: LSPIV_STAGE_THREADS, AVX2 non-temporal stores); float64
+// frames (what pyorc's project_numpy hands over) are narrowed to float32 while they are staged: the kernels
+// convert every sample to float32 first thing anyway (same IEEE round-to-nearest conversion on both sides, so the results are
+// bit-identical), and the PCIe transfer -- the bound of the host entry points -- halves
+using lspiv_host::staged_copy;
+static void staged_narrow(float* dst, const double* src, size_t n) { lspiv_host::staged_narrow(dst, src, n, 1, nullptr); }
 
 // two pinned staging slots of >= one frame each (LSPIV_STAGE_BYTES per slot, default 32 MiB)
 int stage_ring(DeviceCtx* c, size_t frame_bytes) {
@@ -257,6 +223,17 @@ static int env_opt_def(const char* name, int lo, int hi, int def) {
   return v < lo || v > hi ? def : v;
 }
 std::atomic<int> g_opt_rescue{env_opt_def("LSPIV_RESCUE", 0, 1, 1)};
+// float64 host stacks: a frame whose DC offset (host_stage.h, frame_offset) reaches this magnitude has it taken off while it is
+// narrowed to float32 -- PIV entry points only (the per-window normalisation does not see it), and only without a signal threshold
+// (which counts samples != 0).  -1: never.
+std::atomic<int> g_opt_narrow_offset{env_opt_def("LSPIV_NARROW_OFFSET", -1, 1 << 30, 1024)};
+static std::vector<double> narrow_offsets(const double* frames, size_t frame_elems, int64_t n_frames, float signal_threshold) {
+  std::vector<double> off((size_t)n_frames, 0.0);
+  const int min_abs = g_opt_narrow_offset.load();
+  if (min_abs < 0 || signal_threshold >= 0.0f) return off;
+  for (int64_t f = 0; f < n_frames; ++f) off[(size_t)f] = lspiv_host::frame_offset(frames + (size_t)f * frame_elems, frame_elems, (double)min_abs);
+  return off;
+}
 std::atomic<int> g_opt_rescue_kappa{env_opt_def("LSPIV_RESCUE_KAPPA", 0, 1000000, 500)};
 std::atomic<int> g_opt_rescue_tau{env_opt_def("LSPIV_RESCUE_TAU", 0, 1000000, 4000)};
 
@@ -612,6 +589,11 @@ int lspiv_set_option(const char* name, int value) {
     g_opt_rescue.store(value);
     return LSPIV_OK;
   }
+  if (strcmp(name, "narrow_offset") == 0) {
+    if (value < -1) return fail(LSPIV_EINVAL, "narrow_offset must be -1 (never) or the smallest |DC offset| of a float64 frame that is removed while narrowing");
+    g_opt_narrow_offset.store(value);
+    return LSPIV_OK;
+  }
   if (strcmp(name, "rescue_kappa") == 0) {
     if (value < 0 || value > 1000000) return fail(LSPIV_EINVAL, "rescue_kappa must be 0 .. 1000000 (units of 1e-9)");
     g_opt_rescue_kappa.store(value);
@@ -634,6 +616,7 @@ int lspiv_get_option(const char* name, int* value) {
   if (strcmp(name, "norm_clip") == 0) { *value = g_opt_norm_clip.load(); return LSPIV_OK; }
   if (strcmp(name, "std_ddof") == 0) { *value = g_opt_std_ddof.load(); return LSPIV_OK; }
   if (strcmp(name, "round_odd") == 0) { *value = g_opt_round_odd.load(); return LSPIV_OK; }
+  if (strcmp(name, "narrow_offset") == 0) { *value = g_opt_narrow_offset.load(); return LSPIV_OK; }
   if (strcmp(name, "rescue") == 0) { *value = g_opt_rescue.load(); return LSPIV_OK; }
   if (strcmp(name, "rescue_kappa") == 0) { *value = g_opt_rescue_kappa.load(); return LSPIV_OK; }
   if (strcmp(name, "rescue_tau") == 0) { *value = g_opt_rescue_tau.load(); return LSPIV_OK; }
@@ -836,9 +819,11 @@ int lspiv_piv_pairs_at(const void* frames, int dtype, int64_t T, int64_t H, int6
     if (batch >= 2) HIP_TRY(hipEventSynchronize(c->staged[slot]));  // the slot's previous DMA has drained
     const size_t nb = (size_t)(f1 - f0) * frame_bytes;
     const void* dma_src = c->pinned[slot];
-    if (dtype == LSPIV_F64)
-      staged_narrow((float*)c->pinned[slot], (const double*)((const char*)frames + (size_t)f0 * src_frame_bytes), (size_t)(f1 - f0) * H * W);
-    else if (src_pinned)
+    if (dtype == LSPIV_F64) {
+      const double* src64 = (const double*)((const char*)frames + (size_t)f0 * src_frame_bytes);
+      const std::vector<double> off = narrow_offsets(src64, (size_t)H * W, f1 - f0, signal_threshold);
+      lspiv_host::staged_narrow((float*)c->pinned[slot], src64, (size_t)H * W, (size_t)(f1 - f0), off.data());
+    } else if (src_pinned)
       dma_src = (const char*)frames + (size_t)f0 * src_frame_bytes;   // caller's stack is pinned: no staging copy
     else
       staged_copy(c->pinned[slot], (const char*)frames + (size_t)f0 * src_frame_bytes, nb);
@@ -1056,10 +1041,13 @@ int lspiv_ensemble_accumulate(lspiv_ensemble* h, const void* frames, int dtype, 
       const int slot = batch & 1;
       if (batch >= 2) HIP_TRY(hipEventSynchronize(c->staged[slot]));
       const size_t nb = (size_t)(f1 - f0) * frame_bytes;
-      if (dtype == LSPIV_F64)
-        staged_narrow((float*)c->pinned[slot], (const double*)((const char*)frames + (size_t)f0 * src_frame_bytes), (size_t)(f1 - f0) * frame_elems);
-      else
+      if (dtype == LSPIV_F64) {
+        const double* src64 = (const double*)((const char*)frames + (size_t)f0 * src_frame_bytes);
+        const std::vector<double> off = narrow_offsets(src64, frame_elems, f1 - f0, signal_threshold);
+        lspiv_host::staged_narrow((float*)c->pinned[slot], src64, frame_elems, (size_t)(f1 - f0), off.data());
+      } else {
         staged_copy(c->pinned[slot], (const char*)frames + (size_t)f0 * src_frame_bytes, nb);
+      }
       HIP_TRY(hipMemcpyAsync(d_chunk + (size_t)f0 * frame_bytes, c->pinned[slot], nb, hipMemcpyHostToDevice, c->copy_stream));
       HIP_TRY(hipEventRecord(c->staged[slot], c->copy_stream));
       HIP_TRY(hipStreamWaitEvent(c->stream, c->staged[slot], 0));
@@ -2417,6 +2405,16 @@ int lspiv_synth_particles_dev(void* d_frames, int64_t T, int64_t H, int64_t W, u
   return LSPIV_OK;
 }
 
+int lspiv_debug_narrow(const double* frames, int64_t frame_elems, int64_t n_frames, int min_abs, float* out, double* offsets) {
+  // test hook, host only (no device needed): the float64 -> float32 staging conversion of the host entry points
+  if (!frames || !out || frame_elems < 0 || n_frames < 0) return fail(LSPIV_EINVAL, "bad argument");
+  std::vector<double> off((size_t)n_frames, 0.0);
+  if (min_abs >= 0)
+    for (int64_t f = 0; f < n_frames; ++f) off[(size_t)f] = lspiv_host::frame_offset(frames + (size_t)f * frame_elems, (size_t)frame_elems, (double)min_abs);
+  lspiv_host::staged_narrow(out, frames, (size_t)frame_elems, (size_t)n_frames, off.data());
+  if (offsets) memcpy(offsets, off.data(), off.size() * sizeof(double));
+  return lspiv_host::stage_threads();
+}
 int lspiv_debug_segments(int64_t n_pairs, int64_t pair_offset, int seg_len, int64_t* seg_first, int64_t* n_seg) {
   if (n_pairs < 1 || n_pairs > 0x7fffffff || pair_offset < 0 || seg_len < 1 || !seg_first || !n_seg) return LSPIV_EINVAL;
   const lspiv::WalkSegments w = lspiv::walk_segments((uint32_t)n_pairs, pair_offset, (uint32_t)seg_len);

@@ -1109,3 +1109,28 @@ def test_two_host_threads_on_one_stream(gpu):
     for t in th:
         t.join()
     assert not errors, errors
+
+
+def test_float64_stack_on_a_large_dc_offset(gpu):
+    """a float64 host stack whose texture (sigma ~ 1) rides on a DC offset of 1e4.  The reference normalises
+    every window in float64; narrowing the frames to float32 as they are would keep the texture to 1e-3 only.  The staging threads
+    take an integer estimate of each frame's offset off first (option "narrow_offset", csrc/host_stage.cpp) -- the per-window
+    normalisation does not see it --, and the 1e-4 gate holds on every window, per time step and in ensemble mode."""
+    import pyorc_amd
+    from pyorc_amd import _lib, frames as F
+
+    fr = particle_stack(5, 128, 160, seed=9, density=0.03).astype(np.float64) / 60.0 + 1.0e4
+    ws, ov = (32, 32), (16, 16)
+    check_against_oracle(fr, ws, ov, plane_tol=4e-6)
+    got = F.get_piv(fr, 32, ensemble_corr=True, corr_min=0.1, s2n_min=1.5, count_min=0.0)
+    ref = po.get_ffpiv(fr, np.ones(4), ws, ov, 1.0, 1.0, ensemble_corr=True, corr_min=0.1, s2n_min=1.5, count_min=0.0)
+    assert np.array_equal(np.isnan(got["v_x"]), np.isnan(ref["v_x"]))
+    assert rel_err(got["v_x"], ref["v_x"].astype(np.float64)) <= TOL and rel_err(got["v_y"], ref["v_y"].astype(np.float64)) <= TOL
+    uo, vo, cmo, sno = c_oracle.piv_pairs(fr, ws, ov)
+    _lib.set_option("narrow_offset", -1)                      # the plain conversion: what the option is for
+    try:
+        u, v, cm, sn = pyorc_amd.piv_pairs(fr, ws, ov)
+    finally:
+        _lib.set_option("narrow_offset", 1024)
+    assert max(rel_err(u, uo.astype(np.float64)), rel_err(cm, cmo.astype(np.float64))) > TOL
+    assert _lib.get_option("narrow_offset") == 1024

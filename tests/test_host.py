@@ -373,7 +373,8 @@ def test_every_environment_switch_is_documented():
     import re
 
     names = set()
-    for f in glob.glob(os.path.join(ROOT, "pyorc_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "pyorc_amd", "*.py")) + \
+    for f in glob.glob(os.path.join(ROOT, "pyorc_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "pyorc_amd", "csrc", "*.cpp")) + \
+            glob.glob(os.path.join(ROOT, "pyorc_amd", "*.py")) + \
             [os.path.join(ROOT, "bench.py")]:
         names |= set(re.findall(r'(?:getenv\(|environ\.get\(|environ\[|setdefault\()"(LSPIV_[A-Z0-9_]+)"', open(f).read()))
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
@@ -526,3 +527,40 @@ def test_bench_multi_gpu_contract_on_cpu(monkeypatch):
     # the plan's cut: weak = blocks of --pairs, strong = the walking kernels' anchors
     assert shard.block_sizes(8000, 8, 25) == [1000] * 8 and shard.block_sizes(120, 2, 60) == [60, 60]
     assert shard.block_sizes(150, 2, 25) == [75, 75]
+
+
+def test_float64_staging_conversion_and_offset_rule(lib):
+    """Host side of VERDICT r03 item 8 (csrc/host_stage.cpp, no GPU needed): the staging threads narrow float64 frames exactly like
+    numpy's astype(float32) (IEEE round to nearest; AVX2 path, ragged sizes, several frames per batch); a frame riding on a large DC
+    offset has an integer estimate of it removed first -- a function of the frame alone --, small offsets are left alone, so 8-bit-like
+    stacks stay bit-identical to their float32 copies."""
+    import time
+
+    rng = np.random.default_rng(8)
+    for n_frames, elems in ((1, 7), (3, 1025), (2, 640 * 480 + 13), (5, 1 << 20)):
+        fr = rng.normal(30.0, 60.0, (n_frames, elems)) * (1.0 + 1e-9)
+        out = np.empty((n_frames, elems), np.float32)
+        off = np.empty(n_frames, np.float64)
+        nt = lib.lspiv_debug_narrow(_lib.ptr(fr), elems, n_frames, 1024, _lib.ptr(out), _lib.ptr(off))
+        assert nt >= 1 and np.all(off == 0.0) and np.array_equal(out, fr.astype(np.float32))
+    fr = rng.normal(0.0, 1.0, (4, 300 * 200)) + np.array([1.0e4, -7.3e5, 900.0, 2.0e9])[:, None]
+    out = np.empty(fr.shape, np.float32)
+    off = np.empty(4, np.float64)
+    lib.lspiv_debug_narrow(_lib.ptr(fr), fr.shape[1], 4, 1024, _lib.ptr(out), _lib.ptr(off))
+    assert off[2] == 0.0 and np.all(off[[0, 1, 3]] == np.rint(off[[0, 1, 3]])) and np.all(np.abs(off[[0, 1, 3]] - fr[[0, 1, 3]].mean(axis=1)) < 1.0)
+    assert np.array_equal(out, (fr - off[:, None]).astype(np.float32))
+    # what the rule is for: the texture survives the conversion (plain narrowing maps all of 2e9 + noise onto 2e9)
+    assert np.abs(out[3].astype(np.float64) - (fr[3] - off[3])).max() < 1e-6 and np.abs(fr[3].astype(np.float32).astype(np.float64) - fr[3]).max() > 1.0
+    again = np.empty_like(out)
+    lib.lspiv_debug_narrow(_lib.ptr(fr[:2]), fr.shape[1], 2, 1024, _lib.ptr(again[:2]), None)     # a frame's offset does not depend on its chunk
+    assert np.array_equal(again[:2], out[:2])
+    lib.lspiv_debug_narrow(_lib.ptr(fr), fr.shape[1], 4, -1, _lib.ptr(again), _lib.ptr(off))       # switched off
+    assert np.all(off == 0.0) and np.array_equal(again, fr.astype(np.float32))
+    big = rng.random((8, 1080 * 1920))
+    dst = np.empty(big.shape, np.float32)
+    lib.lspiv_debug_narrow(_lib.ptr(big), big.shape[1], 8, 1024, _lib.ptr(dst), None)
+    t0 = time.perf_counter()
+    lib.lspiv_debug_narrow(_lib.ptr(big), big.shape[1], 8, 1024, _lib.ptr(dst), None)
+    dt = time.perf_counter() - t0
+    assert np.array_equal(dst, big.astype(np.float32))
+    print(f"narrowing 8 x 1080p float64 frames: {big.nbytes / dt / 1e9:.1f} GB/s read on {nt} threads")
