@@ -186,6 +186,46 @@ def other_config(lib, name: str, d_frames, pairs: int, H: int, W: int, ws: int, 
     }
 
 
+def ensemble_config(lib, name: str, d_frames, pairs: int, H: int, W: int, ws: int, ov: int, reps: int = 3) -> dict:
+    """Ensemble-correlation mode (pyorc/velocimetry/ffpiv.py:182-376) on the HBM-resident stack: every pair's
+    masked correlation plane is added to the running sum (walking ensemble kernel + the ordered merge of its per-segment partial
+    sums), then one finish (mean planes, peak fit, float64 rescue of the flagged fits).  Launch time by HIP events."""
+    from pyorc_amd import piv
+
+    ens = piv.Ensemble((H, W), (ws, ws), (ov, ov))
+    n_win = ens.n_rows * ens.n_cols
+    d_cs = C.c_void_p()
+    _lib.check(lib.lspiv_dev_malloc(C.byref(d_cs), 8 * pairs * n_win))
+
+    def go():
+        ens.accumulate_dev(d_frames.value, np.uint8, pairs + 1, 0.2, 3.0, d_cs.value)
+
+    go()
+    go()
+    _lib.check(lib.lspiv_synchronize())
+    ms = time_launches(lib, go, reps)
+    t0 = time.perf_counter()
+    u, v, cnt = ens.finish(0.2, 1)
+    fin_ms = (time.perf_counter() - t0) * 1e3
+    st = ens.stats()
+    ens.close()
+    _lib.check(lib.lspiv_dev_free(d_cs))
+    b_alg_pair = 2 * H * W + 8 * n_win           # both frames read once + masked corr_max, s2n per window (the plane sum stays in HBM)
+    achieved = b_alg_pair * pairs / (ms * 1e-3) / 1e9
+    kernel = f"piv_fft_walk_ensemble_kernel<unsigned char, {ws}, false>"
+    tr = measured_traffic(kernel, pairs, H, W, ws, ov)
+    return {
+        "workload": name, "pairs_per_s": round(pairs / (ms * 1e-3), 1), "launch_ms": round(ms, 4), "windows_per_pair": n_win,
+        "kernel": kernel + " + ensemble_merge_kernel", "finish_ms": round(fin_ms, 2), "finite_vectors": round(float(np.isfinite(u).mean()), 4),
+        "final_fit_rescue": {k: st[k] for k in ("flagged", "rescued", "float32_kept")},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                     "algorithmic_bytes_per_pair": b_alg_pair, "traffic": tr["bytes"] if tr else None,
+                     **({"traffic_source": f"profiles/{tr['source']}"} if tr else {}),
+                     "secondary": {"bound": "fp32-valu", "achieved_tflops": round(flop_per_pair(ws, n_win) * pairs / (ms * 1e-3) / 1e12, 2),
+                                   "peak_tflops": FP32_VALU_TFLOPS}},
+    }
+
+
 def host_fed_rates(lib, sample_u8: np.ndarray, ws, ov) -> dict:
     """PCIe-inclusive rates of lspiv_piv_pairs (frames in pageable host memory -> results in host memory) for the three
     frame dtypes pyorc hands over; never `value`."""
@@ -540,6 +580,8 @@ def main():
     if world == 1 and is_c2 and not a.no_extras:
         others = [other_config(lib, "BASELINE.json configs[2]: 1080p, 64x64 windows @ 75 % overlap, same stack",
                                d_frames, a.pairs, H, W, 64, 48)]
+        ensembles = [ensemble_config(lib, "ensemble correlation (ensemble_corr=True), 1080p, 32x32 @ 50 %, same stack", d_frames, a.pairs, H, W, 32, 16),
+                     ensemble_config(lib, "ensemble correlation (ensemble_corr=True), 1080p, 64x64 @ 75 %, same stack", d_frames, a.pairs, H, W, 64, 48)]
         sample = np.empty((min(a.pairs, 200) + 1, H, W), dtype=np.uint8)
         _lib.check(lib.lspiv_memcpy_d2h(_lib.ptr(sample), d_frames, sample.nbytes))
         frames = d_frames = None                      # the 1080p stack goes back (DeviceFrames' caching allocator) ...
@@ -552,7 +594,7 @@ def main():
         others.append(other_config(lib, "BASELINE.json configs[3]: 4K (2160x3840), 32x32 windows @ 50 % overlap",
                                    d4, a.pairs, H4, W4, 32, 16))
         _lib.check(lib.lspiv_dev_free(d4))
-        out["config"]["other_configs"] = others
+        out["config"]["other_configs"] = others + ensembles
         out["config"]["host_fed_pairs_per_s"] = {
             **host_fed_rates(lib, sample, ws, ov),
             "note": f"lspiv_piv_pairs on {sample.shape[0] - 1} pairs in pageable host memory, PCIe-inclusive; never `value`"}

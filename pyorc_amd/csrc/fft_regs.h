@@ -211,6 +211,9 @@ __device__ __forceinline__ void fft64_col(const float (&xr)[64], const float (&x
 #ifndef LSPIV_FFT64_SB
 #define LSPIV_FFT64_SB 1
 #endif
+#ifndef LSPIV_FFT64_PRIO
+#define LSPIV_FFT64_PRIO 0
+#endif
 #define LSPIV_FFT64_BAR do { if (LSPIV_FFT64_SB) __builtin_amdgcn_sched_barrier(0); } while (0)
 template <bool INV, bool CLAMP = false>
 __device__ __forceinline__ void fft64(float (&xr)[64], float (&xi)[64]) {
@@ -225,6 +228,9 @@ __device__ __forceinline__ void fft64(float (&xr)[64], float (&xi)[64]) {
     if (LSPIV_FFT64_SB) __builtin_amdgcn_sched_barrier(0);
   }
   float yr[64], yi[64];
+#if LSPIV_FFT64_PRIO
+  __builtin_amdgcn_s_setprio(1);   // A/B variant: the second radix stage ahead of a neighbour's first
+#endif
   fft64_col<INV, 0, CLAMP>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
   fft64_col<INV, 1, CLAMP>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
   fft64_col<INV, 2, CLAMP>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
@@ -233,6 +239,9 @@ __device__ __forceinline__ void fft64(float (&xr)[64], float (&xi)[64]) {
   fft64_col<INV, 5, CLAMP>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
   fft64_col<INV, 6, CLAMP>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
   fft64_col<INV, 7, CLAMP>(xr, xi, yr, yi); LSPIV_FFT64_BAR;
+#if LSPIV_FFT64_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
   for (int k = 0; k < 64; ++k) { xr[k] = yr[k]; xi[k] = yi[k]; }
 }

@@ -25,24 +25,32 @@ template <bool LANE_MAJOR>
 __global__ __launch_bounds__(256) void ensemble_merge_kernel(const float* __restrict__ part_sum, const float* __restrict__ part_cnt,
                                                              uint32_t n_seg, int64_t n_elems, uint32_t n_win, int n,
                                                              float* __restrict__ corr_sum, float* __restrict__ corr_count) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // four consecutive elements per thread (the planes of the even window sizes hold a multiple of four samples): 16-byte loads of
+  // every segment's slot
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i < n_elems) {
-    int64_t o = i;
+    typedef float f4 __attribute__((ext_vector_type(4)));
     if (LANE_MAJOR) {
-      const int nn = n * n;
+      // slot element e = q * 4 n + y * 4 + (x % 4), x = 4 q + (e % 4): the four elements of a thread are columns x .. x + 3 of row y
+      const int nn = n * n, h = n / 2;
       const int64_t win = i / nn;
-      const int e = (int)(i - win * nn), q = e / (4 * n), r = e - q * 4 * n, y = r >> 2, x = 4 * q + (r & 3), h = n / 2;   // slot[(x / 4) * 4 n + y * 4 + x % 4]
-      const int ip = y + h >= n ? y + h - n : y + h, jp = x + h >= n ? x + h - n : x + h;
-      o = win * nn + ip * n + jp;
+      const int e = (int)(i - win * nn), q = e / (4 * n), y = (e - q * 4 * n) >> 2, x = 4 * q;
+      const int ip = y + h >= n ? y + h - n : y + h, jp = x + h >= n ? x + h - n : x + h;   // (x + 3 stays in the same half: h is a multiple of 4)
+      float* dst = corr_sum + win * nn + ip * n + jp;
+      f4 acc = *reinterpret_cast<const f4*>(dst);
+      for (uint32_t sg = 0; sg < n_seg; ++sg) acc += *reinterpret_cast<const f4*>(part_sum + (int64_t)sg * n_elems + i);
+      *reinterpret_cast<f4*>(dst) = acc;
+    } else {
+      f4 acc = *reinterpret_cast<const f4*>(corr_sum + i);
+      for (uint32_t sg = 0; sg < n_seg; ++sg) acc += *reinterpret_cast<const f4*>(part_sum + (int64_t)sg * n_elems + i);
+      *reinterpret_cast<f4*>(corr_sum + i) = acc;
     }
-    float acc = corr_sum[o];
-    for (uint32_t sg = 0; sg < n_seg; ++sg) acc += part_sum[(int64_t)sg * n_elems + i];
-    corr_sum[o] = acc;
   }
-  if (i < n_win) {
-    float c = corr_count[i];
-    for (uint32_t sg = 0; sg < n_seg; ++sg) c += part_cnt[(int64_t)sg * n_win + i];
-    corr_count[i] = c;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < n_win) {
+    float c = corr_count[t];
+    for (uint32_t sg = 0; sg < n_seg; ++sg) c += part_cnt[(int64_t)sg * n_win + t];
+    corr_count[t] = c;
   }
 }
 
@@ -50,7 +58,8 @@ hipError_t launch_ensemble_merge(const float* part_sum, const float* part_cnt, u
                                  float* corr_sum, float* corr_count, hipStream_t s, int lane_major_n) {
   const int64_t n_elems = (int64_t)n_win * plane_elems;
   if (n_elems == 0) return hipSuccess;
-  const dim3 grid((unsigned)((n_elems + 255) / 256));
+  if (plane_elems % 4 != 0) return hipErrorInvalidValue;   // (walking kernels: even window sizes only)
+  const dim3 grid((unsigned)std::max<int64_t>((n_elems / 4 + 255) / 256, ((int64_t)n_win + 255) / 256));
   if (lane_major_n)
     hipLaunchKernelGGL(ensemble_merge_kernel<true>, grid, dim3(256), 0, s, part_sum, part_cnt, n_seg, n_elems, n_win, lane_major_n, corr_sum, corr_count);
   else
