@@ -193,6 +193,7 @@ def ensemble_config(lib, name: str, d_frames, pairs: int, H: int, W: int, ws: in
     from pyorc_amd import piv
 
     ens = piv.Ensemble((H, W), (ws, ws), (ov, ov))
+    ens.set_retain(piv.Ensemble.RETAIN_BORROW)   # the stack stays in HBM until finish: the final fit can go back to the frames
     n_win = ens.n_rows * ens.n_cols
     d_cs = C.c_void_p()
     _lib.check(lib.lspiv_dev_malloc(C.byref(d_cs), 8 * pairs * n_win))

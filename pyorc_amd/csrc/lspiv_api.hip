@@ -1102,7 +1102,11 @@ static int ensemble_flag(lspiv_ensemble* h, DeviceCtx* c) {
   if (rc) return rc;
   lspiv::EnsRescueHdr* d_hdr = static_cast<lspiv::EnsRescueHdr*>(h->d_rescue);
   HIP_TRY(hipMemsetAsync(d_hdr, 0, hdr_bytes, c->stream));
-  const float k = (float)(2.0 * g_opt_rescue_kappa.load() * 1e-9 / (0.6931471805599453 * 1e-4));
+  // flag model of the per-pair epilogues (fill_params); the block-per-window kernels (kinds 3 / 9 / 10) assume twice the plane noise
+  // of the fused FFT kernels there, and so does the mean of their planes here
+  const int kind = lspiv_kernel_kind(h->wy, h->wx);
+  const double noise_mult = (kind == 3 || kind == 9 || kind == 10) ? 2.0 : 1.0;
+  const float k = (float)(noise_mult * 2.0 * g_opt_rescue_kappa.load() * 1e-9 / (0.6931471805599453 * 1e-4));
   hipError_t e = lspiv::launch_ens_flag(c->d_planes, n_win, h->wy, h->wx, c->d_out, c->d_out + n_win, k, (float)(g_opt_rescue_tau.load() * 1e-9),
                                         d_hdr, ensemble_recs(h), n_win, c->stream);
   if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));

@@ -420,8 +420,9 @@ __global__ __launch_bounds__(RBLOCK) void piv_rescue_amb_kernel(PivParams p) {
 
 // ======== ensemble mode: the final fit of the MEAN plane (lspiv_ensemble_finish) =========================================
 // (i) flag: one wave per window on the float32 mean plane.  Candidates of the arg-max = samples within tau of the maximum; the
-// fit's conditioning by the same model as the per-pair epilogues (peak_cond) with twice the noise allowance (a mean of float32
-// planes summed in float32).  A NaN plane (count filter) or an all-zero one is NaN by construction and never listed.
+// fit's conditioning by the same model and noise allowance as the per-pair epilogues (peak_cond: the mean of float32 planes
+// summed in float32 carries no more noise relative to its maximum than one plane, 1.5e-7 median / 3.8e-7 worst over ensembles
+// of 2 ... 400 pairs, tools/ens_diag.py).  A NaN plane (count filter) or an all-zero one is NaN by construction, never listed.
 __device__ __forceinline__ void wave_argmax_first(float& v, int& idx) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(RBLOCK) void ens_flag_kernel(const float* mean, uin
     gauss_offset_fast(__builtin_amdgcn_logf(cl), l0, __builtin_amdgcn_logf(cr), den_v);
     gauss_offset_fast(__builtin_amdgcn_logf(cd), l0, __builtin_amdgcn_logf(cu), den_u);
     // the results the fit was flagged for are relative to the plane centre, like the per-pair epilogues'
-    fit = peak_cond(best, false, false, cl, cr, den_v, v[w], cd, cu, den_u, u[w], 2.0f * k).fit;
+    fit = peak_cond(best, false, false, cl, cr, den_v, v[w], cd, cu, den_u, u[w], k).fit;
   }
   if (cnt < 2 && !fit) return;
   EnsRescueRec r;
@@ -542,6 +543,98 @@ __global__ __launch_bounds__(RBLOCK) void ens_partial_kernel(PivParams p, EnsRes
         acc[c][0] += l.c0; acc[c][1] += l.cu; acc[c][2] += l.cd; acc[c][3] += l.cl; acc[c][4] += l.cr;
       }
       __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) {
+      double* dst = a.partial + ((size_t)ri * a.n_blk + a.blk0 + blk) * (kEnsMaxCand * 5);
+#pragma unroll
+      for (int c = 0; c < kEnsMaxCand; ++c)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) dst[c * 5 + q] = acc[c][q];
+    }
+  }
+}
+
+// (ii-b) the same for windows whose width is a power of two up to 64 (all the FFT-kernel sizes pyorc uses: 8, 16, 32, 64): a lane owns
+// ONE column x = lane mod WX and walks the rows y = lane / WX, + 64 / WX, ... -- the column wraps of a lag are lane constants, the
+// row wraps one AND per sample --, and the two windows are normalised ONCE per pair into the wave's LDS slice as float32 (b' always,
+// a' when both fit: up to 32 x 32 x 2 samples) instead of once per lag: per sample and candidate 6 LDS reads, 6 conversions and 5
+// float64 multiply-adds where the generic path spends ~100 instructions on index arithmetic and normalisation.  Rounding the
+// NORMALISED samples to float32 costs 6e-8 relative per product, random in sign -- below 1e-8 of every sum, small samples
+// included (it is the float32 FFT's ABSOLUTE noise of 4e-7 of the plane maximum on small samples that the rescue is about).
+// The rescue of a C2-shaped ensemble (395 flagged windows x 2000 pairs) took 4.8 ms with the generic kernel: a third of the
+// accumulation itself.
+constexpr int ENS_LDS_PER_WAVE = 16384;
+template <typename T, int WX>
+__global__ __launch_bounds__(RBLOCK) void ens_partial_pow2_kernel(PivParams p, EnsRescueArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wy = p.wy, n = wy * WX;
+  constexpr int RSTEP = 64 / WX;                       // rows between two samples of a lane
+  const int x = lane & (WX - 1), y_first = lane / WX;
+  const int steps = (wy - y_first + RSTEP - 1) / RSTEP;   // samples of this lane (wy need not be a multiple of RSTEP)
+  const bool a_staged = (size_t)2 * n * sizeof(float) <= (size_t)ENS_LDS_PER_WAVE;
+  float* lb = reinterpret_cast<float*>(fsm + (size_t)wave * ENS_LDS_PER_WAVE);
+  float* la = lb + n;
+  const uint32_t chunk_blks = (a.n_pairs + kEnsPairBlock - 1) / kEnsPairBlock;
+  const uint32_t items = a.n_rec * chunk_blks, n_waves = gridDim.x * (RBLOCK / 64);
+  const double inv_n = 1.0 / (double)n;
+  for (uint32_t it = blockIdx.x * (RBLOCK / 64) + (uint32_t)wave; it < items; it += n_waves) {
+    const uint32_t ri = it / chunk_blks, blk = it - ri * chunk_blks;
+    const EnsRescueRec rec = a.recs[ri];
+    double acc[kEnsMaxCand][5];
+#pragma unroll
+    for (int c = 0; c < kEnsMaxCand; ++c)
+#pragma unroll
+      for (int q = 0; q < 5; ++q) acc[c][q] = 0.0;
+    const uint32_t pa = blk * kEnsPairBlock, pb = min(pa + (uint32_t)kEnsPairBlock, a.n_pairs);
+    for (uint32_t pair = pa; pair < pb && rec.ncand != 0; ++pair) {
+      if (!(a.cmax[(size_t)pair * p.n_win + rec.w] > 0.0f)) continue;   // not in the sum (uniform over the wave)
+      const T* A = window_base<T>(p, pair * p.n_win + rec.w) + x;
+      const T* B = A + p.frame_elems;
+      // statistics: shifted one-pass sums in float64 (window_stats_wave2's arithmetic on this lane -> sample map)
+      const double x0a = (double)window_base<T>(p, pair * p.n_win + rec.w)[0], x0b = (double)(window_base<T>(p, pair * p.n_win + rec.w) + p.frame_elems)[0];
+      double sa = 0.0, sb = 0.0, qa = 0.0, qb = 0.0;
+      for (int j = 0, y = y_first; j < steps; ++j, y += RSTEP) {
+        const double da = (double)A[(int64_t)y * p.W] - x0a, db = (double)B[(int64_t)y * p.W] - x0b;
+        sa += da; qa = fma(da, da, qa);
+        sb += db; qb = fma(db, db, qb);
+      }
+      sa = wave_sum_d(sa); sb = wave_sum_d(sb); qa = wave_sum_d(qa); qb = wave_sum_d(qb);
+      const double va = (qa - sa * sa * inv_n) * inv_n, vb = (qb - sb * sb * inv_n) * inv_n;
+      if (!(va > 0.0) || !(vb > 0.0)) continue;   // (a zero-variance window has corr_max 0 and is never kept)
+      const double mean_a = x0a + sa * inv_n, mean_b = x0b + sb * inv_n;
+      const double sg = p.norm_clip ? (double)p.std_gain : -(double)p.std_gain;
+      const double inv_a = sg / sqrt(va), inv_b = sg / sqrt(vb);
+      __builtin_amdgcn_wave_barrier();   // the previous pair's reads of the slice are done (same wave: program order)
+      for (int j = 0, y = y_first; j < steps; ++j, y += RSTEP) {   // second pass over the (L1-hot) samples: normalise, clip, park
+        lb[y * WX + x] = (float)norm_clip((double)B[(int64_t)y * p.W], mean_b, inv_b);
+        if (a_staged) la[y * WX + x] = (float)norm_clip((double)A[(int64_t)y * p.W], mean_a, inv_a);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int c = 0; c < kEnsMaxCand; ++c) {
+        if (c >= (int)rec.ncand) break;
+        const int ip = (int)(rec.pos[c] >> 16), jp = (int)(rec.pos[c] & 0xffffu);
+        const int ky0 = unshift(ip, wy / 2, wy), kx0 = unshift(jp, WX / 2, WX);
+        const int x0 = (x + kx0) & (WX - 1), xm = (x0 + WX - 1) & (WX - 1), xp = (x0 + 1) & (WX - 1);   // lane constants
+        double c0 = 0.0, cu = 0.0, cd = 0.0, cl = 0.0, cr = 0.0;
+        int yb = y_first + ky0;                      // row of b' under this lane's row of a' at the centre lag, kept in [0, wy)
+        yb = yb >= wy ? yb - wy : yb;
+        for (int j = 0, y = y_first; j < steps; ++j, y += RSTEP) {
+          const double av = a_staged ? (double)la[y * WX + x] : norm_clip((double)A[(int64_t)y * p.W], mean_a, inv_a);
+          const int ym = yb == 0 ? wy - 1 : yb - 1, yp = yb == wy - 1 ? 0 : yb + 1;
+          const float* row = lb + yb * WX;
+          c0 = fma(av, (double)row[x0], c0);
+          cl = fma(av, (double)row[xm], cl);
+          cr = fma(av, (double)row[xp], cr);
+          cu = fma(av, (double)lb[ym * WX + x0], cu);
+          cd = fma(av, (double)lb[yp * WX + x0], cd);
+          yb += RSTEP; yb = yb >= wy ? yb - wy : yb;
+        }
+        auto clip01 = [](double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); };
+        acc[c][0] += clip01(wave_sum_d(c0) * inv_n); acc[c][1] += clip01(wave_sum_d(cu) * inv_n); acc[c][2] += clip01(wave_sum_d(cd) * inv_n);
+        acc[c][3] += clip01(wave_sum_d(cl) * inv_n); acc[c][4] += clip01(wave_sum_d(cr) * inv_n);
+      }
     }
     if (lane == 0) {
       double* dst = a.partial + ((size_t)ri * a.n_blk + a.blk0 + blk) * (kEnsMaxCand * 5);
@@ -620,18 +713,28 @@ hipError_t launch_ens_flag(const float* mean, uint32_t n_win, int wy, int wx, co
   return hipGetLastError();
 }
 
+template <typename T>
+static void launch_ens_partial_t(const PivParams& p, const EnsRescueArgs& a, uint32_t blocks, hipStream_t s) {
+  const int n = p.wy * p.wx;
+  const bool pow2 = (size_t)n * sizeof(float) <= (size_t)ENS_LDS_PER_WAVE && p.wy >= 64 / std::max(p.wx, 1);   // b' fits the slice; every lane has a sample
+  const size_t fast_lds = (size_t)(RBLOCK / 64) * ENS_LDS_PER_WAVE;
+  if (pow2 && p.wx == 64) { hipLaunchKernelGGL((ens_partial_pow2_kernel<T, 64>), dim3(blocks), dim3(RBLOCK), fast_lds, s, p, a); return; }
+  if (pow2 && p.wx == 32) { hipLaunchKernelGGL((ens_partial_pow2_kernel<T, 32>), dim3(blocks), dim3(RBLOCK), fast_lds, s, p, a); return; }
+  if (pow2 && p.wx == 16) { hipLaunchKernelGGL((ens_partial_pow2_kernel<T, 16>), dim3(blocks), dim3(RBLOCK), fast_lds, s, p, a); return; }
+  if (pow2 && p.wx == 8) { hipLaunchKernelGGL((ens_partial_pow2_kernel<T, 8>), dim3(blocks), dim3(RBLOCK), fast_lds, s, p, a); return; }
+  const size_t lds = (size_t)2 * n * sizeof(T) <= (size_t)FIT_LDS_PER_WAVE ? (size_t)(RBLOCK / 64) * FIT_LDS_PER_WAVE : 0;
+  hipLaunchKernelGGL(ens_partial_kernel<T>, dim3(blocks), dim3(RBLOCK), lds, s, p, a);
+}
+
 hipError_t launch_ens_partial(const PivParams& p, int dtype, const EnsRescueArgs& a, hipStream_t s) {
   const uint32_t chunk_blks = (a.n_pairs + kEnsPairBlock - 1) / kEnsPairBlock;
   const uint64_t items = (uint64_t)a.n_rec * chunk_blks;
   if (items == 0) return hipSuccess;
   const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + RBLOCK / 64 - 1) / (RBLOCK / 64), 65536);
-  const int n = p.wy * p.wx;
-  const size_t es = dtype == 0 ? 1 : dtype == 1 ? 4 : 8;
-  const size_t lds = (size_t)2 * n * es <= (size_t)FIT_LDS_PER_WAVE ? (size_t)(RBLOCK / 64) * FIT_LDS_PER_WAVE : 0;
   switch (dtype) {
-    case 0: hipLaunchKernelGGL(ens_partial_kernel<uint8_t>, dim3(blocks), dim3(RBLOCK), lds, s, p, a); break;
-    case 1: hipLaunchKernelGGL(ens_partial_kernel<float>, dim3(blocks), dim3(RBLOCK), lds, s, p, a); break;
-    case 2: hipLaunchKernelGGL(ens_partial_kernel<double>, dim3(blocks), dim3(RBLOCK), lds, s, p, a); break;
+    case 0: launch_ens_partial_t<uint8_t>(p, a, blocks, s); break;
+    case 1: launch_ens_partial_t<float>(p, a, blocks, s); break;
+    case 2: launch_ens_partial_t<double>(p, a, blocks, s); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -60,18 +60,26 @@ for case in range(n_cases):
         got = F.get_piv(fr, ws, time=t, resolution=0.02, ensemble_corr=True, chunksize=cs, signal_threshold=thr, **kw)
         ref = po.get_ffpiv(fr, np.diff(t), (ws_e, ws_e), (ov_e, ov_e), 0.02, 0.02, ensemble_corr=True, chunksize=cs,
                            signal_threshold=thr, **kw)
-        nanbad = sum(int((np.isnan(got[k]) != np.isnan(ref[k])).sum()) for k in ("v_x", "v_y", "corr", "s2n"))
+        # windows whose float64 MEAN plane has an exact tie for the maximum (a flat plane over a constant patch: dozens of equal
+        # samples) are set aside for v_x, v_y, like the exact ties of the per-timestep gate (oracle.c_oracle.exact_tie): which of
+        # the tied samples np.argmax returns -- and with it NaN-on-the-border or not -- is the oracle's own FFT rounding
+        cmean = np.asarray(ref["corr_mean"], dtype=np.float64).reshape(-1, ws_e * ws_e)
+        with np.errstate(all="ignore"):
+            top2 = np.sort(np.nan_to_num(cmean, nan=-1.0), axis=1)[:, -2:]
+            tie = ((top2[:, 1] > 0) & (top2[:, 0] >= top2[:, 1] * (1.0 - 1e-9))).reshape(ref["v_x"].shape[1:])
+        nanbad = sum(int((np.isnan(got[k]) != np.isnan(ref[k])).sum()) for k in ("corr", "s2n")) + \
+            sum(int((np.isnan(got[k][0]) != np.isnan(ref[k][0]))[~tie].sum()) for k in ("v_x", "v_y"))
         e = max(rel(got["corr"], ref["corr"]), rel(got["s2n"], ref["s2n"]))
         dtm = float(np.diff(t).mean())
         # the peak fit of a MEAN plane has no conditioning estimate from the numpy oracle: the bulk must meet the gate; a window
         # on the edge of a constant patch (neighbours of the peak near zero) may exceed it, by little (seed 3 case 130: 8e-5 px)
         with np.errstate(all="ignore"):
-            ee = np.concatenate([(np.abs(got[k].astype(np.float64) - ref[k]) / np.maximum(np.abs(ref[k]), 0.05 * 0.02 / dtm)).ravel()
+            ee = np.concatenate([(np.abs(got[k].astype(np.float64) - ref[k]) / np.maximum(np.abs(ref[k]), 0.05 * 0.02 / dtm))[0][~tie].ravel()
                                  for k in ("v_x", "v_y")])
         ee = ee[np.isfinite(ee)]
         over, ev = (int((ee > 1e-4).sum()), float(ee.max())) if ee.size else (0, 0.0)
         fail = nanbad > 0 or e > 1e-4 or over > 0
-        note = f"nan {nanbad} corr/s2n {e:.1e} v: {over} of {ee.size} above 1e-4, max {ev:.1e} {kw}"
+        note = f"nan {nanbad} corr/s2n {e:.1e} v: {over} of {ee.size} above 1e-4, max {ev:.1e}, {int(tie.sum())} exact ties set aside {kw}"
     else:
         Tp = min(T, 5)
         u, v, cm, sn, planes = pyorc_amd.piv_pairs(fr[:Tp], (ws_e, ws_e), (ov_e, ov_e), thr, return_planes=True)
