@@ -1124,22 +1124,31 @@ __device__ __forceinline__ GlobalF32 uniform_global_ptr(const float* p) {   // v
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
   return (GlobalF32)(((uint64_t)hi << 32) | lo);
 }
+// Addressing of the slot: SGPR base + the lane's 32-bit byte offset + an immediate (written out: left to the compiler the 16
+// store addresses and 4 prefetch bases become loop-invariant VGPR pairs that are spilled and re-loaded every iteration -- 30 of
+// the kernel's 43 scratch loads per iteration, ~40 GB of the 109 GB it fetched per 1000 pairs, profiles/r04_ens64).
 template <int N>
 __device__ __forceinline__ void slot_prefetch_lds(GlobalF32 slot, float* buf) {   // slot: wave-uniform (uniform_global_ptr)
   static_assert(N == 64 && Geo<N>::GROUPS == 1 && Geo<N>::LDS_JOB >= N * N, "one job per wave, the tile holds a plane");
-  const int lane = threadIdx.x & 63;
+  const uint32_t voff = (threadIdx.x & 63u) * 16u;
+  const uint32_t lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uintptr_t)(LdsF32)buf);
   __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the transpose's own reads of the tile have returned
-  // four scalar bases 4 KB apart, four immediate offsets each (the immediate moves the global AND the LDS address): one 32-bit
-  // lane offset, no vector address pairs
+  // M0 = LDS base of the piece (the hardware adds lane * 16), four immediates move the global AND the LDS address by 1 KB each.
+  // (M0 is not in the clobber list -- the compiler reserves it and rejects that; nothing else in these kernels reads M0.)
 #pragma unroll
   for (int qq = 0; qq < N / 16; ++qq) {
-    const GlobalF32 src = slot + qq * 1024 + lane * 4;
-    const LdsF32 dst = (LdsF32)(buf + qq * 1024);
-    __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
-    __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 0);
-    __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 0);
+    const uint64_t base = reinterpret_cast<uint64_t>(slot) + (uint64_t)qq * 4096u;
+    const uint32_t l = lds + qq * 4096u;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072"
+                 :: "v"(voff), "s"(base), "s"(l) : "memory");
   }
+}
+__device__ __forceinline__ void slot_store4(uint64_t base, uint32_t voff, const f32x4 (&v)[4]) {   // 4 x 1 KB of the wave, 1 KB apart
+  asm volatile("global_store_dwordx4 %0, %2, %1\n\tglobal_store_dwordx4 %0, %3, %1 offset:1024\n\t"
+               "global_store_dwordx4 %0, %4, %1 offset:2048\n\tglobal_store_dwordx4 %0, %5, %1 offset:3072"
+               :: "v"(voff), "s"(base), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "memory");
 }
 // acc <- (acc + m0 c0) + m1 c1, m in {0, 1} (exact products: the additions of the masked planes in pair order); `init`: the
 // slot holds nothing yet (no prefetch was issued)
@@ -1153,33 +1162,20 @@ __device__ __forceinline__ void slot_accumulate(GlobalF32 slot, const float* buf
   if (!init && !any) return;
   const float m0 = keep0 ? 1.0f : 0.0f, m1 = keep1 ? 1.0f : 0.0f;
   const float* lsrc = buf + lane * 4;
-  if (init) {
+  const uint32_t voff = (uint32_t)lane * 16u;
 #pragma unroll
-    for (int qq = 0; qq < N / 16; ++qq) {
-      const GlobalF32 dst = slot + qq * 1024 + lane * 4;   // scalar base bumped by 4 KB, the lane's 32-bit offset, immediates below
+  for (int qq = 0; qq < N / 16; ++qq) {
+    f32x4 a[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int q = 4 * qq + k;
-        f32x4 a;
+    for (int k = 0; k < 4; ++k) {
+      const int q = 4 * qq + k;
+      if (init) a[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      else a[k] = *reinterpret_cast<const f32x4*>(lsrc + q * 256);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a[e] = fmaf(c1[4 * q + e], m1, c0[4 * q + e] * m0);
-        *reinterpret_cast<f32x4 __attribute__((address_space(1)))*>(dst + k * 256) = a;
-      }
+      for (int e = 0; e < 4; ++e) a[k][e] = fmaf(c1[4 * q + e], m1, fmaf(c0[4 * q + e], m0, a[k][e]));
     }
-  } else {
-#pragma unroll
-    for (int qq = 0; qq < N / 16; ++qq) {
-      const GlobalF32 dst = slot + qq * 1024 + lane * 4;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int q = 4 * qq + k;
-        f32x4 a = *reinterpret_cast<const f32x4*>(lsrc + q * 256);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) a[e] = fmaf(c1[4 * q + e], m1, fmaf(c0[4 * q + e], m0, a[e]));
-        *reinterpret_cast<f32x4 __attribute__((address_space(1)))*>(dst + k * 256) = a;
-        if (k & 1) __builtin_amdgcn_sched_barrier(0);   // at most two tile reads (8 registers) in flight: all 16 hoisted up front cost 64 registers and spilled the carry
-      }
-    }
+    slot_store4(reinterpret_cast<uint64_t>(slot) + (uint64_t)qq * 4096u, voff, a);
+    __builtin_amdgcn_sched_barrier(0);   // sixteen registers of sums at a time
   }
 }
 
@@ -1807,7 +1803,17 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsWaves<T, N>)) void piv_fft_walk_ens
     if (WANT_NZ && win_dropped) skip[0] = skip[1] = true;
     const bool valid[2] = {job_valid && f > p0, job_valid && has2};
     float vmaxs[2];
-    {
+    if constexpr (kEnsLdsRmw<N>) {
+      // 256 VGPRs, both planes and the carry live: four running maxima per plane instead of the 22-wide first level of plane_max's tree
+      float ma[4] = {xr[0], xr[1], xr[2], xr[3]}, mb[4] = {xi[0], xi[1], xi[2], xi[3]};
+#pragma unroll
+      for (int j = 4; j < N; j += 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ma[e] = fmaxf(ma[e], xr[j + e]); mb[e] = fmaxf(mb[e], xi[j + e]); }
+      }
+      vmaxs[0] = group_max_nonneg<N>(fmaxf(fmaxf(ma[0], ma[1]), fmaxf(ma[2], ma[3])));
+      vmaxs[1] = group_max_nonneg<N>(fmaxf(fmaxf(mb[0], mb[1]), fmaxf(mb[2], mb[3])));
+    } else {
       float row_max;
       vmaxs[0] = plane_max<N>(xr, row_max);
       vmaxs[1] = plane_max<N>(xi, row_max);
