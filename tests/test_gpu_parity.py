@@ -1134,3 +1134,25 @@ def test_float64_stack_on_a_large_dc_offset(gpu):
         _lib.set_option("narrow_offset", 1024)
     assert max(rel_err(u, uo.astype(np.float64)), rel_err(cm, cmo.astype(np.float64))) > TOL
     assert _lib.get_option("narrow_offset") == 1024
+
+
+def test_rescue_totals_survive_a_regrow_and_streams_can_be_released(gpu):
+    """the cumulative counters of lspiv_rescue_stats live in the lists' header; when a larger launch makes the lists grow
+    the header moves along.  lspiv_stream_release drops the lists of a stream (the library's own: NULL); the next launch starts new ones."""
+    import pyorc_amd
+    from pyorc_amd import _lib
+
+    lib = _lib.load()
+    _lib.check(lib.lspiv_stream_release(None))                      # whatever earlier tests left on the library's stream
+    small = particle_stack(3, 96, 128, seed=5)
+    a = pyorc_amd.piv_pairs(small, (32, 32), (16, 16))
+    st1 = _rescue_stats()
+    assert st1[4] == a[0].size                                      # fresh lists: totals start at this launch
+    big = particle_stack(40, 400, 528, seed=6, density=0.015)       # 39 x 24 x 32 windows: more than the first lists hold -> regrow
+    b = pyorc_amd.piv_pairs(big, (32, 32), (16, 16))
+    st2 = _rescue_stats()
+    assert b[0].size // 4 > 4096 and st2[4] == st1[4] + b[0].size and st2[2] == st1[2] + st2[0] and st2[3] == st1[3] + st2[1]
+    _lib.check(lib.lspiv_stream_release(None))
+    assert _rescue_stats()[4] == 0                                  # no lists: nothing to report
+    c = pyorc_amd.piv_pairs(small, (32, 32), (16, 16))
+    assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(a, c)) and _rescue_stats()[4] == a[0].size
