@@ -1213,7 +1213,7 @@ template <typename T, int N, bool WANT_NZ>
 __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row, bool has2, float* buf, int lg,
                                                int partner_byte, int lane0_byte, WalkCarry<N>& c, float (&xr)[N],
                                                float (&xi)[N], float& mean_a, float& mean_b, bool& skip_a, bool& skip_b,
-                                               bool& dead_a, bool& dead_b, GlobalF32 acc_slot = nullptr) {
+                                               bool& dead_a, bool& dead_b, GlobalF32 acc_slot = nullptr, bool acc_slot_uniform = false) {
   using G = Geo<N>;
   constexpr int H = N / 2;
   bool dead0, dead1, fin0 = true, fin1 = true;
@@ -1245,6 +1245,14 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
     prepare_one<T, N, WANT_NZ>(raw0, xr, p.nz_positive != 0, p.std_gain, nz0, fin0, dead0);
     LSPIV_WALK_SB;
     prepare_one<T, N, WANT_NZ>(raw1, xi, p.nz_positive != 0, p.std_gain, nz1, fin1, dead1);
+  }
+  if constexpr (kEnsLdsRmw<N>) {
+    if (acc_slot_uniform) {   // (compile-time false in the per-timestep kernel)
+      // 64 x 64 ensemble kernel: the two "zero-variance window" flags as scalars now -- left as they are, the compiler keeps the
+      // two 1 / std in VGPRs across all four transforms (spilled and re-loaded) to compare them with zero at the very end
+      dead0 = __builtin_amdgcn_readfirstlane((int)dead0) != 0;
+      dead1 = __builtin_amdgcn_readfirstlane((int)dead1) != 0;
+    }
   }
   LSPIV_WALK_SB;
   LSPIV_SETPRIO(0);
@@ -1772,6 +1780,10 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsWaves<T, N>)) void piv_fft_walk_ens
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const uint32_t blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
   uint32_t job = (blk * WAVES_PER_BLOCK + wave) * G::GROUPS + grp;   // job = segment * n_win + window
+  // one job per wave (N > 32): say so -- segment, window, pair range, loop counter, result and slot addresses then live in SGPRs
+  // instead of one VGPR (pair) each (in-loop scratch 15 + 3 -> 11 + 3; the per-timestep kernel got WORSE with the same line,
+  // 8 + 0 -> 12 + 2, and does without)
+  if constexpr (G::GROUPS == 1) job = (uint32_t)__builtin_amdgcn_readfirstlane((int)job);
   const bool job_valid = job < p.n_seg * p.n_win;
   job = job_valid ? job : p.n_seg * p.n_win - 1;
   const uint32_t seg = p.div_nwin.div(job);
@@ -1799,7 +1811,7 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsWaves<T, N>)) void piv_fft_walk_ens
     float xr[N], xi[N], mean[2];
     bool skip[2], keep[2], dead[2];
     walk_iteration<T, N, WANT_NZ>(p, row, has2, buf, lg, partner_byte, lane0_byte, carry, xr, xi, mean[0], mean[1], skip[0], skip[1],
-                                  dead[0], dead[1], (kEnsLdsRmw<N> && !first) ? part_u : nullptr);
+                                  dead[0], dead[1], (kEnsLdsRmw<N> && !first) ? part_u : nullptr, kEnsLdsRmw<N>);
     if (WANT_NZ && win_dropped) skip[0] = skip[1] = true;
     const bool valid[2] = {job_valid && f > p0, job_valid && has2};
     float vmaxs[2];
