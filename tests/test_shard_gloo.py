@@ -137,7 +137,23 @@ class OracleEnsemble:
         self.s = np.asarray(s, np.float64).reshape(self.s.shape) + (self.s if add else 0)
         self.k = np.asarray(k, np.float64) + (self.k if add else 0)
 
+    # the staged finish of pyorc_amd.piv.Ensemble (flag / partials / finish_partials): the float64 oracle never has an ill-conditioned
+    # float32 fit to re-evaluate, so it flags `n_flag` windows only to drive the exchange (a rank's partials are its rank + 1)
+    n_flag = 0
+
+    def flag(self, count_min, n_frames):
+        self._args = (count_min, n_frames)
+        return self.n_flag
+
+    def partials(self):
+        return np.full((self.n_flag, 20), 1.0 + getattr(self, "rank", 0), np.float64), not getattr(self, "lost_frames", False)
+
+    def finish_partials(self, partials):
+        self.summed_partials = np.array(partials)
+        return self.finish(*self._args)
+
     def finish(self, count_min, n_frames):
+        self.plain_finish = not hasattr(self, "summed_partials")
         with np.errstate(all="ignore"):
             mean = self.s / self.k[:, None, None]
             mean[self.k < count_min * n_frames] = np.nan
@@ -149,9 +165,19 @@ def _ens_worker(rank, world, port, n_frames, out_dir, kind):
     comm = _make_comm(kind, rank, world, port, out_dir)
     try:
         stack = particle_stack(n_frames, 64, 96, seed=43)
-        u, v, cnt, cm, sn = shard.sharded_ensemble(lambda a, b: stack[a:b], n_frames - 1,
-                                                   lambda: OracleEnsemble((64, 96), WS, OV), 0.2, 2.0, 0.2, comm, n_chunks=2)
-        np.savez(os.path.join(out_dir, f"e{rank}.npz"), u=u, v=v, cnt=cnt, cm=cm, sn=sn)
+        made = []
+
+        def make():
+            e = OracleEnsemble((64, 96), WS, OV)
+            e.rank, e.n_flag = rank, 3                      # three "flagged" windows: the float64 all-reduce of the partials runs
+            e.lost_frames = (n_frames == 5 and rank == 1)    # one rank of the (3, 5) case could not keep its frames: all ranks fall back
+            made.append(e)
+            return e
+
+        u, v, cnt, cm, sn = shard.sharded_ensemble(lambda a, b: stack[a:b], n_frames - 1, make, 0.2, 2.0, 0.2, comm, n_chunks=2)
+        e = made[0]
+        np.savez(os.path.join(out_dir, f"e{rank}.npz"), u=u, v=v, cnt=cnt, cm=cm, sn=sn, plain=e.plain_finish,
+                 summed=getattr(e, "summed_partials", np.zeros((0, 20))))
     finally:
         comm.close()
 
@@ -171,3 +197,8 @@ def test_sharded_ensemble_equals_single_process(tmp_path, world, n_frames, kind)
         assert np.array_equal(np.isnan(d["u"]), np.isnan(u))
         # the per-rank partial sums are added in float32 by the all-reduce: same peak, sub-pixel within 1e-4
         assert np.nanmax(np.abs(d["u"] - u)) < 1e-4 and np.nanmax(np.abs(d["v"] - v)) < 1e-4
+        # the staged finish: every rank's partials summed over the ranks (1 + 2 [+ 3]); if any rank lost its frames, all finish plainly
+        if n_frames == 5:
+            assert bool(d["plain"]) and d["summed"].size == 0
+        else:
+            assert not bool(d["plain"]) and d["summed"].shape == (3, 20) and np.all(d["summed"] == sum(range(1, world + 1)))
