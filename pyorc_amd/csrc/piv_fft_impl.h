@@ -1134,15 +1134,17 @@ __device__ __forceinline__ void slot_prefetch_lds(GlobalF32 slot, float* buf) { 
   const uint32_t lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uintptr_t)(LdsF32)buf);
   __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the transpose's own reads of the tile have returned
   // M0 = LDS base of the piece (the hardware adds lane * 16), four immediates move the global AND the LDS address by 1 KB each.
-  // (M0 is not in the clobber list -- the compiler reserves it and rejects that; nothing else in these kernels reads M0.)
+  // (The compiler reserves M0 and rejects it in a clobber list: the block saves and restores it.)
 #pragma unroll
   for (int qq = 0; qq < N / 16; ++qq) {
     const uint64_t base = reinterpret_cast<uint64_t>(slot) + (uint64_t)qq * 4096u;
     const uint32_t l = lds + qq * 4096u;
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
-                 "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072"
-                 :: "v"(voff), "s"(base), "s"(l) : "memory");
+    uint32_t m0_saved;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(m0_saved) : "v"(voff), "s"(base), "s"(l) : "memory");
   }
 }
 __device__ __forceinline__ void slot_store4(uint64_t base, uint32_t voff, const f32x4 (&v)[4]) {   // 4 x 1 KB of the wave, 1 KB apart
@@ -1213,7 +1215,7 @@ template <typename T, int N, bool WANT_NZ>
 __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row, bool has2, float* buf, int lg,
                                                int partner_byte, int lane0_byte, WalkCarry<N>& c, float (&xr)[N],
                                                float (&xi)[N], float& mean_a, float& mean_b, bool& skip_a, bool& skip_b,
-                                               bool& dead_a, bool& dead_b, GlobalF32 acc_slot = nullptr, bool acc_slot_uniform = false) {
+                                               bool& dead_a, bool& dead_b, GlobalF32 acc_slot = nullptr, bool one_job_per_wave_ens = false) {
   using G = Geo<N>;
   constexpr int H = N / 2;
   bool dead0, dead1, fin0 = true, fin1 = true;
@@ -1247,7 +1249,7 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
     prepare_one<T, N, WANT_NZ>(raw1, xi, p.nz_positive != 0, p.std_gain, nz1, fin1, dead1);
   }
   if constexpr (kEnsLdsRmw<N>) {
-    if (acc_slot_uniform) {   // (compile-time false in the per-timestep kernel)
+    if (one_job_per_wave_ens) {   // (compile-time false in the per-timestep kernel)
       // 64 x 64 ensemble kernel: the two "zero-variance window" flags as scalars now -- left as they are, the compiler keeps the
       // two 1 / std in VGPRs across all four transforms (spilled and re-loaded) to compare them with zero at the very end
       dead0 = __builtin_amdgcn_readfirstlane((int)dead0) != 0;

@@ -554,97 +554,11 @@ __global__ __launch_bounds__(RBLOCK) void ens_partial_kernel(PivParams p, EnsRes
   }
 }
 
-// (ii-b) the same for windows whose width is a power of two up to 64 (all the FFT-kernel sizes pyorc uses: 8, 16, 32, 64): a lane owns
-// ONE column x = lane mod WX and walks the rows y = lane / WX, + 64 / WX, ... -- the column wraps of a lag are lane constants, the
-// row wraps one AND per sample --, and the two windows are normalised ONCE per pair into the wave's LDS slice as float32 (b' always,
-// a' when both fit: up to 32 x 32 x 2 samples) instead of once per lag: per sample and candidate 6 LDS reads, 6 conversions and 5
-// float64 multiply-adds where the generic path spends ~100 instructions on index arithmetic and normalisation.  Rounding the
-// NORMALISED samples to float32 costs 6e-8 relative per product, random in sign -- below 1e-8 of every sum, small samples
-// included (it is the float32 FFT's ABSOLUTE noise of 4e-7 of the plane maximum on small samples that the rescue is about).
-// The rescue of a C2-shaped ensemble (395 flagged windows x 2000 pairs) took 4.8 ms with the generic kernel: a third of the
-// accumulation itself.
-constexpr int ENS_LDS_PER_WAVE = 16384;
-template <typename T, int WX>
-__global__ __launch_bounds__(RBLOCK) void ens_partial_pow2_kernel(PivParams p, EnsRescueArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wy = p.wy, n = wy * WX;
-  constexpr int RSTEP = 64 / WX;                       // rows between two samples of a lane
-  const int x = lane & (WX - 1), y_first = lane / WX;
-  const int steps = (wy - y_first + RSTEP - 1) / RSTEP;   // samples of this lane (wy need not be a multiple of RSTEP)
-  const bool a_staged = (size_t)2 * n * sizeof(float) <= (size_t)ENS_LDS_PER_WAVE;
-  float* lb = reinterpret_cast<float*>(fsm + (size_t)wave * ENS_LDS_PER_WAVE);
-  float* la = lb + n;
-  const uint32_t chunk_blks = (a.n_pairs + kEnsPairBlock - 1) / kEnsPairBlock;
-  const uint32_t items = a.n_rec * chunk_blks, n_waves = gridDim.x * (RBLOCK / 64);
-  const double inv_n = 1.0 / (double)n;
-  for (uint32_t it = blockIdx.x * (RBLOCK / 64) + (uint32_t)wave; it < items; it += n_waves) {
-    const uint32_t ri = it / chunk_blks, blk = it - ri * chunk_blks;
-    const EnsRescueRec rec = a.recs[ri];
-    double acc[kEnsMaxCand][5];
-#pragma unroll
-    for (int c = 0; c < kEnsMaxCand; ++c)
-#pragma unroll
-      for (int q = 0; q < 5; ++q) acc[c][q] = 0.0;
-    const uint32_t pa = blk * kEnsPairBlock, pb = min(pa + (uint32_t)kEnsPairBlock, a.n_pairs);
-    for (uint32_t pair = pa; pair < pb && rec.ncand != 0; ++pair) {
-      if (!(a.cmax[(size_t)pair * p.n_win + rec.w] > 0.0f)) continue;   // not in the sum (uniform over the wave)
-      const T* A = window_base<T>(p, pair * p.n_win + rec.w) + x;
-      const T* B = A + p.frame_elems;
-      // statistics: shifted one-pass sums in float64 (window_stats_wave2's arithmetic on this lane -> sample map)
-      const double x0a = (double)window_base<T>(p, pair * p.n_win + rec.w)[0], x0b = (double)(window_base<T>(p, pair * p.n_win + rec.w) + p.frame_elems)[0];
-      double sa = 0.0, sb = 0.0, qa = 0.0, qb = 0.0;
-      for (int j = 0, y = y_first; j < steps; ++j, y += RSTEP) {
-        const double da = (double)A[(int64_t)y * p.W] - x0a, db = (double)B[(int64_t)y * p.W] - x0b;
-        sa += da; qa = fma(da, da, qa);
-        sb += db; qb = fma(db, db, qb);
-      }
-      sa = wave_sum_d(sa); sb = wave_sum_d(sb); qa = wave_sum_d(qa); qb = wave_sum_d(qb);
-      const double va = (qa - sa * sa * inv_n) * inv_n, vb = (qb - sb * sb * inv_n) * inv_n;
-      if (!(va > 0.0) || !(vb > 0.0)) continue;   // (a zero-variance window has corr_max 0 and is never kept)
-      const double mean_a = x0a + sa * inv_n, mean_b = x0b + sb * inv_n;
-      const double sg = p.norm_clip ? (double)p.std_gain : -(double)p.std_gain;
-      const double inv_a = sg / sqrt(va), inv_b = sg / sqrt(vb);
-      __builtin_amdgcn_wave_barrier();   // the previous pair's reads of the slice are done (same wave: program order)
-      for (int j = 0, y = y_first; j < steps; ++j, y += RSTEP) {   // second pass over the (L1-hot) samples: normalise, clip, park
-        lb[y * WX + x] = (float)norm_clip((double)B[(int64_t)y * p.W], mean_b, inv_b);
-        if (a_staged) la[y * WX + x] = (float)norm_clip((double)A[(int64_t)y * p.W], mean_a, inv_a);
-      }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int c = 0; c < kEnsMaxCand; ++c) {
-        if (c >= (int)rec.ncand) break;
-        const int ip = (int)(rec.pos[c] >> 16), jp = (int)(rec.pos[c] & 0xffffu);
-        const int ky0 = unshift(ip, wy / 2, wy), kx0 = unshift(jp, WX / 2, WX);
-        const int x0 = (x + kx0) & (WX - 1), xm = (x0 + WX - 1) & (WX - 1), xp = (x0 + 1) & (WX - 1);   // lane constants
-        double c0 = 0.0, cu = 0.0, cd = 0.0, cl = 0.0, cr = 0.0;
-        int yb = y_first + ky0;                      // row of b' under this lane's row of a' at the centre lag, kept in [0, wy)
-        yb = yb >= wy ? yb - wy : yb;
-        for (int j = 0, y = y_first; j < steps; ++j, y += RSTEP) {
-          const double av = a_staged ? (double)la[y * WX + x] : norm_clip((double)A[(int64_t)y * p.W], mean_a, inv_a);
-          const int ym = yb == 0 ? wy - 1 : yb - 1, yp = yb == wy - 1 ? 0 : yb + 1;
-          const float* row = lb + yb * WX;
-          c0 = fma(av, (double)row[x0], c0);
-          cl = fma(av, (double)row[xm], cl);
-          cr = fma(av, (double)row[xp], cr);
-          cu = fma(av, (double)lb[ym * WX + x0], cu);
-          cd = fma(av, (double)lb[yp * WX + x0], cd);
-          yb += RSTEP; yb = yb >= wy ? yb - wy : yb;
-        }
-        auto clip01 = [](double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); };
-        acc[c][0] += clip01(wave_sum_d(c0) * inv_n); acc[c][1] += clip01(wave_sum_d(cu) * inv_n); acc[c][2] += clip01(wave_sum_d(cd) * inv_n);
-        acc[c][3] += clip01(wave_sum_d(cl) * inv_n); acc[c][4] += clip01(wave_sum_d(cr) * inv_n);
-      }
-    }
-    if (lane == 0) {
-      double* dst = a.partial + ((size_t)ri * a.n_blk + a.blk0 + blk) * (kEnsMaxCand * 5);
-#pragma unroll
-      for (int c = 0; c < kEnsMaxCand; ++c)
-#pragma unroll
-        for (int q = 0; q < 5; ++q) dst[c * 5 + q] = acc[c][q];
-    }
-  }
-}
+// (A variant for power-of-two widths -- both windows normalised once per pair into the slice as float32, a lane owning one column so
+// that the column wraps of a lag are lane constants -- was built and measured against this kernel with hundreds of windows flagged:
+// 6.6 vs 4.9 ms (32 x 32, 395 windows x 2000 pairs), 24.2 vs 16.5 ms (64 x 64, 385 windows), 21.9 vs 16.2 and 78.4 vs 54.3 ms at 1 450
+// windows; the per-pair fit kernel through the same machinery: 215 vs 132 us per 32 k records.  The second pass over the samples
+// costs more than the repeated normalisation: a record is a chain of short dependent steps either way.  Removed.)
 
 // (iii) merge a handle's partial sums in pair-block order (one thread per (record, candidate, sample): a fixed order)
 __global__ __launch_bounds__(RBLOCK) void ens_merge_kernel(EnsRescueArgs a, double* totals) {
@@ -716,12 +630,6 @@ hipError_t launch_ens_flag(const float* mean, uint32_t n_win, int wy, int wx, co
 template <typename T>
 static void launch_ens_partial_t(const PivParams& p, const EnsRescueArgs& a, uint32_t blocks, hipStream_t s) {
   const int n = p.wy * p.wx;
-  const bool pow2 = (size_t)n * sizeof(float) <= (size_t)ENS_LDS_PER_WAVE && p.wy >= 64 / std::max(p.wx, 1);   // b' fits the slice; every lane has a sample
-  const size_t fast_lds = (size_t)(RBLOCK / 64) * ENS_LDS_PER_WAVE;
-  if (pow2 && p.wx == 64) { hipLaunchKernelGGL((ens_partial_pow2_kernel<T, 64>), dim3(blocks), dim3(RBLOCK), fast_lds, s, p, a); return; }
-  if (pow2 && p.wx == 32) { hipLaunchKernelGGL((ens_partial_pow2_kernel<T, 32>), dim3(blocks), dim3(RBLOCK), fast_lds, s, p, a); return; }
-  if (pow2 && p.wx == 16) { hipLaunchKernelGGL((ens_partial_pow2_kernel<T, 16>), dim3(blocks), dim3(RBLOCK), fast_lds, s, p, a); return; }
-  if (pow2 && p.wx == 8) { hipLaunchKernelGGL((ens_partial_pow2_kernel<T, 8>), dim3(blocks), dim3(RBLOCK), fast_lds, s, p, a); return; }
   const size_t lds = (size_t)2 * n * sizeof(T) <= (size_t)FIT_LDS_PER_WAVE ? (size_t)(RBLOCK / 64) * FIT_LDS_PER_WAVE : 0;
   hipLaunchKernelGGL(ens_partial_kernel<T>, dim3(blocks), dim3(RBLOCK), lds, s, p, a);
 }
