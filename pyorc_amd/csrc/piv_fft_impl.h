@@ -1085,8 +1085,12 @@ __device__ __forceinline__ void prepare_one(const RowRaw<T, N>& raw, float (&x)[
 #endif
 #define LSPIV_PRIO_ANY (LSPIV_PRIO_T || LSPIV_PRIO_U || LSPIV_PRIO_E || LSPIV_PRIO_P)
 #define LSPIV_SETPRIO(x) do { if constexpr (LSPIV_PRIO_ANY) __builtin_amdgcn_s_setprio(x); } while (0)
+#ifndef LSPIV_WALK_RELAX
+#define LSPIV_WALK_RELAX 0   // experiment: the per-timestep walking kernels without the barriers (bit mask: 1 = 32 x 32, 2 = 64 x 64)
+#endif
+template <typename T, int N> constexpr bool kWalkRelax = ((LSPIV_WALK_RELAX & 1) && N == 32) || ((LSPIV_WALK_RELAX & 2) && N == 64);
 #ifndef LSPIV_WALK_SB
-#define LSPIV_WALK_SB do { if constexpr (N == 32 || N == 64) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define LSPIV_WALK_SB do { if constexpr ((N == 32 || N == 64) && !RELAX) __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif
 
 // float32 rows: every lane reads its own 4 N-byte row 16 bytes at a time.  (Fetching the rows coalesced -- N / 4 consecutive
@@ -1211,7 +1215,9 @@ struct WalkCarry {
 
 // One iteration: rows of frames f (and f + 1 when `has2`) of the job's window -> clipped planes xr (pair f-1) and xi
 // (pair f), their means (DC bins) and NaN flags; the carry moves on to frame f + 1.
-template <typename T, int N, bool WANT_NZ>
+// RELAX: without the scheduling barriers between the phases (a caller with registers to spare: the 32 x 32 ensemble kernel runs two
+// waves per SIMD for its register accumulator and may use 256 VGPRs)
+template <typename T, int N, bool WANT_NZ, bool RELAX = false>
 __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row, bool has2, float* buf, int lg,
                                                int partner_byte, int lane0_byte, WalkCarry<N>& c, float (&xr)[N],
                                                float (&xi)[N], float& mean_a, float& mean_b, bool& skip_a, bool& skip_b,
@@ -1372,8 +1378,8 @@ __global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_kernel
     const bool has2 = f + 1 <= p1;
     float xr[N], xi[N], mean_a, mean_b;
     bool skip_a, skip_b, dead_a, dead_b;
-    walk_iteration<T, N, WANT_NZ>(p, row, has2, buf, lg, partner_byte, lane0_byte, carry, xr, xi, mean_a, mean_b, skip_a, skip_b,
-                                  dead_a, dead_b);
+    walk_iteration<T, N, WANT_NZ, kWalkRelax<T, N>>(p, row, has2, buf, lg, partner_byte, lane0_byte, carry, xr, xi, mean_a, mean_b, skip_a, skip_b,
+                                                    dead_a, dead_b);
     if (WANT_NZ && win_dropped) skip_a = skip_b = true;
     const bool valid_a = job_valid && f > p0, valid_b = job_valid && has2;
     if constexpr (kTwoPlaneEpilogue<N>) {
@@ -1763,11 +1769,20 @@ template <int N> constexpr bool kEnsRegAcc = LSPIV_ENS_REGACC && N <= 32;
 #ifndef LSPIV_WALK_ENS_WAVES_32
 #define LSPIV_WALK_ENS_WAVES_32 2
 #endif
+#ifndef LSPIV_ENS32_RELAX
+#define LSPIV_ENS32_RELAX 1   // measured: 6.78 -> 6.02 ms per 1000 pairs (147 k -> 166 k pairs/s): without the barriers the allocator needs 168 VGPRs instead of 194 and a third wave fits
+#endif
+template <typename T, int N> constexpr bool kEnsRelax = LSPIV_ENS32_RELAX && N == 32 && kEnsRegAcc<N> && sizeof(T) < 8;
 template <typename T, int N>
 constexpr int kWalkEnsWaves = (kEnsRegAcc<N> && N == 32 && sizeof(T) < 8) ? LSPIV_WALK_ENS_WAVES_32 : kWalkWaves<T, N>;
+// Relaxed (no barriers), the uint8 kernel without a signal threshold allocates 168 VGPRs by itself: a third wave fits although the
+// bound says two (166 k pairs/s; bounded at three it spills 28 bytes: 163 k).  The variants that count non-zero samples and the
+// float32 ones come out at 173 - 174 and would run two waves: they are bounded at three (168 VGPRs + 28 ... 44 bytes of scratch).
+template <typename T, int N, bool WANT_NZ>
+constexpr int kWalkEnsBound = (kEnsRelax<T, N> && (WANT_NZ || sizeof(T) == 4)) ? 3 : kWalkEnsWaves<T, N>;
 
 template <typename T, int N, bool WANT_NZ>
-__global__ __launch_bounds__(BLOCK, (kWalkEnsWaves<T, N>)) void piv_fft_walk_ensemble_kernel(PivParams p) {
+__global__ __launch_bounds__(BLOCK, (kWalkEnsBound<T, N, WANT_NZ>)) void piv_fft_walk_ensemble_kernel(PivParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using G = Geo<N>;
   const int lane = threadIdx.x & 63;
@@ -1812,8 +1827,8 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsWaves<T, N>)) void piv_fft_walk_ens
     const bool has2 = f + 1 <= p1;
     float xr[N], xi[N], mean[2];
     bool skip[2], keep[2], dead[2];
-    walk_iteration<T, N, WANT_NZ>(p, row, has2, buf, lg, partner_byte, lane0_byte, carry, xr, xi, mean[0], mean[1], skip[0], skip[1],
-                                  dead[0], dead[1], (kEnsLdsRmw<N> && !first) ? part_u : nullptr, kEnsLdsRmw<N>);
+    walk_iteration<T, N, WANT_NZ, kEnsRelax<T, N>>(p, row, has2, buf, lg, partner_byte, lane0_byte, carry, xr, xi, mean[0], mean[1], skip[0], skip[1],
+                                                   dead[0], dead[1], (kEnsLdsRmw<N> && !first) ? part_u : nullptr, kEnsLdsRmw<N>);
     if (WANT_NZ && win_dropped) skip[0] = skip[1] = true;
     const bool valid[2] = {job_valid && f > p0, job_valid && has2};
     float vmaxs[2];
