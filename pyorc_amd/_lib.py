@@ -178,7 +178,7 @@ def load() -> C.CDLL:
     # of every library source into it.  A build loaded on purpose through LSPIV_LIBRARY (A/B measurements) is exempt.
     if not os.environ.get("LSPIV_LIBRARY") and not os.environ.get("LSPIV_ALLOW_STALE"):
         prov = binary_provenance(lib)
-        if not prov["binary_hash_matches"]:
+        if prov["binary_hash_matches"] is False:
             raise LspivLibraryStale(
                 f"{LIB_PATH} was built from sources with hash {prov['binary_source_hash']}, the tree has {prov['tree_source_hash']}: "
                 "rebuild (`make -C pyorc_amd/csrc`), or set LSPIV_ALLOW_STALE=1 to load it anyway")
@@ -215,7 +215,11 @@ def binary_provenance(lib: Optional[C.CDLL] = None, csrc_dir: Optional[str] = No
         bk, bs = lib.lspiv_build_info(0).decode(), lib.lspiv_build_info(1).decode()
     else:
         bk = bs = "absent"   # a build from before round 4
-    tk, ts = kernel_code_hash(csrc_dir), source_hash(csrc_dir)
+    try:
+        tk, ts = kernel_code_hash(csrc_dir), source_hash(csrc_dir)
+    except OSError:      # a deployment without the sources next to the binary: nothing to compare with
+        return {"binary_kernel_hash": bk, "tree_kernel_hash": None, "binary_source_hash": bs, "tree_source_hash": None,
+                "binary_hash_matches": None}
     return {"binary_kernel_hash": bk, "tree_kernel_hash": tk, "binary_source_hash": bs, "tree_source_hash": ts,
             "binary_hash_matches": bk == tk and bs == ts}
 
