@@ -1882,12 +1882,14 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsBound<T, N, WANT_NZ>)) void piv_fft
   if (job_valid && lg == 0) p.part_cnt[job] = cnt;
 }
 
-// strip width of the walking kernels' job order (strip_order): 32 windows for 64 x 64, row-major for the other sizes;
-// LSPIV_STRIP_W overrides it for every size (0 = row-major; measurements)
-template <int N>
+// strip width of the walking kernels' job order (strip_order): 32 windows for 64 x 64 (HBM fetch of C3 5.2 -> 2.6 GB), 24 for
+// 32 x 32 windows of float32 / float64 frames (13.3 -> 9.5 GB = 1.15 x the stack; uint8 frames fetch MORE in strips, 2.2 -> 3.1 GB,
+// and stay row-major like every other size); times do not move either way.  LSPIV_STRIP_W overrides it for every kernel
+// (0 = row-major; measurements)
+template <typename T, int N>
 static uint32_t walk_strip_width() {
   static const int env = getenv("LSPIV_STRIP_W") ? atoi(getenv("LSPIV_STRIP_W")) : -1;
-  return env >= 0 ? (uint32_t)env : (N == 64 ? 32u : 0u);
+  return env >= 0 ? (uint32_t)env : (N == 64 ? 32u : (N == 32 && sizeof(T) >= 4) ? 24u : 0u);
 }
 
 template <typename T, int N, bool WANT_NZ>
@@ -1897,7 +1899,7 @@ static hipError_t launch_t(const PivParams& p, bool ensemble, hipStream_t s) {
   if (ensemble && p.part_sum) {   // walking ensemble kernel + ordered merge of the per-segment partial sums
     const uint64_t wjobs = (uint64_t)p.n_seg * p.n_win;
     PivParams q = p;
-    q.strip_w = walk_strip_width<N>();
+    q.strip_w = walk_strip_width<T, N>();
     hipLaunchKernelGGL((piv_fft_walk_ensemble_kernel<T, N, WANT_NZ>), dim3((uint32_t)((wjobs + jobs_per_block - 1) / jobs_per_block)),
                        dim3(BLOCK), G::LDS_BYTES, s, q);
     hipError_t e = hipGetLastError();
@@ -1917,7 +1919,7 @@ static hipError_t launch_t(const PivParams& p, bool ensemble, hipStream_t s) {
     PivParams q = p;
     const WalkSegments w = walk_segments(p.n_pairs, p.pair_offset, walk > 1 ? (uint32_t)walk : kWalkAnchor);
     q.seg_len = w.seg_len; q.seg_first = w.seg_first; q.n_seg = w.n_seg;
-    q.strip_w = walk_strip_width<N>();
+    q.strip_w = walk_strip_width<T, N>();
     const uint64_t wjobs = (uint64_t)w.n_seg * p.n_win;
     const uint32_t wblocks = (uint32_t)((wjobs + jobs_per_block - 1) / jobs_per_block);
     constexpr size_t walk_lds = G::LDS_BYTES + (kTwoPlaneEpilogue<N> ? (size_t)WAVES_PER_BLOCK * G::GROUPS * 3 * G::LDS_ROW * 4 : 0);   // + plane b's three rows
