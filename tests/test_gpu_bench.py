@@ -58,6 +58,20 @@ def test_bench_launches_its_own_ranks_and_gathers_over_the_native_comm(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [4, 8])
+def test_bench_at_the_rank_counts_of_the_scaling_run(gpu, n):
+    """The driver's N = 4 and 8, as far as one GPU goes: n self-launched ranks share device 0 over the shared-memory transport --
+    block sizes, the gathered (n, 4, pairs, windows) result against ONE launch, the max-over-ranks clock and the weak-scaling value."""
+    d = run_bench(["--pairs", "25", "--height", "256", "--width", "384", "--steps", "2", "--warmup", "1", "--gpus", str(n)],
+                  {"LSPIV_BENCH_SAME_DEVICE": "1"})
+    comm = d["config"]["comm"]
+    assert d["n_gpus"] == n and d["scaling"] == "weak" and comm["ranks_reported_by_transport"] == n
+    assert comm["pairs_total"] == 25 * n and comm["pairs_rank0"] == 25 and comm["allgather_matches_single_launch"] is True
+    assert comm["allgather_bytes_received_per_rank_per_step"] == (n - 1) * comm["allgather_bytes_per_rank_per_step"]
+    assert abs(d["value"] - 25 * n / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+
+
+@pytest.mark.gpu
 def test_bench_strong_mode_cuts_a_fixed_total(gpu):
     """`--strong`: a fixed total (here 150 pairs) cut over the ranks on the walking kernels' anchors (75 + 75), value = total / time."""
     d = run_bench(SMALL + ["--gpus", "2", "--strong", "--strong-pairs", "150"], {"LSPIV_BENCH_SAME_DEVICE": "1"})

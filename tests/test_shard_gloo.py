@@ -91,6 +91,11 @@ def test_sharded_piv_equals_single_process(tmp_path, world, n_frames, align, kin
     stack = particle_stack(n_frames, 96, 128, seed=42)
     ref = np.stack(_oracle_compute(stack, WS, OV, None))
     n_pairs = n_frames - 1
+    _check_ranks(tmp_path, world, n_frames, align, ref)
+
+
+def _check_ranks(tmp_path, world, n_frames, align, ref):
+    n_pairs = n_frames - 1
     for r in range(world):
         d = np.load(os.path.join(tmp_path, f"r{r}.npz"))
         assert d["full"].shape == ref.shape
@@ -103,6 +108,16 @@ def test_sharded_piv_equals_single_process(tmp_path, world, n_frames, align, kin
             assert d["touched"].size == 0
         assert np.all(d["summed"] == sum(range(1, world + 1)))
         assert d["biggest"][0] == (world - 1) * 1.5
+
+
+@pytest.mark.parametrize("world,n_frames,align", [(4, 14, 3), (8, 27, 3), (8, 6, 1)])
+def test_sharded_piv_at_the_rank_counts_of_the_scaling_run(tmp_path, world, n_frames, align):
+    """4 and 8 ranks (the driver's N = 4, 8) over the native communicator's shared-memory transport, with more ranks than
+    anchored blocks in the last case (ranks with nothing to do still take part in the gather)."""
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_frames, str(tmp_path), "native-shm", align), nprocs=world, join=True)
+    stack = particle_stack(n_frames, 96, 128, seed=42)
+    _check_ranks(tmp_path, world, n_frames, align, np.stack(_oracle_compute(stack, WS, OV, None)))
 
 
 class OracleEnsemble:
