@@ -1811,7 +1811,10 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsBound<T, N, WANT_NZ>)) void piv_fft
   const uint32_t wcol = win - wrow * (uint32_t)p.n_cols;
   const T* row = static_cast<const T*>(p.frames) + ((int64_t)p0 * p.H + (int64_t)(wrow * p.sy + row_of<N>(lg))) * p.W +
                  (int64_t)wcol * p.sx;
-  float* part = p.part_sum + (size_t)job * G::NN;
+  // the job's partial-sum slot is that of its (segment, WINDOW): ensemble_merge_kernel adds the segments' slots of a window in
+  // segment order, whatever order the jobs ran in (strip_order permutes the windows of a segment)
+  const uint32_t pslot = seg * p.n_win + win;
+  float* part = p.part_sum + (size_t)pslot * G::NN;
   const GlobalF32 part_u = kEnsLdsRmw<N> ? uniform_global_ptr(part) : nullptr;   // one job per wave: the slot pointer lives in SGPRs
   const bool win_dropped = WANT_NZ && p.win_keep && !p.win_keep[win];
   float cnt = 0.0f;
@@ -1879,7 +1882,7 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsBound<T, N, WANT_NZ>)) void piv_fft
   if constexpr (kEnsRegAcc<N>) {
     if (job_valid) store_plane_rows<N>(part, lg, acc, false);   // fft-shifted layout, like accumulate_planes
   }
-  if (job_valid && lg == 0) p.part_cnt[job] = cnt;
+  if (job_valid && lg == 0) p.part_cnt[pslot] = cnt;
 }
 
 // strip width of the walking kernels' job order (strip_order): 32 windows for 64 x 64 (HBM fetch of C3 5.2 -> 2.6 GB), 24 for

@@ -603,6 +603,28 @@ def test_ensemble_other_window_size(gpu, monkeypatch, n, T):
     assert rel_err(got["v_x"], ref["v_x"].astype(np.float64)) <= TOL and rel_err(got["v_y"], ref["v_y"].astype(np.float64)) <= TOL
 
 
+@pytest.mark.parametrize("n,ov,dtype,H,W,T", [(64, 48, np.uint8, 200, 640, 5), (64, 48, np.uint8, 160, 700, 28), (32, 16, np.float32, 100, 480, 28),
+                                              (32, 16, np.float64, 90, 520, 5), (64, 32, np.float32, 200, 1300, 4)])
+def test_ensemble_and_per_timestep_on_grids_wider_than_a_job_strip(gpu, n, ov, dtype, H, W, T):
+    """The walking kernels run these shapes' jobs in column strips (strip_order: 32 windows at 64 x 64, 24 for 32 x 32 windows of
+    float frames); the grids here have more columns than a strip, which the small frames of the other tests never have.  (Round 4
+    shipped the ensemble kernel with its partial-sum slot indexed by the permuted job for a while: wrong sums from column 32 on,
+    caught by tests/test_gpu_strip_order.py.)"""
+    from pyorc_amd import frames as F
+
+    fr = particle_stack(T, H, W, seed=91 + n + T, density=0.04)
+    if dtype != np.uint8:
+        fr = fr.astype(dtype) * 0.5 - 7.0
+    for ens in (True, False):
+        kw = dict(corr_min=0.1, s2n_min=1.5) if ens else {}
+        got = F.get_piv(fr, n, overlap=(ov, ov), ensemble_corr=ens, **kw)
+        ref = po.get_ffpiv(fr, np.ones(T - 1), (n, n), (ov, ov), 1.0, 1.0, ensemble_corr=ens, **kw)
+        assert got["v_x"].shape[-1] > 24 + 8 * (n == 64)
+        for k in ("v_x", "v_y", "corr", "s2n"):
+            assert np.array_equal(np.isnan(got[k]), np.isnan(ref[k])), (k, ens)
+            assert rel_err(got[k], np.asarray(ref[k], dtype=np.float64)) <= TOL, (k, ens)
+
+
 def test_pipelined_upload_equals_single_batch(gpu, monkeypatch):
     """Host entry point: staging the stack in sub-batches of frames (two pinned slots, compute overlapped with
     the next DMA; launches cut on the segment anchors) must equal one batch bit for bit with the default kernels, for
