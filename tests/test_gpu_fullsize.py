@@ -175,6 +175,28 @@ def test_config1_ngwerere_geometry(gpu):
     assert rel_err(ds["v_x"][ok], vx_ref[ok], floor=0.05 * 0.3) <= TOL
 
 
+@pytest.mark.parametrize("n,ov,dtype", [(32, 16, np.uint8), (32, 16, np.float32), (64, 48, np.uint8)])
+def test_ensemble_on_the_full_width_1080p_grid(gpu, n, ov, dtype):
+    """Ensemble mode on window grids as wide as BASELINE.json configs[1] / [2] (119 and 117 columns -- wider than the walking kernels'
+    job strips, which no small-frame test is; half the height, to keep the numpy oracle at seconds), a few pairs, every window
+    against the oracle of pyorc/velocimetry/ffpiv.py:182-376."""
+    from oracle import piv_oracle as po
+    from pyorc_amd import frames as F
+    from pyorc_amd.synth import particle_stack
+
+    T = 4
+    fr = particle_stack(T, 540, 1920, seed=20260940 + n, density=0.03)
+    if dtype != np.uint8:
+        fr = fr.astype(dtype) * 0.25 + 3.0
+    kw = dict(corr_min=0.1, s2n_min=1.5)
+    got = F.get_piv(fr, n, overlap=(ov, ov), ensemble_corr=True, **kw)
+    ref = po.get_ffpiv(fr, np.ones(T - 1), (n, n), (ov, ov), 1.0, 1.0, ensemble_corr=True, **kw)
+    assert got["v_x"].shape == ((1, 32, 119) if n == 32 else (1, 30, 117))
+    for k in ("v_x", "v_y", "corr", "s2n"):
+        assert np.array_equal(np.isnan(got[k]), np.isnan(ref[k])), k
+        assert rel_err(got[k], np.asarray(ref[k], dtype=np.float64)) <= TOL, k
+
+
 def test_ngwerere_recipe_window_25(gpu):
     """The window the Ngwerere recipe actually asks for (examples/ngwerere/ngwerere.yml: window_size 25 -> 24 after
     round_to_even, overlap int(round(25) / 2) = 12, quirk Q6): 785 x 875 frames, 64 x 71 windows, the 24-point
