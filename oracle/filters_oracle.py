@@ -22,7 +22,12 @@ def normalize(frames: np.ndarray, samples: int = 15) -> np.ndarray:
     time_interval = round(len(frames) / samples)
     assert time_interval != 0, f"Amount of frames is too small to provide {samples} samples"
     mean = frames[::time_interval].mean(axis=0).astype("float32")
-    frames_reduce = frames.astype("float32") - mean
+    return normalize_with_mean(frames, mean)
+
+
+def normalize_with_mean(frames: np.ndarray, mean: np.ndarray) -> np.ndarray:
+    """The per-frame part of ``normalize`` (frames.py:300-306) for a given sampled mean -- tests of stacks too long for numpy check single frames with it."""
+    frames_reduce = np.asarray(frames).astype("float32") - mean
     frames_min = frames_reduce.min(axis=-1).min(axis=-1)[:, None, None]
     frames_max = frames_reduce.max(axis=-1).max(axis=-1)[:, None, None]
     with np.errstate(all="ignore"):

@@ -220,3 +220,67 @@ def test_ngwerere_recipe_window_25(gpu):
     ens = F.get_piv(fr, 25, time=t, resolution=0.01, ensemble_corr=True)
     assert ens["v_x"].shape == (1, 64, 71) and np.isfinite(ens["v_x"]).mean() > 0.9
     assert abs(float(np.nanmedian(ens["v_x"])) - float(np.nanmedian(ds["v_x"]))) < 0.05
+
+
+def test_device_chain_on_a_stack_beyond_2_31_elements(gpu):
+    """The rows around the hot path on an HBM-resident stack of 1110 x 1080 x 1920 uint8 frames = 2.30 G elements
+    (9.2 GB as float32): element indices pass 2^31 and 2^32 bytes.  numpy cannot hold the oracle of the whole stack, so frames from
+    the start, from either side of the 2^31-element mark (frame 1035 / 1036) and from the end are compared with the oracles of
+    range (the whole stack), normalize, time_diff, minmax, smooth and the orthoprojection (group means) -- bit-exact, blur within 4e-6 of the range, as in the
+    small tests -- and get_piv runs on the projected float32 stack."""
+    from oracle import filters_oracle as fo, project_oracle as pro
+    from pyorc_amd import DeviceFrames, filters
+    from pyorc_amd import frames as F
+    from pyorc_amd.project import Projection
+    from pyorc_amd.synth import projection_maps
+
+    T, H, W = 1110, 1080, 1920
+    cam = DeviceFrames.empty((T, H, W), np.uint8)
+    _lib.check(gpu.lspiv_synth_particles_dev(cam.c_ptr, T, H, W, 20260950, 0.02))
+    _lib.check(gpu.lspiv_synchronize())
+    picks = [0, 1035, 1036, T - 2]
+    full = cam.to_host()                                         # 2.3 GB of bytes: numpy can still reduce those through time
+    host = {k: full[k:k + 2] for k in picks}
+    assert np.array_equal(filters.range(cam), fo.time_range(full))
+
+    norm = filters.normalize(cam, 15)
+    mean = full[::round(T / 15)].mean(axis=0).astype("float32")
+    del full
+    for k in picks:
+        assert np.array_equal(norm[k:k + 2].to_host(), fo.normalize_with_mean(host[k], mean)), k
+
+    diff = filters.time_diff(cam, thres=2.0, abs=True)
+    assert diff.shape == (T - 1, H, W)
+    for k in picks:
+        assert np.array_equal(diff[k:k + 1].to_host(), fo.time_diff(host[k], thres=2.0, abs=True)), k
+    clipped = filters.minmax(diff, min=1.0, max=40.0)
+    for k in picks:
+        assert np.array_equal(clipped[k:k + 1].to_host(), fo.minmax(fo.time_diff(host[k], thres=2.0, abs=True), 1.0, 40.0)), k
+    del diff, clipped
+
+    sm = filters.smooth(cam, 2)
+    for k in picks:
+        ref = fo.smooth(host[k][:1], 2)
+        assert np.abs(sm[k:k + 1].to_host() - ref).max() <= 4e-6 * 255, k
+    del sm
+
+    dst = (810, 1440)                                             # 3/4 of the camera's resolution: 22 % of the cells are group means
+    idx_img, mask, src_idx, uidx, norm_idx = projection_maps((H, W), dst, tilt=0.1, seed=1)
+    p = Projection((H, W), dst, idx_img, mask, src_idx=src_idx, uidx=uidx, norm_idx=norm_idx)
+    assert not p.nearest_only                                     # cells with group means: float32 ortho frames
+    ortho = p.project_frames(norm, keep_uint8=False)
+    assert ortho.dtype == np.float32 and ortho.shape == (T,) + dst and len(uidx) > 200000
+    for k in picks:
+        ref = pro.project_frames(norm[k:k + 1].to_host(), dst, idx_img, mask, src_idx=src_idx, uidx=uidx, norm_idx=norm_idx)
+        assert np.array_equal(ortho[k:k + 1].to_host().astype(np.float64), ref), k
+    p.close()
+    del norm
+
+    ds = F.get_piv(ortho, 32, time=np.arange(T) / 30.0, resolution=0.01)
+    assert ds["v_x"].shape == (T - 1, 49, 89)
+    for k in (0, 1035, T - 2):
+        uo, vo, cmo, sno, cond = c_oracle.piv_pairs(ortho[k:k + 2].to_host(), (32, 32), (16, 16), return_cond=True)
+        ok = ~c_oracle.exact_tie(cond, cmo)
+        assert np.array_equal(np.isnan(ds["corr"][k]), np.isnan(cmo[0])) and rel_err(ds["corr"][k], cmo[0].astype(np.float64)) <= TOL
+        assert rel_err(ds["v_x"][k][ok[0]], (uo[0].astype(np.float64) * 0.3)[ok[0]], floor=0.05 * 0.3) <= TOL, k
+        assert rel_err(ds["v_y"][k][ok[0]], (vo[0].astype(np.float64) * 0.3)[ok[0]], floor=0.05 * 0.3) <= TOL, k
