@@ -1,6 +1,7 @@
 """Randomised differential test of the CALLERS of the kernels: get_piv per time step (random chunk sizes: chunked == one
 call bit for bit, and both against the oracle's get_ffpiv), ensemble mode (random chunk sizes, thresholds), the plane
-volume.  Prints one line per case and a summary; exits non-zero on any violation.  usage: fuzz_modes.py <seed> <cases>"""
+volume.  Prints one line per case and a summary; exits non-zero on any violation.  usage: fuzz_modes.py <seed> <cases>
+FUZZ_MODE=timestep|ensemble|planes: every case in that mode; FUZZ_WIDE=1: wide window grids (more columns than a job strip)."""
 import os, sys, time, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -32,6 +33,9 @@ for case in range(n_cases):
         mode = os.environ["FUZZ_MODE"]
     T = int(rng.integers(3, 9)) if ws > 40 or rng.random() < 0.5 else int(rng.integers(20, 70))
     H = int(rng.integers(2 * ws, 4 * ws + 9)); W = int(rng.integers(2 * ws, 5 * ws + 9))
+    if os.environ.get("FUZZ_WIDE") and ws_e <= 64:   # grids of 26 ... 70 columns: wider than the walking kernels' job strips (24 / 32 windows)
+        W = ws_e + (ws_e - ov_e) * int(rng.integers(25, 70)) + int(rng.integers(0, 5)); H = int(rng.integers(2 * ws, 3 * ws + 9))
+        T = int(rng.integers(3, 7)) if rng.random() < 0.7 else int(rng.integers(26, 32))
     dtype = rng.choice([np.uint8, np.float32, np.float64])
     fr = particle_stack(T, H, W, seed=int(rng.integers(1 << 30)), density=float(rng.uniform(0.02, 0.07)))
     if dtype != np.uint8:

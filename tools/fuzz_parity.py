@@ -1,5 +1,5 @@
 """Randomised differential test: the HIP path vs the C oracle over random shapes / dtypes / windows / overlaps /
-thresholds.  Prints one line per case and a summary; exits non-zero on any gate violation."""
+thresholds.  Prints one line per case and a summary; exits non-zero on any gate violation.  FUZZ_WIDE=1: wide window grids."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -20,6 +20,8 @@ for case in range(n_cases):
     wsy = ws if rng.random() < 0.8 else int(rng.choice([8, 16, 20, 32, 80, 136]))
     ov = (int(rng.integers(0, wsy)), int(rng.integers(0, ws)))
     H = int(rng.integers(wsy, wsy * 4 + 7)); W = int(rng.integers(ws, ws * 5 + 9)); T = int(rng.integers(2, 6)) if rng.random() < 0.6 else int(rng.integers(6, 14)) if rng.random() < 0.8 or ws > 40 else int(rng.integers(26, 60))   # sometimes across a 25-pair anchor
+    if os.environ.get("FUZZ_WIDE") and ws <= 64:   # grids of 26 ... 70 columns: wider than the walking kernels' job strips (24 / 32 windows)
+        W = ws + max(ws - ov[1], 1) * int(rng.integers(25, 70)) + int(rng.integers(0, 5)); H = int(rng.integers(wsy, 2 * wsy + 9))
     dtype = rng.choice([np.uint8, np.float32, np.float64])
     thr = None if rng.random() < 0.6 else float(rng.uniform(0, 0.6))
     fr = particle_stack(T, H, W, seed=int(rng.integers(1 << 30)), density=float(rng.uniform(0.01, 0.08)))
