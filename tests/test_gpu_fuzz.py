@@ -43,6 +43,17 @@ def test_fuzz_ensemble_every_window(gpu, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tool,seed,n", [("fuzz_parity.py", 701, 60), ("fuzz_modes.py", 711, 60)])
+def test_fuzz_on_wide_window_grids(gpu, tool, seed, n):
+    """FUZZ_WIDE=1: grids of 26 ... 70 columns -- wider than the walking kernels' job strips (24 / 32 windows), which the small
+    frames of the runs above never are."""
+    env = dict(os.environ, FUZZ_WIDE="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(seed), str(n)], capture_output=True, text=True, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert f"{n} cases, 0 failures" in out.stdout
+
+
+@pytest.mark.gpu
 def test_fuzz_rows(gpu):
     """tools/fuzz_rows.py: filters, both projections, masks and int16 packing against their oracles over random shapes
     (odd widths, single frames, tiny frames), dtypes and parameters."""
