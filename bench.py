@@ -579,6 +579,17 @@ def main():
         gpu_block = np.empty((4, a.pairs, n_rows, n_cols), dtype=np.float32)
         _lib.check(lib.lspiv_memcpy_d2h(_lib.ptr(gpu_block), d_out, gpu_block.nbytes))
         base = cb.run(sample, ws, ov, gpu_block[:, :n_s])
+        if is_c2 and not a.no_extras and n_s >= 3:
+            # ensemble mode on the full window grids of configs[1] / [2], three pairs: the product against the numpy oracle
+            from pyorc_amd import piv
+
+            base["ensemble_parity"] = []
+            for ews, eov in (((32, 32), (16, 16)), ((64, 64), (48, 48))):
+                ens = piv.Ensemble((H, W), ews, eov)
+                ens.accumulate(sample[:4], 0.2, 3.0)
+                eu, ev, _ = ens.finish(0.2, 1)
+                ens.close()
+                base["ensemble_parity"].append(cb.ensemble_parity(sample[:4], ews, eov, eu, ev, 0.2, 3.0, 0.2))
         out["cpu_baseline"] = base
         if base.get("value"):
             out["config"]["speedup_vs_cpu_baseline"] = round(pairs_per_s / base["value"], 1)

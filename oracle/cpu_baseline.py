@@ -109,3 +109,29 @@ def ties_report(gpu_block, ref, tie) -> dict:
         rep["first"] = [{"pair_row_col": [int(k) for k in i], "gpu_uv": [float(gu[i]), float(gv[i])],
                          "oracle_uv": [float(ru[i]), float(rv[i])], "corr": float(ref[2][i])} for i in map(tuple, idx[:16])]
     return rep
+
+
+def ensemble_parity(frames_sample: np.ndarray, ws, ov, got_u, got_v, corr_min: float, s2n_min: float, count_min: float) -> dict:
+    """Ensemble mode (pyorc/velocimetry/ffpiv.py:182-376) of the numpy oracle on a few frames of the benchmark stack against the
+    product's u, v (1, n_rows, n_cols) for the same frames: every window but exact ties of the oracle's mean-plane maximum."""
+    from . import piv_oracle as po
+
+    T = frames_sample.shape[0]
+    t0 = time.perf_counter()
+    ref = po.get_ffpiv(frames_sample, np.ones(T - 1), tuple(ws), tuple(ov), 1.0, 1.0, ensemble_corr=True, corr_min=corr_min,
+                       s2n_min=s2n_min, count_min=count_min)
+    dt = time.perf_counter() - t0
+    cmean = np.asarray(ref["corr_mean"], dtype=np.float64).reshape(-1, ws[0] * ws[1])
+    with np.errstate(all="ignore"):
+        top2 = np.sort(np.nan_to_num(cmean, nan=-1.0), axis=1)[:, -2:]
+        tie = ((top2[:, 1] > 0) & (top2[:, 0] >= top2[:, 1] * (1.0 - 1e-9))).reshape(ref["v_x"].shape[1:])
+    worst, nan_bad = 0.0, 0
+    for g, k in ((got_u, "v_x"), (got_v, "v_y")):
+        g, r = np.asarray(g, dtype=np.float64).reshape(tie.shape), np.asarray(ref[k], dtype=np.float64)[0]
+        nan_bad += int((np.isnan(g) != np.isnan(r))[~tie].sum())
+        with np.errstate(all="ignore"):
+            e = (np.abs(g - r) / np.maximum(np.abs(r), 0.05))[~tie]
+        if np.isfinite(e).any():
+            worst = max(worst, float(np.nanmax(e)))
+    return {"window": list(ws), "overlap": list(ov), "pairs": T - 1, "windows_checked": int((~tie).sum()), "exact_ties_set_aside": int(tie.sum()),
+            "max_rel_err_vs_oracle": float(f"{worst:.3e}"), "nan_mismatch": nan_bad, "oracle_s": round(dt, 2)}

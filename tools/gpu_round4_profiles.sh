@@ -32,6 +32,7 @@ import json, sys
 d = json.load(open(f'gpurun_out/{sys.argv[1]}_out/bench.json')); c = d.get('cpu_baseline', {})
 print('bench', d['value'], d['ms_per_step'], d['roofline']['kernel_ms_per_launch'], d['roofline'].get('traffic'), d['roofline']['frac'], d['config']['binary']['binary_hash_matches'])
 print(c.get('value'), c.get('cores'), {k: v for k, v in c.items() if k.startswith('parity') and not isinstance(v, dict)})
+print('ensemble parity', c.get('ensemble_parity'))
 for o in d['config'].get('other_configs', []): print(o['workload'][:60], o['pairs_per_s'], o['launch_ms'], o.get('kernel_ms'), o['roofline']['frac'], o['roofline'].get('traffic'), o.get('final_fit_rescue'), o.get('finish_ms'))
 print(d['config'].get('host_fed_pairs_per_s')); print(d['config'].get('camera_to_velocity_pairs_per_s'))
 PY
