@@ -1083,13 +1083,16 @@ def test_ensemble_rescue_of_the_final_fit(gpu, monkeypatch):
     assert st6["rescued"] == 0 and np.array_equal(u6, u0, equal_nan=True)
 
 
-@pytest.mark.parametrize("ws,dtype", [(64, np.uint8), (64, np.float32), (24, np.float64), (9, np.uint8), (40, np.float32), (96, np.uint8)])
-def test_ensemble_rescue_other_kernels(gpu, ws, dtype):
+@pytest.mark.parametrize("ws,dtype,wide", [(64, np.uint8, 0), (64, np.float32, 0), (24, np.float64, 0), (9, np.uint8, 0), (40, np.float32, 0), (96, np.uint8, 0),
+                                           (64, np.uint8, 1), (32, np.float32, 1), (32, np.uint8, 1)])   # wide: 39 columns, more than a job strip
+def test_ensemble_rescue_other_kernels(gpu, ws, dtype, wide):
     """The same through get_piv for the other kernel families and sample types (64 x 64 float32 windows do not fit the rescue
     kernel's LDS slice and are read from L2; odd and > 64 px windows come from the embedded / DFT kernels)."""
     from pyorc_amd import frames as F
 
-    fr = _speckle_and_particles(4, 4 * ws + 8, 6 * ws + 8, 100 + ws)
+    fr = _speckle_and_particles(4, (3 if wide else 4) * ws + 8, (20 if wide else 6) * ws + 8, 100 + ws)
+    if wide:
+        fr = np.ascontiguousarray(fr[:, :, ::-1])   # the speckle half (where the fits get flagged) on the right: columns beyond the first strip
     if dtype != np.uint8:
         fr = fr.astype(dtype) * 0.5 - 3.0      # (the empty background stays exactly constant)
     ws_e = int(np.round(ws / 2.0) * 2)
