@@ -268,6 +268,86 @@ def test_xarray_branches_of_the_mirrors(monkeypatch):
             importlib.reload(mod)
 
 
+def test_pyorc_installed_branch_of_get_piv(monkeypatch):
+    """The tail of the reference accessor (pyorc/api/frames.py:156-196) in ``pyorc_amd.frames.get_piv``: frames that carry a camera
+    configuration (``da.frames.camera_config``) take window size and resolution from a COPY of it, and the result goes through
+    ``ds.velocimetry.add_xy_coords(mesh_coords, coords, attrs)``, ``ds.attrs`` (+ the camera configuration as JSON, with an overridden
+    window size) and ``ds.velocimetry.set_encoding()``.  pyorc / xarray are not installed here: doubles of exactly the members
+    the branch touches (signatures as in the reference), the GPU call replaced by the oracle."""
+    import importlib
+    import sys
+    import types
+
+    from oracle import c_oracle
+    from pyorc_amd.synth import particle_stack
+    from tests import fake_xarray
+
+    calls = {}
+
+    class CameraConfig:
+        def __init__(self):
+            self.window_size, self.resolution = 25, 0.02
+
+        def to_json(self):
+            return f'{{"window_size": {self.window_size}, "resolution": {self.resolution}}}'
+
+    class FramesAccessor:
+        def __init__(self, obj, cc):
+            self._obj, self.camera_config = obj, cc
+
+        def get_piv_coords(self, window_size, search_area_size, overlap):     # pyorc/api/frames.py:60-111
+            calls["get_piv_coords"] = (tuple(window_size), tuple(search_area_size), tuple(overlap))
+            return {"x": None, "y": None}, {"xp": "XP", "yp": "YP", "xs": "XS", "ys": "YS", "lon": "LON", "lat": "LAT"}
+
+    class VelocimetryAccessor:
+        def __init__(self, ds):
+            self.ds = ds
+
+        def add_xy_coords(self, mesh_coords, coords, attrs):                  # pyorc/api/velocimetry.py (same argument order)
+            calls["add_xy_coords"] = (mesh_coords, {k: np.asarray(v) for k, v in coords.items()}, attrs)
+            return self.ds
+
+        def set_encoding(self):
+            calls["set_encoding"] = calls.get("set_encoding", 0) + 1
+
+    monkeypatch.setattr(fake_xarray.Dataset, "velocimetry", property(lambda self: VelocimetryAccessor(self)), raising=False)
+    pyorc = types.ModuleType("pyorc")
+    pyorc.const = types.ModuleType("pyorc.const")
+    pyorc.const.PERSPECTIVE_ATTRS, pyorc.const.GEOGRAPHICAL_ATTRS = {"xp": {"axis": "X"}}, {"lon": {"units": "degrees_east"}}
+    monkeypatch.setitem(sys.modules, "pyorc", pyorc)
+    monkeypatch.setitem(sys.modules, "pyorc.const", pyorc.const)
+    monkeypatch.setitem(sys.modules, "xarray", fake_xarray)
+    import pyorc_amd.frames as F
+    import pyorc_amd.velocimetry as V
+
+    for mod in (V, F):
+        importlib.reload(mod)
+    try:
+        monkeypatch.setattr(V.piv, "piv_pairs", lambda fr, ws, ov, thr=None, pair_offset=0: tuple(a.astype(np.float32) for a in c_oracle.piv_pairs(np.asarray(fr), ws, ov, thr)))
+        monkeypatch.setattr(V.window, "available_memory", lambda: 1e12)
+        fr = particle_stack(5, 96, 128, seed=5)
+        t = np.arange(5) / 25.0
+        da = fake_xarray.DataArray(fr, ("time", "y", "x"), {"time": t, "y": np.arange(96)[::-1] * 0.02, "x": np.arange(128) * 0.02}, attrs={"h_a": 1.5})
+        cc = CameraConfig()
+        da.frames = FramesAccessor(da, cc)
+        ds = F.get_piv(da)                                     # window 25 from the camera configuration -> 24 x 24, overlap int(round(25) / 2) = 12
+        assert calls["get_piv_coords"] == ((24, 24), (24, 24), (12, 12)) and calls["set_encoding"] == 1
+        mesh, coords, attrs = calls["add_xy_coords"]
+        assert mesh["lon"] == "LON" and attrs == {"xp": {"axis": "X"}, "lon": {"units": "degrees_east"}}
+        assert coords["x"].shape == (9,) and coords["y"].shape == (7,) and ds["v_x"].values.shape == (4, 7, 9)
+        assert ds.attrs["h_a"] == 1.5 and ds.attrs["camera_config"] == '{"window_size": 25, "resolution": 0.02}'
+        ref = F.get_piv(fr, 25, time=t, resolution=0.02)      # the same numbers as the plain-array call with the configuration's values
+        for k in ref:
+            assert np.array_equal(ds[k].values, ref[k], equal_nan=True)
+        ds = F.get_piv(da, window_size=32)                     # an argument overrides the COPY: the JSON carries it, the frames' own object does not
+        assert calls["get_piv_coords"] == ((32, 32), (32, 32), (16, 16)) and '"window_size": 32' in ds.attrs["camera_config"]
+        assert cc.window_size == 25 and calls["set_encoding"] == 2
+    finally:
+        monkeypatch.undo()
+        for mod in (V, F):
+            importlib.reload(mod)
+
+
 def test_prime_factor_size_lists_agree(lib):
     """The Makefile's PFA_SIZES (one translation unit per size), common.h's LSPIV_PFA_SIZES (declarations + dispatch) and the
     instantiation files on disk name the same window sizes, and the dispatcher sends exactly those to kind 8."""
