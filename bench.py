@@ -565,6 +565,7 @@ def main():
             "gather_end_after_kernel_end_ms": mean(lag),
             "exposed_comm_ms": round(dt / a.steps * 1e3 - float(np.mean(km)), 4) if len(km) else None,
             "kernel_ms_alone": round(launch_ms, 4),
+            "gather_stream_priority": "high" if plan.gather_priority > 0 else ("low" if plan.gather_priority < 0 else "default"),
             "rccl_env": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "LSPIV_RCCL_MAX_NCHANNELS", "NCCL_ALGO", "NCCL_PROTO")
                          if os.environ.get(k) is not None},
             **({"same_device_plumbing_test": True} if same_device else {})}

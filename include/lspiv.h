@@ -38,7 +38,8 @@ extern "C" {
 #endif
 
 #define LSPIV_ABI_VERSION 4   /* 4 (round 4, additions only): lspiv_build_info, the float64 rescue of the ensemble's final fit
-                               * (lspiv_ensemble_set_retain / _stats / _flag / _partials / _finish_partials), lspiv_stream_release; 3: lspiv_rescue_stats,
+                               * (lspiv_ensemble_set_retain / _stats / _flag / _partials / _finish_partials), lspiv_stream_release,
+                               * lspiv_stream_create_priority; 3: lspiv_rescue_stats,
                                * lspiv_project_frames_u8[_dev], the rescue / v_sign / norm_clip / std_ddof / round_odd options */
 
 /* status codes (mapped by the Python shim onto the reference's exception types) */
@@ -432,6 +433,10 @@ int lspiv_event_destroy(void* ev);
 /* extra HIP streams for hosts that overlap the result exchange with the next launch (bench.py --gpus N): every "_dev"
  * entry point takes such a handle; events recorded on one stream can be waited for on another. */
 int lspiv_stream_create(void** stream);
+/* the same with a scheduling priority: > 0 the device's highest, < 0 its lowest, 0 = lspiv_stream_create.  pyorc_amd.shard puts the
+ * result exchange on a HIGH-priority stream: RCCL's few workgroups must find a compute unit while a PIV kernel of ~80 000
+ * workgroups is draining through all of them on the other stream. */
+int lspiv_stream_create_priority(void** stream, int priority);
 int lspiv_stream_destroy(void* stream);
 /* a stream the CALLER created (hipStreamCreate) and passed to "_dev" entry points: free what the library keeps for it (the
  * rescue lists and their counters); NULL = the library's own stream.  lspiv_stream_destroy does this for its own streams. */

@@ -134,6 +134,7 @@ SIGNATURES = {
     "lspiv_event_elapsed_ms": (_i32, [_vp, _vp, C.POINTER(_f32)]),
     "lspiv_event_destroy": (_i32, [_vp]),
     "lspiv_stream_create": (_i32, [C.POINTER(_vp)]),
+    "lspiv_stream_create_priority": (_i32, [C.POINTER(_vp), _i32]),
     "lspiv_stream_destroy": (_i32, [_vp]),
     "lspiv_stream_release": (_i32, [_vp]),
     "lspiv_stream_synchronize": (_i32, [_vp]),

@@ -2339,6 +2339,19 @@ int lspiv_stream_create(void** stream) {
   *stream = s;
   return LSPIV_OK;
 }
+int lspiv_stream_create_priority(void** stream, int priority) {
+  if (!stream) return fail(LSPIV_EINVAL, "stream is NULL");
+  if (priority == 0) return lspiv_stream_create(stream);
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  int least = 0, greatest = 0;   // HIP: numerically LOWER = higher priority
+  HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  hipStream_t s;
+  HIP_TRY(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority > 0 ? greatest : least));
+  *stream = s;
+  return LSPIV_OK;
+}
 int lspiv_stream_destroy(void* stream) {
   if (!stream) return LSPIV_OK;
   // the rescue lists of that stream go with it (a later stream may get the same handle value)

@@ -18,6 +18,7 @@ the time-walking kernels' segments: the gathered result equals the single-GPU re
 
 from __future__ import annotations
 
+import os
 from typing import Callable, List, Optional, Tuple
 
 import numpy as np
@@ -182,7 +183,10 @@ class ShardedPivDev:
         self.recv = [DeviceFrames.empty((comm.world * 4, self.p_max, self.n_win), np.float32) for _ in range(2)]
         self.comp, self.comm_s = C.c_void_p(), C.c_void_p()
         _lib.check(self.lib.lspiv_stream_create(C.byref(self.comp)))
-        _lib.check(self.lib.lspiv_stream_create(C.byref(self.comm_s)))
+        # the exchange on a HIGH-priority stream: the collective's few workgroups get the next free compute units while the PIV
+        # kernel of the following step (tens of thousands of workgroups) drains through all of them (LSPIV_GATHER_STREAM_PRIORITY=0: equal)
+        self.gather_priority = int(os.environ.get("LSPIV_GATHER_STREAM_PRIORITY", "1"))
+        _lib.check(self.lib.lspiv_stream_create_priority(C.byref(self.comm_s), self.gather_priority))
         self.ev_done = [self._event() for _ in range(2)]             # kernels of buffer b finished
         self.ev_gathered = [self._event() for _ in range(2)]         # gather of buffer b finished
         self._gathered_once = [False, False]

@@ -50,9 +50,9 @@ def test_bench_launches_its_own_ranks_and_gathers_over_the_native_comm(gpu):
     # round 4: the step is the library's own sharded path, and the line diagnoses itself
     assert "ShardedPivDev" in comm["path"] and comm["mode"] == "weak" and comm["pairs_total"] == 120 and comm["pairs_rank0"] == 60
     for key in ("kernel_ms_while_gather_in_flight", "gather_ms_overlapped", "exposed_comm_ms", "gather_end_after_kernel_end_ms",
-                "allgather_ms_alone", "kernel_ms_alone", "allgather_bytes_received_per_rank_per_step", "rccl_env"):
+                "allgather_ms_alone", "kernel_ms_alone", "allgather_bytes_received_per_rank_per_step", "rccl_env", "gather_stream_priority"):
         assert key in comm, key
-    assert comm["kernel_ms_while_gather_in_flight"] > 0 and comm["gather_ms_overlapped"] > 0
+    assert comm["kernel_ms_while_gather_in_flight"] > 0 and comm["gather_ms_overlapped"] > 0 and comm["gather_stream_priority"] == "high"
     assert abs(comm["exposed_comm_ms"] - (d["ms_per_step"] - comm["kernel_ms_while_gather_in_flight"])) < 1e-3
     assert d["config"]["binary"]["binary_hash_matches"] is True
 
