@@ -18,6 +18,7 @@ for f in ("bench_2ranks_shm", "bench_2ranks_shm_strong", "bench_torchrun_2ranks_
     except Exception as e:
         print(f, "FAILED", e)
 PY
+timeout 120 python -c 'import __graft_entry__ as g; g.smoke()' 2>&1 | tail -1
 timeout 1200 python -m pytest tests -m gpu -q --timeout 400 2>&1 | tail -4
 export FUZZ_MODE=ensemble FUZZ_DUMP=$R/gpurun_out/r4l/dump
 for s in $(seq 501 532); do timeout 200 python tools/fuzz_modes.py $s 80 > gpurun_out/r4l/fuzz_ens_$s.log 2>&1; grep -E "FAIL|cases," gpurun_out/r4l/fuzz_ens_$s.log | cut -c1-300 | tail -3; done | sort | uniq -c | sort -rn | head -12
