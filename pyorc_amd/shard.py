@@ -133,12 +133,15 @@ def sharded_ensemble(load_frames: Callable[[int, int], np.ndarray], n_pairs: int
     if hasattr(ens, "flag"):
         n_rec = ens.flag(count_min, n_chunks)
         part, ok = ens.partials()
-        all_ok = float(comm.allreduce(np.array([1.0 if ok else 0.0], dtype=np.float64), SUM)[0]) == comm.world
+        # one small MAX all-reduce settles both questions for everybody: did every rank keep its frames, and do all ranks hold the
+        # same list (they do -- identical sums after the all-reduce --; a rank that disagreed would make the next exchange hang)
+        agreed = comm.allreduce(np.array([0.0 if ok else 1.0, float(n_rec), -float(n_rec)], dtype=np.float64), MAX)
+        all_ok = agreed[0] == 0.0 and agreed[1] == -agreed[2]
         if all_ok:
             if n_rec:
                 part = comm.allreduce(part, SUM)
             u, v, cnt = ens.finish_partials(part)
-        else:      # some rank could not keep its frames: float32 fits everywhere (the ranks agree)
+        else:      # some rank could not keep its frames (or the lists differ): float32 fits everywhere (the ranks agree)
             u, v, cnt = ens.finish(count_min, n_chunks)
     else:
         u, v, cnt = ens.finish(count_min, n_chunks)
