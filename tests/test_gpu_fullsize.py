@@ -242,6 +242,11 @@ def test_device_chain_on_a_stack_beyond_2_31_elements(gpu):
     full = cam.to_host()                                         # 2.3 GB of bytes: numpy can still reduce those through time
     host = {k: full[k:k + 2] for k in picks}
     assert np.array_equal(filters.range(cam), fo.time_range(full))
+    # the host entry point on the same 2.3 GB (pageable memory -> pinned staging slots -> HBM in sub-batches cut on the anchors)
+    # against the HBM-resident stack: the same bits
+    import pyorc_amd
+    for a, b in zip(pyorc_amd.piv_pairs(full, (32, 32), (16, 16)), pyorc_amd.piv_pairs(cam, (32, 32), (16, 16))):
+        assert a.shape == (T - 1, 66, 119) and np.array_equal(a, b, equal_nan=True)
 
     norm = filters.normalize(cam, 15)
     mean = full[::round(T / 15)].mean(axis=0).astype("float32")
