@@ -247,6 +247,13 @@ def test_device_chain_on_a_stack_beyond_2_31_elements(gpu):
     import pyorc_amd
     for a, b in zip(pyorc_amd.piv_pairs(full, (32, 32), (16, 16)), pyorc_amd.piv_pairs(cam, (32, 32), (16, 16))):
         assert a.shape == (T - 1, 66, 119) and np.array_equal(a, b, equal_nan=True)
+    # ... and a float64 host stack of 4.6 GB (what project_numpy hands over; narrowed to float32 by the staging threads, past
+    # 2^32 bytes) against the same frames as float32 in HBM
+    f64 = full[:280].astype(np.float64)
+    dev32 = DeviceFrames.from_host(full[:280].astype(np.float32))
+    for a, b in zip(pyorc_amd.piv_pairs(f64, (32, 32), (16, 16)), pyorc_amd.piv_pairs(dev32, (32, 32), (16, 16))):
+        assert np.array_equal(a, b, equal_nan=True)
+    del f64, dev32
 
     norm = filters.normalize(cam, 15)
     mean = full[::round(T / 15)].mean(axis=0).astype("float32")
