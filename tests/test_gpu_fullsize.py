@@ -254,6 +254,7 @@ def test_device_chain_on_a_stack_beyond_2_31_elements(gpu):
     for a, b in zip(pyorc_amd.piv_pairs(f64, (32, 32), (16, 16)), pyorc_amd.piv_pairs(dev32, (32, 32), (16, 16))):
         assert np.array_equal(a, b, equal_nan=True)
     del f64, dev32
+    sub = full[:230].copy()                                      # for the fixed chain below
 
     norm = filters.normalize(cam, 15)
     mean = full[::round(T / 15)].mean(axis=0).astype("float32")
@@ -285,8 +286,18 @@ def test_device_chain_on_a_stack_beyond_2_31_elements(gpu):
     for k in picks:
         ref = pro.project_frames(norm[k:k + 1].to_host(), dst, idx_img, mask, src_idx=src_idx, uidx=uidx, norm_idx=norm_idx)
         assert np.array_equal(ortho[k:k + 1].to_host().astype(np.float64), ref), k
+    # the fixed chain (pipeline.CameraToVelocity) on 230 frames of the same camera stack: one piece, streamed in time chunks, and
+    # the three stages one by one -- the same bits
+    from pyorc_amd.pipeline import CameraToVelocity
+
+    with CameraToVelocity((H, W), dst, idx_img, mask, src_idx, uidx, norm_idx, window_size=(32, 32), overlap=(16, 16), normalize_samples=15) as chain:
+        one = chain.run(sub, streamed=False)
+        streamed = chain.run(sub, streamed=True)
+    staged = pyorc_amd.piv_pairs(p.project_frames(filters.normalize(DeviceFrames.from_host(sub), 15), keep_uint8=False), (32, 32), (16, 16))
+    for a, b, c in zip(one, streamed, staged):
+        assert a.shape == (229, 49, 89) and np.array_equal(a, b, equal_nan=True) and np.array_equal(a, c, equal_nan=True)
     p.close()
-    del norm
+    del norm, sub
 
     ds = F.get_piv(ortho, 32, time=np.arange(T) / 30.0, resolution=0.01)
     assert ds["v_x"].shape == (T - 1, 49, 89)
