@@ -84,7 +84,7 @@ def test_mask_wrapper_assertions_without_device():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,shape", [(0, (12, 9, 11)), (1, (2, 3, 70)), (2, (40, 17, 5))])
+@pytest.mark.parametrize("seed,shape", [(0, (12, 9, 11)), (1, (2, 3, 70)), (2, (40, 17, 5)), (3, (400, 66, 119))])   # the last: a 1080p grid over 400 pairs
 def test_gpu_masks_equal_oracle(gpu, seed, shape):
     from pyorc_amd import mask as pm
 
