@@ -289,5 +289,14 @@ def test_gpu_project_cv_matches_oracle(gpu, dtype):
         assert np.array_equal(p.project_frames(fr[0]), ref[0])
         p.close()
     assert np.array_equal(project_cv(fr, Kc, dist, M, (300, 400)), pj.project_cv(fr, Kc, dist, M, (300, 400)))
+    # a 1080p camera to a 1080p ortho grid (intrinsics scaled by 3): the quad plan of the remap at the size it was built for
+    big = (rng.random((2, 1080, 1920)) * 255).astype(np.uint8)
+    big = big if dtype == np.uint8 else (big.astype(np.float32) - 100.5) * 0.25
+    K3 = Kc * np.array([[3.0], [2.25], [1.0]])
+    M3 = np.array([[0.9, 0.05, 30.0], [0.02, 0.95, 12.0], [4e-6, 7e-6, 1.0]])
+    p = ProjectionCV((1080, 1920), (1080, 1920), K3, dist, M3)
+    ref = pj.project_cv(big, K3, dist, M3, (1080, 1920))
+    assert np.array_equal(p.project_frames(big), ref) and np.array_equal(p.project_frames(DeviceFrames.from_host(big)).to_host(), ref)
+    p.close()
     with pytest.raises(_lib.LspivError):
         ProjectionCV((480, 640), (10, 10), Kc, [0.1, 0.2, 0.3], M)
