@@ -96,7 +96,7 @@ def test_gpu_masks_equal_oracle(gpu, seed, shape):
     got, ref = pm.run_mask(f, "angle", [0.5 * np.pi, 0.25 * np.pi]), mo.angle(f)
     with np.errstate(invalid="ignore"):
         edge = np.abs(np.abs(np.arctan2(f[0], f[1]) - np.float32(0.5 * np.pi)) - np.float32(0.25 * np.pi)) < 1e-5
-    assert np.array_equal(got[~edge], ref[~edge]) and edge.sum() < 3          # atan2f is not correctly rounded
+    assert np.array_equal(got[~edge], ref[~edge]) and edge.sum() < max(3, 2e-5 * edge.size)   # atan2f is not correctly rounded: cells within 1e-5 rad of the tolerance
     assert np.array_equal(pm.time_mean(f), mo.time_mean(f), equal_nan=True)
     for m in (mo.minmax(f), mo.count(f)):
         assert np.array_equal(pm.apply_mask(f, m), mo.apply(f, m), equal_nan=True)
