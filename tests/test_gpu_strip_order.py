@@ -25,7 +25,7 @@ def run(tmp_path, tag, strip_w, args):
     return np.load(out)
 
 
-@pytest.mark.parametrize("ws,ov,dtype,H,W,pairs,ens", [
+@pytest.mark.parametrize("args", [
     (32, 16, "float32", 400, 1000, 30, 0),     # 61 columns: two strips of 24 + a remainder of 13
     (32, 16, "float64", 300, 340, 27, 0),      # 20 columns: narrower than a strip
     (64, 48, "uint8", 300, 1200, 26, 0),       # 72 columns: two strips of 32 + 8
@@ -33,10 +33,12 @@ def run(tmp_path, tag, strip_w, args):
     (32, 16, "float32", 300, 900, 30, 1),
     (64, 48, "uint8", 200, 1200, 6, 2),        # ... and the plane volume
     (32, 16, "float32", 200, 900, 7, 2),
+    (64, 48, "uint8", 300, 1200, 26, 0, 0.3),  # the signal-threshold variants of the kernels
+    (64, 48, "uint8", 300, 1200, 30, 1, 0.3),
+    (32, 16, "float32", 300, 900, 30, 1, 0.3),
     (32, 16, "uint8", 300, 900, 30, 0),        # row-major by default: a strip order forced on it changes nothing either
 ])
-def test_results_do_not_depend_on_the_job_order(gpu, tmp_path, ws, ov, dtype, H, W, pairs, ens):
-    args = (ws, ov, dtype, H, W, pairs, ens)
+def test_results_do_not_depend_on_the_job_order(gpu, tmp_path, args):
     ref = run(tmp_path, "default", None, args)
     for sw in (0, 7):
         got = run(tmp_path, f"w{sw}", sw, args)
