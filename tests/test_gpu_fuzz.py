@@ -62,3 +62,15 @@ def test_fuzz_rows(gpu):
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "150 cases, 0 failures" in out.stdout
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("switch", ["LSPIV_NORM_FRAME_MAJOR=1", "LSPIV_BLUR_BLOCK=1", "LSPIV_PROJECT_ONE_CELL=1", "LSPIV_PROJECT_FPT=4", "LSPIV_PROJECT_GX=0"])
+def test_fuzz_rows_under_the_ab_switches(gpu, switch):
+    """The kernels kept behind environment switches for A/B timing (frame-major normalize, tile-per-block blur, one-cell projection,
+    other frames-per-thread / grid shapes) must still give the oracles' bits: a comparison against a broken alternative is worthless."""
+    k, v = switch.split("=")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_rows.py"), "41", "80"], capture_output=True, text=True, cwd=ROOT,
+                         env=dict(os.environ, **{k: v}))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "80 cases, 0 failures" in out.stdout
