@@ -37,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from pyorc_amd import _lib, window  # noqa: E402
+from pyorc_amd import comm as _comm_mod  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VALU_TFLOPS = 157.3
@@ -566,8 +567,11 @@ def main():
             "exposed_comm_ms": round(dt / a.steps * 1e3 - float(np.mean(km)), 4) if len(km) else None,
             "kernel_ms_alone": round(launch_ms, 4),
             "gather_stream_priority": "high" if plan.gather_priority > 0 else ("low" if plan.gather_priority < 0 else "default"),
-            "rccl_env": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "LSPIV_RCCL_MAX_NCHANNELS", "NCCL_ALGO", "NCCL_PROTO")
-                         if os.environ.get(k) is not None},
+            # NCCL_MAX_NCHANNELS: what was in force when the RCCL communicator was created (pyorc_amd.comm sets its default only
+            # around ncclCommInitRank and restores the environment afterwards)
+            "rccl_env": {**{k: os.environ.get(k) for k in ("NCCL_MIN_NCHANNELS", "LSPIV_RCCL_MAX_NCHANNELS", "NCCL_ALGO", "NCCL_PROTO")
+                            if os.environ.get(k) is not None},
+                         **({"NCCL_MAX_NCHANNELS": _comm_mod._rccl_channel_cap.applied} if _comm_mod._rccl_channel_cap.applied else {})},
             **({"same_device_plumbing_test": True} if same_device else {})}
     # ---- CPU baseline on a bounded sample of the same stack (rank 0, N = 1 only) --------------
     if world == 1 and a.cpu_pairs != 0:

@@ -37,7 +37,8 @@
 extern "C" {
 #endif
 
-#define LSPIV_ABI_VERSION 4   /* 4 (round 4, additions only): lspiv_build_info, the float64 rescue of the ensemble's final fit
+#define LSPIV_ABI_VERSION 4   /* (round 5 added lspiv_ensemble_flag_digest and the test hook lspiv_debug_hold_lock; no version change: nothing existing moved)
+                               * 4 (round 4, additions only): lspiv_build_info, the float64 rescue of the ensemble's final fit
                                * (lspiv_ensemble_set_retain / _stats / _flag / _partials / _finish_partials), lspiv_stream_release,
                                * lspiv_stream_create_priority; 3: lspiv_rescue_stats,
                                * lspiv_project_frames_u8[_dev], the rescue / v_sign / norm_clip / std_ddof / round_odd options */
@@ -241,6 +242,10 @@ int lspiv_ensemble_stats(lspiv_ensemble* handle, int64_t* stats);
  *   lspiv_ensemble_finish_partials the fits of the flagged windows from the totals, then the outputs of lspiv_ensemble_finish. */
 #define LSPIV_ENS_PARTIAL_DOUBLES 20
 int lspiv_ensemble_flag(lspiv_ensemble* handle, float count_min, float n_frames, int64_t* n_records);
+/* 64-bit digest (FNV-1a) of the last lspiv_ensemble_flag's sorted records -- window, number of candidates, candidate positions --,
+ * 0 without records: ranks compare it (one MAX all-reduce) before they add their partials POSITIONALLY; the same count of
+ * flagged windows does not prove the same windows (round 5). */
+int lspiv_ensemble_flag_digest(lspiv_ensemble* handle, uint64_t* digest);
 int lspiv_ensemble_partials(lspiv_ensemble* handle, double* partials, int* complete);
 int lspiv_ensemble_finish_partials(lspiv_ensemble* handle, const double* partials, float* u, float* v, float* corr_count,
                                    float* corr_mean);
@@ -461,6 +466,11 @@ int lspiv_debug_fft(int n, int inverse, const float* in, float* out, int64_t cou
 /* Test hook (host only): how the time-walking kernels cut a chunk of n_pairs pairs that starts at absolute pair index
  * pair_offset into segments of seg_len pairs anchored at multiples of seg_len: pairs in the first segment, segment count. */
 int lspiv_debug_segments(int64_t n_pairs, int64_t pair_offset, int seg_len, int64_t* seg_first, int64_t* n_seg);
+
+/* Test hook (host only, no HIP call): hold one of device `device`'s locks -- 0 the host-pointer entry points' workspaces, 1 a launch
+ * and its rescue kernels, 2 the rescue lists -- for `milliseconds`.  The locks are per device (round 5; process-wide before): two
+ * threads holding the same lock of two devices overlap, of one device queue.  tests/test_host.py times exactly that. */
+int lspiv_debug_hold_lock(int device, int which, int milliseconds);
 
 #ifdef __cplusplus
 }

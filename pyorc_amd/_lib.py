@@ -81,6 +81,7 @@ SIGNATURES = {
     "lspiv_ensemble_stats": (_i32, [_vp, _pi64]),
     "lspiv_ensemble_flag": (_i32, [_vp, _f32, _f32, _pi64]),
     "lspiv_ensemble_partials": (_i32, [_vp, _vp, C.POINTER(_i32)]),
+    "lspiv_ensemble_flag_digest": (_i32, [_vp, C.POINTER(C.c_uint64)]),
     "lspiv_ensemble_finish_partials": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "lspiv_ensemble_export": (_i32, [_vp, _vp, _vp]),
     "lspiv_ensemble_import": (_i32, [_vp, _vp, _vp, _i32]),
@@ -153,6 +154,7 @@ SIGNATURES = {
     "lspiv_debug_fft": (_i32, [_i32, _i32, _vp, _vp, _i64]),
     "lspiv_debug_narrow": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp]),
     "lspiv_debug_segments": (_i32, [_i64, _i64, _i32, _pi64, _pi64]),
+    "lspiv_debug_hold_lock": (_i32, [_i32, _i32, _i32]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -169,20 +171,26 @@ def load() -> C.CDLL:
             "`make -C pyorc_amd/csrc` (or __graft_entry__.build())."
         )
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
-        if not hasattr(lib, name) and os.environ.get("LSPIV_LIBRARY"):
-            continue  # an older build loaded for an A/B measurement: it simply lacks the newer entry points
-        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
-        fn.restype = res
-        fn.argtypes = args
     # the binary must come from THIS tree (the .so is a build artefact outside the history): csrc/Makefile compiles the hash
-    # of every library source into it.  A build loaded on purpose through LSPIV_LIBRARY (A/B measurements) is exempt.
-    if not os.environ.get("LSPIV_LIBRARY") and not os.environ.get("LSPIV_ALLOW_STALE"):
+    # of every library source into it.  A build loaded on purpose through LSPIV_LIBRARY (A/B measurements) is exempt.  Checked
+    # BEFORE the prototypes are attached: a build from older sources lacks the newer entry points, and "rebuild" is the message
+    # its user needs, not an AttributeError about a symbol.
+    ab_build = bool(os.environ.get("LSPIV_LIBRARY"))
+    if not ab_build and not os.environ.get("LSPIV_ALLOW_STALE"):
         prov = binary_provenance(lib)
         if prov["binary_hash_matches"] is False:
             raise LspivLibraryStale(
                 f"{LIB_PATH} was built from sources with hash {prov['binary_source_hash']}, the tree has {prov['tree_source_hash']}: "
                 "rebuild (`make -C pyorc_amd/csrc`), or set LSPIV_ALLOW_STALE=1 to load it anyway")
+    for name, (res, args) in SIGNATURES.items():
+        if not hasattr(lib, name):
+            if ab_build:
+                continue  # an older build loaded for an A/B measurement: it simply lacks the newer entry points
+            raise LspivLibraryStale(f"{LIB_PATH} does not export {name} (include/lspiv.h declares it): the binary is older than the "
+                                    "header; rebuild (`make -C pyorc_amd/csrc`)")
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
     _lib = lib
     return lib
 

@@ -104,6 +104,30 @@ def exchange_id(rank: int, world: int, transport: int, path: str, timeout: float
         time.sleep(0.02)
 
 
+class _rccl_channel_cap:
+    """``NCCL_MAX_NCHANNELS = LSPIV_RCCL_MAX_NCHANNELS (default 16)`` for the duration of the block, unless the user set
+    ``NCCL_MAX_NCHANNELS`` himself; the previous environment is restored on exit.  ``applied`` records what RCCL saw."""
+
+    applied: Optional[str] = None   # class-wide: the value in force when the last RCCL communicator was created
+
+    def __init__(self, active: bool):
+        self.active = active
+        self.touched = False
+
+    def __enter__(self):
+        if self.active:
+            if "NCCL_MAX_NCHANNELS" not in os.environ:
+                os.environ["NCCL_MAX_NCHANNELS"] = os.environ.get("LSPIV_RCCL_MAX_NCHANNELS", "16")
+                self.touched = True
+            _rccl_channel_cap.applied = os.environ["NCCL_MAX_NCHANNELS"]
+        return self
+
+    def __exit__(self, *exc):
+        if self.touched:
+            os.environ.pop("NCCL_MAX_NCHANNELS", None)
+        return False
+
+
 class Comm:
     """A communicator of ``world`` ranks; ``rank`` r must have made device r its current device (RCCL)."""
 
@@ -113,17 +137,19 @@ class Comm:
         if transport not in _TRANSPORTS:
             raise ValueError(f"transport {transport!r} not in {sorted(_TRANSPORTS)}")
         self.rank, self.world, self.transport = int(rank), int(world), transport
-        if transport == "rccl":
-            # The gather runs on RCCL's own kernels NEXT TO the PIV kernel, which saturates the VALUs of every CU it gets: cap
-            # the channels (one workgroup each) RCCL may take unless the user decided otherwise.  16 channels move the
-            # 126 MB / rank result block of a 1000-pair step well inside the step's 6 ms on xGMI and leave > 90 % of the CUs to
-            # the PIV kernel.  Read by RCCL at ncclCommInitRank, i.e. below.
-            os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("LSPIV_RCCL_MAX_NCHANNELS", "16"))
         self._lib = _lib.load()
         self._h = C.c_void_p()
         path = id_file or default_id_file()
         uid = exchange_id(self.rank, self.world, _TRANSPORTS[transport], path, timeout)
-        _lib.check(self._lib.lspiv_comm_init(self.rank, self.world, uid, _TRANSPORTS[transport], C.byref(self._h)))
+        # The gather runs on RCCL's own kernels NEXT TO the PIV kernel, which saturates the VALUs of every CU it gets: cap the
+        # channels (one workgroup each) RCCL may take unless the user decided otherwise (NCCL_MAX_NCHANNELS already set).  16
+        # channels move the 126 MB / rank result block of a 1000-pair step well inside the step's 6 ms on xGMI and leave > 90 % of
+        # the CUs to the PIV kernel.  The variable is set only AROUND ncclCommInitRank and put back afterwards, so that code which
+        # reads the environment later (a child process, another library) does not inherit a cap it never asked for.  RCCL itself
+        # reads such parameters ONCE per process: the first communicator created in a process fixes the value for all later ones
+        # (torch.distributed's included, either way round) -- see INTEGRATION.md, "RCCL settings".
+        with _rccl_channel_cap(transport == "rccl"):
+            _lib.check(self._lib.lspiv_comm_init(self.rank, self.world, uid, _TRANSPORTS[transport], C.byref(self._h)))
         self.barrier()  # every rank has read the id: rank 0 may remove the file
         if self.rank == 0:
             try:

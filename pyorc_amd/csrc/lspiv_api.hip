@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -97,9 +98,25 @@ struct DeviceCtx {
   hipEvent_t staged[2] = {nullptr, nullptr};
   bool arch_ok = false;
 };
-std::mutex g_mu;
-std::mutex g_host_mu;  // host-pointer entry points share one set of workspaces per device: serialise them
+std::mutex g_mu;        // the table of contexts itself (created lazily); never held while another lock is taken
 std::vector<DeviceCtx*> g_ctx;
+// Locks are PER DEVICE ("one host thread (or process) per GPU"): a process that drives several GPUs from several
+// threads serialises only the calls that share a device's workspaces, not all of them (round 4 had three process-wide mutexes:
+// every launch of every device queued behind one lock).  A fixed table, so that an entry point can take its lock before a context
+// exists (and on a machine without a device: slot 0).
+//   host:     host-pointer entry points share one set of workspaces (upload buffer, result buffer, pinned ring) per device
+//   dispatch: the PIV kernel and the rescue kernels of ONE launch share their stream's lists and counters (see dispatch())
+//   lists:    the per-stream rescue lists of a context (DeviceCtx::rescue)
+// Order when nested: host -> dispatch -> lists.
+constexpr int kMaxDevices = 64;
+struct DeviceLocks { std::mutex host, dispatch, lists; };
+DeviceLocks g_locks[kMaxDevices];
+static int current_device_slot() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+  return dev >= 0 && dev < kMaxDevices ? dev : 0;
+}
+static DeviceLocks& locks_here() { return g_locks[current_device_slot()]; }
 
 int get_ctx(DeviceCtx** out) {
   int ndev = 0;
@@ -240,7 +257,7 @@ std::atomic<int> g_opt_rescue_tau{env_opt_def("LSPIV_RESCUE_TAU", 0, 1000000, 40
 // the rescue lists of stream `s`, large enough for a launch of n_tiles windows (a quarter of them "fit", a sixteenth "amb":
 // beyond that the excess keeps its float32 result -- imagery THAT sparse has no usable peaks)
 int rescue_ws(DeviceCtx* c, hipStream_t s, uint32_t n_tiles, lspiv::PivParams* p) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::mutex> lk(locks_here().lists);
   DeviceCtx::RescueWs* ws = nullptr;
   for (auto& w : c->rescue) if (w.stream == s) ws = &w;
   if (!ws) { c->rescue.push_back({s, nullptr, 0, 0, 0}); ws = &c->rescue.back(); }
@@ -319,14 +336,13 @@ int dispatch_kernels(const lspiv::PivParams& p, int dtype, bool ensemble, hipStr
 // lock, so that two host threads launching on the same stream (NULL -> the library's stream) cannot interleave as PIV 1,
 // PIV 2, rescue 1 -- rescue 1 would then consume launch 2's records with launch 1's parameters.  Launches are asynchronous:
 // the lock is held for microseconds.  (The rescue kernels skip a record whose index is outside their launch all the same.)
-std::mutex g_dispatch_mu;
 int dispatch(const lspiv::PivParams& p0, int dtype, bool ensemble, hipStream_t s) {
   if (ensemble || !g_opt_rescue.load()) return dispatch_kernels(p0, dtype, ensemble, s);
   DeviceCtx* c;
   int rc = get_ctx(&c);
   if (rc) return rc;
   lspiv::PivParams p = p0;
-  std::lock_guard<std::mutex> launch_lock(g_dispatch_mu);
+  std::lock_guard<std::mutex> launch_lock(locks_here().dispatch);
   rc = rescue_ws(c, s, p.n_tiles, &p);
   if (rc) return rc;
   rc = dispatch_kernels(p, dtype, false, s);
@@ -425,7 +441,15 @@ struct lspiv_ensemble {
   struct Kept { void* d_frames; bool owned; int dtype; int64_t T; float* d_cmax; };
   std::vector<Kept> kept;
   int retain_mode;          // "_dev" entry point: LSPIV_RETAIN_*; the host entry point always keeps its upload buffers
-  size_t kept_bytes;
+  size_t kept_bytes;        // HBM held BECAUSE of this handle: owned frame copies, the corr_max records, and the borrowed chunks too
+                            // (they are the caller's allocations, but it keeps them alive for the handle): all against the budget
+  // the chunks' masked corr_max records live in a few large blocks (geometric growth) instead of one hipMalloc per accumulate
+  struct CmaxBlock { char* base; size_t cap, used; };
+  std::vector<CmaxBlock> cmax_blocks;
+  // accumulate_dev may run on caller streams while flag / partials / finish run on the context's stream: one event per stream
+  // that accumulated, recorded after each accumulate, waited for by every reader of the sums and of the kept records
+  struct AccEvent { hipStream_t stream; hipEvent_t ev; };
+  std::vector<AccEvent> acc_events;
   bool retain_complete;     // false: some chunk could not be kept (budget, mode NONE, imported state) -> float32 fits stay
   void* d_rescue; size_t rescue_cap;     // EnsRescueHdr (256 B) + records
   double* d_partial; size_t partial_cap;
@@ -433,6 +457,7 @@ struct lspiv_ensemble {
   int64_t last_flagged, last_rescued, last_skipped;
   bool foreign;             // the sums were replaced by lspiv_ensemble_import: they hold other handles' pairs as well
   uint32_t n_rec;           // records of the last lspiv_ensemble_flag (sorted by window), 0 if none
+  uint64_t rec_digest;      // FNV-1a over (w, ncand, pos[0 .. ncand-1]) of those records: what ranks compare before they sum partials
   float flag_min_count;     // count_min * n_frames of that call
 };
 
@@ -444,28 +469,67 @@ static size_t ensemble_retain_budget() {
   return t / 4;
 }
 static void ensemble_drop_kept(lspiv_ensemble* h) {
-  for (auto& k : h->kept) {
+  for (auto& k : h->kept)
     if (k.owned && k.d_frames) (void)hipFree(k.d_frames);
-    if (k.d_cmax) (void)hipFree(k.d_cmax);
-  }
+  for (auto& b : h->cmax_blocks) (void)hipFree(b.base);
   h->kept.clear();
+  h->cmax_blocks.clear();
   h->kept_bytes = 0;
 }
-// keep the masked corr_max of a chunk (the kernels' keep decisions) next to its frames; on any failure the ensemble simply
-// stops being rescuable (retain_complete = false), the accumulation itself is not affected
-static void ensemble_keep(lspiv_ensemble* h, void* d_frames, bool owned, int dtype, int64_t T, const float* d_cmax, hipStream_t s) {
+// n bytes (256-byte granules) from the handle's record blocks; a new block is twice the last one (>= 1 MiB, >= n, <= 1 GiB unless n
+// is larger): a handle that takes hundreds of chunks calls hipMalloc a dozen times, not hundreds
+static void* ensemble_cmax_alloc(lspiv_ensemble* h, size_t n) {
+  n = (n + 255) & ~(size_t)255;
+  if (!h->cmax_blocks.empty()) {
+    auto& b = h->cmax_blocks.back();
+    if (b.used + n <= b.cap) { void* p = b.base + b.used; b.used += n; return p; }
+  }
+  const size_t last = h->cmax_blocks.empty() ? 0 : h->cmax_blocks.back().cap;
+  const size_t cap = std::max(n, std::min<size_t>(std::max<size_t>(2 * last, (size_t)1 << 20), (size_t)1 << 30));
+  void* base = nullptr;
+  if (hipMalloc(&base, cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  h->cmax_blocks.push_back({(char*)base, cap, n});
+  h->kept_bytes += cap;
+  return base;
+}
+// the handle stops being rescuable: what it kept is of no use any more (the float32 fits stay, lspiv_ensemble_stats says so)
+static void ensemble_give_up_retention(lspiv_ensemble* h) {
+  h->retain_complete = false;
+  ensemble_drop_kept(h);
+}
+// keep the masked corr_max of a chunk (the kernels' keep decisions) next to its frames (`frame_bytes` of them: counted against
+// the budget whether the handle owns them or borrows them); on any failure -- budget, allocation, copy -- the ensemble simply stops
+// being rescuable, the accumulation itself is not affected.  Takes ownership of an `owned` buffer either way.
+static void ensemble_keep(lspiv_ensemble* h, void* d_frames, bool owned, size_t frame_bytes, int dtype, int64_t T, const float* d_cmax,
+                          hipStream_t s) {
   const size_t n_tiles = (size_t)(T - 1) * h->g.n_rows * h->g.n_cols;
   void* cm = nullptr;
-  if (hipMalloc(&cm, n_tiles * sizeof(float)) != hipSuccess ||
+  if (h->kept_bytes + frame_bytes + n_tiles * sizeof(float) > ensemble_retain_budget() ||
+      !(cm = ensemble_cmax_alloc(h, n_tiles * sizeof(float))) ||
       hipMemcpyAsync(cm, d_cmax, n_tiles * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
     (void)hipGetLastError();
-    if (cm) (void)hipFree(cm);
     if (owned) (void)hipFree(d_frames);
-    h->retain_complete = false;
+    ensemble_give_up_retention(h);
     return;
   }
   h->kept.push_back({d_frames, owned, dtype, T, (float*)cm});
-  h->kept_bytes += n_tiles * sizeof(float);
+  h->kept_bytes += frame_bytes;
+}
+// accumulate_dev ran on stream `s`: note where that stream stands; readers on another stream wait for it
+static void ensemble_mark_accumulated(lspiv_ensemble* h, hipStream_t s) {
+  lspiv_ensemble::AccEvent* a = nullptr;
+  for (auto& e : h->acc_events) if (e.stream == s) a = &e;
+  if (!a) {
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(s); return; }
+    h->acc_events.push_back({s, ev});
+    a = &h->acc_events.back();
+  }
+  if (hipEventRecord(a->ev, s) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(s); }
+}
+static void ensemble_wait_accumulated(lspiv_ensemble* h, hipStream_t reader) {
+  for (auto& e : h->acc_events)
+    if (e.stream != reader && hipStreamWaitEvent(reader, e.ev, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(e.stream); }
 }
 
 static std::atomic<int> g_opt_walk{-1};   // lspiv_set_option("walk", v); -1: not set, fall back to the environment
@@ -631,7 +695,7 @@ int lspiv_rescue_stats(void* stream, int64_t* stats) {
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   void* base = nullptr;
   {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(locks_here().lists);
     for (auto& w : c->rescue) if (w.stream == s) base = w.base;
   }
   for (int k = 0; k < 5; ++k) stats[k] = 0;
@@ -772,7 +836,7 @@ int lspiv_piv_pairs_dev(const void* d_frames, int dtype, int64_t T, int64_t H, i
 int lspiv_piv_pairs_at(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, int wy, int wx, int oy, int ox,
                        float signal_threshold, int64_t pair_offset, float* u, float* v, float* corr_max, float* s2n,
                        float* corr_planes) {
-  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  std::lock_guard<std::mutex> host_lock(locks_here().host);
   if (!frames || !u || !v || !corr_max || !s2n) return fail(LSPIV_EINVAL, "NULL buffer");
   if (pair_offset < 0) return fail(LSPIV_EINVAL, "pair_offset %lld is negative", (long long)pair_offset);
   Grid g;
@@ -873,7 +937,7 @@ int lspiv_piv_pairs(const void* frames, int dtype, int64_t T, int64_t H, int64_t
 }
 
 int lspiv_u_v_displacement(const float* corr_planes, int64_t P, int64_t n_win, int wy, int wx, float* u, float* v) {
-  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  std::lock_guard<std::mutex> host_lock(locks_here().host);
   if (!corr_planes || !u || !v) return fail(LSPIV_EINVAL, "NULL buffer");
   if (P < 0 || n_win < 0 || wy < 1 || wx < 1 || wy > 4096 || wx > 4096) return fail(LSPIV_EINVAL, "bad shape");
   const int64_t n = P * n_win;
@@ -977,31 +1041,30 @@ int lspiv_ensemble_accumulate_dev(lspiv_ensemble* h, const void* d_frames, int d
   rc = ensemble_launch(h, c, d_frames, dtype, T, corr_min, s2n_min, signal_threshold, d_corr_s2n, d_corr_s2n + n_tiles, s);
   if (rc) return rc;
   // retention for the float64 rescue of the final fit (lspiv_ensemble_set_retain)
-  if (h->retain_mode == LSPIV_RETAIN_NONE || !h->retain_complete || !g_opt_rescue.load()) { h->retain_complete = false; return LSPIV_OK; }
-  if (h->retain_mode == LSPIV_RETAIN_BORROW) {
-    ensemble_keep(h, const_cast<void*>(d_frames), false, dtype, T, d_corr_s2n, s);
-    return LSPIV_OK;
-  }
   const size_t fbytes = (size_t)T * h->H * h->W * elem_size(dtype);
-  void* copy = nullptr;
-  if (h->kept_bytes + fbytes > ensemble_retain_budget() || hipMalloc(&copy, fbytes) != hipSuccess) {
-    (void)hipGetLastError();
-    h->retain_complete = false;
-    return LSPIV_OK;
+  if (h->retain_mode == LSPIV_RETAIN_NONE || !h->retain_complete || !g_opt_rescue.load()) {
+    if (h->retain_complete) ensemble_give_up_retention(h);
+  } else if (h->retain_mode == LSPIV_RETAIN_BORROW) {
+    ensemble_keep(h, const_cast<void*>(d_frames), false, fbytes, dtype, T, d_corr_s2n, s);
+  } else {
+    void* copy = nullptr;
+    if (h->kept_bytes + fbytes > ensemble_retain_budget() || hipMalloc(&copy, fbytes) != hipSuccess) {
+      (void)hipGetLastError();
+      ensemble_give_up_retention(h);
+    } else if (hipMemcpyAsync(copy, d_frames, fbytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+      (void)hipGetLastError(); (void)hipFree(copy);
+      ensemble_give_up_retention(h);
+    } else {
+      ensemble_keep(h, copy, true, fbytes, dtype, T, d_corr_s2n, s);
+    }
   }
-  if (hipMemcpyAsync(copy, d_frames, fbytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
-    (void)hipGetLastError(); (void)hipFree(copy);
-    h->retain_complete = false;
-    return LSPIV_OK;
-  }
-  h->kept_bytes += fbytes;
-  ensemble_keep(h, copy, true, dtype, T, d_corr_s2n, s);
+  ensemble_mark_accumulated(h, s);   // flag / partials / finish (context stream) wait for the sums, the records and the copies
   return LSPIV_OK;
 }
 
 int lspiv_ensemble_accumulate(lspiv_ensemble* h, const void* frames, int dtype, int64_t T, float corr_min,
                               float s2n_min, float signal_threshold, float* corr_max, float* s2n) {
-  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  std::lock_guard<std::mutex> host_lock(locks_here().host);
   if (!h || !frames || !corr_max || !s2n) return fail(LSPIV_EINVAL, "NULL argument");
   DeviceCtx* c;
   int rc = get_ctx(&c);
@@ -1023,7 +1086,7 @@ int lspiv_ensemble_accumulate(lspiv_ensemble* h, const void* frames, int dtype, 
     if (hipMalloc(&own, (size_t)T * frame_bytes) != hipSuccess) { (void)hipGetLastError(); own = nullptr; }
   }
   if (!own) {
-    h->retain_complete = false;
+    if (h->retain_complete) ensemble_give_up_retention(h);
     rc = ensure(&c->d_frames, &c->frames_cap, (size_t)T * frame_bytes);
     if (rc) return rc;
   }
@@ -1066,8 +1129,7 @@ int lspiv_ensemble_accumulate(lspiv_ensemble* h, const void* frames, int dtype, 
   }
   if (own) {
     own_guard.p = nullptr;          // the handle owns it from here
-    h->kept_bytes += (size_t)T * frame_bytes;
-    ensemble_keep(h, own, true, dev_dtype, T, c->d_out, c->stream);
+    ensemble_keep(h, own, true, (size_t)T * frame_bytes, dev_dtype, T, c->d_out, c->stream);
   }
   HIP_TRY(hipMemcpyAsync(corr_max, c->d_out, n_tiles * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(s2n, c->d_out + n_tiles, n_tiles * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -1079,6 +1141,7 @@ int lspiv_ensemble_accumulate(lspiv_ensemble* h, const void* frames, int dtype, 
 // mean planes (count filter) -> c->d_planes, their float32 fits -> c->d_out [u | v]
 static int ensemble_mean_fit(lspiv_ensemble* h, DeviceCtx* c, float min_count) {
   const size_t n_win = (size_t)h->g.n_rows * h->g.n_cols;
+  ensemble_wait_accumulated(h, c->stream);   // accumulate_dev may have run on caller streams
   int rc = ensure(&c->d_planes, &c->planes_cap, n_win * h->wy * h->wx * sizeof(float));
   if (rc) return rc;
   rc = ensure(&c->d_out, &c->out_cap, 2 * n_win * sizeof(float));
@@ -1116,12 +1179,19 @@ static int ensemble_flag(lspiv_ensemble* h, DeviceCtx* c) {
   h->last_flagged = hdr.n_rec;
   h->last_skipped = hdr.n_skipped;
   const uint32_t n_rec = std::min<uint32_t>(hdr.n_rec, n_win);
-  if (n_rec > 1) {   // the kernel appends in whatever order its waves finish: sort (a few records, once per video)
+  uint64_t digest = 0xcbf29ce484222325ull;   // FNV-1a
+  if (n_rec > 0) {   // the kernel appends in whatever order its waves finish: sort (a few records, once per video)
     std::vector<lspiv::EnsRescueRec> recs(n_rec);
     HIP_TRY(hipMemcpy(recs.data(), ensemble_recs(h), n_rec * sizeof(lspiv::EnsRescueRec), hipMemcpyDeviceToHost));
     std::sort(recs.begin(), recs.end(), [](const lspiv::EnsRescueRec& a, const lspiv::EnsRescueRec& b) { return a.w < b.w; });
-    HIP_TRY(hipMemcpy(ensemble_recs(h), recs.data(), n_rec * sizeof(lspiv::EnsRescueRec), hipMemcpyHostToDevice));
+    if (n_rec > 1) HIP_TRY(hipMemcpy(ensemble_recs(h), recs.data(), n_rec * sizeof(lspiv::EnsRescueRec), hipMemcpyHostToDevice));
+    auto mix = [&digest](uint32_t v) { for (int b = 0; b < 4; ++b) { digest ^= (v >> (8 * b)) & 0xffu; digest *= 0x100000001b3ull; } };
+    for (const auto& r : recs) {
+      mix(r.w); mix(r.ncand);
+      for (uint32_t k = 0; k < std::min<uint32_t>(r.ncand, lspiv::kEnsMaxCand); ++k) mix(r.pos[k]);
+    }
   }
+  h->rec_digest = digest;
   h->n_rec = n_rec;
   return LSPIV_OK;
 }
@@ -1132,6 +1202,7 @@ static int ensemble_partials(lspiv_ensemble* h, DeviceCtx* c, bool* complete) {
   const size_t row = (size_t)lspiv::kEnsMaxCand * 5 * sizeof(double);
   int rc = ensure(&h->d_totals, &h->totals_cap, std::max<size_t>(1, h->n_rec) * row);
   if (rc) return rc;
+  ensemble_wait_accumulated(h, c->stream);   // the kept records and frame copies were written on the accumulating streams
   HIP_TRY(hipMemsetAsync(h->d_totals, 0, std::max<size_t>(1, h->n_rec) * row, c->stream));
   *complete = h->retain_complete;
   if (h->n_rec == 0 || !h->retain_complete || h->kept.empty()) return LSPIV_OK;
@@ -1189,7 +1260,7 @@ static int ensemble_deliver(lspiv_ensemble* h, DeviceCtx* c, float* u, float* v,
 }
 
 int lspiv_ensemble_flag(lspiv_ensemble* h, float count_min, float n_frames, int64_t* n_records) {
-  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  std::lock_guard<std::mutex> host_lock(locks_here().host);
   if (!h || !n_records) return fail(LSPIV_EINVAL, "NULL argument");
   DeviceCtx* c;
   int rc = get_ctx(&c);
@@ -1206,8 +1277,14 @@ int lspiv_ensemble_flag(lspiv_ensemble* h, float count_min, float n_frames, int6
   return LSPIV_OK;
 }
 
+int lspiv_ensemble_flag_digest(lspiv_ensemble* h, uint64_t* digest) {
+  if (!h || !digest) return fail(LSPIV_EINVAL, "NULL argument");
+  *digest = h->n_rec ? h->rec_digest : 0;
+  return LSPIV_OK;
+}
+
 int lspiv_ensemble_partials(lspiv_ensemble* h, double* partials, int* complete) {
-  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  std::lock_guard<std::mutex> host_lock(locks_here().host);
   if (!h || !complete || (h->n_rec && !partials)) return fail(LSPIV_EINVAL, "NULL argument");
   DeviceCtx* c;
   int rc = get_ctx(&c);
@@ -1223,7 +1300,7 @@ int lspiv_ensemble_partials(lspiv_ensemble* h, double* partials, int* complete) 
 }
 
 int lspiv_ensemble_finish_partials(lspiv_ensemble* h, const double* partials, float* u, float* v, float* corr_count, float* corr_mean) {
-  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  std::lock_guard<std::mutex> host_lock(locks_here().host);
   if (!h || !u || !v || (h->n_rec && !partials)) return fail(LSPIV_EINVAL, "NULL argument");
   DeviceCtx* c;
   int rc = get_ctx(&c);
@@ -1257,7 +1334,7 @@ int lspiv_ensemble_stats(lspiv_ensemble* h, int64_t* stats) {
 
 int lspiv_ensemble_finish(lspiv_ensemble* h, float count_min, float n_frames, float* u, float* v, float* corr_count,
                           float* corr_mean) {
-  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  std::lock_guard<std::mutex> host_lock(locks_here().host);
   if (!h || !u || !v) return fail(LSPIV_EINVAL, "NULL argument");
   DeviceCtx* c;
   int rc = get_ctx(&c);
@@ -1289,6 +1366,7 @@ int lspiv_ensemble_export(lspiv_ensemble* h, float* corr_sum, float* corr_count)
   int rc = get_ctx(&c);
   if (rc) return rc;
   const size_t n_win = (size_t)h->g.n_rows * h->g.n_cols;
+  ensemble_wait_accumulated(h, c->stream);
   HIP_TRY(hipMemcpyAsync(corr_sum, h->d_sum, n_win * h->wy * h->wx * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(corr_count, h->d_count, n_win * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1304,8 +1382,9 @@ int lspiv_ensemble_import(lspiv_ensemble* h, const float* corr_sum, const float*
   // the sums now hold pairs whose frames this handle never saw.  Replaced by a total over several handles (multi-GPU: the
   // all-reduced state): the staged finish (lspiv_ensemble_flag / _partials / _finish_partials) still reaches every pair, each handle
   // through its own retained chunks.  Added to: this handle's chunks no longer tell which pairs are in the sum -- float32 fits.
-  if (add) h->retain_complete = false;
+  if (add) ensemble_give_up_retention(h);
   else h->foreign = true;
+  ensemble_wait_accumulated(h, c->stream);
   if (!add) {
     HIP_TRY(hipMemcpyAsync(h->d_sum, corr_sum, np * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(h->d_count, corr_count, n_win * sizeof(float), hipMemcpyHostToDevice, c->stream));
@@ -1327,6 +1406,7 @@ int lspiv_ensemble_destroy(lspiv_ensemble* h) {
   if (h->d_count) hipFree(h->d_count);
   if (h->d_part) hipFree(h->d_part);
   ensemble_drop_kept(h);
+  for (auto& e : h->acc_events) (void)hipEventDestroy(e.ev);
   if (h->d_rescue) hipFree(h->d_rescue);
   if (h->d_partial) hipFree(h->d_partial);
   if (h->d_totals) hipFree(h->d_totals);
@@ -1458,7 +1538,7 @@ int lspiv_project_frames_dev(lspiv_projection* h, const void* d_frames, int dtyp
 }
 
 int lspiv_project_frames(lspiv_projection* h, const void* frames, int dtype, int64_t T, float* out) {
-  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  std::lock_guard<std::mutex> host_lock(locks_here().host);
   if (!h || !frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
   if (dtype < 0 || dtype > 2) return fail(LSPIV_EINVAL, "dtype %d not in {0:u8, 1:f32, 2:f64}", dtype);
   if (T <= 0) return LSPIV_OK;
@@ -1496,7 +1576,7 @@ int lspiv_project_frames_u8_dev(lspiv_projection* h, const uint8_t* d_frames, in
 }
 
 int lspiv_project_frames_u8(lspiv_projection* h, const uint8_t* frames, int64_t T, uint8_t* out) {
-  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  std::lock_guard<std::mutex> host_lock(locks_here().host);
   if (!h || !frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
   if (T <= 0) return LSPIV_OK;
   DeviceCtx* c;
@@ -1723,7 +1803,7 @@ int lspiv_project_cv_frames_dev(lspiv_remap* h, const void* d_frames, int dtype,
 }
 
 int lspiv_project_cv_frames(lspiv_remap* h, const void* frames, int dtype, int64_t T, void* out) {
-  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  std::lock_guard<std::mutex> host_lock(locks_here().host);
   if (!h || !frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
   if (dtype != LSPIV_U8 && dtype != LSPIV_F32) return fail(LSPIV_EINVAL, "project_cv takes uint8 or float32 frames (cv2 keeps the frame dtype)");
   if (T <= 0) return LSPIV_OK;
@@ -1764,7 +1844,7 @@ int lspiv_pack_int16_dev(const float* d_values, int64_t n, float scale, int fill
 }
 
 int lspiv_pack_int16(const float* values, int64_t n, float scale, int fill, int16_t* packed) {
-  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  std::lock_guard<std::mutex> host_lock(locks_here().host);
   if (!values || !packed) return fail(LSPIV_EINVAL, "NULL argument");
   if (n <= 0) return n == 0 ? LSPIV_OK : fail(LSPIV_EINVAL, "bad n");
   DeviceCtx* c;
@@ -1818,7 +1898,7 @@ int lspiv_mask_dev(const float* d_fields, int64_t T, int64_t R, int64_t C, int k
 
 int lspiv_mask(const float* fields, int64_t T, int64_t R, int64_t C, int kind, const double* params, int n_params,
                uint8_t* mask) {
-  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  std::lock_guard<std::mutex> host_lock(locks_here().host);
   int rc = check_fields(fields, T, R, C);
   if (rc) return rc;
   if (!mask) return fail(LSPIV_EINVAL, "NULL argument");
@@ -1852,7 +1932,7 @@ int lspiv_mask_apply_dev(float* d_fields, int64_t T, int64_t R, int64_t C, const
 }
 
 int lspiv_mask_apply(float* fields, int64_t T, int64_t R, int64_t C, const uint8_t* mask, int mask_has_time) {
-  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  std::lock_guard<std::mutex> host_lock(locks_here().host);
   int rc = check_fields(fields, T, R, C);
   if (rc) return rc;
   if (!mask) return fail(LSPIV_EINVAL, "NULL argument");
@@ -1886,7 +1966,7 @@ int lspiv_time_mean_dev(const float* d_fields, int64_t T, int64_t R, int64_t C, 
 }
 
 int lspiv_time_mean(const float* fields, int64_t T, int64_t R, int64_t C, float* out) {
-  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  std::lock_guard<std::mutex> host_lock(locks_here().host);
   int rc = check_fields(fields, T, R, C);
   if (rc) return rc;
   if (!out) return fail(LSPIV_EINVAL, "NULL argument");
@@ -1934,7 +2014,7 @@ int lspiv_window_replace_dev(float* d_fields, int64_t T, int64_t R, int64_t C, i
 
 int lspiv_window_replace(float* fields, int64_t T, int64_t R, int64_t C, int x_min, int x_max, int y_min, int y_max,
                          int iter) {
-  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  std::lock_guard<std::mutex> host_lock(locks_here().host);
   int rc = check_fields(fields, T, R, C);
   if (rc) return rc;
   DeviceCtx* c;
@@ -1984,7 +2064,7 @@ int lspiv_time_diff_dev(const void* d_frames, int dtype, int64_t T, int64_t H, i
 }
 
 int lspiv_time_diff(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, float thres, int use_abs, float* out) {
-  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  std::lock_guard<std::mutex> host_lock(locks_here().host);
   if (!frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
   if (dtype < 0 || dtype > 2) return fail(LSPIV_EINVAL, "dtype %d not in {0:u8, 1:f32, 2:f64}", dtype);
   if (T < 2 || H <= 0 || W <= 0) return fail(LSPIV_ESHAPE, "need >= 2 frames of positive size");
@@ -2017,7 +2097,7 @@ int lspiv_time_range_dev(const void* d_frames, int dtype, int64_t T, int64_t H, 
 }
 
 int lspiv_time_range(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, void* out) {
-  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  std::lock_guard<std::mutex> host_lock(locks_here().host);
   if (!frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
   if (dtype < 0 || dtype > 2) return fail(LSPIV_EINVAL, "dtype %d not in {0:u8, 1:f32, 2:f64}", dtype);
   if (T < 1 || H <= 0 || W <= 0) return fail(LSPIV_ESHAPE, "need >= 1 frame of positive size");
@@ -2049,7 +2129,7 @@ int lspiv_minmax_dev(const float* d_frames, int64_t n, float lo, float hi, float
 }
 
 int lspiv_minmax(const float* frames, int64_t n, float lo, float hi, float* out) {
-  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  std::lock_guard<std::mutex> host_lock(locks_here().host);
   if (!frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
   if (n <= 0) return n == 0 ? LSPIV_OK : fail(LSPIV_EINVAL, "bad n");
   DeviceCtx* c;
@@ -2129,7 +2209,7 @@ int lspiv_normalize_dev(const uint8_t* d_frames, int64_t T, int64_t H, int64_t W
 }
 
 int lspiv_normalize(const uint8_t* frames, int64_t T, int64_t H, int64_t W, int samples, uint8_t* out) {
-  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  std::lock_guard<std::mutex> host_lock(locks_here().host);
   if (!frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
   if (T < 1 || H <= 0 || W <= 0) return fail(LSPIV_ESHAPE, "bad shape");
   DeviceCtx* c;
@@ -2164,7 +2244,7 @@ int lspiv_reduce_rolling_dev(const uint8_t* d_frames, int64_t T, int64_t H, int6
 }
 
 int lspiv_reduce_rolling(const uint8_t* frames, int64_t T, int64_t H, int64_t W, int samples, uint8_t* out) {
-  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  std::lock_guard<std::mutex> host_lock(locks_here().host);
   if (!frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
   if (T < 1 || H <= 0 || W <= 0) return fail(LSPIV_ESHAPE, "bad shape");
   DeviceCtx* c;
@@ -2202,7 +2282,7 @@ static int blur_common_dev(const void* d_frames, int dtype, int64_t T, int64_t H
 static int blur_common_host(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, int k1, int k2, float* out) {
   if (!frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
   if (dtype < 0 || dtype > 2 || T < 1 || H <= 0 || W <= 0) return fail(LSPIV_EINVAL, "bad argument");
-  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  std::lock_guard<std::mutex> host_lock(locks_here().host);
   DeviceCtx* c;
   int rc = get_ctx(&c);
   if (rc) return rc;
@@ -2257,7 +2337,7 @@ int lspiv_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes) {
     // a large pageable source (a frame stack, or a time chunk of one): through the two-slot pinned ring, staging threads
     // overlapped with the DMA of the previous slice, like the host entry points -- ~2x the rate of a plain pageable
     // hipMemcpy.  At least four slices per call, so that the un-overlapped first staging step stays a small part of it.
-    std::lock_guard<std::mutex> host_lock(g_host_mu);
+    std::lock_guard<std::mutex> host_lock(locks_here().host);
     rc = stage_ring(c, 1);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));   // the DMA runs on the copy stream: earlier kernels may still use d_dst
@@ -2355,9 +2435,12 @@ int lspiv_stream_create_priority(void** stream, int priority) {
 int lspiv_stream_destroy(void* stream) {
   if (!stream) return LSPIV_OK;
   // the rescue lists of that stream go with it (a later stream may get the same handle value)
-  std::lock_guard<std::mutex> lk(g_mu);
-  for (DeviceCtx* c : g_ctx) {
+  std::vector<DeviceCtx*> ctxs;
+  { std::lock_guard<std::mutex> lk(g_mu); ctxs = g_ctx; }
+  for (size_t d = 0; d < ctxs.size() && d < (size_t)kMaxDevices; ++d) {
+    DeviceCtx* c = ctxs[d];
     if (!c) continue;
+    std::lock_guard<std::mutex> lk(g_locks[d].lists);
     for (size_t k = 0; k < c->rescue.size(); ++k) {
       if (c->rescue[k].stream != (hipStream_t)stream) continue;
       (void)hipStreamSynchronize((hipStream_t)stream);
@@ -2372,10 +2455,13 @@ int lspiv_stream_destroy(void* stream) {
 int lspiv_stream_release(void* stream) {
   // a stream the caller created itself (hipStreamCreate) and handed to "_dev" entry points: drop what the library keeps for it
   // (the rescue lists) -- lspiv_stream_destroy does the same for streams of lspiv_stream_create
-  std::lock_guard<std::mutex> launch_lock(g_dispatch_mu);
-  std::lock_guard<std::mutex> lk(g_mu);
-  for (DeviceCtx* c : g_ctx) {
+  std::vector<DeviceCtx*> ctxs;
+  { std::lock_guard<std::mutex> lk(g_mu); ctxs = g_ctx; }
+  for (size_t d = 0; d < ctxs.size() && d < (size_t)kMaxDevices; ++d) {
+    DeviceCtx* c = ctxs[d];
     if (!c) continue;
+    std::lock_guard<std::mutex> launch_lock(g_locks[d].dispatch);
+    std::lock_guard<std::mutex> lk(g_locks[d].lists);
     const hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     for (size_t k = 0; k < c->rescue.size(); ++k) {
       if (c->rescue[k].stream != s) continue;
@@ -2431,6 +2517,14 @@ int lspiv_debug_narrow(const double* frames, int64_t frame_elems, int64_t n_fram
   lspiv_host::staged_narrow(out, frames, (size_t)frame_elems, (size_t)n_frames, off.data());
   if (offsets) memcpy(offsets, off.data(), off.size() * sizeof(double));
   return lspiv_host::stage_threads();
+}
+int lspiv_debug_hold_lock(int device, int which, int milliseconds) {
+  if (device < 0 || device >= kMaxDevices || which < 0 || which > 2 || milliseconds < 0 || milliseconds > 10000)
+    return fail(LSPIV_EINVAL, "device %d / lock %d / %d ms out of range", device, which, milliseconds);
+  DeviceLocks& l = g_locks[device];
+  std::lock_guard<std::mutex> lk(which == 0 ? l.host : which == 1 ? l.dispatch : l.lists);
+  std::this_thread::sleep_for(std::chrono::milliseconds(milliseconds));
+  return LSPIV_OK;
 }
 int lspiv_debug_segments(int64_t n_pairs, int64_t pair_offset, int seg_len, int64_t* seg_first, int64_t* n_seg) {
   if (n_pairs < 1 || n_pairs > 0x7fffffff || pair_offset < 0 || seg_len < 1 || !seg_first || !n_seg) return LSPIV_EINVAL;

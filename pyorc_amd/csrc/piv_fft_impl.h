@@ -564,10 +564,44 @@ __device__ __forceinline__ void transpose_plane(float* buf, int lg, float (&x)[N
   lds_row_read<N>(buf + row_of<N>(lg) * LR, x);
   __builtin_amdgcn_wave_barrier();
 }
-template <int N>
+// 64 x 64 transpose through HALF the tile: [[A B] [C D]]^T = [[A^T C^T] [B^T D^T]].  The two lane halves first exchange B and C (32
+// v_permlane32_swap), then each half transposes its two 32 x 32 blocks in place through its own 32 x 36-float region (the upper
+// half's region shifted by 32 dwords: other banks): kHalfTileDwords = 2 x 1152 + 32 dwords = 9.3 KB instead of 17.4, no transient
+// registers.  + 2.4 % in the per-timestep kernel (128 swaps per iteration), + 0.4 % in the ensemble kernel, which uses the 8 KB it frees.
+constexpr int kHalfTileDwords = 2 * 32 * 36 + 32;
+__device__ __forceinline__ void transpose_plane_half64(float* buf, int lg, float (&x)[64]) {
+  constexpr int P = 36;
+  const int l = lg & 31;
+  float* reg = buf + (lg >> 5) * (32 * P + 32);
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    unsigned a = __builtin_bit_cast(unsigned, x[j]), b = __builtin_bit_cast(unsigned, x[32 + j]);
+    permlane32_swap(a, b);                       // x[j] of the upper lanes <-> x[32 + j] of the lower lanes
+    x[j] = __builtin_bit_cast(float, a); x[32 + j] = __builtin_bit_cast(float, b);
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int j = 0; j < 32; ++j) reg[j * P + l] = x[32 * h + j];
+    __builtin_amdgcn_wave_barrier();
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(reg + l * P);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 v = r4[q];
+      x[32 * h + 4 * q] = v[0]; x[32 * h + 4 * q + 1] = v[1]; x[32 * h + 4 * q + 2] = v[2]; x[32 * h + 4 * q + 3] = v[3];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+template <int N, bool HALF = false>
 __device__ __forceinline__ void transpose2(float* buf, int lg, float (&xr)[N], float (&xi)[N]) {
-  transpose_plane<N>(buf, lg, xr);
-  transpose_plane<N>(buf, lg, xi);
+  if constexpr (HALF && N == 64) {
+    transpose_plane_half64(buf, lg, xr);
+    transpose_plane_half64(buf, lg, xi);
+  } else {
+    transpose_plane<N>(buf, lg, xr);
+    transpose_plane<N>(buf, lg, xi);
+  }
 }
 
 // inverse transform whose outputs are clipped to [0, 1] for free (clamp modifier of the last butterfly stage) -- the power-of-two
@@ -1121,6 +1155,20 @@ template <int N> constexpr bool kF32Early = LSPIV_F32_EARLY && Geo<N>::FULL;
 #define LSPIV_ENS_LDS_RMW 1
 #endif
 template <int N> constexpr bool kEnsLdsRmw = LSPIV_ENS_LDS_RMW && N == 64;
+// ... and HALF of the partial sum stays in LDS for the whole segment: with the half-tile transposes above a wave's LDS is a 9.3 KB tile
+// + 8 KB = the 17.4 KB it had, so columns 0 .. 31 of every lane's row (the first 8 KB of the lane-ordered slot) are accumulated in
+// LDS and written to the slot ONCE per segment; columns 32 .. 63 keep the round trip through the tile (now 8 KB per iteration each way).
+// Measured (round 5, session a, 1080p 64 x 64 @ 75 %, 1000 pairs, interleaved with the round-4 kernel on one box): 34.6 -> 31.6 ms
+// (28.9 k -> 31.6 k pairs/s), kernel 30.75 ms in the trace; counters: fetched 6.2 GB (was 60: the 8 KB halves of the 256 live jobs of
+// an XCD are 2 MB and now STAY in its 4 MB L2 -- TCC hit rate 94 %), written 27.8 GB (was 64; every store of the upper half still goes
+// out), 67.6 M cycles per launch -- fewer than the per-timestep kernel's 68.3 M -- at 2 198 MHz (was 2 138).  Results agree with the
+// round-4 kernel to the last bits only (the planes' own bits moved: the compiler contracts the symmetric a b + c d of the un-packing
+// step the other way round in the re-shaped iteration), and with themselves exactly across chunkings and job orders (tests).
+#ifndef LSPIV_ENS_HALF_ACC
+#define LSPIV_ENS_HALF_ACC 1
+#endif
+template <int N> constexpr bool kEnsHalfAcc = LSPIV_ENS_HALF_ACC && kEnsLdsRmw<N>;
+constexpr int kEnsHalfAccWaveDwords = kHalfTileDwords + 2048;   // tile | half accumulator (lane-ordered: (j / 4) * 256 + lane * 4 + j % 4, j < 32)
 typedef float __attribute__((address_space(1))) * GlobalF32;
 typedef float __attribute__((address_space(3))) * LdsF32;
 __device__ __forceinline__ GlobalF32 uniform_global_ptr(const float* p) {   // visibly wave-uniform: scalar base + lane offset addressing
@@ -1142,6 +1190,23 @@ __device__ __forceinline__ void slot_prefetch_lds(GlobalF32 slot, float* buf) { 
 #pragma unroll
   for (int qq = 0; qq < N / 16; ++qq) {
     const uint64_t base = reinterpret_cast<uint64_t>(slot) + (uint64_t)qq * 4096u;
+    const uint32_t l = lds + qq * 4096u;
+    uint32_t m0_saved;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(m0_saved) : "v"(voff), "s"(base), "s"(l) : "memory");
+  }
+}
+// the half-accumulator variant: only the slot's second 8 KB (columns 32 .. 63) come in, to the start of the (half) tile
+__device__ __forceinline__ void slot_prefetch_lds_upper(GlobalF32 slot, float* buf) {
+  const uint32_t voff = (threadIdx.x & 63u) * 16u;
+  const uint32_t lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uintptr_t)(LdsF32)buf);
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the transpose's own reads of the tile have returned
+#pragma unroll
+  for (int qq = 0; qq < 2; ++qq) {
+    const uint64_t base = reinterpret_cast<uint64_t>(slot) + 8192u + (uint64_t)qq * 4096u;
     const uint32_t l = lds + qq * 4096u;
     uint32_t m0_saved;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
@@ -1185,6 +1250,55 @@ __device__ __forceinline__ void slot_accumulate(GlobalF32 slot, const float* buf
   }
 }
 
+// the half-accumulator variant of slot_accumulate: columns 0 .. 31 read-modify-write `hacc` (LDS, stays), columns 32 .. 63 take the
+// prefetched upper half of the slot from the tile and go back to HBM
+__device__ __forceinline__ void slot_accumulate_half(GlobalF32 slot, const float* buf, float* hacc, const float (&c0)[64], bool keep0,
+                                                     const float (&c1)[64], bool keep1, bool init_) {
+  const int lane = threadIdx.x & 63;
+  const bool init = __builtin_amdgcn_readfirstlane((int)init_) != 0;
+  const bool any = __builtin_amdgcn_readfirstlane((int)(keep0 || keep1)) != 0;
+  if (!init && !any) { __builtin_amdgcn_s_waitcnt(0x0F70); return; }   // nothing to add; the prefetch still has to land before the tile is reused
+  const float m0 = keep0 ? 1.0f : 0.0f, m1 = keep1 ? 1.0f : 0.0f;
+  float* lacc = hacc + lane * 4;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {           // columns 4 q .. 4 q + 3 < 32: LDS only
+    f32x4 a = init ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : *reinterpret_cast<const f32x4*>(lacc + q * 256);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = fmaf(c1[4 * q + e], m1, fmaf(c0[4 * q + e], m0, a[e]));
+    *reinterpret_cast<f32x4*>(lacc + q * 256) = a;
+  }
+  if (!init) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the upper half of the slot has landed in the tile
+  const float* lsrc = buf + lane * 4;
+  const uint32_t voff = (uint32_t)lane * 16u;
+#pragma unroll
+  for (int qq = 2; qq < 4; ++qq) {
+    f32x4 a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int q = 4 * qq + k;
+      if (init) a[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      else a[k] = *reinterpret_cast<const f32x4*>(lsrc + (q - 8) * 256);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[k][e] = fmaf(c1[4 * q + e], m1, fmaf(c0[4 * q + e], m0, a[k][e]));
+    }
+    slot_store4(reinterpret_cast<uint64_t>(slot) + (uint64_t)qq * 4096u, voff, a);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// end of the segment: the LDS half goes to the first 8 KB of the slot (ensemble_merge_kernel reads the slot as before)
+__device__ __forceinline__ void slot_flush_half(GlobalF32 slot, const float* hacc) {
+  const int lane = threadIdx.x & 63;
+  const float* lacc = hacc + lane * 4;
+  const uint32_t voff = (uint32_t)lane * 16u;
+#pragma unroll
+  for (int qq = 0; qq < 2; ++qq) {
+    f32x4 a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = *reinterpret_cast<const f32x4*>(lacc + (4 * qq + k) * 256);
+    slot_store4(reinterpret_cast<uint64_t>(slot) + (uint64_t)qq * 4096u, voff, a);
+  }
+}
+
 // Order of a segment's jobs over the window grid.  Row-major (strip_w = 0), or column strips of strip_w windows, each strip top
 // to bottom: the jobs that are resident together then span MORE window rows and fewer columns.  64 x 64 @ 75 % overlap: a
 // window row shares 48 of its 64 image rows with the next one, and 256 resident jobs per XCD are 2.2 rows of a 1080p grid -- the
@@ -1217,7 +1331,7 @@ struct WalkCarry {
 // (pair f), their means (DC bins) and NaN flags; the carry moves on to frame f + 1.
 // RELAX: without the scheduling barriers between the phases (a caller with registers to spare: the 32 x 32 ensemble kernel runs two
 // waves per SIMD for its register accumulator and may use 256 VGPRs)
-template <typename T, int N, bool WANT_NZ, bool RELAX = false>
+template <typename T, int N, bool WANT_NZ, bool RELAX = false, bool HALF_TILE = false>
 __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row, bool has2, float* buf, int lg,
                                                int partner_byte, int lane0_byte, WalkCarry<N>& c, float (&xr)[N],
                                                float (&xi)[N], float& mean_a, float& mean_b, bool& skip_a, bool& skip_b,
@@ -1267,7 +1381,7 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
   fft_n<false>(xr, xi);              // along x
   LSPIV_WALK_SB;
   LSPIV_SETPRIO(LSPIV_PRIO_T);
-  transpose2<N>(buf, lg, xr, xi);    // lane = kx, regs = y
+  transpose2<N, HALF_TILE>(buf, lg, xr, xi);    // lane = kx, regs = y
   LSPIV_WALK_SB;
   LSPIV_SETPRIO(0);
   fft_n<false>(xr, xi);              // along y -> Z[ky][kx]
@@ -1301,11 +1415,11 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
   fft_n<true>(xr, xi);                 // along ky
   LSPIV_WALK_SB;
   LSPIV_SETPRIO(LSPIV_PRIO_T);
-  transpose2<N>(buf, lg, xr, xi);      // lane = y, regs = kx
+  transpose2<N, HALF_TILE>(buf, lg, xr, xi);      // lane = y, regs = kx
   if constexpr (kEnsLdsRmw<N>) {
     // 64 x 64 ensemble kernel: the job's tile is free from here to the next iteration's first transpose -- the running partial
     // sum of the job starts its way from HBM into it now (asynchronously, no registers) and is there when the planes are final
-    if (acc_slot) slot_prefetch_lds<N>(acc_slot, buf);
+    if (acc_slot) { if constexpr (HALF_TILE) slot_prefetch_lds_upper(acc_slot, buf); else slot_prefetch_lds<N>(acc_slot, buf); }
   }
   LSPIV_WALK_SB;
   LSPIV_SETPRIO(0);
@@ -1789,7 +1903,8 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsBound<T, N, WANT_NZ>)) void piv_fft
   const int wave = threadIdx.x >> 6;
   const int grp = lane / G::LG;
   const int lg = lane & (G::LG - 1);
-  float* buf = smem + (wave * G::GROUPS + grp) * G::LDS_JOB;
+  float* buf = smem + (wave * G::GROUPS + grp) * (kEnsHalfAcc<N> ? kEnsHalfAccWaveDwords : G::LDS_JOB);
+  float* hacc = buf + kHalfTileDwords;                             // (kEnsHalfAcc: the job's columns 0 .. 31 of the partial sum)
   const int partner_byte = partner_byte_of<N>(lane, lg);
   const int lane0_byte = lane0_byte_of<N>();
   const uint32_t nb = gridDim.x;                                   // XCD-aware block order, as piv_fft_walk_kernel
@@ -1830,7 +1945,7 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsBound<T, N, WANT_NZ>)) void piv_fft
     const bool has2 = f + 1 <= p1;
     float xr[N], xi[N], mean[2];
     bool skip[2], keep[2], dead[2];
-    walk_iteration<T, N, WANT_NZ, kEnsRelax<T, N>>(p, row, has2, buf, lg, partner_byte, lane0_byte, carry, xr, xi, mean[0], mean[1], skip[0], skip[1],
+    walk_iteration<T, N, WANT_NZ, kEnsRelax<T, N>, kEnsHalfAcc<N>>(p, row, has2, buf, lg, partner_byte, lane0_byte, carry, xr, xi, mean[0], mean[1], skip[0], skip[1],
                                                    dead[0], dead[1], (kEnsLdsRmw<N> && !first) ? part_u : nullptr, kEnsLdsRmw<N>);
     if (WANT_NZ && win_dropped) skip[0] = skip[1] = true;
     const bool valid[2] = {job_valid && f > p0, job_valid && has2};
@@ -1871,7 +1986,10 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsBound<T, N, WANT_NZ>)) void piv_fft
         acc[j] += keep[1] ? xi[j] : 0.0f;
       }
     } else if constexpr (kEnsLdsRmw<N>) {
-      if (job_valid) slot_accumulate<N>(part_u, buf, xr, keep[0], xi, keep[1], first);
+      if constexpr (kEnsHalfAcc<N>) {
+        if (job_valid) slot_accumulate_half(part_u, buf, hacc, xr, keep[0], xi, keep[1], first);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+      } else if (job_valid) slot_accumulate<N>(part_u, buf, xr, keep[0], xi, keep[1], first);
       else __builtin_amdgcn_s_waitcnt(0x0F70);   // (a job past the end stores nothing, but its prefetch still has to land before the tile is reused)
       first = false;
     } else {
@@ -1881,6 +1999,9 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsBound<T, N, WANT_NZ>)) void piv_fft
   }
   if constexpr (kEnsRegAcc<N>) {
     if (job_valid) store_plane_rows<N>(part, lg, acc, false);   // fft-shifted layout, like accumulate_planes
+  }
+  if constexpr (kEnsHalfAcc<N>) {
+    if (job_valid) slot_flush_half(part_u, hacc);
   }
   if (job_valid && lg == 0) p.part_cnt[pslot] = cnt;
 }
@@ -1903,8 +2024,9 @@ static hipError_t launch_t(const PivParams& p, bool ensemble, hipStream_t s) {
     const uint64_t wjobs = (uint64_t)p.n_seg * p.n_win;
     PivParams q = p;
     q.strip_w = walk_strip_width<T, N>();
+    constexpr size_t ens_lds = kEnsHalfAcc<N> ? (size_t)WAVES_PER_BLOCK * kEnsHalfAccWaveDwords * 4 : (size_t)G::LDS_BYTES;
     hipLaunchKernelGGL((piv_fft_walk_ensemble_kernel<T, N, WANT_NZ>), dim3((uint32_t)((wjobs + jobs_per_block - 1) / jobs_per_block)),
-                       dim3(BLOCK), G::LDS_BYTES, s, q);
+                       dim3(BLOCK), ens_lds, s, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_ensemble_merge(p.part_sum, p.part_cnt, p.n_seg, p.n_win, G::NN, p.corr_sum, p.corr_count, s, kEnsLdsRmw<N> ? N : 0);

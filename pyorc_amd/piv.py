@@ -129,6 +129,7 @@ class Ensemble:
         _lib.check(lib.lspiv_ensemble_begin(dim_size[0], dim_size[1], window_size[0], window_size[1],
                                             overlap[0], overlap[1], C.byref(self._h)))
         self._held = []   # DeviceFrames chunks the handle borrows until finish (float64 rescue of the final fit)
+        self._retain_mode = None   # set_retain not called yet: accumulate() of a DeviceFrames chunk picks RETAIN_BORROW
 
     RETAIN_NONE, RETAIN_COPY, RETAIN_BORROW = 0, 1, 2
 
@@ -136,6 +137,9 @@ class Ensemble:
         """How ``accumulate_dev`` keeps the chunks for the float64 rescue of the final fit (include/lspiv.h,
         ``lspiv_ensemble_set_retain``): 0 nothing (float32 fits), 1 the handle copies them, 2 it borrows the caller's pointers."""
         _lib.check(_lib.load().lspiv_ensemble_set_retain(self._h, int(mode)))
+        self._retain_mode = int(mode)
+        if int(mode) != self.RETAIN_BORROW:
+            self._held = []   # nothing is borrowed from here on; what was kept so far the handle drops with the next accumulate
 
     def stats(self) -> dict:
         """Counters of the last ``finish``: windows flagged / re-evaluated in float64 / left with their float32 fit, chunks and
@@ -156,11 +160,19 @@ class Ensemble:
             from .device import DeviceFrames
 
             d = DeviceFrames.empty((2, P, n_win), np.float32)
-            # an HBM-resident stack stays alive as long as this object holds it: the handle borrows the pointer (no copy) and
-            # the final fit can go back to the frames
-            self.set_retain(self.RETAIN_BORROW)
-            self._held.append(a)
+            # an HBM-resident stack stays alive as long as this object holds it: unless the caller chose a mode (set_retain: it is respected),
+            # the handle borrows the pointer (no copy) and the final fit can go back to the frames.  The borrowed bytes count
+            # against the handle's budget (LSPIV_ENSEMBLE_RETAIN_BYTES, a quarter of the HBM by default): beyond it the handle
+            # gives the rescue up (stats()["retain_complete"] False, float32 fits) and this object lets go of every chunk --
+            # a caller streaming more chunks through one ensemble than the budget holds is not pinned into an out-of-memory
+            if self._retain_mode is None:      # no choice made: borrow
+                _lib.check(_lib.load().lspiv_ensemble_set_retain(self._h, self.RETAIN_BORROW))
+                self._retain_mode = self.RETAIN_BORROW
+            if self._retain_mode == self.RETAIN_BORROW:
+                self._held.append(a)
             self.accumulate_dev(a.ptr, a.dtype, a.shape[0], corr_min, s2n_min, d.ptr, signal_threshold)
+            if self._held and not self.stats()["retain_complete"]:
+                self._held = []
             res = d.to_host()
             return np.ascontiguousarray(res[0]), np.ascontiguousarray(res[1])
         cm = np.empty((P, n_win), dtype=np.float32)
@@ -198,6 +210,12 @@ class Ensemble:
         _lib.check(_lib.load().lspiv_ensemble_flag(self._h, float(count_min), float(n_frames), C.byref(n)))
         self._n_rec = int(n.value)
         return self._n_rec
+
+    def flag_digest(self) -> int:
+        """64-bit digest of the last ``flag``'s sorted records (window, candidates): equal on ranks that flagged the same list."""
+        d = C.c_uint64(0)
+        _lib.check(_lib.load().lspiv_ensemble_flag_digest(self._h, C.byref(d)))
+        return int(d.value)
 
     def partials(self):
         """(partials (n_records, 20) float64 over THIS handle's retained chunks, complete: bool)."""

@@ -135,8 +135,12 @@ def sharded_ensemble(load_frames: Callable[[int, int], np.ndarray], n_pairs: int
         part, ok = ens.partials()
         # one small MAX all-reduce settles both questions for everybody: did every rank keep its frames, and do all ranks hold the
         # same list (they do -- identical sums after the all-reduce --; a rank that disagreed would make the next exchange hang)
-        agreed = comm.allreduce(np.array([0.0 if ok else 1.0, float(n_rec), -float(n_rec)], dtype=np.float64), MAX)
-        all_ok = agreed[0] == 0.0 and agreed[1] == -agreed[2]
+        # -- the same LIST, not only the same length: the partials are summed positionally, so the digest of the sorted records
+        # (window, candidates) rides along as two exact 32-bit halves, each with its negative (MAX of x and of -x agree <=> all equal)
+        dg = ens.flag_digest() if hasattr(ens, "flag_digest") else 0
+        hi, lo = float(dg >> 32), float(dg & 0xFFFFFFFF)
+        agreed = comm.allreduce(np.array([0.0 if ok else 1.0, float(n_rec), -float(n_rec), hi, -hi, lo, -lo], dtype=np.float64), MAX)
+        all_ok = agreed[0] == 0.0 and agreed[1] == -agreed[2] and agreed[3] == -agreed[4] and agreed[5] == -agreed[6]
         if all_ok:
             if n_rec:
                 part = comm.allreduce(part, SUM)
@@ -287,7 +291,8 @@ class ShardedPivDev:
 
 def sharded_piv_dev(block, n_pairs: int, window_size, overlap, comm, signal_threshold=None, align: Optional[int] = None) -> np.ndarray:
     """One sharded pass with the rank's frames already in HBM: ``block`` = DeviceFrames of this rank's ``frame_block`` (its
-    pairs + the halo frame; ``None`` for a rank without pairs).  Returns (4, n_pairs, n_rows, n_cols) on every rank --
+    pairs + the halo frame; a rank without pairs passes an empty ``(0, H, W)`` stack -- the frame shape is still needed for the
+    exchange --, ``None`` raises ValueError).  Returns (4, n_pairs, n_rows, n_cols) on every rank --
     bit-identical to ``piv.piv_pairs`` over the whole stack on one GPU."""
     if block is None:
         raise ValueError("sharded_piv_dev needs this rank's DeviceFrames block (ranks without pairs pass an empty (0, H, W) stack)")

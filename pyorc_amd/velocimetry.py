@@ -27,7 +27,7 @@ from typing import Literal, Optional, Tuple
 
 import numpy as np
 
-from . import piv, window
+from . import executor, piv, window
 from .device import is_device
 
 try:  # xarray is optional: the GPU box image does not ship it
@@ -164,6 +164,7 @@ def get_ffpiv(
     count_min: float = 0.2,
     signal_threshold: Optional[float] = None,
     time: Optional[np.ndarray] = None,
+    prefetch: Optional[int] = None,
 ):
     """Compute time-resolved (or ensemble) PIV on the MI355X; signature of pyorc's ``get_ffpiv`` (ffpiv.py:24-42).
 
@@ -172,6 +173,11 @@ def get_ffpiv(
     chunk is staged through the host then, each chunk is one launch on a view of the stack); ``dt``: time step per pair (``T-1``,
     seconds; an ``xr.DataArray`` on ``time[1:]`` in pyorc); ``time``: frame time stamps when ``frames`` is a
     plain array (default ``arange(T)``).  Returns Dataset / PivResult with ``s2n, corr, v_x, v_y``.
+
+    ``prefetch``: how many lazy chunks are materialised (``load_frame_chunk``: dask runs decode + projection + filters there)
+    AHEAD of the chunk being launched, on a worker thread (``pyorc_amd.executor``; default ``LSPIV_PREFETCH_DEPTH`` or 1; 0 = the
+    reference's serial load-then-compute loop, ffpiv.py:399-408).  Same chunks, same order, same results; stacks that are already
+    materialised (numpy, ``DeviceFrames``) have nothing to prefetch.
     """
     if engine != "hip":
         raise ValueError(f"Selected PIV engine {engine} does not exist.")
@@ -197,13 +203,14 @@ def get_ffpiv(
     if dt_arr.shape != (n_frames - 1,):
         raise ValueError(f"dt must have one entry per frame pair ({n_frames - 1}), got shape {dt_arr.shape}")
     frames_chunks = [frames[a:b] for a, b in slices]
+    depth = (executor.default_depth() if prefetch is None else int(prefetch)) if hasattr(frames, "load") else 0
     args = (frames_chunks, slices, y, x, dt_arr, time, res_y, res_x, n_cols, n_rows, window_size, overlap)
     if ensemble_corr:
         # quirk Q3 (ffpiv.py:373): the count filter is scaled with the number of CHUNKS -- of the reference's planner
         # (same formula, fed with HBM figures), not of the aligned chunks actually launched
         return _get_ffpiv_mean(*args, corr_min, s2n_min, count_min, signal_threshold, like=frames,
-                               ref_slices=ref_slices)
-    return _get_ffpiv_timestep(*args, signal_threshold, like=frames)
+                               ref_slices=ref_slices, prefetch=depth)
+    return _get_ffpiv_timestep(*args, signal_threshold, like=frames, prefetch=depth)
 
 
 def _to_velocity(disp: np.ndarray, res, dt_chunk: np.ndarray) -> np.ndarray:
@@ -216,12 +223,14 @@ def _to_velocity(disp: np.ndarray, res, dt_chunk: np.ndarray) -> np.ndarray:
 
 
 def _get_ffpiv_timestep(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_cols, n_rows, window_size, overlap,
-                        signal_threshold, like=None):
-    """Per-chunk loop of pyorc/velocimetry/ffpiv.py:379-443 (one fused GPU call per chunk)."""
+                        signal_threshold, like=None, prefetch=0):
+    """Per-chunk loop of pyorc/velocimetry/ffpiv.py:379-443 (one fused GPU call per chunk); chunk n + 1 is loaded on a worker
+    thread while chunk n is launched (``pyorc_amd.executor.ChunkPrefetcher``; ``prefetch = 0``: the reference's serial order)."""
     parts = {"s2n": [], "corr": [], "v_x": [], "v_y": []}
     times = []
-    for n, (a, b) in enumerate(slices):
-        da = load_frame_chunk(frames_chunks[n])
+    loader = executor.ChunkPrefetcher(frames_chunks, load_frame_chunk, depth=prefetch)
+    for n, da in loader:
+        a, b = slices[n]
         if len(da) >= 2:  # we need at least one image-pair to do PIV
             nb = a + len(da)  # load_frame_chunk may have dropped trailing frames
             u, v, corr_max, s2n = piv.piv_pairs(_values(da), window_size, overlap, signal_threshold, pair_offset=a)
@@ -238,6 +247,7 @@ def _get_ffpiv_timestep(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_c
         # correlation volume, ffpiv.py:437-440; neither exists here, and a collection costs ~1 ms per chunk: dropped.)
         frames_chunks[n] = None
         del da
+    executor.LAST_STATS.clear(); executor.LAST_STATS.update(loader.stats)
     data = {k: vv[0] if len(vv) == 1 else np.concatenate(vv, axis=0) for k, vv in parts.items()}
     if _is_xr(like):
         t = xr.concat(times, dim="time")
@@ -247,15 +257,17 @@ def _get_ffpiv_timestep(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_c
 
 
 def _get_ffpiv_mean(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_cols, n_rows, window_size, overlap,
-                    corr_min, s2n_min, count_min, signal_threshold, like=None, ref_slices=None):
-    """Ensemble correlation of pyorc/velocimetry/ffpiv.py:182-376; corr_sum / corr_count stay in HBM."""
+                    corr_min, s2n_min, count_min, signal_threshold, like=None, ref_slices=None, prefetch=0):
+    """Ensemble correlation of pyorc/velocimetry/ffpiv.py:182-376; corr_sum / corr_count stay in HBM; chunks loaded ahead of
+    their launches like in ``_get_ffpiv_timestep`` (the reference's loop: ffpiv.py:348-370)."""
     dim_size = None
     ens = None
     corr_chunks, s2n_chunks = [], []
     t_first = None
+    loader = executor.ChunkPrefetcher(frames_chunks, load_frame_chunk, depth=prefetch)
     try:
-        for n, (a, b) in enumerate(slices):
-            da = load_frame_chunk(frames_chunks[n])
+        for n, da in loader:
+            a, b = slices[n]
             if len(da) < 2:
                 continue
             arr = _values(da)
@@ -279,8 +291,10 @@ def _get_ffpiv_mean(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_cols,
             t_first = time[ref_slices[-1][0] + 1:ref_slices[-1][0] + 2]
         u, v, corr_count = ens.finish(count_min, n_frames)
     finally:
+        loader.close()
         if ens is not None:
             ens.close()
+    executor.LAST_STATS.clear(); executor.LAST_STATS.update(loader.stats)
     s2n_concat = np.concatenate(s2n_chunks, axis=0)
     corr_max_concat = np.concatenate(corr_chunks, axis=0)
     with warnings.catch_warnings():

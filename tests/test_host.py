@@ -644,3 +644,76 @@ def test_float64_staging_conversion_and_offset_rule(lib):
     dt = time.perf_counter() - t0
     assert np.array_equal(dst, big.astype(np.float32))
     print(f"narrowing 8 x 1080p float64 frames: {big.nbytes / dt / 1e9:.1f} GB/s read on {nt} threads")
+
+
+def test_a_binary_older_than_the_header_is_reported_as_stale(tmp_path, monkeypatch):
+    """a build that lacks entry points the header declares must say "rebuild" (LspivLibraryStale), not AttributeError --
+    also when its hashes cannot tell (here: a stub that reports the TREE's hashes but exports nothing else)."""
+    import subprocess
+
+    src = tmp_path / "stub.c"
+    src.write_text('const char* lspiv_build_info(int k) { return k == 0 ? "%s" : k == 1 ? "%s" : ""; }\n'
+                   % (_lib.kernel_code_hash(), _lib.source_hash()))
+    so = tmp_path / "libstub.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)])
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(so))
+    monkeypatch.delenv("LSPIV_LIBRARY", raising=False)
+    monkeypatch.delenv("LSPIV_ALLOW_STALE", raising=False)
+    with pytest.raises(_lib.LspivLibraryStale, match="does not export lspiv_"):
+        _lib.load()
+    # and one whose hashes differ is caught by them first, before any symbol is looked up
+    src.write_text('const char* lspiv_build_info(int k) { return k < 2 ? "0123456789abcdef" : ""; }\n')
+    so = tmp_path / "libstub2.so"                      # (another path: the loader caches a loaded object by name)
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)])
+    monkeypatch.setattr(_lib, "LIB_PATH", str(so))
+    with pytest.raises(_lib.LspivLibraryStale, match="was built from sources with hash 0123456789abcdef"):
+        _lib.load()
+
+
+def test_locks_are_per_device(lib):
+    """the host-entry-point, launch and list locks are per device, so one process can drive several GPUs from
+    several threads.  The test hook holds a lock without touching HIP: two threads holding the SAME lock of two devices overlap,
+    of one device they queue; different locks of one device are independent of each other."""
+    import threading
+
+    def held(pairs, ms=150):
+        ts = [threading.Thread(target=lambda d=d, w=w: lib.lspiv_debug_hold_lock(d, w, ms)) for d, w in pairs]
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        return time.perf_counter() - t0
+
+    import time
+    for which in (0, 1, 2):
+        same = held([(0, which), (0, which)])
+        other = held([(0, which), (1, which)])
+        assert same >= 0.29, (which, same)
+        assert other <= 0.25, (which, other)
+    assert held([(3, 0), (3, 1), (3, 2)]) <= 0.25
+    assert held([(d, 0) for d in range(8)]) <= 0.3          # eight ranks' worth of host threads in one process
+    assert lib.lspiv_debug_hold_lock(64, 0, 1) == _lib.LSPIV_EINVAL and lib.lspiv_debug_hold_lock(0, 3, 1) == _lib.LSPIV_EINVAL
+
+
+def test_rccl_channel_cap_is_scoped_to_communicator_creation(monkeypatch):
+    """NCCL_MAX_NCHANNELS is set only around ncclCommInitRank and the environment is put back."""
+    from pyorc_amd import comm
+
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS", raising=False)
+    monkeypatch.delenv("LSPIV_RCCL_MAX_NCHANNELS", raising=False)
+    with comm._rccl_channel_cap(True):
+        assert os.environ["NCCL_MAX_NCHANNELS"] == "16"
+    assert "NCCL_MAX_NCHANNELS" not in os.environ and comm._rccl_channel_cap.applied == "16"
+    monkeypatch.setenv("LSPIV_RCCL_MAX_NCHANNELS", "8")
+    with comm._rccl_channel_cap(True):
+        assert os.environ["NCCL_MAX_NCHANNELS"] == "8"
+    assert "NCCL_MAX_NCHANNELS" not in os.environ
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "32")             # the user's own setting is neither overridden nor removed
+    with comm._rccl_channel_cap(True):
+        assert os.environ["NCCL_MAX_NCHANNELS"] == "32"
+    assert os.environ["NCCL_MAX_NCHANNELS"] == "32" and comm._rccl_channel_cap.applied == "32"
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS")
+    with comm._rccl_channel_cap(False):                        # other transports: untouched
+        assert "NCCL_MAX_NCHANNELS" not in os.environ

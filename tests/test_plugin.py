@@ -1,0 +1,142 @@
+"""pyorc_amd.install(): engine="hip" inside an installed, UNMODIFIED pyorc (pyorc_amd/plugin.py).
+
+pyorc is not installed in the build image, so the test builds a double of the package with the members the patch touches
+(pyorc.api.frames.Frames.get_piv with the gate of pyorc/api/frames.py:176-177 and the call of :186-188; pyorc.velocimetry.ffpiv.get_ffpiv
+with the signature of ffpiv.py:24-42; the re-export of pyorc/velocimetry/__init__.py) on the xarray double of tests/fake_xarray.py.
+The GPU call is replaced by the oracle."""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _fake_pyorc(fake_xarray, calls):
+    """A package `pyorc` as far as the engine seam goes."""
+    pyorc = types.ModuleType("pyorc"); pyorc.__path__ = []
+    api = types.ModuleType("pyorc.api"); api.__path__ = []
+    velo = types.ModuleType("pyorc.velocimetry"); velo.__path__ = []
+    ffpiv = types.ModuleType("pyorc.velocimetry.ffpiv")
+    frames = types.ModuleType("pyorc.api.frames")
+
+    def get_ffpiv(frames_, y, x, dt, window_size, overlap, search_area_size, res_y, res_x, chunksize=None, memory_factor=4,
+                  engine="numba", ensemble_corr=False, corr_min=0.2, s2n_min=3, count_min=0.2, signal_threshold=None):
+        calls.append(("cpu_get_ffpiv", engine))
+        ds = fake_xarray.Dataset({}, coords={"y": y, "x": x})
+        ds.cpu = True
+        return ds
+
+    ffpiv.get_ffpiv = get_ffpiv
+    velo.get_ffpiv = get_ffpiv          # pyorc/velocimetry/__init__.py: from .ffpiv import get_ffpiv
+    velo.ffpiv = ffpiv
+
+    class CameraConfig:
+        window_size, resolution = 32, 0.02
+
+    class Frames:
+        def __init__(self, obj):
+            self._obj, self.camera_config = obj, CameraConfig()
+
+        def get_piv(self, window_size=None, overlap=None, engine="numba", ensemble_corr=False, **kwargs):
+            calls.append(("Frames.get_piv", engine))
+            from pyorc_amd import frames as F   # only for the grid arithmetic of this double
+
+            ws, sa, ov = F.resolve_window(self.camera_config.window_size if window_size is None else window_size, overlap)
+            coords, _ = F.get_piv_coords(tuple(self._obj[0].shape), ws, sa, ov, self._obj["x"].values, self._obj["y"].values)
+            dt = self._obj["time"].diff(dim="time")
+            if engine not in ["numba", "numpy"]:
+                raise ValueError(f"Selected PIV engine {engine} does not exist.")
+            kwargs = {**kwargs, "search_area_size": sa, "window_size": ws, "overlap": ov, "res_x": self.camera_config.resolution,
+                      "res_y": self.camera_config.resolution}
+            ds = ffpiv.get_ffpiv(self._obj, coords["y"], coords["x"], dt, engine=engine, ensemble_corr=ensemble_corr, **kwargs)
+            ds.attrs = dict(self._obj.attrs, tail_of_the_reference_method=True)
+            return ds
+
+    frames.Frames, frames.ffpiv = Frames, ffpiv
+    pyorc.api, pyorc.velocimetry, api.frames = api, velo, frames
+    return {"pyorc": pyorc, "pyorc.api": api, "pyorc.api.frames": frames, "pyorc.velocimetry": velo, "pyorc.velocimetry.ffpiv": ffpiv}
+
+
+def test_install_registers_the_hip_engine_in_an_unmodified_pyorc(monkeypatch):
+    from oracle import c_oracle
+    from pyorc_amd import _lib, plugin
+    from pyorc_amd.synth import particle_stack
+    from tests import fake_xarray
+
+    calls = []
+    mods = _fake_pyorc(fake_xarray, calls)
+    for k, v in mods.items():
+        monkeypatch.setitem(sys.modules, k, v)
+    monkeypatch.setitem(sys.modules, "xarray", fake_xarray)
+    import pyorc_amd.frames as F
+    import pyorc_amd.velocimetry as V
+
+    for mod in (V, F):
+        importlib.reload(mod)
+    plugin.uninstall()
+    try:
+        monkeypatch.setattr(V.piv, "piv_pairs", lambda fr, ws, ov, thr=None, pair_offset=0: tuple(a.astype(np.float32) for a in c_oracle.piv_pairs(np.asarray(fr), ws, ov, thr)))
+        monkeypatch.setattr(V.window, "available_memory", lambda: 1e12)
+        monkeypatch.setattr(_lib, "require_device", lambda: None)
+        fr = particle_stack(6, 96, 128, seed=9)
+        t = np.arange(6) / 25.0
+        da = fake_xarray.DataArray(fr, ("time", "y", "x"), {"time": t, "y": np.arange(96)[::-1] * 0.02, "x": np.arange(128) * 0.02}, attrs={"h_a": 0.7})
+        acc = mods["pyorc.api.frames"].Frames(da)
+        with pytest.raises(ValueError, match="Selected PIV engine hip does not exist"):
+            acc.get_piv(engine="hip")                                   # the unpatched gate, pyorc/api/frames.py:176-177
+        assert plugin.pyorc_available() and plugin.install() and plugin.is_installed() and plugin.install()
+        calls.clear()
+        ds = acc.get_piv(engine="hip", chunksize=3)
+        assert calls == [("Frames.get_piv", "numba")]                  # the reference's own method body ran; its CPU engine did not
+        assert ds.attrs == {"h_a": 0.7, "tail_of_the_reference_method": True} and not hasattr(ds, "cpu")
+        ref = F.get_piv(fr, 32, time=t, resolution=0.02)
+        for k in ("v_x", "v_y", "corr", "s2n"):
+            assert np.array_equal(ds[k].values, ref[k], equal_nan=True)
+        assert np.allclose(np.asarray(ds["time"].values, dtype=np.float64), t[1:])
+        # other engines: untouched
+        calls.clear()
+        assert acc.get_piv(engine="numba").cpu and calls == [("Frames.get_piv", "numba"), ("cpu_get_ffpiv", "numba")]
+        with pytest.raises(ValueError, match="Selected PIV engine openpiv does not exist"):
+            acc.get_piv(engine="openpiv")
+        # the wrapper one level down (and its re-export), called the way frames.py:186-188 calls it
+        coords, _ = F.get_piv_coords((96, 128), (32, 32), (32, 32), (16, 16), da["x"].values, da["y"].values)
+        kw = dict(window_size=(32, 32), overlap=(16, 16), search_area_size=(32, 32), res_x=0.02, res_y=0.02)
+        for fn in (mods["pyorc.velocimetry.ffpiv"].get_ffpiv, mods["pyorc.velocimetry"].get_ffpiv):
+            d2 = fn(da, coords["y"], coords["x"], da["time"].diff(dim="time"), engine="hip", **kw)
+            assert np.array_equal(d2["v_x"].values, ref["v_x"], equal_nan=True)
+            calls.clear()
+            assert fn(da, coords["y"], coords["x"], da["time"].diff(dim="time"), engine="numpy", **kw).cpu and calls == [("cpu_get_ffpiv", "numpy")]
+        # a failing hip call leaves no routing behind: the next numba call reaches the CPU engine
+        monkeypatch.setattr(V.piv, "piv_pairs", lambda *a, **k: (_ for _ in ()).throw(RuntimeError("device lost")))
+        with pytest.raises(RuntimeError, match="device lost"):
+            acc.get_piv(engine="hip")
+        calls.clear()
+        assert acc.get_piv(engine="numba").cpu and ("cpu_get_ffpiv", "numba") in calls
+        # no device: engine="hip" fails loudly before any work, other engines are unaffected
+        monkeypatch.setattr(_lib, "require_device", lambda: (_ for _ in ()).throw(_lib.LspivError(-6, "no gfx950 device")))
+        with pytest.raises(_lib.LspivError):
+            acc.get_piv(engine="hip")
+        plugin.uninstall()
+        assert not plugin.is_installed() and mods["pyorc.velocimetry"].get_ffpiv is mods["pyorc.velocimetry.ffpiv"].get_ffpiv
+        with pytest.raises(ValueError, match="Selected PIV engine hip does not exist"):
+            acc.get_piv(engine="hip")
+    finally:
+        plugin.uninstall()
+        monkeypatch.undo()
+        for mod in (V, F):
+            importlib.reload(mod)
+
+
+def test_auto_install_is_silent_without_pyorc_and_can_be_switched_off(monkeypatch):
+    from pyorc_amd import plugin
+
+    plugin.uninstall()
+    assert not plugin.pyorc_available()              # the build image has no pyorc: importing pyorc_amd patched nothing
+    assert plugin.install() is False and plugin.auto_install() is False and not plugin.is_installed()
+    monkeypatch.setenv("LSPIV_NO_AUTO_INSTALL", "1")
+    assert plugin.auto_install() is None

@@ -160,6 +160,9 @@ class OracleEnsemble:
         self._args = (count_min, n_frames)
         return self.n_flag
 
+    def flag_digest(self):
+        return getattr(self, "digest", 0xABCDEF0123456789)
+
     def partials(self):
         return np.full((self.n_flag, 20), 1.0 + getattr(self, "rank", 0), np.float64), not getattr(self, "lost_frames", False)
 
@@ -186,6 +189,8 @@ def _ens_worker(rank, world, port, n_frames, out_dir, kind):
             e = OracleEnsemble((64, 96), WS, OV)
             e.rank, e.n_flag = rank, 3                      # three "flagged" windows: the float64 all-reduce of the partials runs
             e.lost_frames = (n_frames == 5 and rank == 1)    # one rank of the (3, 5) case could not keep its frames: all ranks fall back
+            if n_frames == 9:                                # the (2, 9) case: as many flagged windows everywhere, but not the same ones (digests differ in the low / the high half)
+                e.digest = 0xABCDEF0123456789 + (rank if kind == "gloo" else rank << 40)
             made.append(e)
             return e
 
@@ -198,7 +203,7 @@ def _ens_worker(rank, world, port, n_frames, out_dir, kind):
 
 
 @pytest.mark.parametrize("kind", ["native-shm", "gloo"])
-@pytest.mark.parametrize("world,n_frames", [(2, 7), (3, 5)])
+@pytest.mark.parametrize("world,n_frames", [(2, 7), (3, 5), (2, 9)])
 def test_sharded_ensemble_equals_single_process(tmp_path, world, n_frames, kind):
     port = _free_port()
     mp.spawn(_ens_worker, args=(world, port, n_frames, str(tmp_path), kind), nprocs=world, join=True)
@@ -213,7 +218,7 @@ def test_sharded_ensemble_equals_single_process(tmp_path, world, n_frames, kind)
         # the per-rank partial sums are added in float32 by the all-reduce: same peak, sub-pixel within 1e-4
         assert np.nanmax(np.abs(d["u"] - u)) < 1e-4 and np.nanmax(np.abs(d["v"] - v)) < 1e-4
         # the staged finish: every rank's partials summed over the ranks (1 + 2 [+ 3]); if any rank lost its frames, all finish plainly
-        if n_frames == 5:
+        if n_frames in (5, 9):    # ... and so they do when their lists of flagged windows differ (same length, other digest)
             assert bool(d["plain"]) and d["summed"].size == 0
         else:
             assert not bool(d["plain"]) and d["summed"].shape == (3, 20) and np.all(d["summed"] == sum(range(1, world + 1)))

@@ -26,4 +26,6 @@ _lib.check(lib.lspiv_memcpy_d2h(_lib.ptr(cs), d_o, cs.nbytes))
 s, k = ens.export_state()
 u, v, cnt = ens.finish(0.2, 1)
 h = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+if os.environ.get("ENS_DUMP"):   # the arrays themselves, for tools/ens_diff.py
+    np.savez(os.environ["ENS_DUMP"], corr_sum=s, count=k, cmax_s2n=cs, u=u, v=v)
 print(f"ens_hash {ws}/{ov} P={P} thr={thr}: corr_sum {h(s)} count {h(k)} cmax_s2n {h(cs)} u {h(u)} v {h(v)} kept {float(k.mean()):.2f} finite {float(np.isfinite(u).mean()):.4f}")
