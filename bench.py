@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--overlap", type=int, default=16)
     ap.add_argument("--cpu-pairs", type=int, default=-1, help="pairs of the CPU-baseline sample (-1: auto, 0: skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the other-configs and host-fed legs (N = 1)")
+    ap.add_argument("--sustained-s", type=float, default=10.0,
+                    help="N = 1: seconds of the sustained loop run after the timed steps (clock and socket power sampled; 0: skip)")
+    ap.add_argument("--parity-pairs", type=int, default=50, help="pairs of the full-grid oracle check of configs[2] / configs[3] (0: skip)")
     ap.add_argument("--seed", type=int, default=20260927 + 2)
     ap.add_argument("--strong", action="store_true",
                     help="N > 1: cut a FIXED total of --strong-pairs over the N ranks (north_star's 'strong scaling', literally) "
@@ -150,7 +153,90 @@ def time_launches(lib, launch, reps: int) -> float:
     return ms.value / reps
 
 
-def other_config(lib, name: str, d_frames, pairs: int, H: int, W: int, ws: int, ov: int, reps: int = 3) -> dict:
+def time_kernel_only(lib, launch, reps: int):
+    """Mean duration [ms] of the PIV kernel inside `reps` launches issued the way a caller issues them (rescue pass ON), by the
+    library's own HIP events right around that kernel on the launch stream (include/lspiv.h, lspiv_kernel_times): the quantity
+    `rocprofv3 --kernel-trace` reports per launch of the kernel -- the committed profiles/ summaries hold the same figure."""
+    reps = min(reps, 16)
+    _lib.check(lib.lspiv_synchronize())
+    _lib.set_option("time_kernel", 1)
+    try:
+        buf, n = (C.c_float * 16)(), C.c_int(0)
+        _lib.check(lib.lspiv_kernel_times(buf, 16, C.byref(n)))     # empty the ring
+        for _ in range(reps):
+            launch()
+        _lib.check(lib.lspiv_synchronize())
+        _lib.check(lib.lspiv_kernel_times(buf, 16, C.byref(n)))
+    finally:
+        _lib.set_option("time_kernel", 0)
+    ms = [float(buf[i]) for i in range(n.value)]
+    return (sum(ms) / len(ms) if ms else None), ms
+
+
+class SmiSampler:
+    """Shader clock [MHz] and socket power [W] of device 0 once a second while a measurement runs (rocm-smi in a thread;
+    measurement code only).  Missing tool / unparsable output: no samples, the figures are None."""
+
+    def __init__(self, period: float = 1.0):
+        import threading
+
+        self.period, self.samples, self._stop = period, [], threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import re
+
+        while not self._stop.is_set():
+            try:
+                txt = subprocess.run(["rocm-smi", "-d", "0", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+                clk = re.search(r"sclk clock level:[^\n]*\((\d+)Mhz\)", txt)
+                pw = re.search(r"Package Power \(W\):\s*([0-9.]+)", txt)
+                if clk and pw:
+                    self.samples.append((time.time(), int(clk.group(1)), float(pw.group(1))))
+            except Exception:
+                pass
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._t.join(timeout=15)
+        return False
+
+    def summary(self, t0: float, t1: float) -> dict:
+        inside = [(c, p) for (t, c, p) in self.samples if t0 + 1.0 <= t <= t1]     # (the first second is the clock ramp)
+        if not inside:
+            return {"samples": 0, "sclk_mhz_mean": None, "socket_power_w_mean": None}
+        return {"samples": len(inside), "sclk_mhz_mean": round(float(np.mean([c for c, _ in inside])), 1),
+                "sclk_mhz_min": int(min(c for c, _ in inside)), "socket_power_w_mean": round(float(np.mean([p for _, p in inside])), 1),
+                "socket_power_w_max": round(max(p for _, p in inside), 1)}
+
+
+def sustained_run(lib, step, sync, pairs_per_step: int, seconds: float) -> dict:
+    """The step loop for `seconds` of wall time (>= 10 s by default): what a long job sees once the socket sits at its power limit --
+    `value` times a 20-step burst of 0.12 s (eleven boxes, 151-162 k in bursts, 151 k sustained)."""
+    sync()
+    with SmiSampler() as smi:
+        t0w = time.time()
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            for _ in range(50):
+                step()
+            n += 50
+            sync()
+            if time.perf_counter() - t0 >= seconds:
+                break
+        dt = time.perf_counter() - t0
+        t1w = time.time()
+    return {"seconds": round(dt, 3), "steps": n, "pairs_per_s": round(n * pairs_per_step / dt, 1), "ms_per_step": round(dt / n * 1e3, 4),
+            **smi.summary(t0w, t1w)}
+
+
+def other_config(lib, name: str, d_frames, pairs: int, H: int, W: int, ws: int, ov: int, reps: int = 3, parity_pairs: int = 0) -> dict:
     """One more BASELINE.json single-GPU configuration on an HBM-resident stack: kernel time by HIP events."""
     n_rows, n_cols = window.get_array_shape((H, W), (ws, ws), (ov, ov))
     n_win = n_rows * n_cols
@@ -166,11 +252,20 @@ def other_config(lib, name: str, d_frames, pairs: int, H: int, W: int, ws: int, 
     ms = time_launches(lib, go, reps)                 # the launch as a caller issues it: PIV kernel + rescue kernels
     st = (C.c_int64 * 5)()
     _lib.check(lib.lspiv_rescue_stats(None, st))
-    _lib.set_option("rescue", 0)
-    try:
-        kernel_ms = time_launches(lib, go, reps)      # the dominant kernel alone (roofline)
-    finally:
-        _lib.set_option("rescue", 1)
+    kernel_ms, _ = time_kernel_only(lib, go, reps)    # the dominant kernel inside such launches (roofline; = the profile's per-kernel time)
+    parity = None
+    if parity_pairs > 0:
+        # full-grid oracle check of this configuration on a bounded number of pairs (every driver run, every single-GPU config)
+        from oracle import cpu_baseline as cb   # test infrastructure: parity leg only
+
+        n_s = min(parity_pairs, pairs)
+        sample = np.empty((n_s + 1, H, W), dtype=np.uint8)
+        _lib.check(lib.lspiv_memcpy_d2h(_lib.ptr(sample), d_frames, sample.nbytes))
+        block = np.empty((4, n_s, n_rows, n_cols), dtype=np.float32)     # the first n_s pairs of each of [u | v | corr | s2n]
+        for k in range(4):
+            _lib.check(lib.lspiv_memcpy_d2h(_lib.ptr(block[k]), C.c_void_p(d_out.value + k * pairs * n_win * 4), block[k].nbytes))
+        parity = cb.parity_only(sample, (ws, ws), (ov, ov), block)
+        del sample, block
     _lib.check(lib.lspiv_dev_free(d_out))
     return {
         "workload": name,
@@ -181,6 +276,7 @@ def other_config(lib, name: str, d_frames, pairs: int, H: int, W: int, ws: int, 
         "launch_ms": round(ms, 4),
         "kernel_ms": round(kernel_ms, 4),
         "rescued_windows_per_launch": {"fit": int(st[0]), "amb": int(st[1])},
+        **({"parity_vs_oracle": parity} if parity is not None else {}),
         "roofline": {k: v for k, v in roofline_block(lib, kernel_ms, pairs, H, W, ws, ov, n_win).items()
                      if k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "secondary",
                               "algorithmic_bytes_per_pair")},
@@ -239,6 +335,67 @@ def host_fed_rates(lib, sample_u8: np.ndarray, ws, ov) -> dict:
         t0 = time.perf_counter()
         piv.piv_pairs(arr, ws, ov)
         out[key] = round((arr.shape[0] - 1) / (time.perf_counter() - t0), 1)
+    return out
+
+
+class _LazyOrthoStack:
+    """A stand-in for the dask-backed DataArray pyorc hands to get_ffpiv: slicing along time is free, ``load()`` does per frame what
+    ``project_numpy`` does inside a real ``.load()`` (pyorc/project.py:123-161: a nearest-neighbour gather of the camera frame into the
+    ortho grid, float64 out) -- plain numpy on one core, GIL released inside the gather and the conversion."""
+
+    def __init__(self, cam: np.ndarray, idx: np.ndarray, lo: int = 0, hi=None):
+        self.cam, self.idx, self.lo, self.hi = cam, idx, lo, cam.shape[0] if hi is None else hi
+        self.dtype, self.shape = np.dtype(np.float64), (self.hi - self.lo,) + cam.shape[1:]
+
+    def __len__(self):
+        return self.hi - self.lo
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            a, b, _ = key.indices(len(self))
+            return _LazyOrthoStack(self.cam, self.idx, self.lo + a, self.lo + b)
+        return self.load_frame(self.lo + key)
+
+    def load_frame(self, f):
+        return np.take(self.cam[f].ravel(), self.idx).astype(np.float64).reshape(self.cam.shape[1:])
+
+    def load(self):
+        out = np.empty((len(self),) + self.cam.shape[1:], np.float64)
+        for k in range(len(self)):
+            out[k].reshape(-1)[:] = np.take(self.cam[self.lo + k].ravel(), self.idx)     # gather, then uint8 -> float64
+        return out
+
+
+def lazy_host_chunk_rates(cam: np.ndarray, ws, ov) -> dict:
+    """get_piv over LAZY host chunks: the reference loads a chunk, then computes it (ffpiv.py:399-408); the chunk
+    executor (pyorc_amd/executor.py) loads chunk n + 1 .. n + depth on worker threads while chunk n is uploaded and launched.
+    PCIe- and host-inclusive, never `value`."""
+    from pyorc_amd import executor, frames as F
+
+    T, H, W = cam.shape
+    idx = np.arange(H * W, dtype=np.int64).reshape(H, W)
+    idx = np.roll(idx, 7, axis=1).ravel()                   # a nearest-neighbour plan (a shifted identity: every cell one camera pixel)
+    t = np.arange(T) / 30.0
+    lazy = _LazyOrthoStack(cam, idx)
+    F.get_piv(lazy[:27], ws[0], overlap=ov, time=t[:27], resolution=0.01, chunksize=26, prefetch=0)   # workspaces, pinned ring
+    out = {}
+    ref = None
+    for key, depth, workers in (("serial_like_the_reference", 0, 1), ("prefetch_depth1", 1, 1), ("prefetch_depth4_workers4", 4, 4)):
+        os.environ["LSPIV_PREFETCH_WORKERS"] = str(workers)
+        try:
+            t0 = time.perf_counter()
+            ds = F.get_piv(lazy, ws[0], overlap=ov, time=t, resolution=0.01, chunksize=26, prefetch=depth)
+            dt = time.perf_counter() - t0
+        finally:
+            os.environ.pop("LSPIV_PREFETCH_WORKERS", None)
+        st = dict(executor.LAST_STATS)
+        same = True if ref is None else all(np.array_equal(ds[k], ref[k], equal_nan=True) for k in ("v_x", "v_y", "corr", "s2n"))
+        ref = ds if ref is None else ref
+        out[key] = {"pairs_per_s": round((T - 1) / dt, 1), "wall_s": round(dt, 3), "load_s_total": st.get("load_s"),
+                    "waited_for_loads_s": st.get("waited_s"), "chunks": st.get("chunks"), "same_bits_as_serial": bool(same)}
+    out["note"] = (f"{T - 1} pairs of {H}x{W}: every chunk of 25 pairs is materialised by a per-frame numpy gather + float64 conversion "
+                   "(what project_numpy does inside dask's .load()), then uploaded (narrowed to float32 while staged) and launched; "
+                   "wall = loads + launches for the reference's serial loop, ~ max(loads, launches) with the loads running ahead")
     return out
 
 
@@ -459,10 +616,20 @@ def main():
     # the rescue pass switched off -- the kernel still evaluates its flags, it just appends nothing and no rescue kernel follows
     _lib.set_option("rescue", 0)
     try:
-        kernel_ms = time_launches(lib, launch_all, reps)
+        kernel_ms_rescue_off = time_launches(lib, launch_all, reps)
     finally:
         _lib.set_option("rescue", 1)
+    # ... and the dominant kernel INSIDE the launch as issued (rescue on: it appends its records), by the library's events right
+    # around it: what rocprofv3 --kernel-trace reports for it, and what roofline.achieved is computed from (the
+    # rescue-off figure was ~3 % kinder than the profile the line cites)
+    kernel_ms, kernel_ms_each = time_kernel_only(lib, launch_all, reps)
+    if kernel_ms is None:
+        kernel_ms = launch_ms
     launch_all()                                              # leave d_out as a full launch (with the rescue pass) produces it
+    sustained = None
+    if world == 1 and a.sustained_s > 0:
+        sustained = sustained_run(lib, step, sync, total_pairs, a.sustained_s)
+        launch_all()
 
     # float64 rescue pass: how many windows of one launch the kernels flagged (the launches above ran on the library's stream)
     rescue = None
@@ -543,6 +710,15 @@ def main():
         },
         "roofline": roofline_block(lib, kernel_ms, a.pairs, H, W, a.window, a.overlap, n_win, launch_ms),
     }
+    out["roofline"]["kernel_timing"] = ("mean of HIP-event pairs recorded by the library right around the dominant kernel in " + str(len(kernel_ms_each)) +
+                                        " launches issued as a caller issues them (rescue pass on), on the launch stream -- the per-kernel "
+                                        "duration of `rocprofv3 --kernel-trace`; profiles/*_summary.json hold the trace's own mean")
+    out["roofline"]["kernel_ms_same_launch_rescue_off"] = round(kernel_ms_rescue_off, 4)
+    if sustained is not None:
+        # value / ms_per_step time a burst of --steps launches (0.12 s); this is the same step loop held for >= 10 s
+        out["sustained_pairs_per_s"] = sustained["pairs_per_s"]
+        out["config"]["sustained"] = {**sustained, "note": "the timed step loop repeated for >= --sustained-s seconds after the timed region; "
+                                      "clock and socket power by rocm-smi once a second (first second dropped); `value` is the burst"}
     out["config"]["binary"] = _lib.binary_provenance(lib)   # hashes compiled into the loaded .so next to the tree's
     if rescue is not None:
         out["config"]["rescue"] = rescue
@@ -601,7 +777,7 @@ def main():
     # ---- the other single-GPU BASELINE configs + host-fed rates (N = 1, default shape only) ----
     if world == 1 and is_c2 and not a.no_extras:
         others = [other_config(lib, "BASELINE.json configs[2]: 1080p, 64x64 windows @ 75 % overlap, same stack",
-                               d_frames, a.pairs, H, W, 64, 48)]
+                               d_frames, a.pairs, H, W, 64, 48, parity_pairs=a.parity_pairs if a.cpu_pairs != 0 else 0)]
         ensembles = [ensemble_config(lib, "ensemble correlation (ensemble_corr=True), 1080p, 32x32 @ 50 %, same stack", d_frames, a.pairs, H, W, 32, 16),
                      ensemble_config(lib, "ensemble correlation (ensemble_corr=True), 1080p, 64x64 @ 75 %, same stack", d_frames, a.pairs, H, W, 64, 48)]
         sample = np.empty((min(a.pairs, 200) + 1, H, W), dtype=np.uint8)
@@ -614,13 +790,14 @@ def main():
         d4 = dev_alloc((a.pairs + 1) * H4 * W4)
         _lib.check(lib.lspiv_synth_particles_dev(d4, a.pairs + 1, H4, W4, a.seed + 2, 0.02))
         others.append(other_config(lib, "BASELINE.json configs[3]: 4K (2160x3840), 32x32 windows @ 50 % overlap",
-                                   d4, a.pairs, H4, W4, 32, 16))
+                                   d4, a.pairs, H4, W4, 32, 16, parity_pairs=a.parity_pairs if a.cpu_pairs != 0 else 0))
         _lib.check(lib.lspiv_dev_free(d4))
         out["config"]["other_configs"] = others + ensembles
         out["config"]["host_fed_pairs_per_s"] = {
             **host_fed_rates(lib, sample, ws, ov),
             "note": f"lspiv_piv_pairs on {sample.shape[0] - 1} pairs in pageable host memory, PCIe-inclusive; never `value`"}
         out["config"]["camera_to_velocity_pairs_per_s"] = camera_to_velocity_rates(sample, ws, ov)
+        out["config"]["lazy_host_chunks"] = lazy_host_chunk_rates(sample[:101], ws, ov)
     os.write(json_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:
         comm.barrier()

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define LSPIV_ABI_VERSION 4   /* (round 5 added lspiv_ensemble_flag_digest and the test hook lspiv_debug_hold_lock; no version change: nothing existing moved)
+#define LSPIV_ABI_VERSION 4   /* (round 5 added lspiv_ensemble_flag_digest, lspiv_kernel_times + the "time_kernel" option and the test hook lspiv_debug_hold_lock; no version change: nothing existing moved)
                                * 4 (round 4, additions only): lspiv_build_info, the float64 rescue of the ensemble's final fit
                                * (lspiv_ensemble_set_retain / _stats / _flag / _partials / _finish_partials), lspiv_stream_release,
                                * lspiv_stream_create_priority; 3: lspiv_rescue_stats,
@@ -466,6 +466,13 @@ int lspiv_debug_fft(int n, int inverse, const float* in, float* out, int64_t cou
 /* Test hook (host only): how the time-walking kernels cut a chunk of n_pairs pairs that starts at absolute pair index
  * pair_offset into segments of seg_len pairs anchored at multiples of seg_len: pairs in the first segment, segment count. */
 int lspiv_debug_segments(int64_t n_pairs, int64_t pair_offset, int seg_len, int64_t* seg_first, int64_t* n_seg);
+
+/* Measurement (round 5): with lspiv_set_option("time_kernel", 1) every launch records HIP events on its own stream right before and
+ * right after its PIV kernel(s) -- not around the rescue kernels that follow.  lspiv_kernel_times returns the durations [ms] of the
+ * last *n <= min(cap, 16) launches of the calling thread's device, oldest first, and empties the ring: the dominant kernel's time
+ * inside the launch as a caller issues it, which is what `rocprofv3 --kernel-trace` reports for that kernel (bench.py:
+ * roofline.achieved). */
+int lspiv_kernel_times(float* ms, int cap, int* n);
 
 /* Test hook (host only, no HIP call): hold one of device `device`'s locks -- 0 the host-pointer entry points' workspaces, 1 a launch
  * and its rescue kernels, 2 the rescue lists -- for `milliseconds`.  The locks are per device (round 5; process-wide before): two

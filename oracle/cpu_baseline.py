@@ -96,6 +96,28 @@ def run(frames_sample: np.ndarray, ws, ov, gpu_block=None) -> dict:
     return out
 
 
+def parity_only(frames_sample: np.ndarray, ws, ov, gpu_block) -> dict:
+    """The gate of :func:`run` without the timing: the product's (4, P, n_rows, n_cols) block against the C oracle on EVERY window
+    of the sample's P pairs (exact float64 ties of the plane maximum set aside and counted).  bench.py runs it for every single-GPU
+    BASELINE configuration on a bounded number of pairs, so that each driver run carries a full-grid oracle check of all of them."""
+    cores = effective_cores()
+    t0 = time.perf_counter()
+    u, v, cm, sn, cond = c_oracle.piv_pairs(frames_sample, ws, ov, nthreads=cores, return_cond=True)
+    dt = time.perf_counter() - t0
+    tie = ((cond[..., 0] < 1e-12) | (cm < 1e-12)) & (cm > 0)
+    ok = ~tie
+    worst, nan_mismatch = 0.0, 0
+    for g, r in zip(gpu_block, (u, v, cm, sn)):
+        nan_mismatch += int((np.isnan(g) != np.isnan(r))[ok].sum())
+        with np.errstate(all="ignore"):
+            e = (np.abs(g - r) / np.maximum(np.abs(r), 0.05))[ok]
+        if np.isfinite(e).any():
+            worst = max(worst, float(np.nanmax(e)))
+    return {"pairs": int(frames_sample.shape[0] - 1), "windows_checked": int(ok.sum()), "exact_ties_set_aside": int(tie.sum()),
+            "max_rel_err_vs_oracle": float(f"{worst:.3e}"), "nan_mismatch": nan_mismatch, "gate": 1e-4,
+            "passed": bool(worst <= 1e-4 and nan_mismatch == 0), "oracle_s": round(dt, 2)}
+
+
 def ties_report(gpu_block, ref, tie) -> dict:
     """The windows the gate sets aside: exact float64 ties of the plane maximum, listed (first 16) with both answers."""
     idx = np.argwhere(tie)

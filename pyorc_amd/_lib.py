@@ -155,6 +155,7 @@ SIGNATURES = {
     "lspiv_debug_narrow": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp]),
     "lspiv_debug_segments": (_i32, [_i64, _i64, _i32, _pi64, _pi64]),
     "lspiv_debug_hold_lock": (_i32, [_i32, _i32, _i32]),
+    "lspiv_kernel_times": (_i32, [_vp, _i32, C.POINTER(_i32)]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -336,8 +336,32 @@ int dispatch_kernels(const lspiv::PivParams& p, int dtype, bool ensemble, hipStr
 // lock, so that two host threads launching on the same stream (NULL -> the library's stream) cannot interleave as PIV 1,
 // PIV 2, rescue 1 -- rescue 1 would then consume launch 2's records with launch 1's parameters.  Launches are asynchronous:
 // the lock is held for microseconds.  (The rescue kernels skip a record whose index is outside their launch all the same.)
+// "time_kernel" option (measurement only, off by default): HIP events on the launch's own stream right before and right after the
+// PIV kernel(s) of a launch -- NOT around the rescue kernels that follow --, i.e. the duration rocprofv3 --kernel-trace reports for
+// the dominant kernel, inside the launch exactly as a caller issues it (rescue pass on: the kernel appends its records).  A ring of
+// the last 16 launches per device; lspiv_kernel_times reads and empties it.  bench.py's roofline.achieved comes from here.
+std::atomic<int> g_opt_time_kernel{0};
+constexpr int kTimerRing = 16;
+struct KernelTimer { hipEvent_t e0[kTimerRing] = {}, e1[kTimerRing] = {}; int n = 0; };
+KernelTimer g_timers[kMaxDevices];   // guarded by the device's dispatch lock
+static int timed_dispatch_kernels(const lspiv::PivParams& p, int dtype, bool ensemble, hipStream_t s) {
+  if (!g_opt_time_kernel.load()) return dispatch_kernels(p, dtype, ensemble, s);
+  KernelTimer& t = g_timers[current_device_slot()];
+  const int k = t.n % kTimerRing;
+  if (!t.e0[k]) { HIP_TRY(hipEventCreate(&t.e0[k])); HIP_TRY(hipEventCreate(&t.e1[k])); }
+  HIP_TRY(hipEventRecord(t.e0[k], s));
+  const int rc = dispatch_kernels(p, dtype, ensemble, s);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(t.e1[k], s));
+  ++t.n;
+  return LSPIV_OK;
+}
 int dispatch(const lspiv::PivParams& p0, int dtype, bool ensemble, hipStream_t s) {
-  if (ensemble || !g_opt_rescue.load()) return dispatch_kernels(p0, dtype, ensemble, s);
+  if (ensemble || !g_opt_rescue.load()) {
+    if (!g_opt_time_kernel.load()) return dispatch_kernels(p0, dtype, ensemble, s);
+    std::lock_guard<std::mutex> launch_lock(locks_here().dispatch);
+    return timed_dispatch_kernels(p0, dtype, ensemble, s);
+  }
   DeviceCtx* c;
   int rc = get_ctx(&c);
   if (rc) return rc;
@@ -345,7 +369,7 @@ int dispatch(const lspiv::PivParams& p0, int dtype, bool ensemble, hipStream_t s
   std::lock_guard<std::mutex> launch_lock(locks_here().dispatch);
   rc = rescue_ws(c, s, p.n_tiles, &p);
   if (rc) return rc;
-  rc = dispatch_kernels(p, dtype, false, s);
+  rc = timed_dispatch_kernels(p, dtype, false, s);
   if (rc) return rc;
   const hipError_t e = lspiv::launch_piv_rescue(p, dtype, s);
   if (e != hipSuccess) return fail(LSPIV_EHIP, "rescue kernel launch failed: %s", hipGetErrorString(e));
@@ -668,6 +692,11 @@ int lspiv_set_option(const char* name, int value) {
     g_opt_rescue_tau.store(value);
     return LSPIV_OK;
   }
+  if (strcmp(name, "time_kernel") == 0) {
+    if (value < 0 || value > 1) return fail(LSPIV_EINVAL, "time_kernel must be 0 or 1 (HIP events around the PIV kernel of every launch, lspiv_kernel_times)");
+    g_opt_time_kernel.store(value);
+    return LSPIV_OK;
+  }
   return fail(LSPIV_EINVAL, "unknown option '%s'", name);
 }
 int lspiv_get_option(const char* name, int* value) {
@@ -684,7 +713,23 @@ int lspiv_get_option(const char* name, int* value) {
   if (strcmp(name, "rescue") == 0) { *value = g_opt_rescue.load(); return LSPIV_OK; }
   if (strcmp(name, "rescue_kappa") == 0) { *value = g_opt_rescue_kappa.load(); return LSPIV_OK; }
   if (strcmp(name, "rescue_tau") == 0) { *value = g_opt_rescue_tau.load(); return LSPIV_OK; }
+  if (strcmp(name, "time_kernel") == 0) { *value = g_opt_time_kernel.load(); return LSPIV_OK; }
   return fail(LSPIV_EINVAL, "unknown option '%s'", name);
+}
+
+int lspiv_kernel_times(float* ms, int cap, int* n) {
+  if (!ms || !n || cap < 0) return fail(LSPIV_EINVAL, "bad argument");
+  std::lock_guard<std::mutex> launch_lock(locks_here().dispatch);
+  KernelTimer& t = g_timers[current_device_slot()];
+  const int have = std::min(std::min(t.n, kTimerRing), cap);
+  for (int i = 0; i < have; ++i) {
+    const int k = (t.n - have + i) % kTimerRing;
+    HIP_TRY(hipEventSynchronize(t.e1[k]));
+    HIP_TRY(hipEventElapsedTime(&ms[i], t.e0[k], t.e1[k]));
+  }
+  *n = have;
+  t.n = 0;
+  return LSPIV_OK;
 }
 
 int lspiv_rescue_stats(void* stream, int64_t* stats) {

@@ -28,6 +28,7 @@ from concurrent.futures import Future, ThreadPoolExecutor
 from typing import Callable, Iterator, List, Optional, Sequence, Tuple
 
 DEFAULT_DEPTH = 1
+DEFAULT_WORKERS = 1
 
 
 def default_depth() -> int:
@@ -39,6 +40,19 @@ def default_depth() -> int:
     if d < 0:
         raise ValueError(f"LSPIV_PREFETCH_DEPTH must be >= 0, got {d}")
     return d
+
+
+def default_workers() -> int:
+    """Loader threads when the caller does not say: ``LSPIV_PREFETCH_WORKERS``, else 1 (a dask ``.load()`` is parallel inside; more
+    than one thread pays for loaders that run on one core each -- plain numpy, a single-threaded decoder -- and needs
+    ``depth >= workers`` to have that many chunks in flight)."""
+    v = os.environ.get("LSPIV_PREFETCH_WORKERS")
+    if v is None or v == "":
+        return DEFAULT_WORKERS
+    w = int(v)
+    if w < 1:
+        raise ValueError(f"LSPIV_PREFETCH_WORKERS must be >= 1, got {w}")
+    return w
 
 
 class ChunkPrefetcher:
@@ -59,13 +73,13 @@ class ChunkPrefetcher:
     wall time the consumer spent waiting is what prefetching could NOT hide.
     """
 
-    def __init__(self, chunks: Sequence, load: Callable, depth: Optional[int] = None, workers: int = 1):
+    def __init__(self, chunks: Sequence, load: Callable, depth: Optional[int] = None, workers: Optional[int] = None):
         self._chunks: List = list(chunks)
         self._load = load
         self.depth = default_depth() if depth is None else int(depth)
         if self.depth < 0:
             raise ValueError(f"prefetch depth must be >= 0, got {self.depth}")
-        self.workers = max(1, int(workers))
+        self.workers = default_workers() if workers is None else max(1, int(workers))
         self._pool: Optional[ThreadPoolExecutor] = None
         self._futures: dict = {}
         self._next_submit = 0

@@ -30,6 +30,14 @@ def rel_err(got, ref, floor=0.05):
     return float(np.nanmax(e)) if np.isfinite(e).any() else 0.0
 
 
+def _log_tie_share(share, n):
+    """LSPIV_TIE_LOG=<file>: one line per gated comparison -- the test, the share of windows that were gated (1 - exact ties)."""
+    path = os.environ.get("LSPIV_TIE_LOG")
+    if path:
+        with open(path, "a") as fh:
+            fh.write(f"{os.environ.get('PYTEST_CURRENT_TEST', '?')}\t{share:.6f}\t{n}\n")
+
+
 def check_against_oracle(frames, ws, ov, thr=None, plane_tol=2e-6, uv_tol=TOL):
     """GPU vs oracle on ALL windows: NaN masks, corr / s2n, planes, and u, v to 1e-4 of max(|ref|, 0.05 px) -- the float64
     rescue pass (csrc/piv_rescue.hip) covers the windows whose float32 fit is ill-conditioned.  Only exact float64 ties of
@@ -52,6 +60,7 @@ def check_against_oracle(frames, ws, ov, thr=None, plane_tol=2e-6, uv_tol=TOL):
     if ok.any():
         assert rel_err(u[ok], uo[ok].astype(np.float64)) <= uv_tol
         assert rel_err(v[ok], vo[ok].astype(np.float64)) <= uv_tol
+    _log_tie_share(float(ok.mean()), ok.size)
     assert ok.mean() >= 0.5, "test input is mostly exact ties"
     return u, v, cm, sn
 

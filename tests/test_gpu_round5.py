@@ -1,0 +1,174 @@
+"""GPU tests of round 5: the chunk executor through the real engine, the bounded retention of borrowed ensemble chunks, ensemble
+accumulation on a caller stream followed by finish without a synchronisation in between, the digest of the flagged records."""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+import pytest
+
+from pyorc_amd.synth import particle_stack
+
+pytestmark = pytest.mark.gpu
+
+
+class LazyStack:
+    """What a dask-backed DataArray is to get_ffpiv: slicing along time is free, ``load()`` materialises (and takes a while)."""
+
+    def __init__(self, data, seconds=0.0, log=None):
+        self._data, self.seconds, self.log = data, seconds, log if log is not None else []
+        self.dtype, self.shape = data.dtype, data.shape
+
+    def __len__(self):
+        return len(self._data)
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            return LazyStack(self._data[key], self.seconds, self.log)
+        return self._data[key]
+
+    def load(self):
+        self.log.append(len(self._data))
+        time.sleep(self.seconds)
+        return np.array(self._data)      # a fresh array, like a materialised dask chunk
+
+
+@pytest.mark.parametrize("ensemble", [False, True])
+def test_lazy_chunks_prefetched_give_the_bits_of_the_serial_loop(gpu, ensemble):
+    """get_piv over lazy chunks with the loads running ahead (depth 1 and 2) == the reference's serial order (depth 0) == the
+    materialised stack, bit for bit; every chunk is loaded once; with loads as slow as the launches the run takes about the
+    loads alone."""
+    from pyorc_amd import executor, frames as F
+
+    fr = particle_stack(101, 256, 320, seed=77)
+    t = np.arange(101) / 30.0
+    kw = dict(time=t, resolution=0.01, chunksize=26, ensemble_corr=ensemble)
+    ref = F.get_piv(fr, 32, **kw)
+    assert executor.LAST_STATS["depth"] == 0                       # a numpy stack: nothing to prefetch
+    walls = {}
+    for depth in (0, 1, 2):
+        lazy = LazyStack(fr, seconds=0.05)
+        t0 = time.perf_counter()
+        got = F.get_piv(lazy, 32, prefetch=depth, **kw)
+        walls[depth] = time.perf_counter() - t0
+        assert lazy.log == [26, 26, 26, 26], lazy.log              # 100 pairs in chunks of 25 (+ halo frame)
+        assert executor.LAST_STATS["depth"] == depth and executor.LAST_STATS["chunks"] == 4
+        for k in ("v_x", "v_y", "corr", "s2n"):
+            assert np.array_equal(got[k], ref[k], equal_nan=True), (depth, k)
+        assert np.array_equal(got.coords["time"], ref.coords["time"])
+    # serial: 4 loads + 4 launches; prefetched: the first load + the rest hidden behind launches (or the other way round)
+    assert executor.LAST_STATS["waited_s"] < 4 * 0.05
+    assert walls[1] < walls[0]
+
+
+def test_borrowed_ensemble_chunks_respect_the_budget_and_a_chosen_mode(gpu, monkeypatch):
+    """Ensemble.accumulate of DeviceFrames chunks borrows only when the caller has not chosen a mode, counts the
+    borrowed bytes against LSPIV_ENSEMBLE_RETAIN_BYTES, and lets go of everything once the budget is exceeded (float32 fits,
+    retain_complete False) instead of pinning every chunk until close()."""
+    from pyorc_amd import DeviceFrames, piv
+
+    fr = particle_stack(26, 128, 160, seed=5)
+    chunk_bytes = fr.nbytes
+    dev = DeviceFrames.from_host(fr)
+    # (a) default: borrow, complete
+    e = piv.Ensemble((128, 160), (32, 32), (16, 16))
+    e.accumulate(dev, 0.2, 3.0)
+    st = e.stats()
+    assert len(e._held) == 1 and st["retain_complete"] and st["chunks_kept"] == 1 and st["bytes_kept"] >= chunk_bytes
+    u0, v0, c0 = e.finish(0.2, 1)
+    e.close()
+    # (b) an explicit choice is respected: NONE keeps nothing and holds nothing
+    e = piv.Ensemble((128, 160), (32, 32), (16, 16))
+    e.set_retain(e.RETAIN_NONE)
+    e.accumulate(dev, 0.2, 3.0)
+    st = e.stats()
+    assert e._held == [] and not st["retain_complete"] and st["chunks_kept"] == 0 and st["bytes_kept"] == 0
+    u1, v1, c1 = e.finish(0.2, 1)
+    assert np.array_equal(c0, c1) and np.allclose(u0, u1, atol=1e-3, equal_nan=True)
+    e.close()
+    # (c) COPY chosen: the handle owns copies, this object holds nothing
+    e = piv.Ensemble((128, 160), (32, 32), (16, 16))
+    e.set_retain(e.RETAIN_COPY)
+    e.accumulate(dev, 0.2, 3.0)
+    assert e._held == [] and e.stats()["retain_complete"] and e.stats()["chunks_kept"] == 1
+    e.close()
+    # (d) a budget of two and a half chunks: the third chunk exceeds it -> everything is let go, accumulation goes on
+    monkeypatch.setenv("LSPIV_ENSEMBLE_RETAIN_BYTES", str(int(2.5 * chunk_bytes) + (2 << 20)))
+    e = piv.Ensemble((128, 160), (32, 32), (16, 16))
+    for k in range(5):
+        e.accumulate(dev, 0.2, 3.0)
+        st = e.stats()
+        if k < 2:
+            assert st["retain_complete"] and len(e._held) == k + 1 and st["chunks_kept"] == k + 1
+        else:
+            assert not st["retain_complete"] and e._held == [] and st["chunks_kept"] == 0 and st["bytes_kept"] == 0
+    u5, v5, c5 = e.finish(0.2, 1)
+    assert np.array_equal(c5, 5 * c0) and e.stats()["float32_kept"] == e.stats()["flagged"]
+    e.close()
+
+
+def test_finish_waits_for_an_accumulate_on_a_caller_stream(gpu):
+    """accumulate_dev on a caller stream, then finish (the library's stream) with NO synchronisation in between --
+    the handle records an event per accumulating stream and its readers wait for it.  Large enough that the kernels are still
+    running when finish is called; the result must equal the synchronous run's, bit for bit, every time."""
+    from pyorc_amd import _lib, piv
+
+    lib = _lib.load()
+    H, W, T = 540, 960, 201
+    n_win = 32 * 59
+    d_f, d_o = C.c_void_p(), C.c_void_p()
+    _lib.check(lib.lspiv_dev_malloc(C.byref(d_f), T * H * W)); _lib.check(lib.lspiv_dev_malloc(C.byref(d_o), 8 * (T - 1) * n_win))
+    _lib.check(lib.lspiv_synth_particles_dev(d_f, T, H, W, 99, 0.02))
+    ref = None
+    for trial in range(4):
+        s = C.c_void_p()
+        _lib.check(lib.lspiv_stream_create(C.byref(s)))
+        e = piv.Ensemble((H, W), (32, 32), (16, 16))
+        assert e.n_rows * e.n_cols == n_win
+        e.set_retain(e.RETAIN_COPY if trial % 2 else e.RETAIN_BORROW)
+        e.accumulate_dev(d_f.value, np.uint8, T, 0.2, 3.0, d_o.value, None, s.value if trial else None)
+        if trial == 0:
+            _lib.check(lib.lspiv_synchronize())
+        out = e.finish(0.2, 1, return_mean=True)      # trial >= 1: straight after the asynchronous launch on stream s
+        st = e.stats()
+        assert st["retain_complete"] and st["rescued"] == st["flagged"]
+        if ref is None:
+            ref = out
+        else:
+            for a, b in zip(ref, out):
+                assert np.array_equal(a, b, equal_nan=True), trial
+        e.close()
+        _lib.check(lib.lspiv_stream_destroy(s))
+    lib.lspiv_dev_free(d_f); lib.lspiv_dev_free(d_o)
+
+
+def test_flag_digest_names_the_list_not_its_length(gpu):
+    """lspiv_ensemble_flag_digest: equal for handles holding the same sums (whatever order the kernel appended its records in), 0
+    without records, and different when other windows are flagged."""
+    from pyorc_amd import piv
+
+    import pyorc_amd._lib as L
+
+    L.set_option("rescue_kappa", 200000)     # an allowance large enough that some windows are flagged
+    try:
+        fr = particle_stack(8, 160, 224, seed=21, density=0.01)
+        es = []
+        for _ in range(2):
+            e = piv.Ensemble((160, 224), (32, 32), (16, 16))
+            e.accumulate(fr, 0.1, 1.0)
+            es.append(e)
+        n0, n1 = es[0].flag(0.1, 1), es[1].flag(0.1, 1)
+        assert n0 == n1 and n0 > 1
+        d0, d1 = es[0].flag_digest(), es[1].flag_digest()
+        assert d0 == d1 and d0 != 0
+        other = piv.Ensemble((160, 224), (32, 32), (16, 16))
+        other.accumulate(particle_stack(8, 160, 224, seed=22, density=0.01), 0.1, 1.0)
+        if other.flag(0.1, 1):
+            assert other.flag_digest() != d0
+        L.set_option("rescue", 0)                # the pass switched off: no records, digest 0
+        assert es[0].flag(0.1, 1) == 0 and es[0].flag_digest() == 0
+        for e in es + [other]:
+            e.close()
+    finally:
+        L.set_option("rescue_kappa", 500)
+        L.set_option("rescue", 1)
