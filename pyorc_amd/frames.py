@@ -77,7 +77,9 @@ def get_piv(frames, window_size=None, overlap=None, engine: str = "hip", ensembl
         dt = t.diff(dim="time")
         xs, ys = frames["x"].values, frames["y"].values
     else:
-        if not velocimetry.is_device(frames):   # DeviceFrames: HBM-resident stack, used as it is
+        # DeviceFrames: HBM-resident stack, used as it is; a lazy stack (anything with ``load()``: time slices materialise on demand,
+        # like the dask-backed DataArray of the xarray branch) is left lazy -- get_ffpiv loads it chunk by chunk, ahead of the launches
+        if not velocimetry.is_device(frames) and not hasattr(frames, "load"):
             frames = np.asarray(frames)
         t = np.arange(frames.shape[0], dtype=np.float64) if time is None else np.asarray(time, dtype=np.float64)
         dt = np.diff(t)

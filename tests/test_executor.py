@@ -245,3 +245,38 @@ def test_get_ffpiv_gives_the_same_dataset_with_and_without_prefetch(monkeypatch)
 
         for mod in (V2, F2):
             importlib.reload(mod)
+
+
+def test_a_lazy_stack_without_xarray_stays_lazy_in_get_piv(monkeypatch):
+    """get_piv on a plain (non-xarray) stack whose time slices materialise on ``load()``: it must NOT be converted to one numpy array
+    up front (that would load every frame before the first launch) but reach get_ffpiv lazy, chunk by chunk, ahead of the launches."""
+    from oracle import c_oracle
+    from pyorc_amd import frames as F, velocimetry as V
+    from pyorc_amd.synth import particle_stack
+
+    loads = []
+
+    class Lazy:
+        def __init__(self, data):
+            self._d, self.dtype, self.shape = data, data.dtype, data.shape
+
+        def __len__(self):
+            return len(self._d)
+
+        def __getitem__(self, key):
+            return Lazy(self._d[key]) if isinstance(key, slice) else self._d[key]
+
+        def load(self):
+            loads.append(len(self._d))
+            return np.array(self._d)
+
+    monkeypatch.setattr(V.piv, "piv_pairs", lambda fr, ws, ov, thr=None, pair_offset=0: tuple(a.astype(np.float32) for a in c_oracle.piv_pairs(np.asarray(fr), ws, ov, thr)))
+    monkeypatch.setattr(V.window, "available_memory", lambda: 1e12)
+    monkeypatch.setattr(V.window, "chunk_alignment", lambda ws: 5)
+    fr = particle_stack(16, 64, 96, seed=2)
+    t = np.arange(16) / 25.0
+    ref = F.get_piv(fr, 32, time=t, resolution=0.02, chunksize=6)
+    got = F.get_piv(Lazy(fr), 32, time=t, resolution=0.02, chunksize=6)
+    assert loads == [6, 6, 6] and executor.LAST_STATS["depth"] == 1 and executor.LAST_STATS["chunks"] == 3
+    for k in ref:
+        assert np.array_equal(got[k], ref[k], equal_nan=True)
