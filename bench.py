@@ -797,7 +797,7 @@ def main():
             **host_fed_rates(lib, sample, ws, ov),
             "note": f"lspiv_piv_pairs on {sample.shape[0] - 1} pairs in pageable host memory, PCIe-inclusive; never `value`"}
         out["config"]["camera_to_velocity_pairs_per_s"] = camera_to_velocity_rates(sample, ws, ov)
-        out["config"]["lazy_host_chunks"] = lazy_host_chunk_rates(sample[:101], ws, ov)
+        out["config"]["lazy_host_chunks"] = lazy_host_chunk_rates(sample, ws, ov)
     os.write(json_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:
         comm.barrier()

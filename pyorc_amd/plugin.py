@@ -15,6 +15,13 @@ touching pyorc's files:
   ``ffpiv.get_ffpiv`` routed to the HIP engine through a context variable.  Whatever version of pyorc is installed keeps its own
   code around the engine call; nothing of it is re-implemented here.
 
+A second seam needs no wrapping at all: ``Frames.project`` looks its method up BY NAME, ``getattr(project, f"project_{method}")``
+(pyorc/api/frames.py:254-257), so ``install()`` simply adds :func:`project_hip` to ``pyorc.project`` and
+``frames.project(method="hip")`` works in an unmodified pyorc: the same lazy graph as ``project_numpy`` (pyorc/project.py:164-230:
+``xr.apply_ufunc(..., dask="parallelized")``), whose blocks run the orthoprojection kernel on whole time chunks instead of
+``img_to_ortho`` frame by frame.  It is that graph that executes inside ``load_frame_chunk`` ("large in real
+runs"), ahead of the PIV launches (pyorc_amd.executor).
+
 ``import pyorc_amd`` calls ``install()`` by itself when a ``pyorc`` package can be found (``LSPIV_NO_AUTO_INSTALL=1`` turns that
 off); ``uninstall()`` restores the originals.  Recipes then simply say ``velocimetry: get_piv: {engine: hip}``.
 """
@@ -84,6 +91,83 @@ def _wrap_get_piv(orig):
     return get_piv
 
 
+_PLANS: dict = {}          # id(plan_args) -> (plan_args, Projection): the blocks of one graph share one tuple object
+_PLANS_MAX = 4
+_PLANS_LOCK = __import__("threading").Lock()
+
+
+def _projection_plan(src_shape, dst_shape, plan_args):
+    """Device-resident plan for these index maps: uploaded once per graph (dask's threads call the blocks of a graph concurrently,
+    all with the SAME ``plan_args`` tuple -- its identity is the key, no hashing of megabytes of indices per block), a few graphs
+    kept.  An evicted plan is only dropped here; it closes itself when the last block that uses it has returned."""
+    from .project import Projection
+
+    key = (id(plan_args), tuple(src_shape), tuple(dst_shape))
+    with _PLANS_LOCK:
+        hit = _PLANS.get(key)
+        if hit is not None and hit[0] is plan_args:
+            return hit[1]
+        while len(_PLANS) >= _PLANS_MAX:
+            _PLANS.pop(next(iter(_PLANS)))
+        plan = Projection(src_shape, dst_shape, *plan_args)
+        _PLANS[key] = (plan_args, plan)
+        return plan
+
+
+def _project_block(block, plan_args=None, dst_shape=None):
+    """One dask block of frames, core dimensions last: (..., Hc, Wc) -> (..., Ho, Wo) float32, every leading index (time; rgb when the
+    frames carry it) projected by ONE kernel call."""
+    import numpy as np
+
+    a = np.asarray(block)
+    lead, src_shape = a.shape[:-2], a.shape[-2:]
+    if a.dtype not in (np.dtype(np.uint8), np.dtype(np.float32), np.dtype(np.float64)):
+        a = a.astype(np.float32)
+    if a.size == 0:
+        return np.zeros(lead + tuple(dst_shape), np.float32)
+    plan = _projection_plan(src_shape, dst_shape, plan_args)
+    out = plan.project_frames(np.ascontiguousarray(a.reshape((-1,) + src_shape)), keep_uint8=False)
+    return np.asarray(out, dtype=np.float32).reshape(lead + tuple(dst_shape))
+
+
+def project_hip(da, cc, x, y, z, reducer="mean"):
+    """``pyorc.project.project_hip``: the signature and the result of ``project_numpy`` (pyorc/project.py:164-230) with the gather on the
+    MI355X.  The index maps come from the camera configuration exactly as there (``cc.map_idx_img_ortho``,
+    ``cc.map_mean_idx_img_ortho`` for ``reducer="mean"``); the frames stay a lazy DataArray -- ``xr.apply_ufunc`` with
+    ``dask="parallelized"`` over the time chunks, core dimensions ``(y, x) -> (new_y, new_x)`` --, each block is one call of the
+    projection kernel (``pyorc_amd.project.Projection``: bit-identical to ``img_to_ortho``, NaN-free), float32 out (the reference
+    declares the frames' dtype and delivers float64; the PIV kernels read float32)."""
+    import numpy as np
+    import xarray as xr
+
+    from . import _lib
+
+    _lib.load()
+    _lib.require_device()   # fail when the graph is BUILT, not in the middle of a dask computation
+    idx_img, idx_ortho = cc.map_idx_img_ortho(x, y, z)
+    if reducer == "mean":
+        src_idx, uidx, norm_idx = cc.map_mean_idx_img_ortho(x, y, z)
+    else:
+        src_idx = uidx = norm_idx = None
+    dst_shape = (len(y), len(x))
+    da_proj = xr.apply_ufunc(
+        _project_block,
+        da,
+        kwargs={"plan_args": (idx_img, idx_ortho, src_idx, uidx, norm_idx), "dst_shape": dst_shape},
+        input_core_dims=[["y", "x"]],
+        output_core_dims=[["new_y", "new_x"]],
+        dask_gufunc_kwargs={"output_sizes": {"new_y": len(y), "new_x": len(x)}},
+        output_dtypes=[np.float32],
+        vectorize=False,                 # a block arrives whole, (time_chunk, y, x): one kernel call per block
+        exclude_dims=set(("y", "x")),
+        dask="parallelized",
+        keep_attrs=True,
+    ).rename({"new_y": "y", "new_x": "x"})
+    da_proj["y"] = y
+    da_proj["x"] = x
+    return da_proj
+
+
 def install(pyorc_module=None) -> bool:
     """Make ``frames.get_piv(engine="hip")`` and ``get_ffpiv(engine="hip")`` of the installed pyorc run on the MI355X.
 
@@ -109,7 +193,16 @@ def install(pyorc_module=None) -> bool:
     if reexported:
         velo_pkg.get_ffpiv = wrapped
     frames_cls.get_piv = _wrap_get_piv(orig_get_piv)
-    _installed.update(ffpiv_mod=ffpiv_mod, frames_cls=frames_cls, velo_pkg=velo_pkg, orig_ffpiv=orig_ffpiv,
+    project_mod = None
+    try:   # Frames.project(method="hip"): found by name (frames.py:254-257)
+        project_mod = importlib.import_module(name + ".project")
+        if not hasattr(project_mod, "project_hip"):
+            project_mod.project_hip = project_hip
+        else:
+            project_mod = None   # somebody else's: leave it
+    except ImportError:
+        project_mod = None
+    _installed.update(project_mod=project_mod, ffpiv_mod=ffpiv_mod, frames_cls=frames_cls, velo_pkg=velo_pkg, orig_ffpiv=orig_ffpiv,
                       orig_get_piv=orig_get_piv, reexported=reexported)
     return True
 
@@ -122,6 +215,10 @@ def uninstall() -> None:
     if _installed["reexported"]:
         _installed["velo_pkg"].get_ffpiv = _installed["orig_ffpiv"]
     _installed["frames_cls"].get_piv = _installed["orig_get_piv"]
+    if _installed.get("project_mod") is not None and getattr(_installed["project_mod"], "project_hip", None) is project_hip:
+        del _installed["project_mod"].project_hip
+    with _PLANS_LOCK:
+        _PLANS.clear()
     _installed.clear()
 
 

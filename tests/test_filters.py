@@ -148,7 +148,7 @@ def test_gpu_recipe_chain_normalize_project_piv(gpu):
     uo, vo, cmo, sno, cond = c_oracle.piv_pairs(ref_ortho, (32, 32), (16, 16), return_cond=True)
     ok = ~c_oracle.exact_tie(cond, cmo)   # all windows but exact float64 ties (float64 rescue pass)
     e = lambda g, r: float(np.nanmax(np.abs(g - r) / np.maximum(np.abs(r), 0.05)))
-    assert ok.mean() > 0.5 and e(cm, cmo) <= 1e-4 and e(u[ok], uo[ok]) <= 1e-4 and e(v[ok], vo[ok]) <= 1e-4
+    assert ok.mean() > 0.99 and e(cm, cmo) <= 1e-4 and e(u[ok], uo[ok]) <= 1e-4 and e(v[ok], vo[ok]) <= 1e-4
 
 
 @pytest.mark.gpu

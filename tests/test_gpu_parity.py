@@ -7,6 +7,7 @@ float64 rescue pass (csrc/piv_rescue.hip) re-evaluates them from the frames.  On
 maximum are set aside (oracle.c_oracle.exact_tie): there the oracle's own pick is a matter of its FFT's rounding.
 """
 import ctypes as C
+import json
 import os
 
 import warnings
@@ -28,6 +29,26 @@ def rel_err(got, ref, floor=0.05):
     with np.errstate(all="ignore"):
         e = np.abs(np.asarray(got, dtype=np.float64) - ref) / np.maximum(np.abs(ref), floor)
     return float(np.nanmax(e)) if np.isfinite(e).any() else 0.0
+
+
+# Which windows are set aside is decided by the ORACLE's own float64 planes (c_oracle.exact_tie on the oracle's outputs), never by
+# anything the kernel returned -- a kernel cannot hide windows here.  The share that is gated is nevertheless pinned (VERDICT r04 item
+# 8): tests/golden/tie_shares.json holds, per test and call, the share measured when the fixture was recorded (the degenerate inputs
+# of some tests -- empty frames, constant corners -- put up to 31 % of their windows into exact ties); a comparison must reproduce its
+# recorded share to 0.02, and one without a record must gate at least 90 % of its windows.
+_TIE_SHARES = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tie_shares.json")))
+_tie_calls = {}
+
+
+def _check_tie_share(share, n):
+    _log_tie_share(share, n)
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" (")[0].split("/")[-1]
+    k = _tie_calls[test] = _tie_calls.get(test, -1) + 1
+    rec = _TIE_SHARES.get(test)
+    if rec is not None and k < len(rec):
+        assert abs(share - rec[k]) <= 0.02, f"{test} call {k}: {share:.4f} of the windows gated, {rec[k]:.4f} when the fixture was recorded"
+    else:
+        assert share >= 0.9, f"{test} call {k}: only {share:.4f} of the windows gated and no recorded expectation (tools/record_tie_shares.py)"
 
 
 def _log_tie_share(share, n):
@@ -60,8 +81,7 @@ def check_against_oracle(frames, ws, ov, thr=None, plane_tol=2e-6, uv_tol=TOL):
     if ok.any():
         assert rel_err(u[ok], uo[ok].astype(np.float64)) <= uv_tol
         assert rel_err(v[ok], vo[ok].astype(np.float64)) <= uv_tol
-    _log_tie_share(float(ok.mean()), ok.size)
-    assert ok.mean() >= 0.5, "test input is mostly exact ties"
+    _check_tie_share(float(ok.mean()), ok.size)
     return u, v, cm, sn
 
 
@@ -819,7 +839,7 @@ def test_embedded_and_direct_kernels_agree(gpu):
     for b in outs[1:]:                                                 # direct kernel; the 24-point FFT kernel (default)
         assert np.array_equal(np.isnan(a), np.isnan(b))
         assert rel_err(a[2:], b[2:].astype(np.float64)) <= 1e-5          # corr_max, s2n
-        assert ok.mean() > 0.5 and rel_err(a[0][ok], b[0][ok].astype(np.float64)) <= TOL and rel_err(a[1][ok], b[1][ok].astype(np.float64)) <= TOL
+        assert ok.mean() > 0.99 and rel_err(a[0][ok], b[0][ok].astype(np.float64)) <= TOL and rel_err(a[1][ok], b[1][ok].astype(np.float64)) <= TOL
 
 
 @pytest.mark.parametrize("seg,P,ws", [("1", 3, 32), ("1", 4, 32), ("3", 10, 32), ("5", 11, 32), ("7", 23, 32), ("31", 40, 32),

@@ -93,7 +93,8 @@ def test_borrowed_ensemble_chunks_respect_the_budget_and_a_chosen_mode(gpu, monk
     assert e._held == [] and e.stats()["retain_complete"] and e.stats()["chunks_kept"] == 1
     e.close()
     # (d) a budget of two and a half chunks: the third chunk exceeds it -> everything is let go, accumulation goes on
-    monkeypatch.setenv("LSPIV_ENSEMBLE_RETAIN_BYTES", str(int(2.5 * chunk_bytes) + (2 << 20)))
+    # (the handle's first block of corr_max records is 1 MiB and counts as well)
+    monkeypatch.setenv("LSPIV_ENSEMBLE_RETAIN_BYTES", str(int(2.5 * chunk_bytes) + (1 << 20) + 65536))
     e = piv.Ensemble((128, 160), (32, 32), (16, 16))
     for k in range(5):
         e.accumulate(dev, 0.2, 3.0)
@@ -172,3 +173,47 @@ def test_flag_digest_names_the_list_not_its_length(gpu):
     finally:
         L.set_option("rescue_kappa", 500)
         L.set_option("rescue", 1)
+
+
+def test_project_hip_blocks_on_the_gpu(gpu, monkeypatch):
+    """pyorc.project.project_hip (pyorc_amd.plugin) with the real projection kernel behind the apply_ufunc double: blocks of a graph
+    share one device-resident plan, the result equals the numpy oracle's img_to_ortho bit for bit, also when the graph's blocks are
+    run by several threads at once (dask's threaded scheduler)."""
+    import sys
+    import threading
+
+    from oracle import project_oracle as pro
+    from pyorc_amd import plugin
+    from pyorc_amd.synth import projection_maps
+    from tests import fake_xarray
+
+    monkeypatch.setitem(sys.modules, "xarray", fake_xarray)
+    src, dst = (270, 480), (200, 360)
+    maps = projection_maps(src, dst, tilt=0.15, seed=6)
+
+    class CC:
+        def map_idx_img_ortho(self, x, y, z):
+            return maps[0], maps[1]
+
+        def map_mean_idx_img_ortho(self, x, y, z):
+            return maps[2], maps[3], maps[4]
+
+    cam = particle_stack(24, src[0], src[1], seed=31)
+    da = fake_xarray.DataArray(cam, ("time", "y", "x"), {"time": np.arange(24) / 25.0}, attrs={"_blocks": 4})
+    y, x = np.arange(dst[0])[::-1] * 0.01, np.arange(dst[1]) * 0.01
+    out = plugin.project_hip(da, CC(), x, y, 0.0, "mean")
+    ref = pro.project_frames(cam, dst, *maps)
+    assert out.values.dtype == np.float32 and np.array_equal(out.values.astype(np.float64), ref)
+    assert len(plugin._PLANS) == 1
+    # the blocks of ONE graph from four threads
+    plan_args = (maps[0], maps[1], maps[2], maps[3], maps[4])
+    res = [None] * 4
+    def work(k):
+        res[k] = plugin._project_block(cam[6 * k:6 * k + 6], plan_args=plan_args, dst_shape=dst)
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert np.array_equal(np.concatenate(res).astype(np.float64), ref) and len(plugin._PLANS) == 2
+    plugin.uninstall()

@@ -140,3 +140,104 @@ def test_auto_install_is_silent_without_pyorc_and_can_be_switched_off(monkeypatc
     assert plugin.install() is False and plugin.auto_install() is False and not plugin.is_installed()
     monkeypatch.setenv("LSPIV_NO_AUTO_INSTALL", "1")
     assert plugin.auto_install() is None
+
+
+class _ProjectDoubles:
+    """pyorc.project + the camera-configuration members Frames.project touches around the method lookup of pyorc/api/frames.py:254-257."""
+
+    def __init__(self, fake_xarray, maps, dst_shape):
+        self.maps, self.dst_shape, self.calls = maps, dst_shape, []
+        project = types.ModuleType("pyorc.project")
+        project.xr = fake_xarray
+
+        def project_numpy(da, cc, x, y, z, reducer="mean"):      # only so that the module looks like the reference's
+            raise AssertionError("the CPU projection must not run")
+
+        project.project_numpy = project_numpy
+        self.module = project
+        outer = self
+
+        class CameraConfig:
+            def map_idx_img_ortho(self, x, y, z):
+                outer.calls.append(("map_idx_img_ortho", len(x), len(y), z))
+                return outer.maps[0], outer.maps[1]
+
+            def map_mean_idx_img_ortho(self, x, y, z):
+                outer.calls.append(("map_mean_idx_img_ortho", len(x), len(y), z))
+                return outer.maps[2], outer.maps[3], outer.maps[4]
+
+        self.cc = CameraConfig()
+
+    def frames_project(self, da, method, reducer="mean"):
+        """The lookup-by-name of Frames.project (pyorc/api/frames.py:254-258) and the fillna that follows it."""
+        y, x = np.arange(self.dst_shape[0])[::-1] * 0.01, np.arange(self.dst_shape[1]) * 0.01
+        if not hasattr(self.module, f"project_{method}"):
+            raise ValueError(f"Selected projection method {method} does not exist.")
+        proj_method = getattr(self.module, f"project_{method}")
+        return proj_method(da, self.cc, x, y, 1.25, reducer), x, y
+
+
+def test_install_adds_project_hip_found_by_name(monkeypatch):
+    """``Frames.project(method="hip")`` in an unmodified pyorc: the method is looked up by name in pyorc.project (frames.py:254-257),
+    install() puts ``project_hip`` there.  It builds the same apply_ufunc graph as project_numpy (an eager double here, cut in blocks
+    like dask's time chunks); every block is one call of the projection plan.  CPU: the plan is replaced by the numpy oracle."""
+    from oracle import project_oracle as pro
+    from pyorc_amd import _lib, plugin
+    from pyorc_amd import project as P
+    from pyorc_amd.synth import particle_stack, projection_maps
+    from tests import fake_xarray
+
+    src, dst = (96, 128), (72, 100)
+    maps = projection_maps(src, dst, tilt=0.2, seed=4)      # idx_img, idx_ortho, src_idx, uidx, norm_idx
+    dbl = _ProjectDoubles(fake_xarray, maps, dst)
+    calls = []
+    mods = _fake_pyorc(fake_xarray, calls)
+    mods["pyorc.project"] = dbl.module
+    mods["pyorc"].project = dbl.module
+    for k, v in mods.items():
+        monkeypatch.setitem(sys.modules, k, v)
+    monkeypatch.setitem(sys.modules, "xarray", fake_xarray)
+    made = []
+
+    class OraclePlan:
+        def __init__(self, src_shape, dst_shape, *m):
+            made.append(self)
+            self.src_shape, self.dst_shape, self.m, self.blocks = tuple(src_shape), tuple(dst_shape), m, []
+
+        def project_frames(self, frames, keep_uint8=None):
+            self.blocks.append(frames.shape)
+            assert keep_uint8 is False and frames.flags.c_contiguous
+            return pro.project_frames(frames, self.dst_shape, *self.m).astype(np.float32)
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(P, "Projection", OraclePlan)
+    monkeypatch.setattr(_lib, "require_device", lambda: None)
+    plugin.uninstall()
+    try:
+        cam = particle_stack(10, src[0], src[1], seed=12)
+        da = fake_xarray.DataArray(cam, ("time", "y", "x"), {"time": np.arange(10) / 25.0}, attrs={"h_a": 1.0, "_blocks": 3})
+        with pytest.raises(ValueError, match="Selected projection method hip does not exist"):
+            dbl.frames_project(da, "hip")
+        assert plugin.install() and dbl.module.project_hip is plugin.project_hip
+        out, x, y = dbl.frames_project(da, "hip")
+        assert out.dims == ("time", "y", "x") and out.values.shape == (10,) + dst and out.values.dtype == np.float32
+        assert np.array_equal(out["x"].values, x) and np.array_equal(out["y"].values, y) and out.attrs["h_a"] == 1.0
+        assert np.array_equal(out.values.astype(np.float64), pro.project_frames(cam, dst, *maps))
+        assert len(made) == 1 and made[0].blocks == [(4, 96, 128), (3, 96, 128), (3, 96, 128)]     # one plan per graph, one call per block
+        assert [c[0] for c in dbl.calls] == ["map_idx_img_ortho", "map_mean_idx_img_ortho"] and dbl.calls[0][1:] == (100, 72, 1.25)
+        # another reducer: nearest neighbour only, no group-mean maps asked for
+        dbl.calls.clear()
+        out2, _, _ = dbl.frames_project(da, "hip", reducer="max")
+        assert [c[0] for c in dbl.calls] == ["map_idx_img_ortho"] and len(made) == 2 and made[1].m[2:] == (None, None, None)
+        assert np.array_equal(out2.values.astype(np.float64), pro.project_frames(cam, dst, maps[0], maps[1]))
+        # frames with a trailing rgb axis: core dimensions are (y, x), rgb is a loop dimension like time
+        rgb = fake_xarray.DataArray(np.stack([cam, cam // 2, cam // 3], axis=-1), ("time", "y", "x", "rgb"), {"time": np.arange(10) / 25.0})
+        out3, _, _ = dbl.frames_project(rgb, "hip")
+        assert out3.dims == ("time", "rgb", "y", "x") and np.array_equal(out3.values[:, 1].astype(np.float64), pro.project_frames(cam // 2, dst, *maps))
+        plugin.uninstall()
+        assert not hasattr(dbl.module, "project_hip")
+    finally:
+        plugin.uninstall()
+        monkeypatch.undo()
