@@ -1158,12 +1158,15 @@ template <int N> constexpr bool kEnsLdsRmw = LSPIV_ENS_LDS_RMW && N == 64;
 // ... and HALF of the partial sum stays in LDS for the whole segment: with the half-tile transposes above a wave's LDS is a 9.3 KB tile
 // + 8 KB = the 17.4 KB it had, so columns 0 .. 31 of every lane's row (the first 8 KB of the lane-ordered slot) are accumulated in
 // LDS and written to the slot ONCE per segment; columns 32 .. 63 keep the round trip through the tile (now 8 KB per iteration each way).
-// Measured (round 5, session a, 1080p 64 x 64 @ 75 %, 1000 pairs, interleaved with the round-4 kernel on one box): 34.6 -> 31.6 ms
+// Measured (round 5, sessions a / b, 1080p 64 x 64 @ 75 %, 1000 pairs, interleaved with the round-4 kernel on one box): 34.6 -> 31.6 ms
 // (28.9 k -> 31.6 k pairs/s), kernel 30.75 ms in the trace; counters: fetched 6.2 GB (was 60: the 8 KB halves of the 256 live jobs of
 // an XCD are 2 MB and now STAY in its 4 MB L2 -- TCC hit rate 94 %), written 27.8 GB (was 64; every store of the upper half still goes
-// out), 67.6 M cycles per launch -- fewer than the per-timestep kernel's 68.3 M -- at 2 198 MHz (was 2 138).  Results agree with the
-// round-4 kernel to the last bits only (the planes' own bits moved: the compiler contracts the symmetric a b + c d of the un-packing
-// step the other way round in the re-shaped iteration), and with themselves exactly across chunkings and job orders (tests).
+// out), 67.6 M cycles per launch -- fewer than the per-timestep kernel's 68.3 M -- at 2 198 MHz (was 2 138).  Against the round-4
+// kernel the results move by rounding only (tools/ens_hash.py + ens_diff.py, 120 pairs: 17 % of the samples of corr_sum differ, by at
+// most 7e-7 of the plane maximum; masked corr_max / s2n by at most 2.4e-7 relative; u, v of 89 of 7 488 windows by at most 3.8e-6 px;
+// the counts are identical): the additions are the same in the same order, but the compiler contracts the symmetric a b + c d
+// products of the un-packing step the other way round in the re-shaped iteration, so the planes themselves move by an ulp.  Across
+// chunkings and job orders the kernel agrees with itself bit for bit (tests/test_gpu_strip_order.py, the ensemble chunking tests).
 #ifndef LSPIV_ENS_HALF_ACC
 #define LSPIV_ENS_HALF_ACC 1
 #endif
