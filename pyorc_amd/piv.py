@@ -37,13 +37,15 @@ def _check_args(window_size, overlap, search_area_size, normalize, engine):
 
 
 def piv_pairs(imgs, window_size=(32, 32), overlap=(16, 16), signal_threshold: Optional[float] = None,
-              return_planes: bool = False, pair_offset: int = 0):
+              return_planes: bool = False, pair_offset: int = 0, out=None):
     """Fused PIV of every consecutive frame pair of ``imgs`` (T, H, W).
 
     Returns ``(u, v, corr_max, s2n[, planes])``: float32 arrays (T-1, n_rows, n_cols); u, v in
     pixels (u = column shift, v = row shift).  Replaces pyorc/velocimetry/ffpiv.py:446-474.
     ``pair_offset``: index of the chunk's first pair in the whole stack (``lspiv_piv_pairs_at``); chunks that start on
     multiples of ``window.chunk_alignment`` reproduce the whole-stack result bit for bit.
+    ``out``: four C-contiguous float32 arrays (T-1, n_rows, n_cols) that receive u, v, corr_max, s2n (e.g. time slices of the
+    arrays of a whole run: the caller's chunk loop then needs no concatenation); they are what is returned.
     """
     lib = _lib.load()
     _lib.require_device()
@@ -53,9 +55,15 @@ def piv_pairs(imgs, window_size=(32, 32), overlap=(16, 16), signal_threshold: Op
     if T < 2 or n_rows < 1 or n_cols < 1:
         raise ValueError(f"need >= 2 frames at least one window large, got {a.shape} for window {window_size}")
     P = T - 1
+    if out is not None:
+        out = list(out)
+        if len(out) != 4 or any(not isinstance(o, np.ndarray) or o.dtype != np.float32 or o.shape != (P, n_rows, n_cols) or
+                                not o.flags.c_contiguous or not o.flags.writeable for o in out):
+            raise ValueError(f"out must be four writable C-contiguous float32 arrays of shape {(P, n_rows, n_cols)}")
     if is_device(a):   # HBM-resident stack: no staging, one launch, only the result block crosses PCIe
-        return _piv_pairs_device(a, window_size, overlap, signal_threshold, return_planes, pair_offset, n_rows, n_cols)
-    out = [np.empty((P, n_rows, n_cols), dtype=np.float32) for _ in range(4)]
+        return _piv_pairs_device(a, window_size, overlap, signal_threshold, return_planes, pair_offset, n_rows, n_cols, out)
+    if out is None:
+        out = [np.empty((P, n_rows, n_cols), dtype=np.float32) for _ in range(4)]
     planes = None
     if return_planes:
         planes = np.empty((P, n_rows * n_cols, window_size[0], window_size[1]), dtype=np.float32)
@@ -66,7 +74,7 @@ def piv_pairs(imgs, window_size=(32, 32), overlap=(16, 16), signal_threshold: Op
     return (*out, planes) if return_planes else tuple(out)
 
 
-def _piv_pairs_device(a, window_size, overlap, signal_threshold, return_planes, pair_offset, n_rows, n_cols):
+def _piv_pairs_device(a, window_size, overlap, signal_threshold, return_planes, pair_offset, n_rows, n_cols, out=None):
     from .device import DeviceFrames
 
     lib = _lib.load()
@@ -77,8 +85,13 @@ def _piv_pairs_device(a, window_size, overlap, signal_threshold, return_planes, 
     _lib.check(lib.lspiv_piv_pairs_dev_at(a.c_ptr, a.dtype_code, T, H, W, window_size[0], window_size[1], overlap[0], overlap[1],
                                           _sig(signal_threshold), int(pair_offset), d_out.c_ptr,
                                           d_planes.c_ptr if d_planes is not None else None, None))
-    res = d_out.to_host().reshape(4, P, n_rows, n_cols)     # lspiv_memcpy_d2h runs on, and waits for, the library's stream
-    out = tuple(np.ascontiguousarray(res[k]) for k in range(4))
+    if out is not None:    # straight into the caller's arrays: [u | v | corr | s2n] are four consecutive (P, n_win) blocks
+        for k in range(4):
+            _lib.check(lib.lspiv_memcpy_d2h(_lib.ptr(out[k]), C.c_void_p(d_out.ptr + k * P * n_win * 4), out[k].nbytes))
+        out = tuple(out)
+    else:
+        res = d_out.to_host().reshape(4, P, n_rows, n_cols)     # lspiv_memcpy_d2h runs on, and waits for, the library's stream
+        out = tuple(np.ascontiguousarray(res[k]) for k in range(4))
     if return_planes:
         return (*out, d_planes.to_host().reshape(P, n_win, window_size[0], window_size[1]))
     return out

@@ -213,11 +213,13 @@ def get_ffpiv(
     return _get_ffpiv_timestep(*args, signal_threshold, like=frames, prefetch=depth)
 
 
-def _to_velocity(disp: np.ndarray, res, dt_chunk: np.ndarray) -> np.ndarray:
+def _to_velocity(disp: np.ndarray, res, dt_chunk: np.ndarray, out: Optional[np.ndarray] = None) -> np.ndarray:
     """``(disp * res / dt).astype(float32)`` of ffpiv.py:418-419 with the same arithmetic (the product in whatever type numpy
-    gives it, the division in float64, one rounding to float32) but without the two float64 temporaries of the one-liner."""
+    gives it, the division in float64, one rounding to float32) but without the two float64 temporaries of the one-liner;
+    ``out``: where the result goes (a time slice of the run's result array)."""
     prod = disp * res
-    out = prod if prod.dtype == np.float32 else np.empty(prod.shape, dtype=np.float32)
+    if out is None:
+        out = prod if prod.dtype == np.float32 else np.empty(prod.shape, dtype=np.float32)
     np.divide(prod, dt_chunk, out=out, dtype=np.float64, casting="same_kind")
     return out
 
@@ -226,29 +228,49 @@ def _get_ffpiv_timestep(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_c
                         signal_threshold, like=None, prefetch=0):
     """Per-chunk loop of pyorc/velocimetry/ffpiv.py:379-443 (one fused GPU call per chunk); chunk n + 1 is loaded on a worker
     thread while chunk n is launched (``pyorc_amd.executor.ChunkPrefetcher``; ``prefetch = 0``: the reference's serial order)."""
-    parts = {"s2n": [], "corr": [], "v_x": [], "v_y": []}
+    # the four result variables of the WHOLE run are allocated once and every chunk's launch writes its time slice of them (corr, s2n
+    # straight from the library, v_x / v_y through the px -> m/s scaling): no per-chunk arrays to concatenate at the end (the
+    # reference's xr.concat, ffpiv.py:442 -- 125 KB per pair, i.e. as many bytes again as a uint8 chunk's upload at 32 x 32)
+    n_total = slices[-1][1] - 1 if slices else 0
+    names = ("s2n", "corr", "v_x", "v_y")
+    full = None            # name -> (n_total, n_rows, n_cols) float32
+    px = None              # scratch for a chunk's u, v in pixels
+    done = []              # (first pair, one past the last pair) of every chunk that delivered
     times = []
     loader = executor.ChunkPrefetcher(frames_chunks, load_frame_chunk, depth=prefetch)
     for n, da in loader:
         a, b = slices[n]
         if len(da) >= 2:  # we need at least one image-pair to do PIV
             nb = a + len(da)  # load_frame_chunk may have dropped trailing frames
-            u, v, corr_max, s2n = piv.piv_pairs(_values(da), window_size, overlap, signal_threshold, pair_offset=a)
-            if u.shape[1:] != (n_rows, n_cols):
-                raise ValueError(f"grid {u.shape[1:]} does not match coordinates ({n_rows}, {n_cols})")
+            p = nb - 1 - a
+            vals = _values(da)
+            grid = window.get_array_shape(tuple(vals.shape[1:]), window_size, overlap)
+            if tuple(grid) != (n_rows, n_cols):
+                raise ValueError(f"grid {tuple(grid)} does not match coordinates ({n_rows}, {n_cols})")
+            if full is None:
+                full = {k: np.empty((n_total, n_rows, n_cols), dtype=np.float32) for k in names}
+            if px is None or px[0].shape[0] < p:
+                px = [np.empty((p, n_rows, n_cols), dtype=np.float32) for _ in range(2)]
+            u, v = px[0][:p], px[1][:p]
+            piv.piv_pairs(vals, window_size, overlap, signal_threshold, pair_offset=a,
+                          out=(u, v, full["corr"][a:a + p], full["s2n"][a:a + p]))
             dt_chunk = dt[a:nb - 1][:, None, None]  # dt.sel(time=da.time[1:]), ffpiv.py:403-404
             # u and v to meter per second (float64 division, float32 storage: ffpiv.py:418-419)
-            parts["v_x"].append(_to_velocity(u, res_x, dt_chunk))
-            parts["v_y"].append(_to_velocity(v, res_y, dt_chunk))
-            parts["corr"].append(corr_max)
-            parts["s2n"].append(s2n)
+            _to_velocity(u, res_x, dt_chunk, out=full["v_x"][a:a + p])
+            _to_velocity(v, res_y, dt_chunk, out=full["v_y"][a:a + p])
+            done.append((a, a + p))
             times.append(time[a + 1:nb])
         # remove chunk safely from memory.  (The reference follows this with gc.collect() to get rid of its window stack and
         # correlation volume, ffpiv.py:437-440; neither exists here, and a collection costs ~1 ms per chunk: dropped.)
         frames_chunks[n] = None
         del da
     executor.LAST_STATS.clear(); executor.LAST_STATS.update(loader.stats)
-    data = {k: vv[0] if len(vv) == 1 else np.concatenate(vv, axis=0) for k, vv in parts.items()}
+    if not done:
+        raise ValueError("no chunk with at least one frame pair")
+    if done[0][0] == 0 and done[-1][1] == n_total and all(x[1] == y[0] for x, y in zip(done, done[1:])):
+        data = full            # every pair delivered, in order: the arrays are the result
+    else:                      # a chunk lost trailing frames (load_frame_chunk's TypeError retry) or was skipped: close the gaps
+        data = {k: np.concatenate([full[k][i:j] for i, j in done], axis=0) for k in names}
     if _is_xr(like):
         t = xr.concat(times, dim="time")
     else:

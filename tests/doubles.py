@@ -1,0 +1,15 @@
+"""Stand-ins for the GPU calls in the CPU tests of the host mirrors: the same signatures, the oracle behind them."""
+import numpy as np
+
+
+def oracle_piv_pairs(fr, ws, ov, thr=None, pair_offset=0, out=None):
+    """``pyorc_amd.piv.piv_pairs`` (signature as of round 5, with ``out``) computed by the C oracle."""
+    from oracle import c_oracle
+
+    res = tuple(a.astype(np.float32) for a in c_oracle.piv_pairs(np.asarray(fr), ws, ov, thr))
+    if out is None:
+        return res
+    for dst, src in zip(out, res):
+        assert dst.dtype == np.float32 and dst.shape == src.shape and dst.flags.c_contiguous
+        dst[...] = src
+    return tuple(out)

@@ -192,10 +192,12 @@ def test_get_ffpiv_gives_the_same_dataset_with_and_without_prefetch(monkeypatch)
                 time.sleep(load_s)
                 return super().load()
 
-        def fake_pairs(fr, ws, ov, thr=None, pair_offset=0):
+        def fake_pairs(fr, ws, ov, thr=None, pair_offset=0, out=None):
+            from tests.doubles import oracle_piv_pairs
+
             order.append(pair_offset)
             time.sleep(compute_s)
-            return tuple(a.astype(np.float32) for a in c_oracle.piv_pairs(np.asarray(fr), ws, ov, thr))
+            return oracle_piv_pairs(fr, ws, ov, thr, pair_offset, out)
 
         class SlowEnsemble(OracleEnsemble):
             def accumulate(self, frames, corr_min, s2n_min, thr=None):
@@ -270,7 +272,7 @@ def test_a_lazy_stack_without_xarray_stays_lazy_in_get_piv(monkeypatch):
             loads.append(len(self._d))
             return np.array(self._d)
 
-    monkeypatch.setattr(V.piv, "piv_pairs", lambda fr, ws, ov, thr=None, pair_offset=0: tuple(a.astype(np.float32) for a in c_oracle.piv_pairs(np.asarray(fr), ws, ov, thr)))
+    monkeypatch.setattr(V.piv, "piv_pairs", __import__("tests.doubles", fromlist=["x"]).oracle_piv_pairs)
     monkeypatch.setattr(V.window, "available_memory", lambda: 1e12)
     monkeypatch.setattr(V.window, "chunk_alignment", lambda ws: 5)
     fr = particle_stack(16, 64, 96, seed=2)
@@ -280,3 +282,42 @@ def test_a_lazy_stack_without_xarray_stays_lazy_in_get_piv(monkeypatch):
     assert loads == [6, 6, 6] and executor.LAST_STATS["depth"] == 1 and executor.LAST_STATS["chunks"] == 3
     for k in ref:
         assert np.array_equal(got[k], ref[k], equal_nan=True)
+
+
+def test_a_chunk_that_lost_its_last_frame_leaves_no_gap_in_the_result(monkeypatch):
+    """load_frame_chunk's TypeError retry (ffpiv.py:17-21) shortens a chunk by a frame: that chunk delivers one pair less.  The run's
+    result arrays are allocated for every pair and written slice by slice; the missing pair must not show up as a hole of
+    uninitialised memory -- the result holds exactly the delivered pairs, in order, with their time stamps."""
+    from pyorc_amd import frames as F, velocimetry as V
+    from pyorc_amd.synth import particle_stack
+    from tests.doubles import oracle_piv_pairs
+
+    class Lazy:
+        def __init__(self, data, lo=0, flaky=True):
+            self._d, self.lo, self.flaky, self.dtype, self.shape = data, lo, flaky, data.dtype, data.shape
+
+        def __len__(self):
+            return len(self._d)
+
+        def __getitem__(self, key):
+            if isinstance(key, slice):
+                a, b, _ = key.indices(len(self._d))
+                return Lazy(self._d[key], self.lo + a, self.flaky and not (a == 0 and b == len(self._d) - 1))
+            return self._d[key]
+
+        def load(self):
+            if self.flaky and self.lo == 5 and len(self._d) == 6:      # the second chunk (frames 5 .. 10) fails once at full length
+                raise TypeError("cannot decode the last frame of this block")
+            return np.array(self._d)
+
+    monkeypatch.setattr(V.piv, "piv_pairs", oracle_piv_pairs)
+    monkeypatch.setattr(V.window, "available_memory", lambda: 1e12)
+    monkeypatch.setattr(V.window, "chunk_alignment", lambda ws: 5)
+    fr = particle_stack(16, 64, 96, seed=2)
+    t = np.arange(16) / 25.0
+    ref = F.get_piv(fr, 32, time=t, resolution=0.02, chunksize=6)             # pairs 0 .. 14
+    got = F.get_piv(Lazy(fr), 32, time=t, resolution=0.02, chunksize=6)       # pair 9 (frames 9, 10) is lost with frame 10
+    keep = [p for p in range(15) if p != 9]
+    assert got["v_x"].shape[0] == 14 and np.array_equal(got.coords["time"], t[1:][keep])
+    for k in ref:
+        assert np.array_equal(got[k], ref[k][keep], equal_nan=True), k

@@ -240,7 +240,7 @@ def test_xarray_branches_of_the_mirrors(monkeypatch):
         importlib.reload(mod)
     try:
         assert V.xr is fake_xarray
-        monkeypatch.setattr(V.piv, "piv_pairs", lambda fr, ws, ov, thr=None, pair_offset=0: tuple(a.astype(np.float32) for a in c_oracle.piv_pairs(np.asarray(fr), ws, ov, thr)))
+        monkeypatch.setattr(V.piv, "piv_pairs", __import__("tests.doubles", fromlist=["x"]).oracle_piv_pairs)
         monkeypatch.setattr(V.window, "available_memory", lambda: 1e12)
         fr = particle_stack(7, 96, 128, seed=3)
         t = np.arange(7) / 25.0
@@ -323,7 +323,7 @@ def test_pyorc_installed_branch_of_get_piv(monkeypatch):
     for mod in (V, F):
         importlib.reload(mod)
     try:
-        monkeypatch.setattr(V.piv, "piv_pairs", lambda fr, ws, ov, thr=None, pair_offset=0: tuple(a.astype(np.float32) for a in c_oracle.piv_pairs(np.asarray(fr), ws, ov, thr)))
+        monkeypatch.setattr(V.piv, "piv_pairs", __import__("tests.doubles", fromlist=["x"]).oracle_piv_pairs)
         monkeypatch.setattr(V.window, "available_memory", lambda: 1e12)
         fr = particle_stack(5, 96, 128, seed=5)
         t = np.arange(5) / 25.0

@@ -80,7 +80,7 @@ def test_install_registers_the_hip_engine_in_an_unmodified_pyorc(monkeypatch):
         importlib.reload(mod)
     plugin.uninstall()
     try:
-        monkeypatch.setattr(V.piv, "piv_pairs", lambda fr, ws, ov, thr=None, pair_offset=0: tuple(a.astype(np.float32) for a in c_oracle.piv_pairs(np.asarray(fr), ws, ov, thr)))
+        monkeypatch.setattr(V.piv, "piv_pairs", __import__("tests.doubles", fromlist=["x"]).oracle_piv_pairs)
         monkeypatch.setattr(V.window, "available_memory", lambda: 1e12)
         monkeypatch.setattr(_lib, "require_device", lambda: None)
         fr = particle_stack(6, 96, 128, seed=9)
