@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define LSPIV_ABI_VERSION 4   /* (round 5 added lspiv_ensemble_flag_digest, lspiv_kernel_times + the "time_kernel" option and the test hook lspiv_debug_hold_lock; no version change: nothing existing moved)
+#define LSPIV_ABI_VERSION 4   /* (round 5 added lspiv_chunk_alignment_grid, lspiv_ensemble_flag_digest, lspiv_kernel_times + the "time_kernel" option and the test hook lspiv_debug_hold_lock; no version change: nothing existing moved)
                                * 4 (round 4, additions only): lspiv_build_info, the float64 rescue of the ensemble's final fit
                                * (lspiv_ensemble_set_retain / _stats / _flag / _partials / _finish_partials), lspiv_stream_release,
                                * lspiv_stream_create_priority; 3: lspiv_rescue_stats,
@@ -174,8 +174,13 @@ int lspiv_piv_pairs_dev(const void* d_frames, int dtype, int64_t T, int64_t H, i
  * Chunks that start on such a multiple therefore reproduce, bit for bit, what one call over the whole stack returns
  * (tested); a chunk that starts elsewhere is still correct but its first (alignment - offset % alignment) pairs may
  * differ from the whole-stack run in the last float32 bit.  lspiv_piv_pairs[_dev] == these with pair_offset 0.
- * lspiv_chunk_alignment: pairs; 1 for window sizes served by per-pair kernels and with option "walk" = 0.  Host-only. */
+ * lspiv_chunk_alignment: pairs; 1 for window sizes served by per-pair kernels and with option "walk" = 0.  Host-only.
+ * Round 5: the run length depends on the window GRID as well -- 25 pairs, or 125 on grids with at least as many windows as the chip
+ * has lane groups for that window family (1080p 32 x 32 @ 50 %, 64 x 64 @ 75 %, 4K: less per-segment overhead, csrc/common.h
+ * walk_anchor).  lspiv_chunk_alignment_grid(H, W, ...) is the figure to cut chunks on for frames of that shape (a multiple of
+ * lspiv_chunk_alignment(wy, wx), which remains the run length on small grids); negative status for a bad shape. */
 int lspiv_chunk_alignment(int wy, int wx);
+int lspiv_chunk_alignment_grid(int64_t H, int64_t W, int wy, int wx, int oy, int ox);
 int lspiv_piv_pairs_at(const void* frames, int dtype, int64_t T, int64_t H, int64_t W,
                        int wy, int wx, int oy, int ox, float signal_threshold, int64_t pair_offset,
                        float* u, float* v, float* corr_max, float* s2n, float* corr_planes);

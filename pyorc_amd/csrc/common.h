@@ -92,6 +92,7 @@ struct PivParams {
   uint32_t seg_len, n_seg; // pairs per segment (odd), number of segments
   uint32_t seg_first;      // pairs in segment 0: seg_len, or what is left up to the next anchor when the chunk starts off-anchor
   uint32_t n_pairs;        // T-1
+  uint32_t xcd_by_windows; // walking kernels: 0 = every XCD gets a contiguous range of (segment, window) jobs; 1 = an eighth of the windows of every segment (piv_fft_impl.h, walk_job)
   uint32_t strip_w;        // walking kernels: 0 = a segment's jobs run over the window grid row by row; w > 0 = in column strips of w
                            // windows, every strip top to bottom (the vertically overlapping windows of a band share a round of jobs)
   int64_t pair_offset;     // absolute index of the chunk's first pair in the caller's stack: the walking kernels cut
@@ -425,6 +426,21 @@ int walk_setting();
 // of 2.5 k ... 32 k windows, rounds x iterations of L = 25 stays within 2.5 % of the best per-chunk choice at 1000 pairs
 // and within 6 % at 200 (59 ... 63, the best length for 1000-pair chunks, loses 15 - 40 % at 200).
 constexpr uint32_t kWalkAnchor = 25;
+// Round 5: LONG anchors for grids with enough windows.  What a longer segment saves is per-segment overhead -- the first iteration of a
+// segment yields one plane instead of two (13 iterations per 25 pairs, 63 per 125: - 3 %), and in ensemble mode every segment flushes
+// and later merges a partial sum per window -- : 1080p, 1000 pairs, anchors 25 -> 125: ensemble 64 x 64 33.3 -> 34.7 k pairs/s, ensemble
+// 32 x 32 167.6 -> 175.9 k, per-timestep 64 x 64 35.5 -> 36.6 k, 32 x 32 164.8 -> 166.0 k (one box, interleaved).  What it costs is
+// parallelism per segment: a segment is n_win jobs, and with fewer of them than the chip has lane groups the tail of every round of
+// jobs idles for 63 iterations instead of 13.  So the anchor is a function of the window grid alone (NOT of the chunk: results must
+// not depend on the chunking): 125 when the grid has at least as many windows as the chip has lane groups of that window family
+// (nominal MI355X: 256 CUs x 4 SIMDs x waves x groups per wave), 25 otherwise.  It needs the XCD partition BY WINDOWS
+// (piv_fft_impl.h, walk_job): with whole segments per XCD a long anchor runs XCDs dry (300 pairs: 26 k instead of 33 k).
+// Chunks must then be cut on multiples of lspiv_chunk_alignment_grid() -- 125 for such grids -- to reproduce one call bit for bit.
+constexpr uint32_t kWalkAnchorLong = 125;
+inline uint32_t walk_long_min_windows(int n) {          // lane groups on the chip, per window family
+  return n <= 16 ? 256u * 4u * 3u * 4u : n <= 32 ? 256u * 4u * 3u * 2u : 256u * 4u * 2u;   // 12 288 / 6 144 / 2 048
+}
+inline uint32_t walk_anchor(int n, uint32_t n_win) { return n_win >= walk_long_min_windows(n) ? kWalkAnchorLong : kWalkAnchor; }
 struct WalkSegments { uint32_t seg_len, seg_first, n_seg; };
 inline WalkSegments walk_segments(uint32_t n_pairs, int64_t pair_offset, uint32_t seg_len) {
   WalkSegments w;

@@ -844,6 +844,18 @@ int lspiv_chunk_alignment(int wy, int wx) {
   if (!kind_walks(kind) || walk == 0) return 1;
   return walk > 1 ? walk : (int)lspiv::kWalkAnchor;
 }
+// the anchor length the walking kernels use on a grid of n_win windows (common.h, walk_anchor)
+static int chunk_alignment_for(int wy, int wx, int64_t n_win) {
+  const int base = lspiv_chunk_alignment(wy, wx);
+  if (base <= 1 || lspiv::walk_setting() > 1) return base;     // per-pair kernels, or a forced anchor length
+  return (int)lspiv::walk_anchor(wy, (uint32_t)std::min<int64_t>(n_win, 0x7fffffff));
+}
+int lspiv_chunk_alignment_grid(int64_t H, int64_t W, int wy, int wx, int oy, int ox) {
+  Grid g;
+  const int rc = make_grid(H, W, wy, wx, oy, ox, &g);
+  if (rc) return rc;
+  return chunk_alignment_for(wy, wx, g.n_rows * g.n_cols);
+}
 
 int lspiv_piv_pairs_dev_at(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, int wy, int wx, int oy,
                            int ox, float signal_threshold, int64_t pair_offset, float* d_out, float* d_corr_planes,
@@ -917,7 +929,7 @@ int lspiv_piv_pairs_at(const void* frames, int dtype, int64_t T, int64_t H, int6
   if (rc) return rc;
   const int64_t fpb = std::max<int64_t>(1, (int64_t)(c->pinned_cap / frame_bytes));
   const bool src_pinned = dtype != LSPIV_F64 && is_pinned(frames);
-  const int64_t align = std::max(1, lspiv_chunk_alignment(wy, wx));
+  const int64_t align = std::max(1, chunk_alignment_for(wy, wx, (int64_t)n_win));
   // "stack" signal mode scores a window position over ALL frames of the chunk: one launch once everything is resident
   const bool whole_chunk_only = g_opt_signal_mode.load() == 1 && signal_threshold >= 0.0f;
   int64_t launched = 0;   // pairs [0, launched) have been issued
@@ -1056,7 +1068,7 @@ static int ensemble_launch(lspiv_ensemble* h, DeviceCtx* c, const void* d_frames
   if (kind_walks(kind) && walk != 0) {
     // segments anchored at multiples of the anchor length of the absolute pair index (common.h): the partial sums, and
     // the order they are merged in, are the same for every chunking whose boundaries are multiples of that length
-    const lspiv::WalkSegments w = lspiv::walk_segments(p.n_pairs, p.pair_offset, walk > 1 ? (uint32_t)walk : lspiv::kWalkAnchor);
+    const lspiv::WalkSegments w = lspiv::walk_segments(p.n_pairs, p.pair_offset, walk > 1 ? (uint32_t)walk : lspiv::walk_anchor(h->wy, p.n_win));
     p.seg_len = w.seg_len; p.seg_first = w.seg_first; p.n_seg = w.n_seg;
     const size_t plane = (size_t)h->wy * h->wx;
     const size_t need = (size_t)p.n_seg * p.n_win * (plane + 1) * sizeof(float);
@@ -1140,7 +1152,7 @@ int lspiv_ensemble_accumulate(lspiv_ensemble* h, const void* frames, int dtype, 
   rc = stage_ring(c, frame_bytes);
   if (rc) return rc;
   const int64_t fpb = std::max<int64_t>(1, (int64_t)(c->pinned_cap / frame_bytes));
-  const int64_t align = std::max(1, lspiv_chunk_alignment(h->wy, h->wx)), base_offset = h->pairs_done;
+  const int64_t align = std::max(1, chunk_alignment_for(h->wy, h->wx, (int64_t)n_win)), base_offset = h->pairs_done;
   int64_t launched = 0;
   {
     int batch = 0;

@@ -1151,6 +1151,9 @@ template <int N> constexpr bool kF32Early = LSPIV_F32_EARLY && Geo<N>::FULL;
 // (No-return float atomics into lane-major slots were measured first: 44.6 ms -- the L2 atomic units take ~3.5 TB/s, 61 GB of
 // adds per 1000 pairs do not hide behind the arithmetic; at 32 x 32 the same scheme LOSES to the register accumulator, 11.6
 // against 7.0 ms.  docs/history.md, round 4.)
+#ifndef LSPIV_XCD_ORDER_DEFAULT
+#define LSPIV_XCD_ORDER_DEFAULT 1
+#endif
 #ifndef LSPIV_ENS_LDS_RMW
 #define LSPIV_ENS_LDS_RMW 1
 #endif
@@ -1317,6 +1320,54 @@ __device__ __forceinline__ uint32_t strip_order(uint32_t idx, uint32_t strip_w, 
   return row * n_cols + sidx * strip_w + (rem - row * w);
 }
 
+// Which (segment, index in the segment's job order) a lane group of a walking kernel works on.  The hardware hands block b to XCD
+// b % 8, and an XCD works through its blocks in order.
+//   by_windows = 0 (rounds 2 - 4): every XCD gets ONE CONTIGUOUS RANGE of the jobs segment * n_win + window, i.e. whole segments, so a
+//     frame is pulled into one L2 only -- but the partition is static: where segments differ in length (the shorter last one; anchors
+//     that do not divide the chunk) the XCD that holds the short jobs runs dry while the others work (1080p 64 x 64, 300 pairs at an
+//     anchor of 125: 26.2 k against 32.8 k pairs/s at 25).
+//   by_windows = 1 (round 5): every XCD gets an eighth of the WINDOWS -- a contiguous range of the job order, i.e. whole rows / strips
+//     -- of EVERY segment, segment after segment: the same work per XCD whatever the segments' lengths, a frame's band still goes to
+//     one L2 (neighbouring bands share the windows' overlap).
+// `local`: the lane group's index within its block (wave * GROUPS + group); JPB: jobs per block.  Blocks per launch: walk_blocks.
+struct WalkJob { uint32_t seg, widx; bool valid; };
+template <uint32_t JPB>
+__device__ __forceinline__ WalkJob walk_job(uint32_t local, uint32_t n_seg, uint32_t n_win, const FastDiv& div_nwin, uint32_t by_windows) {
+  WalkJob j;
+  const uint32_t xcd = blockIdx.x & 7u, lb = blockIdx.x >> 3;
+  if (by_windows) {
+    const uint32_t wlo = (uint32_t)(((uint64_t)xcd * n_win) >> 3), nw = (uint32_t)(((uint64_t)(xcd + 1) * n_win) >> 3) - wlo;
+    const uint32_t i = lb * JPB + local;                  // index among this XCD's jobs
+    j.valid = i < n_seg * nw;                             // (an XCD without windows, n_win < 8: never)
+    const uint32_t ii = j.valid ? i : 0u;
+    j.seg = nw ? ii / nw : 0u;
+    j.widx = wlo + (ii - j.seg * nw);
+    if (!j.valid) { j.seg = n_seg - 1; j.widx = n_win - 1; }   // a job past the end recomputes the last one and stores nothing
+  } else {
+    const uint32_t nb = gridDim.x;
+    const uint32_t q = nb >> 3, r = nb & 7u;
+    const uint32_t blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + lb;
+    uint32_t job = blk * JPB + local;
+    j.valid = job < n_seg * n_win;
+    job = j.valid ? job : n_seg * n_win - 1;
+    j.seg = div_nwin.div(job);
+    j.widx = job - j.seg * n_win;
+  }
+  return j;
+}
+static inline uint32_t walk_blocks(uint32_t n_seg, uint32_t n_win, uint32_t jobs_per_block, uint32_t by_windows) {
+  if (by_windows) {   // every XCD: the blocks of its largest possible share, n_seg * ceil(n_win / 8) jobs
+    const uint64_t per_xcd = (uint64_t)n_seg * ((n_win + 7) / 8);
+    return (uint32_t)(8 * ((per_xcd + jobs_per_block - 1) / jobs_per_block));
+  }
+  return (uint32_t)(((uint64_t)n_seg * n_win + jobs_per_block - 1) / jobs_per_block);
+}
+// LSPIV_XCD_ORDER: 0 / 1 = by_windows above (A/B; read once per process)
+static inline uint32_t walk_xcd_by_windows() {
+  static const int env = getenv("LSPIV_XCD_ORDER") ? atoi(getenv("LSPIV_XCD_ORDER")) : LSPIV_XCD_ORDER_DEFAULT;
+  return env != 0 ? 1u : 0u;
+}
+
 // what a walking job carries from one iteration to the next
 template <int N>
 struct WalkCarry {
@@ -1468,17 +1519,11 @@ __global__ __launch_bounds__(BLOCK, (kWalkWaves<T, N>)) void piv_fft_walk_kernel
   const int partner_byte = partner_byte_of<N>(lane, lg);
   const int lane0_byte = lane0_byte_of<N>();
 
-  // XCD-aware block order (block b runs on XCD b % 8): every XCD gets one contiguous range of jobs = whole segments,
-  // so a frame is pulled into one L2 only
-  const uint32_t nb = gridDim.x;
-  const uint32_t q = nb >> 3, r = nb & 7u;
-  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-  const uint32_t blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  uint32_t job = (blk * WAVES_PER_BLOCK + wave) * G::GROUPS + grp;   // job = segment * n_win + window
-  const bool job_valid = job < n_seg * p.n_win;
-  job = job_valid ? job : n_seg * p.n_win - 1;
-  const uint32_t seg = p.div_nwin.div(job);
-  const uint32_t win = strip_order(job - seg * p.n_win, p.strip_w, (uint32_t)p.n_rows, (uint32_t)p.n_cols);
+  // XCD-aware job order (walk_job): which segment, which window
+  const WalkJob wj = walk_job<WAVES_PER_BLOCK * G::GROUPS>((uint32_t)(wave * G::GROUPS + grp), n_seg, p.n_win, p.div_nwin, p.xcd_by_windows);
+  const bool job_valid = wj.valid;
+  const uint32_t seg = wj.seg;
+  const uint32_t win = strip_order(wj.widx, p.strip_w, (uint32_t)p.n_rows, (uint32_t)p.n_cols);
   // segments are anchored at absolute pair indices (common.h, kWalkAnchor): segment 0 ends at the first anchor
   const uint32_t p0 = seg == 0 ? 0u : p.seg_first + (seg - 1) * seg_len;
   const uint32_t p1 = min(seg == 0 ? p.seg_first : p0 + seg_len, p.n_pairs);   // pairs [p0, p1) = frames p0 .. p1
@@ -1910,19 +1955,16 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsBound<T, N, WANT_NZ>)) void piv_fft
   float* hacc = buf + kHalfTileDwords;                             // (kEnsHalfAcc: the job's columns 0 .. 31 of the partial sum)
   const int partner_byte = partner_byte_of<N>(lane, lg);
   const int lane0_byte = lane0_byte_of<N>();
-  const uint32_t nb = gridDim.x;                                   // XCD-aware block order, as piv_fft_walk_kernel
-  const uint32_t q = nb >> 3, r = nb & 7u;
-  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-  const uint32_t blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  uint32_t job = (blk * WAVES_PER_BLOCK + wave) * G::GROUPS + grp;   // job = segment * n_win + window
+  // XCD-aware job order, as piv_fft_walk_kernel (walk_job).
   // one job per wave (N > 32): say so -- segment, window, pair range, loop counter, result and slot addresses then live in SGPRs
   // instead of one VGPR (pair) each (in-loop scratch 15 + 3 -> 11 + 3; the per-timestep kernel got WORSE with the same line,
   // 8 + 0 -> 12 + 2, and does without)
-  if constexpr (G::GROUPS == 1) job = (uint32_t)__builtin_amdgcn_readfirstlane((int)job);
-  const bool job_valid = job < p.n_seg * p.n_win;
-  job = job_valid ? job : p.n_seg * p.n_win - 1;
-  const uint32_t seg = p.div_nwin.div(job);
-  const uint32_t win = strip_order(job - seg * p.n_win, p.strip_w, (uint32_t)p.n_rows, (uint32_t)p.n_cols);
+  uint32_t local = (uint32_t)(wave * G::GROUPS + grp);
+  if constexpr (G::GROUPS == 1) local = (uint32_t)__builtin_amdgcn_readfirstlane((int)local);
+  const WalkJob wj = walk_job<WAVES_PER_BLOCK * G::GROUPS>(local, p.n_seg, p.n_win, p.div_nwin, p.xcd_by_windows);
+  const bool job_valid = wj.valid;
+  const uint32_t seg = wj.seg;
+  const uint32_t win = strip_order(wj.widx, p.strip_w, (uint32_t)p.n_rows, (uint32_t)p.n_cols);
   const uint32_t p0 = seg == 0 ? 0u : p.seg_first + (seg - 1) * p.seg_len;
   const uint32_t p1 = min(seg == 0 ? p.seg_first : p0 + p.seg_len, p.n_pairs);
   const uint32_t wrow = p.div_ncols.div(win);
@@ -2024,11 +2066,11 @@ static hipError_t launch_t(const PivParams& p, bool ensemble, hipStream_t s) {
   using G = Geo<N>;
   constexpr uint32_t jobs_per_block = WAVES_PER_BLOCK * G::GROUPS;
   if (ensemble && p.part_sum) {   // walking ensemble kernel + ordered merge of the per-segment partial sums
-    const uint64_t wjobs = (uint64_t)p.n_seg * p.n_win;
     PivParams q = p;
     q.strip_w = walk_strip_width<T, N>();
+    q.xcd_by_windows = walk_xcd_by_windows();
     constexpr size_t ens_lds = kEnsHalfAcc<N> ? (size_t)WAVES_PER_BLOCK * kEnsHalfAccWaveDwords * 4 : (size_t)G::LDS_BYTES;
-    hipLaunchKernelGGL((piv_fft_walk_ensemble_kernel<T, N, WANT_NZ>), dim3((uint32_t)((wjobs + jobs_per_block - 1) / jobs_per_block)),
+    hipLaunchKernelGGL((piv_fft_walk_ensemble_kernel<T, N, WANT_NZ>), dim3(walk_blocks(p.n_seg, p.n_win, jobs_per_block, q.xcd_by_windows)),
                        dim3(BLOCK), ens_lds, s, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -2040,16 +2082,16 @@ static hipError_t launch_t(const PivParams& p, bool ensemble, hipStream_t s) {
     hipLaunchKernelGGL((piv_fft_ensemble_kernel<T, N, WANT_NZ>), dim3(blocks), dim3(BLOCK), G::LDS_BYTES, s, p);
     return hipGetLastError();
   }
-  // LSPIV_WALK: 0 = per-pair kernel; unset / 1 = time-walking kernel, segments anchored every kWalkAnchor pairs of the
+  // LSPIV_WALK: 0 = per-pair kernel; unset / 1 = time-walking kernel, segments anchored every walk_anchor(N, n_win) = 25 / 125 pairs of the
   // absolute pair index (results independent of the chunking); n > 1 = anchor length n (odd values waste no half iteration)
   const int walk = walk_setting();   // option or environment, read per launch
   if (walk != 0) {
     PivParams q = p;
-    const WalkSegments w = walk_segments(p.n_pairs, p.pair_offset, walk > 1 ? (uint32_t)walk : kWalkAnchor);
+    const WalkSegments w = walk_segments(p.n_pairs, p.pair_offset, walk > 1 ? (uint32_t)walk : walk_anchor(N, p.n_win));
     q.seg_len = w.seg_len; q.seg_first = w.seg_first; q.n_seg = w.n_seg;
     q.strip_w = walk_strip_width<T, N>();
-    const uint64_t wjobs = (uint64_t)w.n_seg * p.n_win;
-    const uint32_t wblocks = (uint32_t)((wjobs + jobs_per_block - 1) / jobs_per_block);
+    q.xcd_by_windows = walk_xcd_by_windows();
+    const uint32_t wblocks = walk_blocks(w.n_seg, p.n_win, jobs_per_block, q.xcd_by_windows);
     constexpr size_t walk_lds = G::LDS_BYTES + (kTwoPlaneEpilogue<N> ? (size_t)WAVES_PER_BLOCK * G::GROUPS * 3 * G::LDS_ROW * 4 : 0);   // + plane b's three rows
     if (p.planes)
       hipLaunchKernelGGL((piv_fft_walk_kernel<T, N, true, WANT_NZ>), dim3(wblocks), dim3(BLOCK), walk_lds, s, q);

@@ -146,7 +146,7 @@ class CameraToVelocity:
     def _chunk_bounds(self, n_pairs: int, n_chunks: int):
         """Pair indices where the time chunks start (+ n_pairs): multiples of the kernels' anchor length, so that the chunked
         PIV returns the bits of one call (include/lspiv.h, lspiv_chunk_alignment)."""
-        align = max(1, int(_lib.load().lspiv_chunk_alignment(self.window_size[0], self.window_size[1])))
+        align = max(1, int(window.chunk_alignment(self.window_size, self.ortho_shape, self.overlap)))
         per = -(-n_pairs // max(1, int(n_chunks)))          # ceil
         per = max(align, -(-per // align) * align)
         return list(range(0, n_pairs, per)) + [n_pairs]

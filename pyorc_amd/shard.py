@@ -67,12 +67,15 @@ def gather_blocks(local: np.ndarray, n_pairs: int, comm, align: int = 1) -> np.n
 
 
 def sharded_piv(load_frames: Callable[[int, int], np.ndarray], n_pairs: int, window_size, overlap, comm,
-                compute: Optional[Callable] = None, signal_threshold=None, align: Optional[int] = None) -> np.ndarray:
+                compute: Optional[Callable] = None, signal_threshold=None, align: Optional[int] = None,
+                frame_shape=None) -> np.ndarray:
     """Every rank computes its pair block and all ranks receive the full (4, n_pairs, n_rows, n_cols) block.
 
     ``load_frames(start, stop)`` returns frames [start, stop) as (T, H, W) -- each rank only ever touches its
     own time block (+ halo).  ``compute(frames, window_size, overlap, signal_threshold, pair_offset=...)`` ->
     (u, v, corr_max, s2n); default is the HIP engine (``pyorc_amd.piv.piv_pairs``).
+    ``frame_shape`` (H, W): the rank blocks are cut on the anchor length of THAT window grid (``window.chunk_alignment``: 25 pairs, 125 on
+    large grids); without it on the longest anchor of the window family, which is right for every grid.
     """
     if compute is None:
         from . import piv
@@ -81,7 +84,7 @@ def sharded_piv(load_frames: Callable[[int, int], np.ndarray], n_pairs: int, win
     if align is None:
         from . import window
 
-        align = window.chunk_alignment(window_size)
+        align = window.chunk_alignment(window_size, frame_shape, overlap) if frame_shape is not None else window.chunk_alignment_any_grid(window_size)
     f0, f1 = frame_block(n_pairs, comm.rank, comm.world, align)
     if f1 - f0 >= 2:
         u, v, cm, sn = compute(load_frames(f0, f1), window_size, overlap, signal_threshold, pair_offset=f0)
@@ -178,7 +181,7 @@ class ShardedPivDev:
         self.comm, self.n_pairs = comm, int(n_pairs)
         self.window_size, self.overlap = tuple(window_size), tuple(overlap)
         self.H, self.W = int(frame_shape[0]), int(frame_shape[1])
-        self.align = window.chunk_alignment(self.window_size) if align is None else int(align)
+        self.align = window.chunk_alignment(self.window_size, (self.H, self.W), self.overlap) if align is None else int(align)
         self.sizes = block_sizes(self.n_pairs, comm.world, self.align)
         self.a, self.b = pair_block(self.n_pairs, comm.rank, comm.world, self.align)
         self.p_local, self.p_max = self.b - self.a, max(self.sizes)

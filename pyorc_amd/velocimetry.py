@@ -196,7 +196,7 @@ def get_ffpiv(
         return window.required_memory(n_frames=n_chunk_frames, dim_size=dim_size, window_size=window_size, overlap=overlap,
                                       search_area_size=search_area_size, dtype=dtype) <= avail_mem
 
-    slices = aligned_slices(n_frames, chunksize, window.chunk_alignment(window_size), n_win=n_rows * n_cols, fits=fits)
+    slices = aligned_slices(n_frames, chunksize, window.chunk_alignment(window_size, dim_size, overlap), n_win=n_rows * n_cols, fits=fits)
     if time is None:
         time = frames["time"] if _is_xr(frames) else np.arange(n_frames)
     dt_arr = np.asarray(_values(dt), dtype=np.float64)

@@ -77,7 +77,24 @@ def available_memory() -> int:
     return free.value
 
 
-def chunk_alignment(window_size) -> int:
-    """Frame pairs between two anchors of the time-walking kernels (``lspiv_chunk_alignment``): time chunks that start
-    on a multiple of it reproduce the whole-stack result bit for bit.  1 for per-pair kernels.  Host-only."""
-    return _lib.check(_lib.load().lspiv_chunk_alignment(int(window_size[0]), int(window_size[1])))
+def chunk_alignment(window_size, dim_size=None, overlap=None) -> int:
+    """Frame pairs between two anchors of the time-walking kernels: time chunks that start on a multiple of it reproduce the
+    whole-stack result bit for bit.  1 for per-pair kernels.  Host-only.
+
+    The anchor length depends on the window GRID since round 5 (25 pairs; 125 on grids with at least as many windows as the chip has
+    lane groups, ``lspiv_chunk_alignment_grid``): pass the frame shape ``dim_size`` and the ``overlap`` whenever chunks of frames of
+    that shape are cut.  Without them the window family's base length comes back (``lspiv_chunk_alignment``) -- the run length on
+    small grids only."""
+    lib = _lib.load()
+    if dim_size is None:
+        return _lib.check(lib.lspiv_chunk_alignment(int(window_size[0]), int(window_size[1])))
+    ov = (int(window_size[0]) // 2, int(window_size[1]) // 2) if overlap is None else overlap
+    return _lib.check(lib.lspiv_chunk_alignment_grid(int(dim_size[0]), int(dim_size[1]), int(window_size[0]), int(window_size[1]),
+                                                     int(ov[0]), int(ov[1])))
+
+
+def chunk_alignment_any_grid(window_size) -> int:
+    """The alignment that is right for EVERY frame shape: the longest anchor length the kernels of this window family use (a multiple
+    of the shorter one).  For callers that cut the time axis before they know the frames (``shard.sharded_piv`` without ``frame_shape``)."""
+    big = 1 << 20
+    return chunk_alignment(window_size, (big, big), (0, 0))

@@ -28,8 +28,8 @@ try:
         return stack[a:b]
 
     if mode == "piv":           # host arrays in, the library's default compute (piv.piv_pairs), default alignment (25)
-        full = shard.sharded_piv(load, n_pairs, WS, OV, comm)
-        np.savez(os.path.join(out_dir, f"r{rank}.npz"), full=full, touched=np.array(touched), align=window.chunk_alignment(WS))
+        full = shard.sharded_piv(load, n_pairs, WS, OV, comm, frame_shape=stack.shape[1:])   # (the grid's anchor length: 25 on these small frames)
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), full=full, touched=np.array(touched), align=window.chunk_alignment(WS, stack.shape[1:], OV))
     elif mode == "piv_dev":     # the rank's block resident in HBM, results gathered between devices
         plan = shard.ShardedPivDev(comm, n_pairs, stack.shape[1:], WS, OV, record_timings=True)
         f0, f1 = plan.frame_block()
@@ -44,7 +44,7 @@ try:
                  gather_ms=np.array(tm["gather_ms"]))
     elif mode == "ensemble":
         u, v, cnt, cm, sn = shard.sharded_ensemble(load, n_pairs, lambda: piv.Ensemble(stack.shape[1:], WS, OV), 0.1, 1.5, 0.2, comm,
-                                                   n_chunks=1, align=window.chunk_alignment(WS))
+                                                   n_chunks=1, align=window.chunk_alignment(WS, stack.shape[1:], OV))
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), u=u, v=v, cnt=cnt, cm=cm, sn=sn, touched=np.array(touched))
     else:
         raise SystemExit(f"unknown mode {mode}")

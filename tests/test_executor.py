@@ -214,7 +214,7 @@ def test_get_ffpiv_gives_the_same_dataset_with_and_without_prefetch(monkeypatch)
 
         monkeypatch.setattr(V.piv, "piv_pairs", fake_pairs)
         monkeypatch.setattr(V.piv, "Ensemble", SlowEnsemble)
-        monkeypatch.setattr(V.window, "chunk_alignment", lambda ws: 5)
+        monkeypatch.setattr(V.window, "chunk_alignment", lambda ws, dim=None, ov=None: 5)
         fr = particle_stack(31, 64, 96, seed=11)
         t = np.arange(31) / 25.0
         da = Lazy(fr, ("time", "y", "x"), {"time": t, "y": np.arange(64)[::-1] * 0.02, "x": np.arange(96) * 0.02})
@@ -274,7 +274,7 @@ def test_a_lazy_stack_without_xarray_stays_lazy_in_get_piv(monkeypatch):
 
     monkeypatch.setattr(V.piv, "piv_pairs", __import__("tests.doubles", fromlist=["x"]).oracle_piv_pairs)
     monkeypatch.setattr(V.window, "available_memory", lambda: 1e12)
-    monkeypatch.setattr(V.window, "chunk_alignment", lambda ws: 5)
+    monkeypatch.setattr(V.window, "chunk_alignment", lambda ws, dim=None, ov=None: 5)
     fr = particle_stack(16, 64, 96, seed=2)
     t = np.arange(16) / 25.0
     ref = F.get_piv(fr, 32, time=t, resolution=0.02, chunksize=6)
@@ -312,7 +312,7 @@ def test_a_chunk_that_lost_its_last_frame_leaves_no_gap_in_the_result(monkeypatc
 
     monkeypatch.setattr(V.piv, "piv_pairs", oracle_piv_pairs)
     monkeypatch.setattr(V.window, "available_memory", lambda: 1e12)
-    monkeypatch.setattr(V.window, "chunk_alignment", lambda ws: 5)
+    monkeypatch.setattr(V.window, "chunk_alignment", lambda ws, dim=None, ov=None: 5)
     fr = particle_stack(16, 64, 96, seed=2)
     t = np.arange(16) / 25.0
     ref = F.get_piv(fr, 32, time=t, resolution=0.02, chunksize=6)             # pairs 0 .. 14

@@ -385,6 +385,21 @@ def test_walking_segments_are_anchored_to_the_absolute_pair_index(lib):
     L = window.chunk_alignment((32, 32))
     assert L == 25 == window.chunk_alignment((64, 64)) == window.chunk_alignment((24, 24))
     assert window.chunk_alignment((32, 16)) == 1 and window.chunk_alignment((31, 31)) == 1   # per-pair kernels
+    # round 5: the anchor length depends on the window GRID -- 125 pairs where the grid has at least as many windows as the chip has
+    # lane groups for that window family (6 144 at 32 x 32, 2 048 at 64 x 64, 12 288 up to 16 x 16), 25 below
+    ca = window.chunk_alignment
+    assert ca((32, 32), (1080, 1920), (16, 16)) == 125 and ca((32, 32), (2160, 3840), (16, 16)) == 125     # 7 854 / 32 026 windows
+    assert ca((32, 32), (720, 1280), (16, 16)) == 25 and ca((32, 32), (785, 875), (16, 16)) == 25         # 3 476 / 2 544
+    assert ca((64, 64), (1080, 1920), (48, 48)) == 125 and ca((64, 64), (1080, 1920), (32, 32)) == 25     # 7 488 / 1 888
+    assert ca((24, 24), (1080, 1920), (12, 12)) == 125 and ca((16, 16), (1080, 1920), (8, 8)) == 125      # 14 151 / 31 866
+    assert ca((16, 16), (540, 960), (8, 8)) == 25 and ca((31, 31), (1080, 1920), (15, 15)) == 1           # 7 854 < 12 288; per-pair kernels
+    assert window.chunk_alignment_any_grid((32, 32)) == 125 and window.chunk_alignment_any_grid((31, 31)) == 1
+    assert lib.lspiv_chunk_alignment_grid(10, 10, 32, 32, 16, 16) < 0                                      # frame smaller than the window
+    _lib.set_option("walk", 49)                                                                            # a forced anchor length wins everywhere
+    try:
+        assert ca((32, 32), (1080, 1920), (16, 16)) == 49 == ca((32, 32)) == ca((32, 32), (270, 480), (16, 16))
+    finally:
+        _lib.set_option("walk", 1)
     whole = cut(1000, 0, L)
     assert whole[0] == (0, 25) and whole[-1] == (975, 1000) and len(whole) == 40
     for bounds in ([0, 250, 500, 1000], [0, 25, 50, 975, 1000], [0, 100, 1000]):       # aligned chunkings: same segments
@@ -438,13 +453,16 @@ def test_streamed_chain_cuts_chunks_on_anchors(lib):
 
     for ws, n_pairs, n_chunks in (((32, 32), 200, 8), ((32, 32), 1000, 8), ((64, 64), 82, 8), ((32, 32), 24, 8), ((32, 32), 26, 3),
                                   ((128, 128), 40, 8), ((33, 33), 10, 4), ((24, 24), 999, 5)):
-        b = CameraToVelocity._chunk_bounds(SimpleNamespace(window_size=ws), n_pairs, n_chunks)
-        align = lib.lspiv_chunk_alignment(*ws)
+        b = CameraToVelocity._chunk_bounds(SimpleNamespace(window_size=ws, ortho_shape=(270, 480), overlap=(ws[0] // 2, ws[1] // 2)), n_pairs, n_chunks)
+        align = lib.lspiv_chunk_alignment(*ws)             # a small grid: the window family's base anchor
         assert b[0] == 0 and b[-1] == n_pairs and all(x < y for x, y in zip(b, b[1:])), (ws, b)
         assert all(x % align == 0 for x in b[:-1]), (ws, align, b)
         assert len(b) - 1 <= max(1, n_chunks) and (len(b) - 1 == 1 or n_pairs > align)
-    assert CameraToVelocity._chunk_bounds(SimpleNamespace(window_size=(32, 32)), 200, 8) == [0, 25, 50, 75, 100, 125, 150, 175, 200]
-    assert CameraToVelocity._chunk_bounds(SimpleNamespace(window_size=(128, 128)), 40, 8) == [0, 5, 10, 15, 20, 25, 30, 35, 40]
+    small = dict(ortho_shape=(270, 480), overlap=(16, 16))
+    assert CameraToVelocity._chunk_bounds(SimpleNamespace(window_size=(32, 32), **small), 200, 8) == [0, 25, 50, 75, 100, 125, 150, 175, 200]
+    assert CameraToVelocity._chunk_bounds(SimpleNamespace(window_size=(128, 128), ortho_shape=(540, 960), overlap=(64, 64)), 40, 8) == [0, 5, 10, 15, 20, 25, 30, 35, 40]
+    # a grid with the long anchors (1080p, 7 854 windows): chunks of 125 pairs
+    assert CameraToVelocity._chunk_bounds(SimpleNamespace(window_size=(32, 32), ortho_shape=(1080, 1920), overlap=(16, 16)), 1000, 8) == list(range(0, 1001, 125))
 
 
 def test_every_environment_switch_is_documented():
