@@ -175,7 +175,7 @@ int lspiv_piv_pairs_dev(const void* d_frames, int dtype, int64_t T, int64_t H, i
  * (tested); a chunk that starts elsewhere is still correct but its first (alignment - offset % alignment) pairs may
  * differ from the whole-stack run in the last float32 bit.  lspiv_piv_pairs[_dev] == these with pair_offset 0.
  * lspiv_chunk_alignment: pairs; 1 for window sizes served by per-pair kernels and with option "walk" = 0.  Host-only.
- * Round 5: the run length depends on the window GRID as well -- 25 pairs, or 125 on grids with at least as many windows as the chip
+ * Round 5: the run length depends on the window GRID as well -- 25 pairs, or 75 on grids with at least as many windows as the chip
  * has lane groups for that window family (1080p 32 x 32 @ 50 %, 64 x 64 @ 75 %, 4K: less per-segment overhead, csrc/common.h
  * walk_anchor).  lspiv_chunk_alignment_grid(H, W, ...) is the figure to cut chunks on for frames of that shape (a multiple of
  * lspiv_chunk_alignment(wy, wx), which remains the run length on small grids); negative status for a bad shape. */

@@ -427,16 +427,20 @@ int walk_setting();
 // and within 6 % at 200 (59 ... 63, the best length for 1000-pair chunks, loses 15 - 40 % at 200).
 constexpr uint32_t kWalkAnchor = 25;
 // Round 5: LONG anchors for grids with enough windows.  What a longer segment saves is per-segment overhead -- the first iteration of a
-// segment yields one plane instead of two (13 iterations per 25 pairs, 63 per 125: - 3 %), and in ensemble mode every segment flushes
-// and later merges a partial sum per window -- : 1080p, 1000 pairs, anchors 25 -> 125: ensemble 64 x 64 33.3 -> 34.7 k pairs/s, ensemble
-// 32 x 32 167.6 -> 175.9 k, per-timestep 64 x 64 35.5 -> 36.6 k, 32 x 32 164.8 -> 166.0 k (one box, interleaved).  What it costs is
-// parallelism per segment: a segment is n_win jobs, and with fewer of them than the chip has lane groups the tail of every round of
-// jobs idles for 63 iterations instead of 13.  So the anchor is a function of the window grid alone (NOT of the chunk: results must
-// not depend on the chunking): 125 when the grid has at least as many windows as the chip has lane groups of that window family
-// (nominal MI355X: 256 CUs x 4 SIMDs x waves x groups per wave), 25 otherwise.  It needs the XCD partition BY WINDOWS
-// (piv_fft_impl.h, walk_job): with whole segments per XCD a long anchor runs XCDs dry (300 pairs: 26 k instead of 33 k).
-// Chunks must then be cut on multiples of lspiv_chunk_alignment_grid() -- 125 for such grids -- to reproduce one call bit for bit.
-constexpr uint32_t kWalkAnchorLong = 125;
+// segment yields one plane instead of two (13 iterations per 25 pairs, 38 per 75: - 2.6 %), and in ensemble mode every segment flushes
+// and later merges a partial sum per window.  What it costs: (1) parallelism per segment -- a segment is n_win jobs, and with fewer of
+// them than the chip has lane groups the tail of every round of jobs idles for a longer job --, so the anchor is a function of the
+// window grid alone (NOT of the chunk: results must not depend on the chunking): long when the grid has at least as many windows as
+// the chip has lane groups of that window family (nominal MI355X: 256 CUs x 4 SIMDs x waves x groups per wave), 25 otherwise;
+// (2) bytes -- the jobs of a round drift apart over a long segment, overlapping windows are no longer at the same frame and share
+// fewer rows in L2 (HBM fetch per 1000 pairs at 1080p, anchors 25 / 51 / 75 / 125: 32 x 32 2.31 / 2.96 / 3.12 / 3.13 GB, 64 x 64 2.81 /
+// 3.46 / 4.06 / 4.44 GB); the kernels are VALU-bound and do not wait for them.  1080p, 1000 pairs, one box (tools/gpu_round5_k.sh),
+// anchors 25 / 51 / 75 / 125: per-timestep 32 x 32 166.5 / 168.7 / 167.9 / 163.7 k pairs/s, 64 x 64 35.3 / 36.3 / 36.7 / 36.3 k,
+// ensemble 64 x 64 33.2 / 34.3 / 34.7 / 34.4 k, 32 x 32 165.7 / 174.1 / 174.9 / 175.3 k: 75 takes what there is at three quarters of
+// 125's extra bytes.  It needs the XCD partition BY WINDOWS (piv_fft_impl.h, walk_job): with whole segments per XCD unequal segments
+// run XCDs dry (300 pairs at 125: 26 k instead of 33 k).  Chunks must be cut on multiples of lspiv_chunk_alignment_grid() -- 75 for
+// such grids -- to reproduce one call bit for bit.
+constexpr uint32_t kWalkAnchorLong = 75;
 inline uint32_t walk_long_min_windows(int n) {          // lane groups on the chip, per window family
   return n <= 16 ? 256u * 4u * 3u * 4u : n <= 32 ? 256u * 4u * 3u * 2u : 256u * 4u * 2u;   // 12 288 / 6 144 / 2 048
 }

@@ -2082,7 +2082,7 @@ static hipError_t launch_t(const PivParams& p, bool ensemble, hipStream_t s) {
     hipLaunchKernelGGL((piv_fft_ensemble_kernel<T, N, WANT_NZ>), dim3(blocks), dim3(BLOCK), G::LDS_BYTES, s, p);
     return hipGetLastError();
   }
-  // LSPIV_WALK: 0 = per-pair kernel; unset / 1 = time-walking kernel, segments anchored every walk_anchor(N, n_win) = 25 / 125 pairs of the
+  // LSPIV_WALK: 0 = per-pair kernel; unset / 1 = time-walking kernel, segments anchored every walk_anchor(N, n_win) = 25 / 75 pairs of the
   // absolute pair index (results independent of the chunking); n > 1 = anchor length n (odd values waste no half iteration)
   const int walk = walk_setting();   // option or environment, read per launch
   if (walk != 0) {

@@ -74,7 +74,7 @@ def sharded_piv(load_frames: Callable[[int, int], np.ndarray], n_pairs: int, win
     ``load_frames(start, stop)`` returns frames [start, stop) as (T, H, W) -- each rank only ever touches its
     own time block (+ halo).  ``compute(frames, window_size, overlap, signal_threshold, pair_offset=...)`` ->
     (u, v, corr_max, s2n); default is the HIP engine (``pyorc_amd.piv.piv_pairs``).
-    ``frame_shape`` (H, W): the rank blocks are cut on the anchor length of THAT window grid (``window.chunk_alignment``: 25 pairs, 125 on
+    ``frame_shape`` (H, W): the rank blocks are cut on the anchor length of THAT window grid (``window.chunk_alignment``: 25 pairs, 75 on
     large grids); without it on the longest anchor of the window family, which is right for every grid.
     """
     if compute is None:

@@ -81,7 +81,7 @@ def chunk_alignment(window_size, dim_size=None, overlap=None) -> int:
     """Frame pairs between two anchors of the time-walking kernels: time chunks that start on a multiple of it reproduce the
     whole-stack result bit for bit.  1 for per-pair kernels.  Host-only.
 
-    The anchor length depends on the window GRID since round 5 (25 pairs; 125 on grids with at least as many windows as the chip has
+    The anchor length depends on the window GRID since round 5 (25 pairs; 75 on grids with at least as many windows as the chip has
     lane groups, ``lspiv_chunk_alignment_grid``): pass the frame shape ``dim_size`` and the ``overlap`` whenever chunks of frames of
     that shape are cut.  Without them the window family's base length comes back (``lspiv_chunk_alignment``) -- the run length on
     small grids only."""

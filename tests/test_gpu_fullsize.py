@@ -3,7 +3,7 @@
 The oracle cannot finish these sizes in seconds, so they are checked through size-independent properties:
   * a sample of pairs spread over the stack equals the oracle (same gate as the small tests);
   * determinism: two launches give bit-identical results;
-  * chunk invariance: the stack processed in time chunks (1-frame halo, cut on the anchors of the grid: 125 pairs at these sizes) equals the
+  * chunk invariance: the stack processed in time chunks (1-frame halo, cut on the anchors of the grid: 75 pairs at these sizes) equals the
     single launch bit for bit, with the default (time-walking) kernels;
   * round trip: a stack made of circular shifts of one frame returns that shift in every window.
 """
@@ -84,9 +84,9 @@ def test_config2_1080p_1000_pairs(gpu):
         assert np.array_equal(out, again, equal_nan=True)                       # deterministic
         check_sample(st, out, ws, ov, starts=[0, 499, 998])                     # oracle on a spread sample
         from pyorc_amd import window
-        assert window.chunk_alignment(ws, (1080, 1920), ov) == 125              # 7 854 windows: the long anchors (round 5)
-        for first, n in ((0, 376), (375, 251), (625, 376)):                     # time chunks with a 1-frame halo, cut on
-            part = st.run(ws, ov, first=first, n_frames=n)                      # anchors (lspiv_chunk_alignment_grid = 125 pairs)
+        assert window.chunk_alignment(ws, (1080, 1920), ov) == 75               # 7 854 windows: the long anchors (round 5)
+        for first, n in ((0, 301), (300, 376), (675, 326)):                     # time chunks with a 1-frame halo, cut on
+            part = st.run(ws, ov, first=first, n_frames=n)                      # anchors (lspiv_chunk_alignment_grid = 75 pairs)
             assert np.array_equal(part, out[:, first:first + n - 1], equal_nan=True)   # bit-identical, like the reference
         u = out[0]
         assert 2.5 < np.nanmedian(u) < 3.5 and np.isnan(u).mean() < 0.05       # flow 3 + 2 sin(.) px/frame
@@ -101,7 +101,7 @@ def test_config3_64x64_overlap48(gpu):
         out = st.run(ws, ov)
         assert out.shape == (4, 1000, 64, 117)
         check_sample(st, out, ws, ov, starts=[0, 498, 998])
-        assert np.array_equal(st.run(ws, ov, first=500, n_frames=126), out[:, 500:625], equal_nan=True)   # anchors every 125 pairs on this grid
+        assert np.array_equal(st.run(ws, ov, first=525, n_frames=151), out[:, 525:675], equal_nan=True)   # anchors every 75 pairs on this grid
         u = out[0]
         assert 2.5 < np.nanmedian(u) < 3.5 and np.isnan(u).mean() < 0.05
     finally:
@@ -115,7 +115,7 @@ def test_config4_4k(gpu):
         out = st.run(ws, ov)
         assert out.shape == (4, 1000, 134, 239)
         check_sample(st, out, ws, ov, starts=[0, 998])
-        assert np.array_equal(st.run(ws, ov, first=750, n_frames=126), out[:, 750:875], equal_nan=True)
+        assert np.array_equal(st.run(ws, ov, first=750, n_frames=151), out[:, 750:900], equal_nan=True)
         u = out[0]
         assert 2.5 < np.nanmedian(u) < 3.5 and np.isnan(u).mean() < 0.05
     finally:
@@ -132,7 +132,7 @@ def test_1080p_window24_prime_factor_kernels(gpu):
         assert out.shape == (4, 300, 89, 159)
         assert np.array_equal(out, st.run(ws, ov), equal_nan=True)               # deterministic
         check_sample(st, out, ws, ov, starts=[0, 150, 298])
-        assert np.array_equal(st.run(ws, ov, first=125, n_frames=126), out[:, 125:250], equal_nan=True)   # aligned chunk (14 151 windows: anchors every 125 pairs)
+        assert np.array_equal(st.run(ws, ov, first=150, n_frames=151), out[:, 150:300], equal_nan=True)   # aligned chunk (14 151 windows: anchors every 75 pairs)
         u = out[0]
         assert 2.5 < np.nanmedian(u) < 3.5 and np.isnan(u).mean() < 0.08
     finally:

@@ -57,17 +57,17 @@ def test_results_do_not_depend_on_the_job_order(gpu, tmp_path, args):
 
 @pytest.mark.parametrize("ws,ov,ens", [(32, 16, 0), (64, 48, 0), (32, 16, 1), (64, 48, 1)])
 def test_long_anchors_on_the_full_1080p_grid(gpu, ws, ov, ens):
-    """Round 5: on grids with at least as many windows as the chip has lane groups the walking kernels' segments are 125 pairs long
-    (lspiv_chunk_alignment_grid).  At 1080p (7 854 / 7 488 windows), 290 pairs resident in HBM: chunks cut on multiples of 125 -- with a
+    """Round 5: on grids with at least as many windows as the chip has lane groups the walking kernels' segments are 75 pairs long
+    (lspiv_chunk_alignment_grid).  At 1080p (7 854 / 7 488 windows), 290 pairs resident in HBM: chunks cut on multiples of 75 -- with a
     ragged end -- reproduce one launch bit for bit, per time step and in ensemble mode; a chunk cut on a multiple of 25 that is no
-    multiple of 125 is still correct but only equal to rounding (which is why the planner cuts on 125 there)."""
+    multiple of 75 is still correct but only equal to rounding (which is why the planner cuts on 75 there)."""
     import ctypes as C
 
     from pyorc_amd import _lib, piv, window
 
     lib = _lib.load()
     H, W, P = 1080, 1920, 290
-    assert window.chunk_alignment((ws, ws), (H, W), (ov, ov)) == 125 and window.chunk_alignment((ws, ws)) == 25
+    assert window.chunk_alignment((ws, ws), (H, W), (ov, ov)) == 75 and window.chunk_alignment((ws, ws)) == 25
     nr, nc = window.get_array_shape((H, W), (ws, ws), (ov, ov))
     n_win = nr * nc
     d_f, d_o = C.c_void_p(), C.c_void_p()
@@ -96,7 +96,7 @@ def test_long_anchors_on_the_full_1080p_grid(gpu, ws, ov, ens):
 
     run_ = ensemble if ens else per_timestep
     whole = run_([0, P])
-    for bounds in ([0, 125, 250, P], [0, 250, P], [0, 125, P]):
+    for bounds in ([0, 75, 225, P], [0, 150, P], [0, 225, P]):
         got = run_(bounds)
         for x, y in zip(whole, got) if ens else ((whole, got),):
             assert np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32)), bounds

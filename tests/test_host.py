@@ -385,15 +385,15 @@ def test_walking_segments_are_anchored_to_the_absolute_pair_index(lib):
     L = window.chunk_alignment((32, 32))
     assert L == 25 == window.chunk_alignment((64, 64)) == window.chunk_alignment((24, 24))
     assert window.chunk_alignment((32, 16)) == 1 and window.chunk_alignment((31, 31)) == 1   # per-pair kernels
-    # round 5: the anchor length depends on the window GRID -- 125 pairs where the grid has at least as many windows as the chip has
-    # lane groups for that window family (6 144 at 32 x 32, 2 048 at 64 x 64, 12 288 up to 16 x 16), 25 below
+    # round 5: the anchor length depends on the window GRID -- 75 pairs where the grid has at least as many windows as the chip has
+    # lane groups for that window family (6 144 at 32 x 32, 2 048 at 64 x 64, 12 288 up to 16 x 16), 25 below (75: csrc/common.h)
     ca = window.chunk_alignment
-    assert ca((32, 32), (1080, 1920), (16, 16)) == 125 and ca((32, 32), (2160, 3840), (16, 16)) == 125     # 7 854 / 32 026 windows
+    assert ca((32, 32), (1080, 1920), (16, 16)) == 75 and ca((32, 32), (2160, 3840), (16, 16)) == 75     # 7 854 / 32 026 windows
     assert ca((32, 32), (720, 1280), (16, 16)) == 25 and ca((32, 32), (785, 875), (16, 16)) == 25         # 3 476 / 2 544
-    assert ca((64, 64), (1080, 1920), (48, 48)) == 125 and ca((64, 64), (1080, 1920), (32, 32)) == 25     # 7 488 / 1 888
-    assert ca((24, 24), (1080, 1920), (12, 12)) == 125 and ca((16, 16), (1080, 1920), (8, 8)) == 125      # 14 151 / 31 866
+    assert ca((64, 64), (1080, 1920), (48, 48)) == 75 and ca((64, 64), (1080, 1920), (32, 32)) == 25     # 7 488 / 1 888
+    assert ca((24, 24), (1080, 1920), (12, 12)) == 75 and ca((16, 16), (1080, 1920), (8, 8)) == 75      # 14 151 / 31 866
     assert ca((16, 16), (540, 960), (8, 8)) == 25 and ca((31, 31), (1080, 1920), (15, 15)) == 1           # 7 854 < 12 288; per-pair kernels
-    assert window.chunk_alignment_any_grid((32, 32)) == 125 and window.chunk_alignment_any_grid((31, 31)) == 1
+    assert window.chunk_alignment_any_grid((32, 32)) == 75 and window.chunk_alignment_any_grid((31, 31)) == 1
     assert lib.lspiv_chunk_alignment_grid(10, 10, 32, 32, 16, 16) < 0                                      # frame smaller than the window
     _lib.set_option("walk", 49)                                                                            # a forced anchor length wins everywhere
     try:
@@ -461,8 +461,8 @@ def test_streamed_chain_cuts_chunks_on_anchors(lib):
     small = dict(ortho_shape=(270, 480), overlap=(16, 16))
     assert CameraToVelocity._chunk_bounds(SimpleNamespace(window_size=(32, 32), **small), 200, 8) == [0, 25, 50, 75, 100, 125, 150, 175, 200]
     assert CameraToVelocity._chunk_bounds(SimpleNamespace(window_size=(128, 128), ortho_shape=(540, 960), overlap=(64, 64)), 40, 8) == [0, 5, 10, 15, 20, 25, 30, 35, 40]
-    # a grid with the long anchors (1080p, 7 854 windows): chunks of 125 pairs
-    assert CameraToVelocity._chunk_bounds(SimpleNamespace(window_size=(32, 32), ortho_shape=(1080, 1920), overlap=(16, 16)), 1000, 8) == list(range(0, 1001, 125))
+    # a grid with the long anchors (1080p, 7 854 windows): chunks of a multiple of 75 pairs
+    assert CameraToVelocity._chunk_bounds(SimpleNamespace(window_size=(32, 32), ortho_shape=(1080, 1920), overlap=(16, 16)), 1000, 8) == [0, 150, 300, 450, 600, 750, 900, 1000]
 
 
 def test_every_environment_switch_is_documented():
