@@ -59,11 +59,65 @@ __global__ __launch_bounds__(kBlock) void mask_pointwise_kernel(const float* __r
 // "start from the first element" exactly, sign of zero included.
 constexpr int kCells = 64, kCh = 64;
 
+// A grid of ONE cell (R = C = 1) is the exception: the time axis is then the array's contiguous inner axis and np.add.reduce sums it
+// PAIRWISE (numpy/core/src/umath/loops_utils.h.src, pairwise_sum: below 8 elements in order from 0., up to 128 in eight strided partial
+// sums combined as ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)) plus a tail in order, above that split at n / 2 rounded down to a
+// multiple of 8, left + right).  Found by tools/fuzz_rows.py (seed 1108, round 5); restated here with an explicit stack; one thread.
+template <bool SQ>
+__device__ float np_pairwise_time(const float* __restrict__ col, int64_t stride, int64_t T, float avg, int* cnt) {
+  auto get = [&](int64_t t) -> float {
+    const float x = col[t * stride];
+    if (SQ) { const float d = x != x ? 0.0f : sub_rn(x, avg); return mul_rn(d, d); }
+    return nan0(x);
+  };
+  if (!SQ) { int c = 0; for (int64_t t = 0; t < T; ++t) { const float x = col[t * stride]; c += x == x; } *cnt = c; }
+  auto leaf = [&](int64_t lo, int64_t n) -> float {
+    if (n < 8) { float r = 0.0f; for (int64_t i = 0; i < n; ++i) r = add_rn(r, get(lo + i)); return r; }
+    float r[8];
+    for (int j = 0; j < 8; ++j) r[j] = get(lo + j);
+    int64_t i = 8;
+    for (; i < n - (n % 8); i += 8)
+      for (int j = 0; j < 8; ++j) r[j] = add_rn(r[j], get(lo + i + j));
+    float res = add_rn(add_rn(add_rn(r[0], r[1]), add_rn(r[2], r[3])), add_rn(add_rn(r[4], r[5]), add_rn(r[6], r[7])));
+    for (; i < n; ++i) res = add_rn(res, get(lo + i));
+    return res;
+  };
+  struct Frame { int64_t lo, n; float left; int stage; };
+  Frame st[32];   // depth: log2(T / 128) + 1
+  int sp = 0;
+  st[0] = {0, T, 0.0f, 0};
+  float ret = 0.0f;
+  while (sp >= 0) {
+    Frame& f = st[sp];
+    if (f.stage == 0) {
+      if (f.n <= 128) { ret = leaf(f.lo, f.n); --sp; continue; }
+      f.stage = 1;
+      int64_t n2 = f.n / 2; n2 -= n2 % 8;
+      st[sp + 1] = {f.lo, n2, 0.0f, 0};
+      ++sp;
+    } else if (f.stage == 1) {
+      f.left = ret;
+      f.stage = 2;
+      int64_t n2 = f.n / 2; n2 -= n2 % 8;
+      st[sp + 1] = {f.lo + n2, f.n - n2, 0.0f, 0};
+      ++sp;
+    } else {
+      ret = add_rn(f.left, ret);
+      --sp;
+    }
+  }
+  return ret;
+}
+
 template <int NV, bool SQ>
 __device__ __forceinline__ void column_pass(const float* __restrict__ f, int64_t var_stride, int64_t T, int64_t n,
                                             int64_t cell, bool valid, float (*tile)[kCh][kCells], float avg, float* acc,
                                             int* cnt) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (n == 1) {   // a single cell: numpy's pairwise order (np_pairwise_time); lane 0 of wave v does variable v
+    if (w < NV && lane == 0 && valid) *acc = np_pairwise_time<SQ>(f + w * var_stride, 1, T, avg, cnt);
+    return;
+  }
   for (int64_t t0 = 0; t0 < T; t0 += kCh) {
     const int rows = (int)(T - t0 < kCh ? T - t0 : kCh);
 #pragma unroll 4

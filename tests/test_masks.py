@@ -103,6 +103,33 @@ def test_gpu_masks_equal_oracle(gpu, seed, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T", [2, 7, 8, 9, 20, 64, 128, 129, 136, 300, 1000])
+def test_gpu_time_reductions_on_a_single_cell_grid(gpu, T):
+    """A window grid of ONE cell (R = C = 1): the time axis is the array's contiguous inner axis and numpy sums it PAIRWISE (below 8
+    elements in order, up to 128 in eight strided partial sums, above that by halves) instead of sequentially as for every other
+    grid -- found by tools/fuzz_rows.py seed 1108 in round 5 (time_mean differed in the last bit).  time_mean and the masks built on
+    nanmean / nanstd over time, every length class of the pairwise scheme, with NaNs."""
+    from pyorc_amd import mask as pm
+
+    rng = np.random.default_rng(T)
+    f = np.empty((4, T, 1, 1), np.float32)
+    f[0] = rng.normal(0.6, 0.5, (T, 1, 1)); f[1] = rng.normal(-0.1, 0.3, (T, 1, 1)); f[2] = rng.random((T, 1, 1)); f[3] = rng.random((T, 1, 1)) * 30
+    f[:, rng.random((T, 1, 1)) < 0.2] = np.nan
+    if T > 2:
+        f[:, 1] = np.float32(0.37)      # at least two finite samples
+        f[:, 2] = np.float32(-0.21)
+    assert np.array_equal(pm.time_mean(f), mo.time_mean(f), equal_nan=True)
+    for name, kw, params in (("outliers", dict(tolerance=1.0, mode="or"), [1.0, 0]), ("outliers", dict(tolerance=0.7, mode="and"), [0.7, 1]),
+                             ("variance", dict(tolerance=5, mode="and"), [5, 1]), ("variance", dict(tolerance=1e-31, mode="or"), [1e-31, 0]),
+                             ("count", dict(tolerance=0.5), [0.5])):
+        got, ref = pm.run_mask(f, name, params), getattr(mo, name)(f, **kw)
+        assert got.shape == ref.shape and np.array_equal(got, ref), (name, kw)
+    # and a grid of two cells keeps the sequential order (the reduction axis is no longer the inner one)
+    g = np.concatenate([f, f[:, :, :, ::-1] * np.float32(1.5)], axis=3)
+    assert np.array_equal(pm.time_mean(g), mo.time_mean(g), equal_nan=True)
+
+
+@pytest.mark.gpu
 def test_gpu_mask_methods_follow_the_reference_wrapper(gpu):
     from pyorc_amd.mask import Mask
     from pyorc_amd.velocimetry import PivResult
