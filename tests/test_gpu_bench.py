@@ -8,7 +8,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--pairs", "60", "--height", "256", "--width", "384", "--steps", "3", "--warmup", "1"]
+SMALL = ["--pairs", "60", "--height", "256", "--width", "384", "--steps", "3", "--warmup", "1", "--sustained-s", "1"]
 
 
 def run_bench(args, env_extra=None):
@@ -32,6 +32,10 @@ def test_bench_json_contract_single_gpu(gpu):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert r["algorithmic_bytes_per_pair"] == 2 * 256 * 384 + 16 * d["config"]["windows_per_pair"]
+    # round 5: the dominant kernel timed INSIDE the launch as issued (library events), the burst's sustained twin
+    assert "kernel_timing" in r and r["kernel_ms_per_launch"] > 0 and r["kernel_ms_same_launch_rescue_off"] > 0
+    assert r["kernel_ms_per_launch"] <= r["launch_ms_with_rescue_kernels"] * 1.05
+    assert d["sustained_pairs_per_s"] > 0 and d["config"]["sustained"]["steps"] >= 50 and d["config"]["sustained"]["seconds"] >= 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
     assert c["parity_nan_mismatch"] == 0 and c["parity_max_rel_err_vs_oracle"] <= 1e-4 and "parity_float64_ties" in c and c["parity_windows_ill_posed"] == 0

@@ -735,3 +735,29 @@ def test_rccl_channel_cap_is_scoped_to_communicator_creation(monkeypatch):
     monkeypatch.delenv("NCCL_MAX_NCHANNELS")
     with comm._rccl_channel_cap(False):                        # other transports: untouched
         assert "NCCL_MAX_NCHANNELS" not in os.environ
+
+
+def test_bench_reads_clock_and_power_from_rocm_smi_text(monkeypatch):
+    """bench.py's sampler of the sustained loop parses `rocm-smi --showpower --showclocks` (text as the tool prints it on the MI355X boxes);
+    a missing tool or another format gives no samples and None figures, never an exception."""
+    import subprocess as sp
+    import time as _t
+
+    import bench
+
+    text = ("GPU[0]\t\t: fclk clock level: 0: (1400Mhz)\nGPU[0]\t\t: mclk clock level: 3: (2000Mhz)\nGPU[0]\t\t: sclk clock level: 1: (2293Mhz)\n"
+            "GPU[0]\t\t: socclk clock level: 3: (1143Mhz)\nGPU[0]\t\t: Current Socket Graphics Package Power (W): 1334.0\n")
+
+    class R:
+        stdout = text
+
+    monkeypatch.setattr(sp, "run", lambda *a, **k: R())
+    t0 = _t.time() - 2.0
+    with bench.SmiSampler(period=0.05) as smi:
+        _t.sleep(0.3)
+    s = smi.summary(t0, _t.time() + 1)
+    assert s["samples"] >= 2 and s["sclk_mhz_mean"] == 2293.0 and s["socket_power_w_mean"] == 1334.0 and s["sclk_mhz_min"] == 2293
+    monkeypatch.setattr(sp, "run", lambda *a, **k: (_ for _ in ()).throw(FileNotFoundError("rocm-smi")))
+    with bench.SmiSampler(period=0.05) as smi2:
+        _t.sleep(0.15)
+    assert smi2.summary(t0, _t.time() + 1) == {"samples": 0, "sclk_mhz_mean": None, "socket_power_w_mean": None}
