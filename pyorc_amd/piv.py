@@ -162,13 +162,19 @@ class Ensemble:
         return {"flagged": int(st[0]), "rescued": int(st[1]), "float32_kept": int(st[2]), "chunks_kept": int(st[3]),
                 "bytes_kept": int(st[4]), "retain_complete": bool(st[5])}
 
-    def accumulate(self, imgs, corr_min: float, s2n_min: float, signal_threshold: Optional[float] = None):
-        """Add one frame chunk; returns masked per-pair (corr_max, s2n), each (T-1, n_win) float32."""
+    def accumulate(self, imgs, corr_min: float, s2n_min: float, signal_threshold: Optional[float] = None, out=None):
+        """Add one frame chunk; returns masked per-pair (corr_max, s2n), each (T-1, n_win) float32.  ``out``: two C-contiguous float32
+        arrays of that shape to receive them (time slices of a whole run's arrays: no concatenation afterwards)."""
         a = imgs if is_device(imgs) else _lib.as_frames(imgs)
         if tuple(a.shape[1:]) != self.dim_size:
             raise ValueError(f"chunk shape {a.shape[1:]} != ensemble shape {self.dim_size}")
         P = a.shape[0] - 1
         n_win = self.n_rows * self.n_cols
+        if out is not None:
+            out = tuple(out)
+            if len(out) != 2 or any(not isinstance(o, np.ndarray) or o.dtype != np.float32 or o.shape != (P, n_win) or
+                                    not o.flags.c_contiguous or not o.flags.writeable for o in out):
+                raise ValueError(f"out must be two writable C-contiguous float32 arrays of shape {(P, n_win)}")
         if is_device(a):
             from .device import DeviceFrames
 
@@ -186,10 +192,13 @@ class Ensemble:
             self.accumulate_dev(a.ptr, a.dtype, a.shape[0], corr_min, s2n_min, d.ptr, signal_threshold)
             if self._held and not self.stats()["retain_complete"]:
                 self._held = []
+            if out is not None:
+                for k in range(2):
+                    _lib.check(_lib.load().lspiv_memcpy_d2h(_lib.ptr(out[k]), C.c_void_p(d.ptr + k * P * n_win * 4), out[k].nbytes))
+                return out
             res = d.to_host()
             return np.ascontiguousarray(res[0]), np.ascontiguousarray(res[1])
-        cm = np.empty((P, n_win), dtype=np.float32)
-        sn = np.empty((P, n_win), dtype=np.float32)
+        cm, sn = out if out is not None else (np.empty((P, n_win), dtype=np.float32), np.empty((P, n_win), dtype=np.float32))
         _lib.check(_lib.load().lspiv_ensemble_accumulate(self._h, _lib.ptr(a), _lib.DTYPE_CODES[a.dtype], a.shape[0],
                                                          float(corr_min), float(s2n_min), _sig(signal_threshold),
                                                          _lib.ptr(cm), _lib.ptr(sn)))

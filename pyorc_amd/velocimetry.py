@@ -284,7 +284,11 @@ def _get_ffpiv_mean(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_cols,
     their launches like in ``_get_ffpiv_timestep`` (the reference's loop: ffpiv.py:348-370)."""
     dim_size = None
     ens = None
-    corr_chunks, s2n_chunks = [], []
+    # the masked per-pair corr_max / s2n of the whole run: allocated once, every chunk writes its time slice (Ensemble.accumulate(out=))
+    n_total = slices[-1][1] - 1 if slices else 0
+    n_win = n_rows * n_cols
+    full = None
+    done = []
     t_first = None
     loader = executor.ChunkPrefetcher(frames_chunks, load_frame_chunk, depth=prefetch)
     try:
@@ -293,12 +297,13 @@ def _get_ffpiv_mean(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_cols,
             if len(da) < 2:
                 continue
             arr = _values(da)
+            p = len(da) - 1
             if ens is None:
                 dim_size = tuple(arr.shape[1:])
                 ens = piv.Ensemble(dim_size, window_size, overlap)
-            corr_max, s2n = ens.accumulate(arr, corr_min, s2n_min, signal_threshold)
-            corr_chunks.append(corr_max)
-            s2n_chunks.append(s2n)
+                full = (np.empty((n_total, n_win), dtype=np.float32), np.empty((n_total, n_win), dtype=np.float32))
+            ens.accumulate(arr, corr_min, s2n_min, signal_threshold, out=(full[0][a:a + p], full[1][a:a + p]))
+            done.append((a, a + p))
             t_first = time[a + 1:a + 2]
             frames_chunks[n] = None
             del da
@@ -307,7 +312,7 @@ def _get_ffpiv_mean(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_cols,
         # quirk Q3: `n_frames` is the number of CHUNKS, not pairs (ffpiv.py:373), and `time[0:1]` of the LAST chunk ends
         # up on the result (ffpiv.py:336) -- both taken from the reference's own chunk plan, not from the aligned
         # chunks that were launched, so neither depends on the segment anchoring
-        n_frames = len(corr_chunks)
+        n_frames = len(done)
         if ref_slices:
             n_frames = len(ref_slices)
             t_first = time[ref_slices[-1][0] + 1:ref_slices[-1][0] + 2]
@@ -317,8 +322,11 @@ def _get_ffpiv_mean(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_cols,
         if ens is not None:
             ens.close()
     executor.LAST_STATS.clear(); executor.LAST_STATS.update(loader.stats)
-    s2n_concat = np.concatenate(s2n_chunks, axis=0)
-    corr_max_concat = np.concatenate(corr_chunks, axis=0)
+    if done[0][0] == 0 and done[-1][1] == n_total and all(x[1] == y[0] for x, y in zip(done, done[1:])):
+        corr_max_concat, s2n_concat = full
+    else:   # a chunk lost trailing frames (load_frame_chunk's TypeError retry) or was skipped
+        corr_max_concat = np.concatenate([full[0][i:j] for i, j in done], axis=0)
+        s2n_concat = np.concatenate([full[1][i:j] for i, j in done], axis=0)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", category=RuntimeWarning)
         # very low amounts of found valid correlations are entirely filtered out (ffpiv.py:280-286)

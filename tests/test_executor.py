@@ -200,9 +200,9 @@ def test_get_ffpiv_gives_the_same_dataset_with_and_without_prefetch(monkeypatch)
             return oracle_piv_pairs(fr, ws, ov, thr, pair_offset, out)
 
         class SlowEnsemble(OracleEnsemble):
-            def accumulate(self, frames, corr_min, s2n_min, thr=None):
+            def accumulate(self, frames, corr_min, s2n_min, thr=None, out=None):
                 time.sleep(compute_s)
-                return super().accumulate(np.asarray(frames), corr_min, s2n_min, thr)
+                return super().accumulate(np.asarray(frames), corr_min, s2n_min, thr, out)
 
             def finish(self, count_min, n_frames):
                 mean = self.s / np.maximum(self.k, 1)[:, None, None]

@@ -134,7 +134,7 @@ class OracleEnsemble:
         self.s = np.zeros((n,) + ws, np.float64)
         self.k = np.zeros(n, np.float64)
 
-    def accumulate(self, frames, corr_min, s2n_min, thr=None):
+    def accumulate(self, frames, corr_min, s2n_min, thr=None, out=None):
         _, _, corr = self.po.cross_corr(frames, self.ws, self.ov, signal_threshold=thr)
         with np.errstate(all="ignore"):
             cm = corr.max(axis=(-1, -2))
@@ -143,6 +143,10 @@ class OracleEnsemble:
         corr[~keep] = 0.0; cm[~keep] = 0.0; sn[~keep] = 0.0
         self.s += corr.sum(axis=0)
         self.k += (cm > 1e-6).sum(axis=0)
+        if out is not None:     # pyorc_amd.piv.Ensemble.accumulate(out=): the caller's time slices receive the results
+            out[0][...] = cm
+            out[1][...] = sn
+            return out
         return cm.astype(np.float32), sn.astype(np.float32)
 
     def export_state(self):
