@@ -761,3 +761,35 @@ def test_bench_reads_clock_and_power_from_rocm_smi_text(monkeypatch):
     with bench.SmiSampler(period=0.05) as smi2:
         _t.sleep(0.15)
     assert smi2.summary(t0, _t.time() + 1) == {"samples": 0, "sclk_mhz_mean": None, "socket_power_w_mean": None}
+
+
+def test_sharded_piv_cuts_rank_blocks_on_the_grids_anchor(lib, monkeypatch):
+    """shard.sharded_piv picks its default alignment from the window grid when it is told the frame shape (25 pairs on small grids,
+    75 where the walking kernels use long anchors) and falls back to the window family's longest anchor -- right for every grid --
+    when it is not; an explicit `align` wins.  One rank, the oracle as compute: host logic only."""
+    from pyorc_amd import shard
+    from pyorc_amd.synth import particle_stack
+    from tests.doubles import oracle_piv_pairs
+
+    seen = []
+    real = shard.frame_block
+    monkeypatch.setattr(shard, "frame_block", lambda n, r, w, align: (seen.append(align), real(n, r, w, align))[1])
+
+    class OneRank:
+        rank, world = 0, 1
+
+        def allreduce(self, a, op=None):
+            return a
+
+        def allgather(self, a):
+            return np.asarray(a)[None]
+
+    stack = particle_stack(6, 96, 128, seed=1)
+    compute = lambda fr, ws, ov, thr, pair_offset=0: oracle_piv_pairs(fr, ws, ov, thr)
+    ref = np.stack(oracle_piv_pairs(stack, (32, 32), (16, 16)))
+    for kw, want in ((dict(), 75), (dict(frame_shape=(96, 128)), 25), (dict(frame_shape=(1080, 1920)), 75), (dict(align=7), 7),
+                     (dict(frame_shape=(1080, 1920), align=25), 25)):
+        full = shard.sharded_piv(lambda a, b: stack[a:b], 5, (32, 32), (16, 16), OneRank(), compute=compute, **kw)
+        assert seen[-1] == want, (kw, seen[-1])
+        assert np.array_equal(full, ref, equal_nan=True)
+    assert shard.block_sizes(8000, 8, 75) == [975, 975, 1050, 975, 975, 1050, 975, 1025] and sum(shard.block_sizes(8000, 8, 75)) == 8000
