@@ -241,3 +241,58 @@ def test_install_adds_project_hip_found_by_name(monkeypatch):
     finally:
         plugin.uninstall()
         monkeypatch.undo()
+
+
+REF_FRAMES = "/root/reference/pyorc/api/frames.py"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_FRAMES), reason="reference checkout not present (GPU box)")
+def test_the_reference_has_the_seams_the_plugin_patches():
+    """The plug-in assumptions of pyorc_amd/plugin.py read off the reference's SOURCE (parsed, not imported: pyorc's dependencies are
+    not installable here): Frames.get_piv's parameters, the engine gate, the one call of ffpiv.get_ffpiv with `engine=` as a keyword
+    through the module attribute, pyorc.velocimetry's re-export, and Frames.project's lookup of `project_<method>` by name with the
+    (da, cc, x, y, z, reducer) call."""
+    import ast
+
+    tree = ast.parse(open(REF_FRAMES).read())
+    frames_cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "Frames")
+    meth = {n.name: n for n in frames_cls.body if isinstance(n, ast.FunctionDef)}
+    # get_piv(self, window_size=None, overlap=None, engine="numba", ensemble_corr=False, **kwargs)
+    gp = meth["get_piv"]
+    assert [a.arg for a in gp.args.args] == ["self", "window_size", "overlap", "engine", "ensemble_corr"] and gp.args.kwarg.arg == "kwargs"
+    assert [ast.literal_eval(d) for d in gp.args.defaults] == [None, None, "numba", False]
+    src = ast.get_source_segment(open(REF_FRAMES).read(), gp)
+    assert 'if engine not in ["numba", "numpy"]:' in src and "raise ValueError" in src            # the gate the wrapper satisfies
+    calls = [n for n in ast.walk(gp) if isinstance(n, ast.Call) and isinstance(n.func, ast.Attribute) and n.func.attr == "get_ffpiv"]
+    assert len(calls) == 1 and isinstance(calls[0].func.value, ast.Name) and calls[0].func.value.id == "ffpiv"   # looked up on the module at call time
+    kw = {k.arg for k in calls[0].keywords}
+    assert "engine" in kw and "ensemble_corr" in kw and None in kw and len(calls[0].args) == 4     # (self._obj, y, x, dt, engine=..., **kwargs)
+    imports = [n for n in tree.body if isinstance(n, ast.ImportFrom)]
+    assert any(n.module == "pyorc.velocimetry" and any(a.name == "ffpiv" for a in n.names) for n in imports)
+    assert any(n.module == "pyorc" and any(a.name == "project" for a in n.names) for n in imports)
+    # Frames.project(method=...): getattr(project, f"project_{method}") and proj_method(self._obj, cc, x, y, z, reducer)
+    pj = ast.get_source_segment(open(REF_FRAMES).read(), meth["project"])
+    assert 'getattr(project, f"project_{method}")' in pj and "proj_method(self._obj, cc, x, y, z, reducer)" in pj
+    # pyorc/velocimetry/__init__.py re-exports get_ffpiv; ffpiv.get_ffpiv's parameters are the ones pyorc_amd.velocimetry.get_ffpiv mirrors
+    init = open("/root/reference/pyorc/velocimetry/__init__.py").read()
+    assert "from .ffpiv import get_ffpiv" in init
+    ftree = ast.parse(open("/root/reference/pyorc/velocimetry/ffpiv.py").read())
+    ref_fn = next(n for n in ftree.body if isinstance(n, ast.FunctionDef) and n.name == "get_ffpiv")
+    import inspect
+
+    from pyorc_amd import velocimetry
+
+    ours = list(inspect.signature(velocimetry.get_ffpiv).parameters)
+    theirs = [a.arg for a in ref_fn.args.args]
+    assert ours[:len(theirs)] == theirs and ours[len(theirs):] == ["time", "prefetch"]           # same names, same order; two extensions at the end
+    ref_defaults = dict(zip(theirs[-len(ref_fn.args.defaults):], [ast.literal_eval(d) for d in ref_fn.args.defaults]))
+    sig = inspect.signature(velocimetry.get_ffpiv).parameters
+    for name, val in ref_defaults.items():
+        if name != "engine":
+            assert sig[name].default == val, name
+    # project_numpy's signature is the one project_hip takes
+    ptree = ast.parse(open("/root/reference/pyorc/project.py").read())
+    pn = next(n for n in ptree.body if isinstance(n, ast.FunctionDef) and n.name == "project_numpy")
+    from pyorc_amd import plugin
+
+    assert [a.arg for a in pn.args.args] == list(inspect.signature(plugin.project_hip).parameters)
