@@ -296,3 +296,33 @@ def test_the_reference_has_the_seams_the_plugin_patches():
     from pyorc_amd import plugin
 
     assert [a.arg for a in pn.args.args] == list(inspect.signature(plugin.project_hip).parameters)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_FRAMES), reason="reference checkout not present (GPU box)")
+def test_messages_and_planner_constants_are_the_references():
+    """What a user SEES must be the reference's: the OverflowError / UserWarning texts of the chunk planner (ffpiv.py:132-139), the
+    ValueError of an unknown engine (frames.py:177), the planner's constants (memory_factor 4, chunksize floor 5) and the int16 encoding
+    of the result variables (const.py) -- compared with the reference's source text (parsed, not imported)."""
+    import ast
+
+    from pyorc_amd import frames as F, velocimetry as V
+
+    ffpiv_src = open("/root/reference/pyorc/velocimetry/ffpiv.py").read()
+    ref_fn = next(n for n in ast.parse(ffpiv_src).body if isinstance(n, ast.FunctionDef) and n.name == "get_ffpiv")
+
+    def norm(t):   # the reference builds its messages from adjacent (f-)string literals; compare the fixed words
+        return " ".join(t.replace("{chunks}", " ").replace("{chunksize}", " ").replace("{avail_mem}", " ").replace("{engine}", " ").split())
+
+    ref_text = norm(" ".join(n.value for n in ast.walk(ref_fn) if isinstance(n, ast.Constant) and isinstance(n.value, str) and len(n.value) > 12
+                             and n is not ast.get_docstring(ref_fn)))
+    for ours in (V.CHUNK_SIZE_ERROR, V.CHUNK_SIZE_WARNING):
+        words = norm(ours).split()
+        # every run of five consecutive words of our message occurs in the reference's literals
+        assert all(" ".join(words[i:i + 5]) in ref_text for i in range(0, len(words) - 5, 5)), ours
+    frames_src = open(REF_FRAMES).read()
+    assert 'f"Selected PIV engine {engine} does not exist."' in frames_src
+    with pytest.raises(ValueError, match="Selected PIV engine numba does not exist."):
+        F.get_piv(np.zeros((2, 64, 64), np.uint8), 32, engine="numba")
+    assert "memory_factor: float = 4" in ffpiv_src and "chunksize <= 5" in ffpiv_src and "chunksize = 5" in ffpiv_src
+    const_src = open("/root/reference/pyorc/const.py").read()
+    assert '"scale_factor": 0.01' in const_src and "-9999" in const_src and "int16" in const_src
