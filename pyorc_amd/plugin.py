@@ -56,9 +56,25 @@ def is_installed() -> bool:
 
 
 def _wrap_get_ffpiv(orig):
+    import inspect
+
+    try:
+        sig = inspect.signature(orig)
+    except (TypeError, ValueError):
+        sig = None
+
     @functools.wraps(orig)
     def get_ffpiv(frames, y, x, dt, *args, **kwargs):
-        if kwargs.get("engine") == ENGINE or _route_hip.get():
+        engine = kwargs.get("engine")
+        if engine is None and sig is not None and args:     # `engine` handed over by position (ffpiv.py:24-42: the 12th parameter)
+            try:
+                bound = sig.bind_partial(frames, y, x, dt, *args, **kwargs)
+                engine = bound.arguments.get("engine")
+                if engine == ENGINE or _route_hip.get():
+                    args, kwargs = (), {k: v for k, v in bound.arguments.items() if k not in ("frames", "y", "x", "dt")}
+            except TypeError:
+                pass
+        if engine == ENGINE or _route_hip.get():
             from . import velocimetry
 
             kwargs["engine"] = ENGINE

@@ -111,6 +111,10 @@ def test_install_registers_the_hip_engine_in_an_unmodified_pyorc(monkeypatch):
             assert np.array_equal(d2["v_x"].values, ref["v_x"], equal_nan=True)
             calls.clear()
             assert fn(da, coords["y"], coords["x"], da["time"].diff(dim="time"), engine="numpy", **kw).cpu and calls == [("cpu_get_ffpiv", "numpy")]
+        # ... and with every argument by position, `engine` being the 12th (ffpiv.py:24-42)
+        d3 = mods["pyorc.velocimetry.ffpiv"].get_ffpiv(da, coords["y"], coords["x"], da["time"].diff(dim="time"), (32, 32), (16, 16), (32, 32), 0.02, 0.02,
+                                                       None, 4, "hip")
+        assert np.array_equal(d3["v_x"].values, ref["v_x"], equal_nan=True)
         # a failing hip call leaves no routing behind: the next numba call reaches the CPU engine
         monkeypatch.setattr(V.piv, "piv_pairs", lambda *a, **k: (_ for _ in ()).throw(RuntimeError("device lost")))
         with pytest.raises(RuntimeError, match="device lost"):
