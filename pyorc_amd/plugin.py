@@ -71,7 +71,8 @@ def _wrap_get_ffpiv(orig):
                 bound = sig.bind_partial(frames, y, x, dt, *args, **kwargs)
                 engine = bound.arguments.get("engine")
                 if engine == ENGINE or _route_hip.get():
-                    args, kwargs = (), {k: v for k, v in bound.arguments.items() if k not in ("frames", "y", "x", "dt")}
+                    first4 = list(sig.parameters)[:4]     # frames, y, x, dt under whatever names
+                    args, kwargs = (), {k: v for k, v in bound.arguments.items() if k not in first4}
             except TypeError:
                 pass
         if engine == ENGINE or _route_hip.get():
