@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define LSPIV_ABI_VERSION 4   /* (round 5 added lspiv_chunk_alignment_grid, lspiv_ensemble_flag_digest, lspiv_kernel_times + the "time_kernel" option and the test hook lspiv_debug_hold_lock; no version change: nothing existing moved)
+#define LSPIV_ABI_VERSION 4   /* (round 5 added lspiv_chunk_alignment_grid, lspiv_piv_velocity_at, lspiv_ensemble_flag_digest, lspiv_kernel_times + the "time_kernel" option and the test hook lspiv_debug_hold_lock; no version change: nothing existing moved)
                                * 4 (round 4, additions only): lspiv_build_info, the float64 rescue of the ensemble's final fit
                                * (lspiv_ensemble_set_retain / _stats / _flag / _partials / _finish_partials), lspiv_stream_release,
                                * lspiv_stream_create_priority; 3: lspiv_rescue_stats,
@@ -187,6 +187,15 @@ int lspiv_piv_pairs_at(const void* frames, int dtype, int64_t T, int64_t H, int6
 int lspiv_piv_pairs_dev_at(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W,
                            int wy, int wx, int oy, int ox, float signal_threshold, int64_t pair_offset,
                            float* d_out, float* d_corr_planes, void* stream);
+/* lspiv_piv_pairs_at with the per-chunk scaling of _get_ffpiv_timestep (pyorc/velocimetry/ffpiv.py:418-419) applied on the device
+ * before the results cross PCIe (round 5): v_x = (u * res_x / dt[pair]).astype(float32), v_y likewise -- the product in float32 (what
+ * numpy computes for a float32 array times a Python float), the division in float64, one rounding; dt: seconds per pair, T - 1
+ * doubles.  The Python mirror uses it when the resolutions are Python floats (pyorc: camera_config.resolution) and keeps numpy's own
+ * arithmetic for anything else. */
+int lspiv_piv_velocity_at(const void* frames, int dtype, int64_t T, int64_t H, int64_t W,
+                          int wy, int wx, int oy, int ox, float signal_threshold, int64_t pair_offset,
+                          double res_x, double res_y, const double* dt,
+                          float* v_x, float* v_y, float* corr_max, float* s2n);
 
 /* replaces ffpiv.u_v_displacement on an existing plane volume (pyorc/velocimetry/ffpiv.py:324,471):
  * planes (P, n_win, wy, wx) float32 -> u, v (P * n_win) float32 in pixels.                   */

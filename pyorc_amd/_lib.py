@@ -72,6 +72,7 @@ SIGNATURES = {
     "lspiv_chunk_alignment": (_i32, [_i32, _i32]),
     "lspiv_chunk_alignment_grid": (_i32, [_i64, _i64, _i32, _i32, _i32, _i32]),
     "lspiv_piv_pairs_at": (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "lspiv_piv_velocity_at": (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _i64, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     "lspiv_piv_pairs_dev_at": (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _i64, _vp, _vp, _vp]),
     "lspiv_u_v_displacement": (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _vp]),
     "lspiv_ensemble_begin": (_i32, [_i64, _i64, _i32, _i32, _i32, _i32, C.POINTER(_vp)]),

@@ -890,9 +890,28 @@ int lspiv_piv_pairs_dev(const void* d_frames, int dtype, int64_t T, int64_t H, i
   return lspiv_piv_pairs_dev_at(d_frames, dtype, T, H, W, wy, wx, oy, ox, signal_threshold, 0, d_out, d_corr_planes, stream);
 }
 
+// the host entry point, optionally with the px -> m/s scaling of pyorc/velocimetry/ffpiv.py:418-419 applied on the device before the
+// results come back (dt != NULL: seconds per pair, T - 1 entries)
+static int piv_pairs_host(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, int wy, int wx, int oy, int ox,
+                          float signal_threshold, int64_t pair_offset, float* u, float* v, float* corr_max, float* s2n,
+                          float* corr_planes, const double* dt, double res_x, double res_y);
+
 int lspiv_piv_pairs_at(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, int wy, int wx, int oy, int ox,
                        float signal_threshold, int64_t pair_offset, float* u, float* v, float* corr_max, float* s2n,
                        float* corr_planes) {
+  return piv_pairs_host(frames, dtype, T, H, W, wy, wx, oy, ox, signal_threshold, pair_offset, u, v, corr_max, s2n, corr_planes, nullptr, 1.0, 1.0);
+}
+
+int lspiv_piv_velocity_at(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, int wy, int wx, int oy, int ox,
+                          float signal_threshold, int64_t pair_offset, double res_x, double res_y, const double* dt, float* v_x, float* v_y,
+                          float* corr_max, float* s2n) {
+  if (!dt) return fail(LSPIV_EINVAL, "dt is NULL");
+  return piv_pairs_host(frames, dtype, T, H, W, wy, wx, oy, ox, signal_threshold, pair_offset, v_x, v_y, corr_max, s2n, nullptr, dt, res_x, res_y);
+}
+
+static int piv_pairs_host(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, int wy, int wx, int oy, int ox,
+                          float signal_threshold, int64_t pair_offset, float* u, float* v, float* corr_max, float* s2n,
+                          float* corr_planes, const double* dt, double res_x, double res_y) {
   std::lock_guard<std::mutex> host_lock(locks_here().host);
   if (!frames || !u || !v || !corr_max || !s2n) return fail(LSPIV_EINVAL, "NULL buffer");
   if (pair_offset < 0) return fail(LSPIV_EINVAL, "pair_offset %lld is negative", (long long)pair_offset);
@@ -976,6 +995,15 @@ int lspiv_piv_pairs_at(const void* frames, int dtype, int64_t T, int64_t H, int6
       launched = p1;
     }
     f0 = f1;
+  }
+  if (dt) {
+    // u, v to metres per second where they are: (u * res / dt).astype(float32) -- float32 product, float64 division, one rounding
+    // (masks.hip, scale_velocity_kernel: bit for bit what numpy computes for a python-float resolution, tests/test_masks.py)
+    rc = ensure(&c->d_scratch, &c->scratch_cap, (size_t)(T - 1) * sizeof(double));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_scratch, dt, (size_t)(T - 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const hipError_t e = lspiv::launch_scale_velocity(c->d_out, T - 1, (int64_t)n_win, (float)res_x, (float)res_y, (const double*)c->d_scratch, c->stream);
+    if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
   }
   const size_t ob = n_tiles * sizeof(float);
   HIP_TRY(hipMemcpyAsync(u, c->d_out, ob, hipMemcpyDeviceToHost, c->stream));

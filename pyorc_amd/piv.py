@@ -37,7 +37,7 @@ def _check_args(window_size, overlap, search_area_size, normalize, engine):
 
 
 def piv_pairs(imgs, window_size=(32, 32), overlap=(16, 16), signal_threshold: Optional[float] = None,
-              return_planes: bool = False, pair_offset: int = 0, out=None):
+              return_planes: bool = False, pair_offset: int = 0, out=None, scale=None):
     """Fused PIV of every consecutive frame pair of ``imgs`` (T, H, W).
 
     Returns ``(u, v, corr_max, s2n[, planes])``: float32 arrays (T-1, n_rows, n_cols); u, v in
@@ -46,6 +46,9 @@ def piv_pairs(imgs, window_size=(32, 32), overlap=(16, 16), signal_threshold: Op
     multiples of ``window.chunk_alignment`` reproduce the whole-stack result bit for bit.
     ``out``: four C-contiguous float32 arrays (T-1, n_rows, n_cols) that receive u, v, corr_max, s2n (e.g. time slices of the
     arrays of a whole run: the caller's chunk loop then needs no concatenation); they are what is returned.
+    ``scale = (res_x, res_y, dt)``: u, v come back in metres per second, ``(u * res_x / dt[:, None, None]).astype(float32)`` (ffpiv.py:
+    418-419) computed on the device before the results cross PCIe -- float32 product, float64 division, one rounding: numpy's own
+    arithmetic for PYTHON-FLOAT resolutions (the caller checks that, :func:`device_scaling_is_numpys`); ``dt``: (T-1,) float64 seconds.
     """
     lib = _lib.load()
     _lib.require_device()
@@ -60,13 +63,26 @@ def piv_pairs(imgs, window_size=(32, 32), overlap=(16, 16), signal_threshold: Op
         if len(out) != 4 or any(not isinstance(o, np.ndarray) or o.dtype != np.float32 or o.shape != (P, n_rows, n_cols) or
                                 not o.flags.c_contiguous or not o.flags.writeable for o in out):
             raise ValueError(f"out must be four writable C-contiguous float32 arrays of shape {(P, n_rows, n_cols)}")
+    dt = None
+    if scale is not None:
+        if return_planes:
+            raise ValueError("scale and return_planes exclude each other")
+        dt = np.ascontiguousarray(scale[2], dtype=np.float64).reshape(-1)
+        if dt.shape != (P,):
+            raise ValueError(f"scale: dt must have one entry per frame pair ({P}), got shape {dt.shape}")
     if is_device(a):   # HBM-resident stack: no staging, one launch, only the result block crosses PCIe
-        return _piv_pairs_device(a, window_size, overlap, signal_threshold, return_planes, pair_offset, n_rows, n_cols, out)
+        return _piv_pairs_device(a, window_size, overlap, signal_threshold, return_planes, pair_offset, n_rows, n_cols, out,
+                                 None if scale is None else (float(scale[0]), float(scale[1]), dt))
     if out is None:
         out = [np.empty((P, n_rows, n_cols), dtype=np.float32) for _ in range(4)]
     planes = None
     if return_planes:
         planes = np.empty((P, n_rows * n_cols, window_size[0], window_size[1]), dtype=np.float32)
+    if scale is not None:
+        _lib.check(lib.lspiv_piv_velocity_at(_lib.ptr(a), _lib.DTYPE_CODES[a.dtype], T, H, W, window_size[0], window_size[1],
+                                             overlap[0], overlap[1], _sig(signal_threshold), int(pair_offset), float(scale[0]), float(scale[1]),
+                                             _lib.ptr(dt), _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.ptr(out[3])))
+        return tuple(out)
     _lib.check(lib.lspiv_piv_pairs_at(_lib.ptr(a), _lib.DTYPE_CODES[a.dtype], T, H, W, window_size[0], window_size[1],
                                       overlap[0], overlap[1], _sig(signal_threshold), int(pair_offset),
                                       _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.ptr(out[3]),
@@ -74,7 +90,14 @@ def piv_pairs(imgs, window_size=(32, 32), overlap=(16, 16), signal_threshold: Op
     return (*out, planes) if return_planes else tuple(out)
 
 
-def _piv_pairs_device(a, window_size, overlap, signal_threshold, return_planes, pair_offset, n_rows, n_cols, out=None):
+def device_scaling_is_numpys(res_x, res_y) -> bool:
+    """Is ``(u * res / dt).astype(float32)`` with THESE resolutions what the device computes (float32 product)?  numpy multiplies a
+    float32 array by a Python float in float32; by a numpy float64 scalar in float64 (numpy >= 2) -- then the host keeps numpy's own
+    arithmetic.  (``np.float64`` is a subclass of ``float``: the test is on the exact type.)"""
+    return type(res_x) in (float, int, np.float32) and type(res_y) in (float, int, np.float32)
+
+
+def _piv_pairs_device(a, window_size, overlap, signal_threshold, return_planes, pair_offset, n_rows, n_cols, out=None, scale=None):
     from .device import DeviceFrames
 
     lib = _lib.load()
@@ -85,6 +108,8 @@ def _piv_pairs_device(a, window_size, overlap, signal_threshold, return_planes, 
     _lib.check(lib.lspiv_piv_pairs_dev_at(a.c_ptr, a.dtype_code, T, H, W, window_size[0], window_size[1], overlap[0], overlap[1],
                                           _sig(signal_threshold), int(pair_offset), d_out.c_ptr,
                                           d_planes.c_ptr if d_planes is not None else None, None))
+    if scale is not None:  # px / frame -> m / s in place on the [u | v] blocks (lspiv_scale_velocity_dev: the same kernel as the host entry point's)
+        _lib.check(lib.lspiv_scale_velocity_dev(d_out.c_ptr, P, n_win, scale[0], scale[1], _lib.ptr(scale[2]), None))
     if out is not None:    # straight into the caller's arrays: [u | v | corr | s2n] are four consecutive (P, n_win) blocks
         for k in range(4):
             _lib.check(lib.lspiv_memcpy_d2h(_lib.ptr(out[k]), C.c_void_p(d_out.ptr + k * P * n_win * 4), out[k].nbytes))

@@ -237,6 +237,7 @@ def _get_ffpiv_timestep(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_c
     px = None              # scratch for a chunk's u, v in pixels
     done = []              # (first pair, one past the last pair) of every chunk that delivered
     times = []
+    on_device = piv.device_scaling_is_numpys(res_x, res_y)
     loader = executor.ChunkPrefetcher(frames_chunks, load_frame_chunk, depth=prefetch)
     for n, da in loader:
         a, b = slices[n]
@@ -249,15 +250,21 @@ def _get_ffpiv_timestep(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_c
                 raise ValueError(f"grid {tuple(grid)} does not match coordinates ({n_rows}, {n_cols})")
             if full is None:
                 full = {k: np.empty((n_total, n_rows, n_cols), dtype=np.float32) for k in names}
-            if px is None or px[0].shape[0] < p:
-                px = [np.empty((p, n_rows, n_cols), dtype=np.float32) for _ in range(2)]
-            u, v = px[0][:p], px[1][:p]
-            piv.piv_pairs(vals, window_size, overlap, signal_threshold, pair_offset=a,
-                          out=(u, v, full["corr"][a:a + p], full["s2n"][a:a + p]))
-            dt_chunk = dt[a:nb - 1][:, None, None]  # dt.sel(time=da.time[1:]), ffpiv.py:403-404
-            # u and v to meter per second (float64 division, float32 storage: ffpiv.py:418-419)
-            _to_velocity(u, res_x, dt_chunk, out=full["v_x"][a:a + p])
-            _to_velocity(v, res_y, dt_chunk, out=full["v_y"][a:a + p])
+            dt_chunk = dt[a:nb - 1]  # dt.sel(time=da.time[1:]), ffpiv.py:403-404
+            if on_device:
+                # u and v to meter per second on the device, before they cross PCIe: the arithmetic of ffpiv.py:418-419 for
+                # python-float resolutions (float32 product, float64 division, float32 storage)
+                piv.piv_pairs(vals, window_size, overlap, signal_threshold, pair_offset=a, scale=(res_x, res_y, dt_chunk),
+                              out=(full["v_x"][a:a + p], full["v_y"][a:a + p], full["corr"][a:a + p], full["s2n"][a:a + p]))
+            else:
+                if px is None or px[0].shape[0] < p:
+                    px = [np.empty((p, n_rows, n_cols), dtype=np.float32) for _ in range(2)]
+                u, v = px[0][:p], px[1][:p]
+                piv.piv_pairs(vals, window_size, overlap, signal_threshold, pair_offset=a,
+                              out=(u, v, full["corr"][a:a + p], full["s2n"][a:a + p]))
+                # ... on the host with numpy's own arithmetic for any other kind of resolution (a numpy float64 scalar makes the product float64)
+                _to_velocity(u, res_x, dt_chunk[:, None, None], out=full["v_x"][a:a + p])
+                _to_velocity(v, res_y, dt_chunk[:, None, None], out=full["v_y"][a:a + p])
             done.append((a, a + p))
             times.append(time[a + 1:nb])
         # remove chunk safely from memory.  (The reference follows this with gc.collect() to get rid of its window stack and

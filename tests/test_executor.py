@@ -192,12 +192,12 @@ def test_get_ffpiv_gives_the_same_dataset_with_and_without_prefetch(monkeypatch)
                 time.sleep(load_s)
                 return super().load()
 
-        def fake_pairs(fr, ws, ov, thr=None, pair_offset=0, out=None):
+        def fake_pairs(fr, ws, ov, thr=None, pair_offset=0, out=None, scale=None):
             from tests.doubles import oracle_piv_pairs
 
             order.append(pair_offset)
             time.sleep(compute_s)
-            return oracle_piv_pairs(fr, ws, ov, thr, pair_offset, out)
+            return oracle_piv_pairs(fr, ws, ov, thr, pair_offset, out, scale)
 
         class SlowEnsemble(OracleEnsemble):
             def accumulate(self, frames, corr_min, s2n_min, thr=None, out=None):

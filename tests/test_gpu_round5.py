@@ -217,3 +217,39 @@ def test_project_hip_blocks_on_the_gpu(gpu, monkeypatch):
         t.join()
     assert np.array_equal(np.concatenate(res).astype(np.float64), ref) and len(plugin._PLANS) == 2
     plugin.uninstall()
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float64])
+def test_velocity_scaling_on_the_device_is_numpys(gpu, dtype):
+    """get_piv scales u, v to m/s on the device before they cross PCIe when the resolution is a Python float (round 5:
+    lspiv_piv_velocity_at / lspiv_scale_velocity_dev): bit for bit ``(u * res / dt[:, None, None]).astype(float32)`` as the reference
+    writes it (ffpiv.py:418-419) -- uneven time steps, chunked, host frames and an HBM-resident stack; a numpy float64 resolution keeps
+    numpy's own (float64-product) arithmetic on the host."""
+    import pyorc_amd
+    from pyorc_amd import DeviceFrames, frames as F
+
+    fr = particle_stack(61, 160, 224, seed=14).astype(dtype)
+    rng = np.random.default_rng(3)
+    t = np.cumsum(rng.uniform(0.02, 0.05, 61))
+    dt = np.diff(t)
+    res = 0.0123
+    u, v, cm, sn = pyorc_amd.piv_pairs(fr, (32, 32), (16, 16))
+    want_x = (u * res / np.expand_dims(dt, (1, 2))).astype(np.float32)
+    want_y = (v * res / np.expand_dims(dt, (1, 2))).astype(np.float32)
+    for stack in (fr, DeviceFrames.from_host(fr)):
+        for cs in (None, 26):
+            ds = F.get_piv(stack, 32, time=t, resolution=res, **({} if cs is None else {"chunksize": cs}))
+            assert np.array_equal(ds["v_x"].view(np.uint32), want_x.view(np.uint32)) and np.array_equal(ds["v_y"].view(np.uint32), want_y.view(np.uint32))
+            assert np.array_equal(ds["corr"], cm, equal_nan=True) and np.array_equal(ds["s2n"], sn, equal_nan=True)
+    # the entry point itself, and the guard on the kind of resolution
+    vx, vy, cm2, sn2 = pyorc_amd.piv_pairs(fr, (32, 32), (16, 16), scale=(res, res, dt))
+    assert np.array_equal(vx.view(np.uint32), want_x.view(np.uint32)) and np.array_equal(vy.view(np.uint32), want_y.view(np.uint32))
+    from pyorc_amd import piv, velocimetry as V
+
+    assert piv.device_scaling_is_numpys(0.01, 1) and piv.device_scaling_is_numpys(np.float32(0.01), 0.5) and not piv.device_scaling_is_numpys(np.float64(0.01), 0.01)
+    coords, _ = F.get_piv_coords((160, 224), (32, 32), (32, 32), (16, 16))
+    ds64 = V.get_ffpiv(fr, coords["y"], coords["x"], dt, (32, 32), (16, 16), (32, 32), np.float64(res), np.float64(res), time=t)
+    host_x = (u * np.float64(res) / np.expand_dims(dt, (1, 2))).astype(np.float32)       # numpy's arithmetic for that scalar type, whatever it is
+    assert np.array_equal(ds64["v_x"].view(np.uint32), host_x.view(np.uint32))
+    with pytest.raises(ValueError):
+        pyorc_amd.piv_pairs(fr, (32, 32), (16, 16), scale=(res, res, dt[:-1]))
