@@ -37,7 +37,11 @@
 extern "C" {
 #endif
 
-#define LSPIV_ABI_VERSION 4   /* (round 5 added lspiv_chunk_alignment_grid, lspiv_piv_velocity_at, lspiv_ensemble_flag_digest, lspiv_kernel_times + the "time_kernel" option and the test hook lspiv_debug_hold_lock; no version change: nothing existing moved)
+#define LSPIV_ABI_VERSION 5   /* 5 (round 6): lspiv_chunk_alignment(wy, wx) without a grid now returns the alignment that is right on EVERY grid (75
+                               * where it returned 25: callers that cut chunks on it stay bit-reproducible on large grids); additions:
+                               * lspiv_upload_frames, lspiv_trace / lspiv_trace_read; the host-pointer projection entry points no longer
+                               * share the PIV host entry points' lock and workspaces.
+                               * (round 5 added lspiv_chunk_alignment_grid, lspiv_piv_velocity_at, lspiv_ensemble_flag_digest, lspiv_kernel_times + the "time_kernel" option and the test hook lspiv_debug_hold_lock; no version change: nothing existing moved)
                                * 4 (round 4, additions only): lspiv_build_info, the float64 rescue of the ensemble's final fit
                                * (lspiv_ensemble_set_retain / _stats / _flag / _partials / _finish_partials), lspiv_stream_release,
                                * lspiv_stream_create_priority; 3: lspiv_rescue_stats,
@@ -177,8 +181,9 @@ int lspiv_piv_pairs_dev(const void* d_frames, int dtype, int64_t T, int64_t H, i
  * lspiv_chunk_alignment: pairs; 1 for window sizes served by per-pair kernels and with option "walk" = 0.  Host-only.
  * Round 5: the run length depends on the window GRID as well -- 25 pairs, or 75 on grids with at least as many windows as the chip
  * has lane groups for that window family (1080p 32 x 32 @ 50 %, 64 x 64 @ 75 %, 4K: less per-segment overhead, csrc/common.h
- * walk_anchor).  lspiv_chunk_alignment_grid(H, W, ...) is the figure to cut chunks on for frames of that shape (a multiple of
- * lspiv_chunk_alignment(wy, wx), which remains the run length on small grids); negative status for a bad shape. */
+ * walk_anchor).  lspiv_chunk_alignment_grid(H, W, ...) is the figure to cut chunks on for frames of that shape; negative status for
+ * a bad shape.  lspiv_chunk_alignment(wy, wx), without a grid, is the alignment that is right for EVERY frame shape (ABI 5: the
+ * longest run length of the family, a multiple of every grid's; ABI 4 returned the run length of small grids). */
 int lspiv_chunk_alignment(int wy, int wx);
 int lspiv_chunk_alignment_grid(int64_t H, int64_t W, int wy, int wx, int oy, int ox);
 int lspiv_piv_pairs_at(const void* frames, int dtype, int64_t T, int64_t H, int64_t W,
@@ -196,6 +201,15 @@ int lspiv_piv_velocity_at(const void* frames, int dtype, int64_t T, int64_t H, i
                           int wy, int wx, int oy, int ox, float signal_threshold, int64_t pair_offset,
                           double res_x, double res_y, const double* dt,
                           float* v_x, float* v_y, float* corr_max, float* s2n);
+
+/* Host frames into a slice of an HBM-resident stack, the way lspiv_piv_pairs brings them in -- pinned ring, staging threads,
+ * float64 narrowed to float32 with the "narrow_offset" guard (so d_dst receives n_frames * H * W samples of LSPIV_F32 for LSPIV_F64
+ * input, of `dtype` otherwise) -- without launching anything: what lets the chunk loop of pyorc/velocimetry/ffpiv.py:399-440 keep a
+ * LAZY stack resident in HBM, filled in whatever pieces dask delivers (its own blocks: no frame is decoded twice) and launched on
+ * the kernels' anchors (pyorc_amd/resident.py).  signal_threshold: that of the PIV call which will read the frames (it decides the
+ * guard exactly as there).  Blocking; waits for the library's stream before the first DMA. */
+int lspiv_upload_frames(void* d_dst, const void* frames, int dtype, int64_t n_frames, int64_t H, int64_t W,
+                        float signal_threshold);
 
 /* replaces ffpiv.u_v_displacement on an existing plane volume (pyorc/velocimetry/ffpiv.py:324,471):
  * planes (P, n_win, wy, wx) float32 -> u, v (P * n_win) float32 in pixels.                   */
@@ -488,8 +502,22 @@ int lspiv_debug_segments(int64_t n_pairs, int64_t pair_offset, int seg_len, int6
  * roofline.achieved). */
 int lspiv_kernel_times(float* ms, int cap, int* n);
 
-/* Test hook (host only, no HIP call): hold one of device `device`'s locks -- 0 the host-pointer entry points' workspaces, 1 a launch
- * and its rescue kernels, 2 the rescue lists -- for `milliseconds`.  The locks are per device (round 5; process-wide before): two
+/* Measurement / tests (round 6): lspiv_trace(1) makes the library record HIP event pairs -- on the streams the work runs on --
+ * around the spans below, lspiv_trace(0) stops and forgets them; lspiv_trace_read returns up to `cap` of the *n recorded spans of the
+ * calling thread's device, in recording order, as milliseconds since lspiv_trace(1) (it synchronises the device first).
+ *   LSPIV_TRACE_PIV_HOST      one host-pointer PIV call (lspiv_piv_pairs[_at], lspiv_piv_velocity_at): from before its first kernel
+ *                             to after its last download;
+ *   LSPIV_TRACE_PROJECT_HOST  the projection kernel(s) of one host-pointer projection call (lspiv_project_frames[_u8],
+ *                             lspiv_project_cv_frames), between its upload and its download.
+ * A projection span that starts inside a PIV span shows what a wall clock cannot: the two calls, issued by two host threads on one
+ * device, overlapped on the GPU (they share neither lock, nor stream, nor workspaces since round 6). */
+#define LSPIV_TRACE_PIV_HOST 0
+#define LSPIV_TRACE_PROJECT_HOST 1
+int lspiv_trace(int enable);
+int lspiv_trace_read(int64_t cap, int32_t* kind, double* start_ms, double* end_ms, int64_t* n);
+
+/* Test hook (host only, no HIP call): hold one of device `device`'s locks -- 0 the host-pointer PIV entry points' workspaces, 1 a launch
+ * and its rescue kernels, 2 the rescue lists, 3 / 4 the two slots of the host-pointer projection entry points -- for `milliseconds`.  The locks are per device (round 5; process-wide before): two
  * threads holding the same lock of two devices overlap, of one device queue.  tests/test_host.py times exactly that. */
 int lspiv_debug_hold_lock(int device, int which, int milliseconds);
 

@@ -96,6 +96,13 @@ struct DeviceCtx {
   std::vector<RescueWs> rescue;
   void* pinned[2] = {nullptr, nullptr}; size_t pinned_cap = 0;  // H2D staging ring
   hipEvent_t staged[2] = {nullptr, nullptr};
+  // host-pointer projection entry points (round 6): kProjSlots independent sets of {stream, input buffer, output buffer}, each under
+  // its own lock (DeviceLocks::project), none of them shared with the PIV host entry points -- a project_hip block that dask runs
+  // on a worker thread neither waits for the `host` lock a PIV call holds for its whole upload + kernels + download, nor for the
+  // other block in flight: block k + 1 crosses PCIe while block k's kernel runs and its result goes back
+  struct ProjWs { hipStream_t stream = nullptr; void* d_in = nullptr; size_t in_cap = 0; void* d_out = nullptr; size_t out_cap = 0; };
+  static constexpr int kProjSlots = 2;
+  ProjWs proj[kProjSlots];
   bool arch_ok = false;
 };
 std::mutex g_mu;        // the table of contexts itself (created lazily); never held while another lock is taken
@@ -107,9 +114,10 @@ std::vector<DeviceCtx*> g_ctx;
 //   host:     host-pointer entry points share one set of workspaces (upload buffer, result buffer, pinned ring) per device
 //   dispatch: the PIV kernel and the rescue kernels of ONE launch share their stream's lists and counters (see dispatch())
 //   lists:    the per-stream rescue lists of a context (DeviceCtx::rescue)
+//   project:  one per projection slot (DeviceCtx::proj): the host-pointer projection entry points; never nested with the others
 // Order when nested: host -> dispatch -> lists.
 constexpr int kMaxDevices = 64;
-struct DeviceLocks { std::mutex host, dispatch, lists; };
+struct DeviceLocks { std::mutex host, dispatch, lists, project[DeviceCtx::kProjSlots]; std::atomic<unsigned> next_project{0}; };
 DeviceLocks g_locks[kMaxDevices];
 static int current_device_slot() {
   int dev = 0;
@@ -139,6 +147,50 @@ int get_ctx(DeviceCtx** out) {
   }
   *out = g_ctx[dev];
   return LSPIV_OK;
+}
+
+// A projection slot of the current device, locked: the first free one, else the next in turn (callers queue fairly on two locks).
+struct ProjSlot {
+  std::unique_lock<std::mutex> lk;
+  DeviceCtx::ProjWs* ws = nullptr;
+};
+static int take_proj_slot(DeviceCtx* c, ProjSlot* out) {
+  DeviceLocks& l = locks_here();
+  int k = -1;
+  for (int i = 0; i < DeviceCtx::kProjSlots && k < 0; ++i) {
+    std::unique_lock<std::mutex> t(l.project[i], std::try_to_lock);
+    if (t.owns_lock()) { out->lk = std::move(t); k = i; }
+  }
+  if (k < 0) {
+    k = (int)(l.next_project.fetch_add(1) % DeviceCtx::kProjSlots);
+    out->lk = std::unique_lock<std::mutex>(l.project[k]);
+  }
+  out->ws = &c->proj[k];
+  if (!out->ws->stream) HIP_TRY(hipStreamCreateWithFlags(&out->ws->stream, hipStreamNonBlocking));
+  return LSPIV_OK;
+}
+
+// "trace" (tests / measurement only, off by default): HIP events the LIBRARY records around the spans below, on the streams the work
+// runs on; lspiv_trace_read returns them in milliseconds since lspiv_trace(1).  What a wall clock cannot show -- that a projection
+// block's kernel ran INSIDE a concurrent PIV host call on the same device -- two event pairs can.
+struct TraceRec { int kind; hipEvent_t e0, e1; };
+struct Trace { std::mutex mu; std::atomic<bool> on{false}; hipEvent_t base = nullptr; std::vector<TraceRec> recs; };
+Trace g_trace[kMaxDevices];
+struct TraceSpan { Trace* t = nullptr; TraceRec r{}; };
+static void trace_begin(TraceSpan* sp, int kind, hipStream_t s) {
+  Trace& t = g_trace[current_device_slot()];
+  if (!t.on.load()) return;
+  sp->r.kind = kind;
+  if (hipEventCreate(&sp->r.e0) != hipSuccess || hipEventCreate(&sp->r.e1) != hipSuccess) { (void)hipGetLastError(); return; }
+  if (hipEventRecord(sp->r.e0, s) != hipSuccess) { (void)hipGetLastError(); return; }
+  sp->t = &t;
+}
+static void trace_end(TraceSpan* sp, hipStream_t s) {
+  if (!sp->t) return;
+  if (hipEventRecord(sp->r.e1, s) != hipSuccess) { (void)hipGetLastError(); return; }
+  std::lock_guard<std::mutex> lk(sp->t->mu);
+  sp->t->recs.push_back(sp->r);
+  sp->t = nullptr;
 }
 
 // host memory registered with HIP (hipHostMalloc / lspiv_host_alloc / hipHostRegister) can be DMA'd in place
@@ -422,6 +474,33 @@ int dispatch_kernels(const lspiv::PivParams& p, int dtype, bool ensemble, hipStr
     default: return fail(LSPIV_EUNSUPPORTED, "no kernel for window %dx%d", p.wy, p.wx);
   }
   if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return LSPIV_OK;
+}
+
+// Host-pointer projection (what a project_hip dask block calls): a projection slot's own stream and buffers under the slot's own lock
+// (round 6) -- not the PIV host entry points' workspaces and `host` lock, which a concurrent lspiv_piv_pairs holds from its first
+// upload to its last download.
+template <typename Launch>
+static int project_host(size_t ib, size_t ob, const void* frames, void* out, Launch&& launch) {
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  ProjSlot slot;
+  rc = take_proj_slot(c, &slot);
+  if (rc) return rc;
+  DeviceCtx::ProjWs* w = slot.ws;
+  rc = ensure(&w->d_in, &w->in_cap, ib);
+  if (rc) return rc;
+  rc = ensure(&w->d_out, &w->out_cap, ob);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(w->d_in, frames, ib, hipMemcpyHostToDevice, w->stream));
+  TraceSpan span;
+  trace_begin(&span, LSPIV_TRACE_PROJECT_HOST, w->stream);
+  rc = launch(w->d_in, w->d_out, w->stream);
+  if (rc) return rc;
+  trace_end(&span, w->stream);
+  HIP_TRY(hipMemcpyAsync(out, w->d_out, ob, hipMemcpyDeviceToHost, w->stream));
+  HIP_TRY(hipStreamSynchronize(w->stream));
   return LSPIV_OK;
 }
 
@@ -837,16 +916,25 @@ int lspiv_available_bytes(int64_t* free_bytes, int64_t* total_bytes) {
   return LSPIV_OK;
 }
 
-int lspiv_chunk_alignment(int wy, int wx) {
+// run length of the window family on small grids (kWalkAnchor), 1 for per-pair kernels, a forced length as it is
+static int base_alignment(int wy, int wx) {
   const int kind = lspiv_kernel_kind(wy, wx);
   if (kind < 0) return kind;
   const int walk = lspiv::walk_setting();
   if (!kind_walks(kind) || walk == 0) return 1;
   return walk > 1 ? walk : (int)lspiv::kWalkAnchor;
 }
+// Without a grid: the alignment that is right for EVERY frame shape -- the longest run length the family uses, a multiple of the
+// shorter one (ABI 5; it returned the short one before, which cut chunks off the anchors of large grids: ADVICE r05)
+int lspiv_chunk_alignment(int wy, int wx) {
+  const int base = base_alignment(wy, wx);
+  if (base <= 1 || lspiv::walk_setting() > 1) return base;
+  static_assert(lspiv::kWalkAnchorLong % lspiv::kWalkAnchor == 0, "the long anchor must be a multiple of the short one");
+  return (int)lspiv::kWalkAnchorLong;
+}
 // the anchor length the walking kernels use on a grid of n_win windows (common.h, walk_anchor)
 static int chunk_alignment_for(int wy, int wx, int64_t n_win) {
-  const int base = lspiv_chunk_alignment(wy, wx);
+  const int base = base_alignment(wy, wx);
   if (base <= 1 || lspiv::walk_setting() > 1) return base;     // per-pair kernels, or a forced anchor length
   return (int)lspiv::walk_anchor(wy, (uint32_t)std::min<int64_t>(n_win, 0x7fffffff));
 }
@@ -953,6 +1041,8 @@ static int piv_pairs_host(const void* frames, int dtype, int64_t T, int64_t H, i
   const bool whole_chunk_only = g_opt_signal_mode.load() == 1 && signal_threshold >= 0.0f;
   int64_t launched = 0;   // pairs [0, launched) have been issued
   int batch = 0;
+  TraceSpan span;
+  trace_begin(&span, LSPIV_TRACE_PIV_HOST, c->stream);
   for (int64_t f0 = 0; f0 < T; ++batch) {
     const int64_t f1 = std::min<int64_t>(T, f0 + fpb);
     const int slot = batch & 1;
@@ -1012,6 +1102,7 @@ static int piv_pairs_host(const void* frames, int dtype, int64_t T, int64_t H, i
   HIP_TRY(hipMemcpyAsync(s2n, c->d_out + 3 * n_tiles, ob, hipMemcpyDeviceToHost, c->stream));
   if (corr_planes)
     HIP_TRY(hipMemcpyAsync(corr_planes, c->d_planes, n_tiles * wy * wx * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  trace_end(&span, c->stream);
   HIP_TRY(hipStreamSynchronize(c->stream));
   return LSPIV_OK;
 }
@@ -1623,25 +1714,14 @@ int lspiv_project_frames_dev(lspiv_projection* h, const void* d_frames, int dtyp
 }
 
 int lspiv_project_frames(lspiv_projection* h, const void* frames, int dtype, int64_t T, float* out) {
-  std::lock_guard<std::mutex> host_lock(locks_here().host);
   if (!h || !frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
   if (dtype < 0 || dtype > 2) return fail(LSPIV_EINVAL, "dtype %d not in {0:u8, 1:f32, 2:f64}", dtype);
   if (T <= 0) return LSPIV_OK;
-  DeviceCtx* c;
-  int rc = get_ctx(&c);
-  if (rc) return rc;
   const size_t ib = (size_t)T * h->src_h * h->src_w * elem_size(dtype);
   const size_t ob = (size_t)T * h->dst_h * h->dst_w * sizeof(float);
-  rc = ensure(&c->d_frames, &c->frames_cap, ib);
-  if (rc) return rc;
-  rc = ensure(&c->d_planes, &c->planes_cap, ob);
-  if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(c->d_frames, frames, ib, hipMemcpyHostToDevice, c->stream));
-  rc = lspiv_project_frames_dev(h, c->d_frames, dtype, T, c->d_planes, c->stream);
-  if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(out, c->d_planes, ob, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return LSPIV_OK;
+  return project_host(ib, ob, frames, out, [&](void* d_in, void* d_out, hipStream_t s) {
+    return lspiv_project_frames_dev(h, d_in, dtype, T, (float*)d_out, s);
+  });
 }
 
 int lspiv_project_frames_u8_dev(lspiv_projection* h, const uint8_t* d_frames, int64_t T, uint8_t* d_out, void* stream) {
@@ -1661,23 +1741,12 @@ int lspiv_project_frames_u8_dev(lspiv_projection* h, const uint8_t* d_frames, in
 }
 
 int lspiv_project_frames_u8(lspiv_projection* h, const uint8_t* frames, int64_t T, uint8_t* out) {
-  std::lock_guard<std::mutex> host_lock(locks_here().host);
   if (!h || !frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
   if (T <= 0) return LSPIV_OK;
-  DeviceCtx* c;
-  int rc = get_ctx(&c);
-  if (rc) return rc;
   const size_t ib = (size_t)T * h->src_h * h->src_w, ob = (size_t)T * h->dst_h * h->dst_w;
-  rc = ensure(&c->d_frames, &c->frames_cap, ib);
-  if (rc) return rc;
-  rc = ensure(&c->d_planes, &c->planes_cap, ob);
-  if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(c->d_frames, frames, ib, hipMemcpyHostToDevice, c->stream));
-  rc = lspiv_project_frames_u8_dev(h, (const uint8_t*)c->d_frames, T, (uint8_t*)c->d_planes, c->stream);
-  if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(out, c->d_planes, ob, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return LSPIV_OK;
+  return project_host(ib, ob, frames, out, [&](void* d_in, void* d_out, hipStream_t s) {
+    return lspiv_project_frames_u8_dev(h, (const uint8_t*)d_in, T, (uint8_t*)d_out, s);
+  });
 }
 
 int lspiv_projection_destroy(lspiv_projection* h) {
@@ -1705,6 +1774,7 @@ struct lspiv_remap {
   int *d_qb1, *d_qb2, *d_slow1, *d_slow2;
   uint64_t *d_qd1, *d_qd2;
   int n_slow1, n_slow2;
+  std::mutex host_mu;                      // host-pointer calls on ONE handle queue: they share d_tmp (two handles run side by side)
 };
 
 namespace {
@@ -1888,24 +1958,14 @@ int lspiv_project_cv_frames_dev(lspiv_remap* h, const void* d_frames, int dtype,
 }
 
 int lspiv_project_cv_frames(lspiv_remap* h, const void* frames, int dtype, int64_t T, void* out) {
-  std::lock_guard<std::mutex> host_lock(locks_here().host);
   if (!h || !frames || !out) return fail(LSPIV_EINVAL, "NULL argument");
   if (dtype != LSPIV_U8 && dtype != LSPIV_F32) return fail(LSPIV_EINVAL, "project_cv takes uint8 or float32 frames (cv2 keeps the frame dtype)");
   if (T <= 0) return LSPIV_OK;
-  DeviceCtx* c;
-  int rc = get_ctx(&c);
-  if (rc) return rc;
   const size_t fb = (size_t)T * h->src_h * h->src_w * elem_size(dtype), ob = (size_t)T * h->dst_h * h->dst_w * elem_size(dtype);
-  rc = ensure(&c->d_frames, &c->frames_cap, fb);
-  if (rc) return rc;
-  rc = ensure(&c->d_planes, &c->planes_cap, ob);
-  if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(c->d_frames, frames, fb, hipMemcpyHostToDevice, c->stream));
-  rc = lspiv_project_cv_frames_dev(h, c->d_frames, dtype, T, c->d_planes, c->stream);
-  if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(out, c->d_planes, ob, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return LSPIV_OK;
+  std::lock_guard<std::mutex> handle_lock(h->host_mu);
+  return project_host(fb, ob, frames, out, [&](void* d_in, void* d_out, hipStream_t s) {
+    return lspiv_project_cv_frames_dev(h, d_in, dtype, T, d_out, s);
+  });
 }
 
 int lspiv_project_cv_destroy(lspiv_remap* h) {
@@ -2451,6 +2511,85 @@ int lspiv_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   return LSPIV_OK;
 }
+// Host frames into a slice of an HBM-resident stack, the way the PIV host entry points bring them in (the same staging threads, the
+// same float64 -> float32 conversion and DC-offset guard: a stack filled by this call holds the bytes lspiv_piv_pairs would have
+// computed on), without launching anything.  Blocking.
+int lspiv_upload_frames(void* d_dst, const void* frames, int dtype, int64_t n_frames, int64_t H, int64_t W, float signal_threshold) {
+  if (!d_dst || !frames) return fail(LSPIV_EINVAL, "NULL argument");
+  if (dtype < 0 || dtype > 2) return fail(LSPIV_EINVAL, "dtype %d not in {0:u8, 1:f32, 2:f64}", dtype);
+  if (n_frames < 0 || H <= 0 || W <= 0) return fail(LSPIV_ESHAPE, "bad shape (%lld, %lld, %lld)", (long long)n_frames, (long long)H, (long long)W);
+  if (n_frames == 0) return LSPIV_OK;
+  std::lock_guard<std::mutex> host_lock(locks_here().host);
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  const int dev_dtype = dtype == LSPIV_F64 ? LSPIV_F32 : dtype;
+  const size_t frame_elems = (size_t)H * W, frame_bytes = frame_elems * elem_size(dev_dtype), src_frame_bytes = frame_elems * elem_size(dtype);
+  rc = stage_ring(c, frame_bytes);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));   // the DMA runs on the copy stream: earlier kernels may still use d_dst
+  const bool src_pinned = dtype != LSPIV_F64 && is_pinned(frames);
+  // at least four slices per call, so that the un-overlapped first staging step stays a small part of it
+  const int64_t fpb = std::max<int64_t>(1, std::min<int64_t>((int64_t)(c->pinned_cap / frame_bytes), (n_frames + 3) / 4));
+  int batch = 0;
+  for (int64_t f0 = 0; f0 < n_frames; ++batch) {
+    const int64_t f1 = std::min<int64_t>(n_frames, f0 + fpb);
+    const int slot = batch & 1;
+    if (batch >= 2) HIP_TRY(hipEventSynchronize(c->staged[slot]));
+    const size_t nb = (size_t)(f1 - f0) * frame_bytes;
+    const void* dma_src = c->pinned[slot];
+    if (dtype == LSPIV_F64) {
+      const double* src64 = (const double*)((const char*)frames + (size_t)f0 * src_frame_bytes);
+      const std::vector<double> off = narrow_offsets(src64, frame_elems, f1 - f0, signal_threshold);
+      lspiv_host::staged_narrow((float*)c->pinned[slot], src64, frame_elems, (size_t)(f1 - f0), off.data());
+    } else if (src_pinned)
+      dma_src = (const char*)frames + (size_t)f0 * src_frame_bytes;
+    else
+      staged_copy(c->pinned[slot], (const char*)frames + (size_t)f0 * src_frame_bytes, nb);
+    HIP_TRY(hipMemcpyAsync((char*)d_dst + (size_t)f0 * frame_bytes, dma_src, nb, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(hipEventRecord(c->staged[slot], c->copy_stream));
+    f0 = f1;
+  }
+  HIP_TRY(hipStreamSynchronize(c->copy_stream));
+  return LSPIV_OK;
+}
+
+int lspiv_trace(int enable) {
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  Trace& t = g_trace[current_device_slot()];
+  HIP_TRY(hipDeviceSynchronize());
+  std::lock_guard<std::mutex> lk(t.mu);
+  for (TraceRec& r : t.recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  t.recs.clear();
+  if (enable) {
+    if (!t.base) HIP_TRY(hipEventCreate(&t.base));
+    HIP_TRY(hipEventRecord(t.base, c->stream));
+    HIP_TRY(hipEventSynchronize(t.base));
+  }
+  t.on.store(enable != 0);
+  return LSPIV_OK;
+}
+int lspiv_trace_read(int64_t cap, int32_t* kind, double* start_ms, double* end_ms, int64_t* n) {
+  if (!n || cap < 0 || (cap > 0 && (!kind || !start_ms || !end_ms))) return fail(LSPIV_EINVAL, "bad argument");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  Trace& t = g_trace[current_device_slot()];
+  HIP_TRY(hipDeviceSynchronize());
+  std::lock_guard<std::mutex> lk(t.mu);
+  *n = (int64_t)t.recs.size();
+  if (!t.base) return LSPIV_OK;
+  for (int64_t i = 0; i < std::min<int64_t>(cap, *n); ++i) {
+    float a = 0.0f, b = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&a, t.base, t.recs[(size_t)i].e0));
+    HIP_TRY(hipEventElapsedTime(&b, t.base, t.recs[(size_t)i].e1));
+    kind[i] = t.recs[(size_t)i].kind; start_ms[i] = a; end_ms[i] = b;
+  }
+  return LSPIV_OK;
+}
+
 int lspiv_host_alloc(void** h_ptr, size_t bytes) {
   if (!h_ptr) return fail(LSPIV_EINVAL, "h_ptr is NULL");
   DeviceCtx* c;
@@ -2604,10 +2743,10 @@ int lspiv_debug_narrow(const double* frames, int64_t frame_elems, int64_t n_fram
   return lspiv_host::stage_threads();
 }
 int lspiv_debug_hold_lock(int device, int which, int milliseconds) {
-  if (device < 0 || device >= kMaxDevices || which < 0 || which > 2 || milliseconds < 0 || milliseconds > 10000)
+  if (device < 0 || device >= kMaxDevices || which < 0 || which > 2 + DeviceCtx::kProjSlots || milliseconds < 0 || milliseconds > 10000)
     return fail(LSPIV_EINVAL, "device %d / lock %d / %d ms out of range", device, which, milliseconds);
   DeviceLocks& l = g_locks[device];
-  std::lock_guard<std::mutex> lk(which == 0 ? l.host : which == 1 ? l.dispatch : l.lists);
+  std::lock_guard<std::mutex> lk(which == 0 ? l.host : which == 1 ? l.dispatch : which == 2 ? l.lists : l.project[which - 3]);
   std::this_thread::sleep_for(std::chrono::milliseconds(milliseconds));
   return LSPIV_OK;
 }

@@ -124,6 +124,31 @@ class DeviceFrames:
         _lib.check(_lib.load().lspiv_memcpy_h2d(d.c_ptr, _lib.ptr(a), a.nbytes))
         return d
 
+    @staticmethod
+    def device_dtype(host_dtype) -> np.dtype:
+        """The sample type a host stack of ``host_dtype`` has once it is in HBM: uint8 and float32 as they are, everything else
+        float32 (float64 is narrowed while it is staged, like the PIV host entry points do: the kernels compute in float32)."""
+        dt = np.dtype(host_dtype)
+        return dt if dt in (np.dtype(np.uint8), np.dtype(np.float32)) else np.dtype(np.float32)
+
+    def upload(self, f0: int, frames, signal_threshold=None) -> int:
+        """Host frames ``(n, H, W)`` into frames ``[f0, f0 + n)`` of this stack, the way ``lspiv_piv_pairs`` brings a host stack in
+        (``lspiv_upload_frames``: pinned ring + staging threads, float64 narrowed to float32 with the DC-offset guard that
+        ``signal_threshold`` -- the one of the PIV call that will read the frames -- switches exactly as there).  Returns ``n``."""
+        a = _lib.as_frames(frames)
+        n = int(a.shape[0])
+        if a.shape[1:] != self.shape[1:]:
+            raise ValueError(f"frames are {a.shape[1:]}, the stack holds {self.shape[1:]}")
+        if not 0 <= f0 <= self.shape[0] - n:
+            raise IndexError(f"frames [{f0}, {f0 + n}) do not fit a stack of {self.shape[0]}")
+        if self.device_dtype(a.dtype) != self.dtype:
+            raise TypeError(f"{a.dtype} frames arrive as {self.device_dtype(a.dtype)} in HBM, the stack is {self.dtype}")
+        if n:
+            frame_bytes = self.shape[1] * self.shape[2] * self.dtype.itemsize
+            _lib.check(_lib.load().lspiv_upload_frames(C.c_void_p(self.ptr + int(f0) * frame_bytes), _lib.ptr(a), _lib.DTYPE_CODES[a.dtype], n,
+                                                       self.shape[1], self.shape[2], -1.0 if signal_threshold is None else float(signal_threshold)))
+        return n
+
     # ---- array-like surface ------------------------------------------------------------------
     @property
     def ptr(self) -> int:

@@ -176,8 +176,9 @@ class Ensemble:
         ``lspiv_ensemble_set_retain``): 0 nothing (float32 fits), 1 the handle copies them, 2 it borrows the caller's pointers."""
         _lib.check(_lib.load().lspiv_ensemble_set_retain(self._h, int(mode)))
         self._retain_mode = int(mode)
-        if int(mode) != self.RETAIN_BORROW:
-            self._held = []   # nothing is borrowed from here on; what was kept so far the handle drops with the next accumulate
+        # what was borrowed so far STAYS pinned by this object until close(): lspiv_ensemble_set_retain only stores the mode, the handle
+        # keeps the earlier borrowed pointers (in COPY mode for good, in NONE mode until the next accumulate), and a finish without
+        # another accumulate reads them -- dropping them here let the caller free HBM the final fit's float64 rescue still read (ADVICE r05)
 
     def stats(self) -> dict:
         """Counters of the last ``finish``: windows flagged / re-evaluated in float64 / left with their float32 fit, chunks and

@@ -22,8 +22,17 @@ A second seam needs no wrapping at all: ``Frames.project`` looks its method up B
 ``img_to_ortho`` frame by frame.  It is that graph that executes inside ``load_frame_chunk`` ("large in real
 runs"), ahead of the PIV launches (pyorc_amd.executor).
 
-``import pyorc_amd`` calls ``install()`` by itself when a ``pyorc`` package can be found (``LSPIV_NO_AUTO_INSTALL=1`` turns that
-off); ``uninstall()`` restores the originals.  Recipes then simply say ``velocimetry: get_piv: {engine: hip}``.
+``import pyorc_amd`` arranges for ``install()`` by itself (``LSPIV_NO_AUTO_INSTALL=1`` turns that off): at once when ``pyorc`` is already
+imported, otherwise the moment it IS imported (a post-import hook on ``sys.meta_path``; ``import pyorc_amd`` alone never imports pyorc
+with its xarray / dask / cv2 / numba -- ranks and worker processes that only need the engine stay light).  A failing installation warns
+instead of hiding.  ``uninstall()`` restores the originals.  Recipes then simply say ``velocimetry: get_piv: {engine: hip}``.
+
+Third seam (round 6), between the two: when the stack handed to ``get_ffpiv(engine="hip")`` IS the product of ``project_hip`` -- with
+nothing but ``Frames.project``'s ``fillna(0.0)`` (pyorc/api/frames.py:265; a no-op on the kernel's NaN-free output) after it, which is
+how pyorc's own service strings the two together (pyorc/service/velocimetry.py:537-538) --, the projected frames never travel: the
+CAMERA chunk is loaded and uploaded, the orthoprojection kernel writes into the HBM-resident stack the PIV kernels read
+(``pyorc_amd.resident``).  ``project_hip`` registers its graph node, :func:`hip_projection_source` recognises it; anything else between
+``project`` and ``get_piv`` takes the generic path (the blocks run the kernel, the float32 frames come back and go up again).
 """
 
 from __future__ import annotations
@@ -31,9 +40,13 @@ from __future__ import annotations
 import contextvars
 import functools
 import importlib
+import importlib.abc
 import importlib.util
 import os
 import sys
+import threading
+import warnings
+from collections import OrderedDict
 from typing import Optional
 
 _route_hip: contextvars.ContextVar = contextvars.ContextVar("lspiv_route_hip", default=False)
@@ -87,20 +100,41 @@ def _wrap_get_ffpiv(orig):
 
 
 def _wrap_get_piv(orig):
+    import inspect
+
+    try:
+        sig = inspect.signature(orig)
+    except (TypeError, ValueError):
+        sig = None
+
     @functools.wraps(orig)
-    def get_piv(self, window_size=None, overlap=None, engine="numba", ensemble_corr=False, **kwargs):
+    def get_piv(self, *args, **kwargs):
+        # `engine` wherever the installed pyorc's signature has it (frames.py:114-121: the third parameter today): bound by the
+        # ORIGINAL's signature, not by a copy of it that another release may not match
+        engine, bound = kwargs.get("engine"), None
+        if sig is not None and "engine" in sig.parameters:
+            try:
+                bound = sig.bind(self, *args, **kwargs)
+                engine = bound.arguments.get("engine", sig.parameters["engine"].default)
+            except TypeError:
+                bound = None      # let the original raise its own TypeError
         if engine != ENGINE:
-            return orig(self, window_size=window_size, overlap=overlap, engine=engine, ensemble_corr=ensemble_corr, **kwargs)
+            return orig(self, *args, **kwargs)
         # fail before any work if there is no MI355X / no library: the reference raises ValueError for an engine it cannot run
         from . import _lib
 
         _lib.load()
         _lib.require_device()
+        if bound is not None:
+            bound.arguments["engine"] = "numba"
+            call_args, call_kwargs = bound.args, bound.kwargs
+        else:
+            call_args, call_kwargs = (self,) + args, {**kwargs, "engine": "numba"}
         token = _route_hip.set(True)
         try:
             # the reference's own method body; its gate (frames.py:176-177) sees an engine it knows, its call of
             # ffpiv.get_ffpiv (frames.py:186-188) is the wrapped function above, which sees the context variable
-            return orig(self, window_size=window_size, overlap=overlap, engine="numba", ensemble_corr=ensemble_corr, **kwargs)
+            return orig(*call_args, **call_kwargs)
         finally:
             _route_hip.reset(token)
 
@@ -108,18 +142,18 @@ def _wrap_get_piv(orig):
     return get_piv
 
 
-_PLANS: dict = {}          # id(plan_args) -> (plan_args, Projection): the blocks of one graph share one tuple object
+_PLANS: dict = {}          # (id(plan_args), shapes, device) -> (plan_args, Projection): the blocks of one graph share one tuple object
 _PLANS_MAX = 4
-_PLANS_LOCK = __import__("threading").Lock()
+_PLANS_LOCK = threading.Lock()
 
 
-def _projection_plan(src_shape, dst_shape, plan_args):
-    """Device-resident plan for these index maps: uploaded once per graph (dask's threads call the blocks of a graph concurrently,
-    all with the SAME ``plan_args`` tuple -- its identity is the key, no hashing of megabytes of indices per block), a few graphs
-    kept.  An evicted plan is only dropped here; it closes itself when the last block that uses it has returned."""
+def _projection_plan(src_shape, dst_shape, plan_args, device=None):
+    """Device-resident plan for these index maps: uploaded once per graph and device (dask's threads call the blocks of a graph
+    concurrently, all with the SAME ``plan_args`` tuple -- its identity is the key, no hashing of megabytes of indices per block), a few
+    graphs kept.  An evicted plan is only dropped here; it closes itself when the last block that uses it has returned."""
     from .project import Projection
 
-    key = (id(plan_args), tuple(src_shape), tuple(dst_shape))
+    key = (id(plan_args), tuple(src_shape), tuple(dst_shape), device)
     with _PLANS_LOCK:
         hit = _PLANS.get(key)
         if hit is not None and hit[0] is plan_args:
@@ -131,20 +165,104 @@ def _projection_plan(src_shape, dst_shape, plan_args):
         return plan
 
 
-def _project_block(block, plan_args=None, dst_shape=None):
+def _project_block(block, plan_args=None, dst_shape=None, device=None):
     """One dask block of frames, core dimensions last: (..., Hc, Wc) -> (..., Ho, Wo) float32, every leading index (time; rgb when the
-    frames carry it) projected by ONE kernel call."""
+    frames carry it) projected by ONE kernel call -- on the device the graph was built for (``hipSetDevice`` is per thread, and dask's
+    worker threads are nobody's in particular: without this every rank's blocks would pile onto device 0)."""
     import numpy as np
 
+    from . import executor
+
+    executor.bind_device(device)
     a = np.asarray(block)
     lead, src_shape = a.shape[:-2], a.shape[-2:]
     if a.dtype not in (np.dtype(np.uint8), np.dtype(np.float32), np.dtype(np.float64)):
         a = a.astype(np.float32)
     if a.size == 0:
         return np.zeros(lead + tuple(dst_shape), np.float32)
-    plan = _projection_plan(src_shape, dst_shape, plan_args)
+    plan = _projection_plan(src_shape, dst_shape, plan_args, device)
     out = plan.project_frames(np.ascontiguousarray(a.reshape((-1,) + src_shape)), keep_uint8=False)
     return np.asarray(out, dtype=np.float32).reshape(lead + tuple(dst_shape))
+
+
+# ---- the graph nodes project_hip produced: what lets get_ffpiv load the CAMERA frames and project them where the PIV kernels read ----
+_PROJECTIONS: "OrderedDict[str, dict]" = OrderedDict()     # dask array name of a project_hip result -> its recipe
+_PROJECTIONS_MAX = 8
+_PASS_NOT = ("invert", "logical_not", "notnull")
+_PASS_NAN = ("isnan", "isnull")
+
+
+def _graph_name(obj):
+    data = getattr(obj, "data", None)
+    name = getattr(data, "name", None)
+    return (name, data) if isinstance(name, str) else (None, None)
+
+
+def _register_projection(da_proj, source, plan_args, dst_shape, device) -> None:
+    name, _ = _graph_name(da_proj)
+    if name is None:          # an eager result (no dask): nothing lazy to short-cut
+        return
+    with _PLANS_LOCK:
+        _PROJECTIONS[name] = {"source": source, "plan_args": plan_args, "dst_shape": tuple(int(v) for v in dst_shape), "device": device}
+        while len(_PROJECTIONS) > _PROJECTIONS_MAX:
+            _PROJECTIONS.popitem(last=False)
+
+
+def _prefix(name: str) -> str:
+    return name.rsplit("-", 1)[0] if "-" in name else name
+
+
+def _match_projection(name, graph):
+    """The registered ``project_hip`` node that ``name`` IS, or is ``fillna`` of: ``where(~isnan(P), P, c)`` -- xarray's
+    ``duck_array_ops.fillna`` on a dask array, three element-wise layers ``where`` <- {``invert`` <- ``isnan`` <- P, P} (or
+    ``where`` <- {``notnull`` <- P, P}).  Anything else (another filter, a spatial selection, a dtype change, a persisted / optimised
+    graph without layer names): None, and the generic path runs."""
+    with _PLANS_LOCK:
+        if name in _PROJECTIONS:
+            return _PROJECTIONS[name]
+        known = dict(_PROJECTIONS)
+    deps = getattr(graph, "dependencies", None)
+    if not isinstance(deps, dict) or _prefix(name) != "where":
+        return None
+    top = set(deps.get(name, ()))
+    hits = [d for d in top if d in known]
+    if len(top) != 2 or len(hits) != 1:
+        return None
+    p, cond = hits[0], next(iter(top - {hits[0]}))
+    d1 = set(deps.get(cond, ()))
+    if _prefix(cond) == "notnull" and d1 == {p}:
+        return known[p]
+    if _prefix(cond) in _PASS_NOT and len(d1) == 1:
+        inner = next(iter(d1))
+        if _prefix(inner) in _PASS_NAN and set(deps.get(inner, ())) == {p}:
+            return known[p]
+    return None
+
+
+def hip_projection_source(frames) -> Optional[dict]:
+    """``{"source", "plan_args", "dst_shape", "device"}`` when ``frames`` is the product of :func:`project_hip` (module docstring, third
+    seam) over a plain ``(time, y, x)`` camera stack of the same length, else None."""
+    import numpy as np
+
+    name, data = _graph_name(frames)
+    if name is None or not _PROJECTIONS:
+        return None
+    try:
+        hit = _match_projection(name, getattr(data, "dask", None))
+        if hit is None:
+            return None
+        src = hit["source"]
+        ok = (len(src.shape) == 3 and len(frames.shape) == 3 and len(src) == len(frames) and tuple(frames.shape[1:]) == hit["dst_shape"]
+              and np.dtype(frames.dtype) == np.float32)
+        return hit if ok else None
+    except Exception:
+        return None
+
+
+def projection_for(handoff: dict):
+    """The device-resident :class:`pyorc_amd.project.Projection` of a recognised ``project_hip`` node (shared with its dask blocks)."""
+    src = handoff["source"]
+    return _projection_plan(tuple(int(v) for v in src.shape[-2:]), handoff["dst_shape"], handoff["plan_args"], handoff["device"])
 
 
 def project_hip(da, cc, x, y, z, reducer="mean"):
@@ -167,10 +285,14 @@ def project_hip(da, cc, x, y, z, reducer="mean"):
     else:
         src_idx = uidx = norm_idx = None
     dst_shape = (len(y), len(x))
+    from . import executor
+
+    device = executor.current_device()      # the graph's blocks run on whatever threads dask has: they select THIS device first
+    plan_args = (idx_img, idx_ortho, src_idx, uidx, norm_idx)
     da_proj = xr.apply_ufunc(
         _project_block,
         da,
-        kwargs={"plan_args": (idx_img, idx_ortho, src_idx, uidx, norm_idx), "dst_shape": dst_shape},
+        kwargs={"plan_args": plan_args, "dst_shape": dst_shape, "device": device},
         input_core_dims=[["y", "x"]],
         output_core_dims=[["new_y", "new_x"]],
         dask_gufunc_kwargs={"output_sizes": {"new_y": len(y), "new_x": len(x)}},
@@ -182,6 +304,7 @@ def project_hip(da, cc, x, y, z, reducer="mean"):
     ).rename({"new_y": "y", "new_x": "x"})
     da_proj["y"] = y
     da_proj["x"] = x
+    _register_projection(da_proj, da, plan_args, dst_shape, device)
     return da_proj
 
 
@@ -236,15 +359,86 @@ def uninstall() -> None:
         del _installed["project_mod"].project_hip
     with _PLANS_LOCK:
         _PLANS.clear()
+        _PROJECTIONS.clear()
     _installed.clear()
+    _remove_hook()
 
 
-def auto_install() -> Optional[bool]:
-    """What ``import pyorc_amd`` does: install when pyorc is there, silently do nothing when it is not or when it does not
-    import (a half-installed pyorc must not break ``import pyorc_amd``); None = switched off by ``LSPIV_NO_AUTO_INSTALL``."""
+class _InstallAfterImport(importlib.abc.MetaPathFinder):
+    """Post-import hook: lets the regular finders locate ``pyorc``, wraps the loader's ``exec_module`` and patches the package right
+    after its own ``__init__`` has run.  Removes itself after the first use, whatever the outcome."""
+
+    def __init__(self):
+        self._busy = threading.local()
+
+    def find_spec(self, fullname, path=None, target=None):
+        if fullname != "pyorc" or getattr(self._busy, "on", False):
+            return None
+        self._busy.on = True
+        try:
+            spec = importlib.util.find_spec(fullname)
+        except (ImportError, ValueError):
+            spec = None
+        finally:
+            self._busy.on = False
+        loader = getattr(spec, "loader", None)
+        if spec is None or loader is None or not hasattr(loader, "exec_module"):
+            return None
+        exec_module = loader.exec_module
+
+        def exec_and_install(module):
+            _remove_hook()
+            try:
+                exec_module(module)
+            finally:
+                try:
+                    loader.exec_module = exec_module
+                except Exception:
+                    pass
+            _install_or_warn(module)
+
+        try:
+            loader.exec_module = exec_and_install
+        except Exception:       # a loader that does not take attributes: stay out of the way
+            return None
+        return spec
+
+
+_hook: Optional[_InstallAfterImport] = None
+
+
+def _remove_hook() -> None:
+    global _hook
+    if _hook is not None:
+        try:
+            sys.meta_path.remove(_hook)
+        except ValueError:
+            pass
+        _hook = None
+
+
+def _install_or_warn(module=None) -> bool:
+    try:
+        return install(module)
+    except Exception as exc:
+        warnings.warn(f"pyorc_amd could not register engine='hip' in pyorc ({type(exc).__name__}: {exc}); "
+                      "get_piv(engine='hip') will raise pyorc's 'engine does not exist' -- call pyorc_amd.install() to see the error",
+                      RuntimeWarning, stacklevel=2)
+        return False
+
+
+def auto_install():
+    """What ``import pyorc_amd`` does: None = switched off by ``LSPIV_NO_AUTO_INSTALL``; pyorc already imported -> ``install()`` now (a
+    failure WARNS, it is not swallowed: ADVICE r05); pyorc importable but not imported -> ``"deferred"``: a post-import hook installs
+    the moment somebody imports it (``import pyorc_amd`` itself never pulls in pyorc's xarray / dask / cv2 / numba); no pyorc -> False."""
+    global _hook
     if os.environ.get("LSPIV_NO_AUTO_INSTALL"):
         return None
-    try:
-        return install()
-    except Exception:  # pragma: no cover - depends on the environment
+    if "pyorc" in sys.modules:
+        return _install_or_warn()
+    if not pyorc_available():
         return False
+    if _hook is None:
+        _hook = _InstallAfterImport()
+        sys.meta_path.insert(0, _hook)
+    return "deferred"

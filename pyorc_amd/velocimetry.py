@@ -7,7 +7,13 @@ but each chunk is ONE fused GPU call instead of cross_corr + numpy reductions +
 u_v_displacement over a materialised (T-1, n_win, wy, wx) volume.
 
 Differences, all deliberate and documented in DESIGN.md:
-  * the chunk size is planned against free HBM, not host RAM, and rounded down to a multiple of
+  * a LAZY stack (anything with ``load()``: pyorc's dask-backed DataArray) is kept resident in HBM while it runs (``pyorc_amd.resident``,
+    round 6): what ``.load()`` materialises at a time is planned against free HOST memory like in the reference (``available_memory() /
+    memory_factor``, ffpiv.py:129; same warning text), divided by the number of loads the chunk executor keeps in flight, cut on dask's
+    own block boundaries and WITHOUT the reference's halo frame (no block is decoded + projected twice); the kernels are launched on
+    their anchors as the frames arrive.  When the stack is the direct product of ``project_hip`` (``pyorc_amd.plugin``), the CAMERA
+    frames are loaded and projected on the device: ortho frames never exist on the host;
+  * for a materialised stack (numpy, ``DeviceFrames``) the chunk size is planned against free HBM, not host RAM, and rounded down to a multiple of
     ``window.chunk_alignment`` (>= one multiple): chunks then start on the anchors of the time-walking kernels'
     segments, so the result is the same, bit for bit, whatever chunk size the planner or the user picked -- as in the
     reference, which computes every window independently;
@@ -27,7 +33,7 @@ from typing import Literal, Optional, Tuple
 
 import numpy as np
 
-from . import executor, piv, window
+from . import executor, piv, resident, window
 from .device import is_device
 
 try:  # xarray is optional: the GPU box image does not ship it
@@ -188,6 +194,7 @@ def get_ffpiv(
     dtype = frames.dtype if np.dtype(frames.dtype) in (np.dtype(np.uint8), np.dtype(np.float32)) else np.float64
     n_rows, n_cols = len(y), len(x)
     # compute memory availability and size of problem (HBM instead of host RAM)
+    user_chunksize = chunksize
     req_mem = window.required_memory(n_frames=n_frames, dim_size=dim_size, window_size=window_size,
                                      overlap=overlap, search_area_size=search_area_size, dtype=dtype)
     avail_mem = window.available_memory() / memory_factor
@@ -202,6 +209,11 @@ def get_ffpiv(
     dt_arr = np.asarray(_values(dt), dtype=np.float64)
     if dt_arr.shape != (n_frames - 1,):
         raise ValueError(f"dt must have one entry per frame pair ({n_frames - 1}), got shape {dt_arr.shape}")
+    if _is_lazy(frames) and n_frames >= 2 and not _stack_signal_mode(signal_threshold):
+        # a lazy stack: resident in HBM, loads planned against HOST memory and cut where dask cuts, launches on the anchors
+        plan = plan_lazy(frames, n_frames, dim_size, window_size, overlap, n_rows * n_cols, user_chunksize, memory_factor, engine, prefetch)
+        return _get_ffpiv_lazy(frames, plan, y, x, dt_arr, time, res_y, res_x, n_cols, n_rows, window_size, overlap, ensemble_corr,
+                               corr_min, s2n_min, count_min, signal_threshold, ref_slices)
     frames_chunks = [frames[a:b] for a, b in slices]
     depth = (executor.default_depth() if prefetch is None else int(prefetch)) if hasattr(frames, "load") else 0
     args = (frames_chunks, slices, y, x, dt_arr, time, res_y, res_x, n_cols, n_rows, window_size, overlap)
@@ -239,39 +251,44 @@ def _get_ffpiv_timestep(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_c
     times = []
     on_device = piv.device_scaling_is_numpys(res_x, res_y)
     loader = executor.ChunkPrefetcher(frames_chunks, load_frame_chunk, depth=prefetch)
-    for n, da in loader:
-        a, b = slices[n]
-        if len(da) >= 2:  # we need at least one image-pair to do PIV
-            nb = a + len(da)  # load_frame_chunk may have dropped trailing frames
-            p = nb - 1 - a
-            vals = _values(da)
-            grid = window.get_array_shape(tuple(vals.shape[1:]), window_size, overlap)
-            if tuple(grid) != (n_rows, n_cols):
-                raise ValueError(f"grid {tuple(grid)} does not match coordinates ({n_rows}, {n_cols})")
-            if full is None:
-                full = {k: np.empty((n_total, n_rows, n_cols), dtype=np.float32) for k in names}
-            dt_chunk = dt[a:nb - 1]  # dt.sel(time=da.time[1:]), ffpiv.py:403-404
-            if on_device:
-                # u and v to meter per second on the device, before they cross PCIe: the arithmetic of ffpiv.py:418-419 for
-                # python-float resolutions (float32 product, float64 division, float32 storage)
-                piv.piv_pairs(vals, window_size, overlap, signal_threshold, pair_offset=a, scale=(res_x, res_y, dt_chunk),
-                              out=(full["v_x"][a:a + p], full["v_y"][a:a + p], full["corr"][a:a + p], full["s2n"][a:a + p]))
-            else:
-                if px is None or px[0].shape[0] < p:
-                    px = [np.empty((p, n_rows, n_cols), dtype=np.float32) for _ in range(2)]
-                u, v = px[0][:p], px[1][:p]
-                piv.piv_pairs(vals, window_size, overlap, signal_threshold, pair_offset=a,
-                              out=(u, v, full["corr"][a:a + p], full["s2n"][a:a + p]))
-                # ... on the host with numpy's own arithmetic for any other kind of resolution (a numpy float64 scalar makes the product float64)
-                _to_velocity(u, res_x, dt_chunk[:, None, None], out=full["v_x"][a:a + p])
-                _to_velocity(v, res_y, dt_chunk[:, None, None], out=full["v_y"][a:a + p])
-            done.append((a, a + p))
-            times.append(time[a + 1:nb])
-        # remove chunk safely from memory.  (The reference follows this with gc.collect() to get rid of its window stack and
-        # correlation volume, ffpiv.py:437-440; neither exists here, and a collection costs ~1 ms per chunk: dropped.)
-        frames_chunks[n] = None
-        del da
-    executor.LAST_STATS.clear(); executor.LAST_STATS.update(loader.stats)
+    try:
+        for n, da in loader:
+            a, b = slices[n]
+            if len(da) >= 2:  # we need at least one image-pair to do PIV
+                nb = a + len(da)  # load_frame_chunk may have dropped trailing frames
+                p = nb - 1 - a
+                vals = _values(da)
+                grid = window.get_array_shape(tuple(vals.shape[1:]), window_size, overlap)
+                if tuple(grid) != (n_rows, n_cols):
+                    raise ValueError(f"grid {tuple(grid)} does not match coordinates ({n_rows}, {n_cols})")
+                if full is None:
+                    full = {k: np.empty((n_total, n_rows, n_cols), dtype=np.float32) for k in names}
+                dt_chunk = dt[a:nb - 1]  # dt.sel(time=da.time[1:]), ffpiv.py:403-404
+                if on_device:
+                    # u and v to meter per second on the device, before they cross PCIe: the arithmetic of ffpiv.py:418-419 for
+                    # python-float resolutions (float32 product, float64 division, float32 storage)
+                    piv.piv_pairs(vals, window_size, overlap, signal_threshold, pair_offset=a, scale=(res_x, res_y, dt_chunk),
+                                  out=(full["v_x"][a:a + p], full["v_y"][a:a + p], full["corr"][a:a + p], full["s2n"][a:a + p]))
+                else:
+                    if px is None or px[0].shape[0] < p:
+                        px = [np.empty((p, n_rows, n_cols), dtype=np.float32) for _ in range(2)]
+                    u, v = px[0][:p], px[1][:p]
+                    piv.piv_pairs(vals, window_size, overlap, signal_threshold, pair_offset=a,
+                                  out=(u, v, full["corr"][a:a + p], full["s2n"][a:a + p]))
+                    # ... on the host with numpy's own arithmetic for any other kind of resolution (a numpy float64 scalar makes the product float64)
+                    _to_velocity(u, res_x, dt_chunk[:, None, None], out=full["v_x"][a:a + p])
+                    _to_velocity(v, res_y, dt_chunk[:, None, None], out=full["v_y"][a:a + p])
+                done.append((a, a + p))
+                times.append(time[a + 1:nb])
+            # remove chunk safely from memory.  (The reference follows this with gc.collect() to get rid of its window stack and
+            # correlation volume, ffpiv.py:437-440; neither exists here, and a collection costs ~1 ms per chunk: dropped.)
+            frames_chunks[n] = None
+            del da
+    finally:
+        # also when a launch raises in the loop body: the worker threads stop loading the next chunks NOW, not when the traceback is
+        # collected, and the statistics of what ran are kept
+        loader.close()
+        executor.LAST_STATS.clear(); executor.LAST_STATS.update(loader.stats)
     if not done:
         raise ValueError("no chunk with at least one frame pair")
     if done[0][0] == 0 and done[-1][1] == n_total and all(x[1] == y[0] for x, y in zip(done, done[1:])):
@@ -348,3 +365,181 @@ def _get_ffpiv_mean(frames_chunks, slices, y, x, dt, time, res_y, res_x, n_cols,
         "v_y": (v * res_y / dt_av).astype(np.float32),
     }
     return _dataset(data, t_first, y, x, like)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# lazy stacks (round 6): resident in HBM, loads against the host budget on dask's block boundaries, launches on the anchors
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _is_lazy(frames) -> bool:
+    """Something that materialises on ``load()``: pyorc's dask-backed DataArray.  An ``xr.DataArray`` that is already in memory has a
+    ``load()`` too; its ``.data`` (the backing array: looking at it computes nothing) is a numpy array, and it runs as one."""
+    if is_device(frames) or not hasattr(frames, "load"):
+        return False
+    return not isinstance(getattr(frames, "data", None), np.ndarray)
+
+
+def _stack_signal_mode(signal_threshold) -> bool:
+    """The "stack" reading of ``signal_threshold`` scores a window position over all frames of a CHUNK (include/lspiv.h, option
+    ``signal_mode`` = 1): its results depend on the chunking by definition, so such a run keeps the chunk loop it was defined on."""
+    if signal_threshold is None:
+        return False
+    from . import _lib
+
+    try:
+        return _lib.get_option("signal_mode") == 1
+    except Exception:
+        return False
+
+
+class LazyPlan(dict):
+    """What :func:`plan_lazy` decided (a dict, for the tests and ``executor.LAST_STATS``): ``windows`` [(w0, w1)] frame ranges resident at
+    a time, ``loads`` per window [(f0, f1)], ``load_frames``, ``host_budget`` / ``host_frame_bytes`` / ``peak_host_bytes``, ``depth`` (None =
+    adaptive) and ``max_depth``, ``align``, ``blocks`` (dask's), ``source`` ("frames" | "camera": the pre-projection stack of project_hip)."""
+
+
+def plan_lazy(frames, n_frames, dim_size, window_size, overlap, n_win, chunksize, memory_factor, engine, prefetch,
+              host_available=None, hbm_available=None) -> LazyPlan:
+    """How a lazy stack runs.  The reference's planner (ffpiv.py:119-139) with its own quantities where they still mean something:
+
+    * what a load materialises is bounded by the HOST: ``available_memory() / memory_factor`` (ffpiv.py:129) divided by the loads the
+      executor may keep in flight (``max_depth + 1``, or ``prefetch + 1`` when the caller fixed it), in frames of the stack that is
+      actually loaded (the camera frames when the stack is ``project_hip``'s product); at 5 frames or fewer the reference's warning is
+      raised and 5 it is (ffpiv.py:131-137); a user ``chunksize`` is honoured as the load size;
+    * below that bound, loads are the overlap granule of ``pyorc_amd.resident.load_size`` -- at least ``MIN_LOADS`` of them when the
+      stack has that many anchors -- in whole dask blocks;
+    * what is resident at a time is bounded by HBM (``lspiv_available_bytes / memory_factor``): normally everything."""
+    from . import plugin
+
+    align = window.chunk_alignment(window_size, dim_size, overlap)
+    handoff = plugin.hip_projection_source(frames)
+    src = frames if handoff is None else handoff["source"]
+    src_shape = tuple(int(v) for v in (src[0].shape if handoff is not None else dim_size))
+    host_frame_bytes = int(np.prod(src_shape)) * np.dtype(src.dtype).itemsize
+    blocks = resident.time_blocks(src)
+    if prefetch is None and executor.adaptive_by_default():
+        depth, deepest = None, executor.max_depth()
+    else:
+        depth = executor.default_depth() if prefetch is None else int(prefetch)
+        deepest = depth
+    host_avail = window.available_host_memory() if host_available is None else host_available
+    host_budget = host_avail / memory_factor
+    if chunksize is None:
+        host_frames = int(host_budget // ((deepest + 1) * host_frame_bytes))
+        if host_frames <= 5:
+            warnings.warn(CHUNK_SIZE_WARNING.format(avail_mem=host_budget / 1e9, chunksize=host_frames, engine=engine), stacklevel=4)
+            host_frames = 5  # hard override, try to manage with 5
+        load_frames = resident.load_size(n_frames, align, host_frames, blocks)
+    else:
+        load_frames = int(chunksize)
+        if load_frames < 2:
+            raise OverflowError(CHUNK_SIZE_ERROR.format(chunks=int(np.ceil(n_frames / max(load_frames, 1)))))
+    # HBM: the narrowed stack + the result block (+ one load of camera frames next to it when they are projected on the device)
+    dev_itemsize = 4 if handoff is not None else resident.DeviceFrames.device_dtype(frames.dtype).itemsize
+    hbm_avail = (window.available_memory() if hbm_available is None else hbm_available) / memory_factor
+    per_frame = int(np.prod(dim_size)) * dev_itemsize + 16 * n_win
+    scratch = load_frames * host_frame_bytes if handoff is not None else 0
+    frames_per_window = max(align + 1, int((hbm_avail - scratch) // per_frame))
+    frames_per_window = min(frames_per_window, max(2, MAX_WINDOWS_PER_LAUNCH // max(n_win, 1)))
+    windows = resident.hbm_windows(n_frames, frames_per_window, align, blocks)
+    loads = [resident.plan_loads(w1, load_frames, blocks, first=w0) for w0, w1 in windows]
+    biggest = max((b - a for ls in loads for a, b in ls), default=0)
+    return LazyPlan(windows=windows, loads=loads, load_frames=load_frames, align=align, blocks=blocks, depth=depth, max_depth=deepest,
+                    host_budget=host_budget, host_frame_bytes=host_frame_bytes, peak_host_bytes=(deepest + 1) * biggest * host_frame_bytes,
+                    source="frames" if handoff is None else "camera", handoff=handoff)
+
+
+def _get_ffpiv_lazy(frames, plan, y, x, dt, time, res_y, res_x, n_cols, n_rows, window_size, overlap, ensemble_corr,
+                    corr_min, s2n_min, count_min, signal_threshold, ref_slices):
+    """The loops of pyorc/velocimetry/ffpiv.py:348-370 and :399-440 over a lazy stack: pieces are loaded ahead (``ChunkPrefetcher``),
+    pushed into an HBM-resident stack (``ResidentStack``) and launched on the anchors; results land in the run's arrays."""
+    from . import plugin
+
+    n_total = len(frames) - 1
+    n_win = n_rows * n_cols
+    dim_size = tuple(int(v) for v in frames[0].shape)
+    handoff = plan["handoff"]
+    lazy = frames if handoff is None else handoff["source"]
+    projection = None if handoff is None else plugin.projection_for(handoff)
+    names = ("s2n", "corr", "v_x", "v_y")
+    done = []
+    ens = None
+    on_device = piv.device_scaling_is_numpys(res_x, res_y)
+    if ensemble_corr:
+        ens = piv.Ensemble(dim_size, window_size, overlap)
+        full = (np.empty((n_total, n_win), dtype=np.float32), np.empty((n_total, n_win), dtype=np.float32))
+
+        def launch(view, p0, p1):
+            ens.accumulate(view, corr_min, s2n_min, signal_threshold, out=(full[0][p0:p1], full[1][p0:p1]))
+            done.append((p0, p1))
+    else:
+        full = {k: np.empty((n_total, n_rows, n_cols), dtype=np.float32) for k in names}
+        px = []
+
+        def launch(view, p0, p1):
+            p = p1 - p0
+            if on_device:
+                piv.piv_pairs(view, window_size, overlap, signal_threshold, pair_offset=p0, scale=(res_x, res_y, dt[p0:p1]),
+                              out=(full["v_x"][p0:p1], full["v_y"][p0:p1], full["corr"][p0:p1], full["s2n"][p0:p1]))
+            else:
+                if not px or px[0].shape[0] < p:
+                    px[:] = [np.empty((p, n_rows, n_cols), dtype=np.float32) for _ in range(2)]
+                u, v = px[0][:p], px[1][:p]
+                piv.piv_pairs(view, window_size, overlap, signal_threshold, pair_offset=p0, out=(u, v, full["corr"][p0:p1], full["s2n"][p0:p1]))
+                _to_velocity(u, res_x, dt[p0:p1, None, None], out=full["v_x"][p0:p1])
+                _to_velocity(v, res_y, dt[p0:p1, None, None], out=full["v_y"][p0:p1])
+            done.append((p0, p1))
+
+    stats = {"plan": {k: plan[k] for k in ("windows", "load_frames", "align", "depth", "max_depth", "source", "peak_host_bytes", "host_budget")},
+             "load_s": 0.0, "waited_s": 0.0, "upload_s": 0.0, "launch_s": 0.0, "chunks": 0, "depth_per_chunk": []}
+    try:
+        for (w0, w1), loads in zip(plan["windows"], plan["loads"]):
+            stack = resident.ResidentStack(w0, w1 - w0, dim_size, frames.dtype, plan["align"], launch, signal_threshold, projection)
+            pieces = [lazy[f0:f1] for f0, f1 in loads]
+            with executor.ChunkPrefetcher(pieces, load_frame_chunk, depth=plan["depth"]) as loader:
+                try:
+                    for n, da in loader:
+                        pieces[n] = None
+                        if len(da):
+                            stack.push(loads[n][0], _values(da))
+                        del da
+                finally:
+                    loader.close()
+                    st = loader.stats
+                    stats["load_s"] += st["load_s"]; stats["waited_s"] += st["waited_s"]; stats["chunks"] += st["chunks"]
+                    stats["depth_per_chunk"] += st["depth_per_chunk"]
+                    stats["depth"], stats["workers"], stats["adaptive"] = st["depth"], st["workers"], st["adaptive"]
+            stack.finish()
+            stats["upload_s"] += stack.upload_s; stats["launch_s"] += stack.launch_s
+            del stack
+        if not done:
+            raise ValueError("no chunk with at least one frame pair")
+        if ens is not None:
+            # quirk Q3: `n_frames` is the number of CHUNKS of the reference's plan (ffpiv.py:373), `time[0:1]` that of its LAST chunk (:336)
+            n_chunks = len(ref_slices) if ref_slices else len(plan["loads"][0])
+            u, v, corr_count = ens.finish(count_min, n_chunks)
+    finally:
+        executor.LAST_STATS.clear(); executor.LAST_STATS.update({k: (round(v, 6) if isinstance(v, float) else v) for k, v in stats.items()})
+        if ens is not None:
+            ens.close()
+    done.sort()
+    whole = done[0][0] == 0 and done[-1][1] == n_total and all(a[1] == b[0] for a, b in zip(done, done[1:]))
+    if ens is not None:
+        cm, sn = full if whole else tuple(np.concatenate([f[i:j] for i, j in done], axis=0) for f in full)
+        t_first = time[ref_slices[-1][0] + 1:ref_slices[-1][0] + 2] if ref_slices else time[1:2]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", category=RuntimeWarning)
+            cm[:, corr_count < count_min * n_chunks] = np.nan
+            corr_max_mean = np.nanmean(cm, axis=0).reshape(-1, n_rows, n_cols)
+            s2n_mean = np.nanmean(sn, axis=0).reshape(-1, n_rows, n_cols)
+        dt_av = dt.mean()
+        data = {"s2n": s2n_mean, "corr": corr_max_mean, "v_x": (u * res_x / dt_av).astype(np.float32), "v_y": (v * res_y / dt_av).astype(np.float32)}
+        return _dataset(data, t_first, y, x, frames)
+    data = full if whole else {k: np.concatenate([full[k][i:j] for i, j in done], axis=0) for k in names}
+    times = [time[i + 1:j + 1] for i, j in done]
+    if len(times) == 1:
+        t = times[0]
+    elif _is_xr(frames):
+        t = xr.concat(times, dim="time")
+    else:
+        t = np.concatenate([np.asarray(tt) for tt in times])
+    return _dataset(data, t, y, x, frames)

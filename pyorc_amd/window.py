@@ -77,14 +77,33 @@ def available_memory() -> int:
     return free.value
 
 
+def available_host_memory() -> int:
+    """Free host RAM in bytes -- what ``ffpiv.window.available_memory`` answers in the reference (pyorc/velocimetry/ffpiv.py:129), and
+    what bounds how much of a LAZY stack ``get_ffpiv`` may materialise at a time (the chunks that ``.load()`` brings in live on the
+    host before they cross PCIe).  ``psutil`` when importable, ``/proc/meminfo`` otherwise."""
+    try:
+        import psutil
+
+        return int(psutil.virtual_memory().available)
+    except Exception:
+        try:
+            with open("/proc/meminfo") as fh:
+                for line in fh:
+                    if line.startswith("MemAvailable:"):
+                        return int(line.split()[1]) * 1024
+        except OSError:
+            pass
+    return 8 << 30   # nothing to ask: a conservative 8 GiB
+
+
 def chunk_alignment(window_size, dim_size=None, overlap=None) -> int:
     """Frame pairs between two anchors of the time-walking kernels: time chunks that start on a multiple of it reproduce the
     whole-stack result bit for bit.  1 for per-pair kernels.  Host-only.
 
     The anchor length depends on the window GRID since round 5 (25 pairs; 75 on grids with at least as many windows as the chip has
     lane groups, ``lspiv_chunk_alignment_grid``): pass the frame shape ``dim_size`` and the ``overlap`` whenever chunks of frames of
-    that shape are cut.  Without them the window family's base length comes back (``lspiv_chunk_alignment``) -- the run length on
-    small grids only."""
+    that shape are cut.  Without them the alignment that is right on EVERY grid comes back (``lspiv_chunk_alignment``, ABI 5: the
+    longest anchor length of the window family, a multiple of every grid's -- 75 where ABI 4 answered 25)."""
     lib = _lib.load()
     if dim_size is None:
         return _lib.check(lib.lspiv_chunk_alignment(int(window_size[0]), int(window_size[1])))
@@ -94,7 +113,6 @@ def chunk_alignment(window_size, dim_size=None, overlap=None) -> int:
 
 
 def chunk_alignment_any_grid(window_size) -> int:
-    """The alignment that is right for EVERY frame shape: the longest anchor length the kernels of this window family use (a multiple
-    of the shorter one).  For callers that cut the time axis before they know the frames (``shard.sharded_piv`` without ``frame_shape``)."""
-    big = 1 << 20
-    return chunk_alignment(window_size, (big, big), (0, 0))
+    """The alignment that is right for EVERY frame shape (= ``chunk_alignment(window_size)`` since ABI 5).  For callers that cut the time
+    axis before they know the frames (``shard.sharded_piv`` without ``frame_shape``)."""
+    return chunk_alignment(window_size)

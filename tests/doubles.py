@@ -19,3 +19,54 @@ def oracle_piv_pairs(fr, ws, ov, thr=None, pair_offset=0, out=None, scale=None):
         assert dst.dtype == np.float32 and dst.shape == src.shape and dst.flags.c_contiguous
         dst[...] = src
     return tuple(out)
+
+
+class HostStack:
+    """``pyorc_amd.device.DeviceFrames`` as far as ``pyorc_amd.resident.ResidentStack`` and the oracle double above use it, backed by
+    numpy: ``empty``, ``device_dtype``, ``upload`` (float64 narrowed to float32: what ``lspiv_upload_frames`` does for 8-bit-like
+    imagery), time slices as views, ``from_host``.  ``uploads`` records (first frame, number of frames) of every piece."""
+
+    uploads = []
+
+    def __init__(self, arr):
+        self.arr = arr
+        self.shape, self.dtype = arr.shape, arr.dtype
+
+    @classmethod
+    def empty(cls, shape, dtype=np.uint8):
+        return cls(np.zeros(shape, dtype))
+
+    @classmethod
+    def from_host(cls, frames):
+        return cls(np.ascontiguousarray(frames))
+
+    @staticmethod
+    def device_dtype(host_dtype):
+        dt = np.dtype(host_dtype)
+        return dt if dt in (np.dtype(np.uint8), np.dtype(np.float32)) else np.dtype(np.float32)
+
+    def upload(self, f0, frames, signal_threshold=None):
+        a = np.asarray(frames)
+        assert a.shape[1:] == self.shape[1:] and self.device_dtype(a.dtype) == self.dtype
+        self.arr[f0:f0 + len(a)] = a.astype(self.dtype)
+        HostStack.uploads.append((int(f0), len(a)))
+        return len(a)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, key):
+        assert isinstance(key, slice)
+        return HostStack(self.arr[key])
+
+    def __array__(self, dtype=None, copy=None):
+        return self.arr if dtype is None else self.arr.astype(dtype)
+
+
+def use_host_stacks(monkeypatch):
+    """Route ``pyorc_amd.resident`` to :class:`HostStack` (CPU tests of the lazy path: no HBM here)."""
+    from pyorc_amd import resident
+
+    HostStack.uploads = []
+    monkeypatch.setattr(resident, "DeviceFrames", HostStack)
+    return HostStack

@@ -15,6 +15,7 @@ class DataArray:
         self.attrs = dict(attrs or {})
         self.loaded = 0
 
+    data = property(lambda self: self.values)       # xarray: the backing array (numpy when in memory, dask when lazy)
     dtype = property(lambda self: self.values.dtype)
     shape = property(lambda self: self.values.shape)
     ndim = property(lambda self: self.values.ndim)

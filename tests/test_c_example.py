@@ -29,7 +29,7 @@ def test_header_is_strict_c99_and_the_c_example_links(tmp_path):
 
     n = _lib.device_count()
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
-    assert "ABI 4" in r.stdout
+    assert "ABI 5" in r.stdout
     if n == 0:
         assert r.returncode == 2 and "no gfx950 device" in r.stderr      # loud, not a CPU answer
 

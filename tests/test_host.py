@@ -28,7 +28,7 @@ def test_library_exports_every_header_symbol(lib):
         assert hasattr(lib, s), f"{s} declared in include/lspiv.h but not exported by liblspiv_hip.so"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes prototype in pyorc_amd/_lib.py"
     assert sorted(_lib.SIGNATURES) == syms
-    assert lib.lspiv_abi_version() == 4
+    assert lib.lspiv_abi_version() == 5
     assert b"gfx950" in lib.lspiv_version()
 
 
@@ -382,8 +382,10 @@ def test_walking_segments_are_anchored_to_the_absolute_pair_index(lib):
         assert p == n_pairs
         return edges
 
-    L = window.chunk_alignment((32, 32))
-    assert L == 25 == window.chunk_alignment((64, 64)) == window.chunk_alignment((24, 24))
+    L = window.chunk_alignment((32, 32), (128, 160), (16, 16))      # a small grid: the window family's base anchor
+    assert L == 25 == window.chunk_alignment((64, 64), (256, 256), (32, 32)) == window.chunk_alignment((24, 24), (128, 160), (12, 12))
+    # without a grid (ABI 5): the alignment that is right on EVERY grid -- the longest anchor, a multiple of the short one (ABI 4: 25)
+    assert window.chunk_alignment((32, 32)) == 75 == window.chunk_alignment((64, 64)) == window.chunk_alignment((24, 24)) and 75 % L == 0
     assert window.chunk_alignment((32, 16)) == 1 and window.chunk_alignment((31, 31)) == 1   # per-pair kernels
     # round 5: the anchor length depends on the window GRID -- 75 pairs where the grid has at least as many windows as the chip has
     # lane groups for that window family (6 144 at 32 x 32, 2 048 at 64 x 64, 12 288 up to 16 x 16), 25 below (75: csrc/common.h)
@@ -454,7 +456,7 @@ def test_streamed_chain_cuts_chunks_on_anchors(lib):
     for ws, n_pairs, n_chunks in (((32, 32), 200, 8), ((32, 32), 1000, 8), ((64, 64), 82, 8), ((32, 32), 24, 8), ((32, 32), 26, 3),
                                   ((128, 128), 40, 8), ((33, 33), 10, 4), ((24, 24), 999, 5)):
         b = CameraToVelocity._chunk_bounds(SimpleNamespace(window_size=ws, ortho_shape=(270, 480), overlap=(ws[0] // 2, ws[1] // 2)), n_pairs, n_chunks)
-        align = lib.lspiv_chunk_alignment(*ws)             # a small grid: the window family's base anchor
+        align = lib.lspiv_chunk_alignment_grid(270, 480, ws[0], ws[1], ws[0] // 2, ws[1] // 2)   # a small grid: the window family's base anchor
         assert b[0] == 0 and b[-1] == n_pairs and all(x < y for x, y in zip(b, b[1:])), (ws, b)
         assert all(x % align == 0 for x in b[:-1]), (ws, align, b)
         assert len(b) - 1 <= max(1, n_chunks) and (len(b) - 1 == 1 or n_pairs > align)
@@ -604,7 +606,7 @@ def test_loaded_binary_is_tied_to_the_tree(lib, tmp_path, monkeypatch):
     with pytest.raises(_lib.LspivLibraryStale, match="rebuild"):
         _lib.load()
     monkeypatch.setenv("LSPIV_ALLOW_STALE", "1")
-    assert _lib.load().lspiv_abi_version() == 4
+    assert _lib.load().lspiv_abi_version() == 5
 
 
 def test_bench_multi_gpu_contract_on_cpu(monkeypatch):
@@ -712,7 +714,10 @@ def test_locks_are_per_device(lib):
         assert other <= 0.25, (which, other)
     assert held([(3, 0), (3, 1), (3, 2)]) <= 0.25
     assert held([(d, 0) for d in range(8)]) <= 0.3          # eight ranks' worth of host threads in one process
-    assert lib.lspiv_debug_hold_lock(64, 0, 1) == _lib.LSPIV_EINVAL and lib.lspiv_debug_hold_lock(0, 3, 1) == _lib.LSPIV_EINVAL
+    assert lib.lspiv_debug_hold_lock(64, 0, 1) == _lib.LSPIV_EINVAL and lib.lspiv_debug_hold_lock(0, 5, 1) == _lib.LSPIV_EINVAL
+    # round 6: the host-pointer projection entry points have two slots of their own (locks 3 and 4): a projection block queues behind
+    # neither a PIV host call (lock 0) nor the other slot
+    assert held([(0, 0), (0, 3), (0, 4)]) <= 0.25 and held([(0, 3), (0, 3)]) >= 0.29
 
 
 def test_rccl_channel_cap_is_scoped_to_communicator_creation(monkeypatch):
