@@ -367,9 +367,10 @@ class _LazyOrthoStack:
 
 
 def lazy_host_chunk_rates(cam: np.ndarray, ws, ov) -> dict:
-    """get_piv over LAZY host chunks: the reference loads a chunk, then computes it (ffpiv.py:399-408); the chunk
-    executor (pyorc_amd/executor.py) loads chunk n + 1 .. n + depth on worker threads while chunk n is uploaded and launched.
-    PCIe- and host-inclusive, never `value`."""
+    """get_piv over a LAZY host stack with DEFAULT arguments (no ``chunksize=``): the planner cuts loads against host
+    memory and the overlap granule, the stack stays resident in HBM, launches go on the anchors (pyorc_amd/resident.py), and the chunk
+    executor's depth adapts to the run (pyorc_amd/executor.py).  Against the reference's serial order (``prefetch=0``: load a piece, then
+    upload + launch it) and a fixed depth of one.  PCIe- and host-inclusive, never `value`."""
     from pyorc_amd import executor, frames as F
 
     T, H, W = cam.shape
@@ -377,25 +378,73 @@ def lazy_host_chunk_rates(cam: np.ndarray, ws, ov) -> dict:
     idx = np.roll(idx, 7, axis=1).ravel()                   # a nearest-neighbour plan (a shifted identity: every cell one camera pixel)
     t = np.arange(T) / 30.0
     lazy = _LazyOrthoStack(cam, idx)
-    F.get_piv(lazy[:27], ws[0], overlap=ov, time=t[:27], resolution=0.01, chunksize=26, prefetch=0)   # workspaces, pinned ring
+    F.get_piv(lazy[:27], ws[0], overlap=ov, time=t[:27], resolution=0.01, prefetch=0)   # workspaces, pinned ring
     out = {}
     ref = None
-    for key, depth, workers in (("serial_like_the_reference", 0, 1), ("prefetch_depth1", 1, 1), ("prefetch_depth4_workers4", 4, 4)):
-        os.environ["LSPIV_PREFETCH_WORKERS"] = str(workers)
-        try:
-            t0 = time.perf_counter()
-            ds = F.get_piv(lazy, ws[0], overlap=ov, time=t, resolution=0.01, chunksize=26, prefetch=depth)
-            dt = time.perf_counter() - t0
-        finally:
-            os.environ.pop("LSPIV_PREFETCH_WORKERS", None)
+    for key, depth in (("serial_like_the_reference", 0), ("default_arguments", None), ("prefetch_depth1", 1)):
+        t0 = time.perf_counter()
+        ds = F.get_piv(lazy, ws[0], overlap=ov, time=t, resolution=0.01, prefetch=depth)
+        dt = time.perf_counter() - t0
         st = dict(executor.LAST_STATS)
         same = True if ref is None else all(np.array_equal(ds[k], ref[k], equal_nan=True) for k in ("v_x", "v_y", "corr", "s2n"))
         ref = ds if ref is None else ref
         out[key] = {"pairs_per_s": round((T - 1) / dt, 1), "wall_s": round(dt, 3), "load_s_total": st.get("load_s"),
-                    "waited_for_loads_s": st.get("waited_s"), "chunks": st.get("chunks"), "same_bits_as_serial": bool(same)}
-    out["note"] = (f"{T - 1} pairs of {H}x{W} in {st.get('chunks')} chunks: every chunk is materialised by a per-frame numpy gather + float64 conversion "
-                   "(what project_numpy does inside dask's .load()), then uploaded (narrowed to float32 while staged) and launched; "
-                   "wall = loads + launches for the reference's serial loop, ~ max(loads, launches) with the loads running ahead")
+                    "waited_for_loads_s": st.get("waited_s"), "upload_s": st.get("upload_s"), "launch_s": st.get("launch_s"),
+                    "chunks": st.get("chunks"), "depth_per_chunk": st.get("depth_per_chunk"), "same_bits_as_serial": bool(same)}
+    out["speedup_default_over_serial"] = round(out["serial_like_the_reference"]["wall_s"] / max(out["default_arguments"]["wall_s"], 1e-9), 2)
+    out["plan"] = {k: v for k, v in (st.get("plan") or {}).items() if k in ("load_frames", "align", "max_depth", "source", "peak_host_bytes")}
+    out["note"] = (f"{T - 1} pairs of {H}x{W} in {st.get('chunks')} loads planned by get_ffpiv itself: every load is materialised by a per-frame numpy gather + "
+                   "float64 conversion (what project_numpy does inside dask's .load()), uploaded to its place in the HBM-resident stack (narrowed to "
+                   "float32 while staged) and launched on the kernels' anchors; wall = loads + uploads for the reference's serial loop, "
+                   "~ max(loads, uploads) with the loads running ahead")
+    return out
+
+
+def dropin_rates(cam: np.ndarray, maps, dst, ws, ov, t, plan) -> dict:
+    """The reference-shaped DROP-IN flow: ``frames.project(method="hip")`` -> ``frames.get_piv(engine="hip")`` on a
+    lazy camera stack in 20-frame blocks, i.e. ``pyorc_amd.plugin.project_hip`` (found by name by pyorc's ``Frames.project``, which adds
+    its ``fillna(0.0)``) and ``pyorc_amd.velocimetry.get_ffpiv`` with their default arguments.  xarray and dask are absent on the GPU box:
+    the lazy DataArray is the double of tests/lazy_doubles.py (blocks computed on a thread pool, dask-style graph names).  Camera frames
+    are the normalised uint8 stack already in host memory (decode and ``normalize`` are the caller's dask graph, not this engine's);
+    timed: building the projection graph + get_piv, results in host memory.  Compared bit for bit with the reference's data flow on the
+    same frames (host stacks, float64 ortho frames into get_piv), and timed next to the generic path (one more layer between project
+    and get_piv: the projected blocks come back to the host and go up again)."""
+    import sys as _sys
+
+    from pyorc_amd import executor, filters, frames as F, plugin
+    from tests import lazy_doubles
+
+    norm = filters.normalize(cam, 15)
+    had = _sys.modules.get("xarray")
+    _sys.modules["xarray"] = lazy_doubles
+    try:
+        def run(extra_layer):
+            video = lazy_doubles.from_frames(norm, block=20, coords={"time": t})
+            ortho = lazy_doubles.frames_project(video, maps, dst, plugin.project_hip)
+            if extra_layer:
+                ortho = ortho.map_time(lambda blk: blk, "astype")
+            return F.get_piv(ortho, ws[0], overlap=ov, time=t, resolution=0.01)
+
+        out, results = {}, {}
+        for key, extra in (("dropin_project_hip_get_piv_hip", False), ("dropin_generic_path", True)):
+            run(extra)
+            t0 = time.perf_counter()
+            results[key] = run(extra)
+            dt = time.perf_counter() - t0
+            st = dict(executor.LAST_STATS)
+            out[key] = round((len(cam) - 1) / dt, 1)
+            out[key + "_detail"] = {"wall_s": round(dt, 4), "source_loaded": (st.get("plan") or {}).get("source"), "loads": st.get("chunks"),
+                                    "load_s": st.get("load_s"), "upload_and_project_s": st.get("upload_s"), "launch_s": st.get("launch_s"),
+                                    "waited_for_loads_s": st.get("waited_s")}
+    finally:
+        if had is None:
+            _sys.modules.pop("xarray", None)
+        else:
+            _sys.modules["xarray"] = had
+        plugin.uninstall()
+    ref = F.get_piv(plan.project_frames(norm).astype(np.float64), ws[0], overlap=ov, time=t, resolution=0.01)    # host_stacks_float64's data flow
+    out["dropin_bit_equal_to_host_stacks_float64"] = bool(all(np.array_equal(results[k][v], ref[v], equal_nan=True)
+                                                           for k in results for v in ("v_x", "v_y", "corr", "s2n")))
     return out
 
 
@@ -428,6 +477,7 @@ def camera_to_velocity_rates(cam: np.ndarray, ws, ov) -> dict:
 
     from pyorc_amd.pipeline import CameraToVelocity
     chain = CameraToVelocity((H, W), (Ho, Wo), *maps, window_size=ws, overlap=ov, normalize_samples=15)
+    dropin = dropin_rates(cam, maps, (Ho, Wo), ws, ov, t, p)
 
     out = {}
     for key, fn in (("device_resident_stages", device_chain), ("streamed_chain", lambda: chain.run(cam, streamed=True)),
@@ -464,6 +514,7 @@ def camera_to_velocity_rates(cam: np.ndarray, ws, ov) -> dict:
         del d_ortho
     del d_res
     out["hbm_resident_project_then_piv"] = res
+    out.update(dropin)
     pn.close()
     del d_norm
     p.close()
@@ -471,6 +522,25 @@ def camera_to_velocity_rates(cam: np.ndarray, ws, ov) -> dict:
                    f"to a {Ho}x{Wo} grid (synthetic homography; {averaged_cells} of its {Ho * Wo} cells are group means of 2+ camera pixels, the rest "
                    f"nearest neighbour) -> get_piv {ws[0]}x{ws[1]}; PCIe-inclusive, never `value`")
     return out
+
+
+def c_oracle_uv(sample, ws, ov, cores):
+    """u, v of the C port for the first pairs of the sample (what cpu_baseline.numpy_pocketfft states its agreement with)."""
+    from oracle import c_oracle
+
+    n = min(sample.shape[0] - 1, 2 * cores)
+    u, v, _, _ = c_oracle.piv_pairs(sample[:n + 1], ws, ov, nthreads=cores)
+    return u, v
+
+
+def rows_block(lib) -> list:
+    """The HBM-bound rows around the path, each with its own roofline block: tools/rows_launch.py."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("rows_launch", os.path.join(ROOT, "tools", "rows_launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.measure_rows(lib)
 
 
 def spawn_ranks(a) -> int:
@@ -657,6 +727,35 @@ def main():
         _lib.check(lib.lspiv_event_destroy(e0))
         _lib.check(lib.lspiv_event_destroy(e1))
 
+    # ---- one STRONG pass next to the weak one (north_star says "strong scaling"; the driver runs the default) ----
+    strong = None
+    if plan is not None and not a.strong and a.strong_pairs > 0:
+        from pyorc_amd import shard
+
+        plan_s = shard.ShardedPivDev(comm, a.strong_pairs, (H, W), ws, ov, align=None)
+        need = plan_s.p_local + 1 if plan_s.p_local else 0
+        if need <= T:
+            block_s = frames[:need]
+        else:                                   # fewer ranks than the total was meant for: this rank's block is longer than the weak one
+            block_s = DeviceFrames.empty((need, H, W), np.uint8)
+            _lib.check(lib.lspiv_synth_particles_dev(block_s.c_ptr, need, H, W, a.seed + rank, 0.02))
+            _lib.check(lib.lspiv_synchronize())
+        for _ in range(2):
+            plan_s.step(block_s)
+        plan_s.drain(); sync(); barrier(); sync()
+        t0s = time.perf_counter()
+        for _ in range(a.steps):
+            plan_s.step(block_s)
+        plan_s.drain(); sync(); barrier(); sync()
+        dts = time.perf_counter() - t0s
+        dts = float(comm.allreduce(np.array([dts], dtype=np.float64), 1)[0])   # MAX over ranks
+        strong = {"strong_pairs_total": a.strong_pairs, "strong_pairs_rank0": plan_s.p_local, "strong_ms_per_step": round(dts / a.steps * 1e3, 4),
+                  "strong_pairs_per_s": round(a.strong_pairs * a.steps / dts, 2),
+                  "strong_note": "the same step loop with --strong-pairs pairs IN TOTAL cut over the ranks on the kernels' anchors (what `--strong` times as "
+                                 "`value`), run after the weak timed region: north_star's strong-scaling reading beside the default weak one"}
+        plan_s.close()
+        del block_s
+
     dist_check = None
     if plan is not None and plan.k > 0:
         # this rank's slice of the all-gathered block must equal its own single-launch result bit for bit; cheap, outside the
@@ -743,6 +842,7 @@ def main():
             "exposed_comm_ms": round(dt / a.steps * 1e3 - float(np.mean(km)), 4) if len(km) else None,
             "kernel_ms_alone": round(launch_ms, 4),
             "gather_stream_priority": "high" if plan.gather_priority > 0 else ("low" if plan.gather_priority < 0 else "default"),
+            **(strong or {}),
             # NCCL_MAX_NCHANNELS: what was in force when the RCCL communicator was created (pyorc_amd.comm sets its default only
             # around ncclCommInitRank and restores the environment afterwards)
             "rccl_env": {**{k: os.environ.get(k) for k in ("NCCL_MIN_NCHANNELS", "LSPIV_RCCL_MAX_NCHANNELS", "NCCL_ALGO", "NCCL_PROTO")
@@ -771,6 +871,13 @@ def main():
                 eu, ev, _ = ens.finish(0.2, 1)
                 ens.close()
                 base["ensemble_parity"].append(cb.ensemble_parity(sample[:4], ews, eov, eu, ev, 0.2, 3.0, 0.2))
+        if not a.no_extras:
+            # the numpy / pocketfft reading of the same sample beside the C port (one process per core)
+            try:
+                ref_uv = c_oracle_uv(sample, ws, ov, base["cores"])
+                base["numpy_pocketfft"] = cb.numpy_pocketfft(sample, ws, ov, check=ref_uv)
+            except Exception as exc:   # a baseline leg must not take the line down
+                base["numpy_pocketfft"] = {"error": f"{type(exc).__name__}: {exc}"}
         out["cpu_baseline"] = base
         if base.get("value"):
             out["config"]["speedup_vs_cpu_baseline"] = round(pairs_per_s / base["value"], 1)
@@ -799,6 +906,10 @@ def main():
         out["config"]["camera_to_velocity_pairs_per_s"] = camera_to_velocity_rates(sample, ws, ov)
         # (a 720p crop: 3 476 windows, anchors every 25 pairs -- 1080p grids are cut on 125 pairs, two chunks of this sample)
         out["config"]["lazy_host_chunks"] = lazy_host_chunk_rates(np.ascontiguousarray(sample[:, :720, :1280]), ws, ov)
+        try:
+            out["config"]["rows"] = rows_block(lib)
+        except Exception as exc:
+            out["config"]["rows"] = {"error": f"{type(exc).__name__}: {exc}"}
     os.write(json_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:
         comm.barrier()

@@ -157,3 +157,54 @@ def ensemble_parity(frames_sample: np.ndarray, ws, ov, got_u, got_v, corr_min: f
             worst = max(worst, float(np.nanmax(e)))
     return {"window": list(ws), "overlap": list(ov), "pairs": T - 1, "windows_checked": int((~tie).sum()), "exact_ties_set_aside": int(tie.sum()),
             "max_rel_err_vs_oracle": float(f"{worst:.3e}"), "nan_mismatch": nan_bad, "oracle_s": round(dt, 2)}
+
+
+# ---- numpy / pocketfft reading of the same sample (promised beside the C port) -----------------------------
+_NP_SAMPLE = None      # (frames, ws, ov) inherited by the forked workers
+
+
+def _np_pairs(span):
+    from . import piv_oracle as po
+
+    frames, ws, ov = _NP_SAMPLE
+    a, b = span
+    n_cols = po.get_axis_shape(frames.shape[2], ws[1], ov[1])
+    n_rows = po.get_axis_shape(frames.shape[1], ws[0], ov[0])
+    u, v, cm, sn = po.get_uv_timestep(frames[a:b + 1], n_cols, n_rows, tuple(ws), tuple(ov))
+    return a, np.asarray(u, np.float64), np.asarray(v, np.float64)
+
+
+def numpy_pocketfft(frames_sample: np.ndarray, ws, ov, pairs_per_core: int = 2, check=None) -> dict:
+    """The numpy oracle's path -- ``sliding_window_stack`` + batched ``numpy.fft.rfft2`` / ``irfft2`` (pocketfft, the FFT family
+    rocket_fft wraps) + numpy reductions, float64: the reference's own data flow, window stack and correlation volume included -- on
+    the first pairs of the same sample, one PROCESS per core (``multiprocessing``, fork), ``pairs_per_core`` pairs each.  Reported
+    beside the C port; ``check``: (u, v) of the C port for those pairs, to state the agreement of the two restatements."""
+    import multiprocessing as mp
+
+    global _NP_SAMPLE
+    cores = effective_cores()
+    n_pairs = int(min(frames_sample.shape[0] - 1, max(1, pairs_per_core) * cores))
+    spans = [(p, p + 1) for p in range(n_pairs)]
+    _NP_SAMPLE = (frames_sample[:n_pairs + 1], tuple(ws), tuple(ov))
+    try:
+        ctx = mp.get_context("fork")
+        with ctx.Pool(processes=cores) as pool:
+            pool.map(_np_pairs, spans[:cores])          # warm-up: imports, page faults, one pair per worker
+            t0 = time.perf_counter()
+            res = pool.map(_np_pairs, spans, chunksize=1)
+            dt = time.perf_counter() - t0
+    finally:
+        _NP_SAMPLE = None
+    out = {"value": round(n_pairs / dt, 3), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+           "sample": f"first {n_pairs} frame-pairs of the same sample, numpy oracle (oracle/piv_oracle.py: window stack + batched numpy.fft.rfft2 / "
+                     f"irfft2 = pocketfft, float64, numpy reductions), {cores} processes x 1 thread, {dt:.1f} s wall"}
+    if check is not None:
+        worst = 0.0
+        for a, u, v in res:
+            for g, r in ((u[0], check[0][a]), (v[0], check[1][a])):
+                with np.errstate(all="ignore"):
+                    e = np.abs(g - r) / np.maximum(np.abs(r), 0.05)
+                if np.isfinite(e).any():
+                    worst = max(worst, float(np.nanmax(e[np.isfinite(e)])))
+        out["max_rel_diff_vs_c_port"] = float(f"{worst:.3e}")
+    return out

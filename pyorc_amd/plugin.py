@@ -142,26 +142,29 @@ def _wrap_get_piv(orig):
     return get_piv
 
 
-_PLANS: dict = {}          # (id(plan_args), shapes, device) -> (plan_args, Projection): the blocks of one graph share one tuple object
+_PLANS: dict = {}          # (ids of the index-map arrays, shapes, device) -> (the arrays, Projection): the blocks of one graph share the arrays
 _PLANS_MAX = 4
 _PLANS_LOCK = threading.Lock()
 
 
 def _projection_plan(src_shape, dst_shape, plan_args, device=None):
-    """Device-resident plan for these index maps: uploaded once per graph and device (dask's threads call the blocks of a graph
-    concurrently, all with the SAME ``plan_args`` tuple -- its identity is the key, no hashing of megabytes of indices per block), a few
-    graphs kept.  An evicted plan is only dropped here; it closes itself when the last block that uses it has returned."""
+    """Device-resident plan for these index maps: uploaded once per graph and device, a few graphs kept.  dask's threads call the blocks
+    of a graph concurrently, all with the SAME index-map arrays -- their identities are the key (no hashing of megabytes of indices per
+    block).  The identities of the ARRAYS, not of the tuple that carries them: a real dask re-creates the tuple for every task (tuples
+    are its task syntax), which made round 5's ``id(plan_args)`` key miss on every block -- a plan upload per block; found by
+    tests/test_real_dask.py.  An evicted plan is only dropped here; it closes itself when the last block that uses it has returned."""
     from .project import Projection
 
-    key = (id(plan_args), tuple(src_shape), tuple(dst_shape), device)
+    maps = tuple(plan_args)
+    key = (tuple(id(m) for m in maps), tuple(src_shape), tuple(dst_shape), device)
     with _PLANS_LOCK:
         hit = _PLANS.get(key)
-        if hit is not None and hit[0] is plan_args:
+        if hit is not None and len(hit[0]) == len(maps) and all(a is b for a, b in zip(hit[0], maps)):
             return hit[1]
         while len(_PLANS) >= _PLANS_MAX:
             _PLANS.pop(next(iter(_PLANS)))
-        plan = Projection(src_shape, dst_shape, *plan_args)
-        _PLANS[key] = (plan_args, plan)
+        plan = Projection(src_shape, dst_shape, *maps)
+        _PLANS[key] = (maps, plan)       # holds the arrays: their ids cannot be recycled while the entry lives
         return plan
 
 

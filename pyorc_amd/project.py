@@ -96,6 +96,17 @@ class Projection:
         _lib.check(_lib.load().lspiv_project_frames_dev(self._h, C.c_void_p(d_frames), _lib.DTYPE_CODES[np.dtype(dtype)], T,
                                                         C.c_void_p(d_out), C.c_void_p(stream) if stream else None))
 
+    def project_into(self, frames, out, f0: int = 0) -> None:
+        """``DeviceFrames`` camera frames -> frames ``[f0, f0 + len(frames))`` of the HBM-resident ortho stack ``out`` (float32; uint8 for
+        a nearest-neighbour-only plan fed with uint8): how ``pyorc_amd.resident`` fills the stack the PIV kernels read."""
+        n = frames.shape[0]
+        if frames.shape[1:] != self.src_shape or out.shape[1:] != self.dst_shape or not 0 <= f0 <= out.shape[0] - n:
+            raise ValueError(f"{frames.shape} frames do not project into frames [{f0}, {f0 + n}) of a {out.shape} stack with this plan")
+        if out.dtype not in (np.dtype(np.float32), np.dtype(np.uint8)):
+            raise TypeError(f"ortho stacks are float32 (or uint8), got {out.dtype}")
+        fb = self.dst_shape[0] * self.dst_shape[1] * out.dtype.itemsize
+        self.project_frames_dev(frames.ptr, frames.dtype, n, out.ptr + int(f0) * fb, keep_uint8=out.dtype == np.uint8)
+
     def close(self):
         if self._h:
             _lib.load().lspiv_projection_destroy(self._h)

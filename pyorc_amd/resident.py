@@ -91,7 +91,7 @@ class ResidentStack:
     pairs ``[p0, p1)`` have become computable: ``p0`` is where the previous launch ended (``first`` at the start, a multiple of
     ``align`` afterwards), ``p1`` the last multiple of ``align`` below the frames that have arrived -- everything at :meth:`finish`.
     ``projection``: a ``pyorc_amd.project.Projection``; pieces are then CAMERA frames, uploaded to a scratch stack and projected into
-    place (``Projection.project_frames_dev``), float32 out like ``project_hip``'s blocks."""
+    place (``Projection.project_into``), float32 out like ``project_hip``'s blocks."""
 
     def __init__(self, first: int, capacity: int, frame_shape, host_dtype, align: int, launch: Callable, signal_threshold=None,
                  projection=None):
@@ -128,8 +128,7 @@ class ResidentStack:
             self.stack.upload(f0 - self.first, frames, self.signal_threshold)
         else:
             cam = DeviceFrames.from_host(frames)
-            fb = self.frame_shape[0] * self.frame_shape[1] * self.dtype.itemsize
-            self.projection.project_frames_dev(cam.ptr, cam.dtype, n, self.stack.ptr + (f0 - self.first) * fb)
+            self.projection.project_into(cam, self.stack, f0 - self.first)
             del cam      # stream-ordered: the block goes back to the pool, the next upload waits for the library's stream first
         self.upload_s += _time.perf_counter() - t0
         self.have = f0 + n

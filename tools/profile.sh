@@ -8,7 +8,7 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 20 --warmup 3 --cpu-pairs 0 --no-extras --sustained-s 0 ${BENCH_ARGS}"
 [ -n "$PROFILE_CMD" ] && CMD="$PROFILE_CMD"   # another workload through the same passes (tools/f32_launch.py)
-KF='--kernel-include-regex piv_'
+KF=${PROFILE_KF:-'--kernel-include-regex piv_'}   # PROFILE_KF: the counter passes of another kernel family (tools/rows_launch.py)
 run() { name=$1; shift; timeout 600 rocprofv3 "$@" --output-format csv -d /tmp/prof_$name -o $name -- $CMD > $OUT/$name.log 2>&1; \
         find /tmp/prof_$name -name "*.csv" -size -8M -exec cp {} $OUT/ \; ; }
 # the trace pass runs 100 timed steps so that the cold first launches do not weigh on the kernel's mean duration

@@ -16,18 +16,23 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pyorc_amd._lib import kernel_code_hash  # noqa: E402  (the same function bench.py checks a summary against)
 
+import re
+
 src, tag = sys.argv[1], sys.argv[2]
+# SUMMARY_KERNELS: regex of the kernels to summarise (default: the fused PIV kernels); SUMMARY_ROW_FRAMES / SUMMARY_CALLS: a row of
+# tools/rows_launch.py -- frames per call and calls made, so that kernels launched several times per call are weighted
+KRE = re.compile(os.environ.get("SUMMARY_KERNELS", "piv_"))
 # optional: the launch shape the profile was taken on (bench.py defaults), so bench.py can match it: pairs H W window overlap
 shape = [int(x) for x in sys.argv[3:8]] if len(sys.argv) >= 8 else [1000, 1080, 1920, 32, 16]
 acc = collections.defaultdict(list)
 for f in glob.glob(os.path.join(src, "pmc_*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if "piv_" in r["Kernel_Name"]:
+        if KRE.search(r["Kernel_Name"]):
             acc[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
 kernels = sorted({k for k, _ in acc})
 stats = {}
 for r in csv.DictReader(open(os.path.join(src, "trace_kernel_stats.csv"))):
-    if "piv_" in r["Name"]:
+    if KRE.search(r["Name"]):
         stats[r["Name"]] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"])}
 # code_hash: the PIV kernel sources this profile was taken on; bench.py reports `traffic: null` for a summary whose hash is not
 # the tree's (a number measured on other kernel code is not this kernel's traffic)
@@ -45,6 +50,15 @@ for k in kernels:
         d["valu_inst_per_simd_per_4cyc"] = c["SQ_INSTS_VALU"] / (1024.0 * cycles / 4.0)
         d["valu_inst_per_wave"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
     out["kernels"][k] = d
+if os.environ.get("SUMMARY_ROW_FRAMES"):
+    from tools.rows_launch import rows_source_hash  # noqa: E402
+
+    out["launch"] = {"frames": int(os.environ["SUMMARY_ROW_FRAMES"]), "H": 1080, "W": 1920}
+    out["rows_source_hash"] = rows_source_hash()
+    calls = float(os.environ.get("SUMMARY_CALLS", "0"))
+    for k, d in out["kernels"].items():
+        if d.get("trace") and calls:
+            d["launches_per_call"] = d["trace"]["calls"] / calls
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"{tag}_summary.json")
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])
