@@ -35,9 +35,12 @@ class _Pool:
     def __init__(self):
         import os
 
+        import threading
+
         self.limit = int(os.environ.get("LSPIV_POOL_BYTES", 16 << 30))
         self.free = {}      # bucket size -> [raw pointer values]
         self.cached = 0
+        self._lock = threading.RLock()   # stacks are made and dropped on several threads (the chunk executor's loaders stage their pieces)
 
     @staticmethod
     def bucket(nbytes: int) -> int:
@@ -47,10 +50,11 @@ class _Pool:
 
     def take(self, nbytes: int):
         b = self.bucket(nbytes)
-        lst = self.free.get(b)
-        if lst:
-            self.cached -= b
-            return C.c_void_p(lst.pop()), b
+        with self._lock:
+            lst = self.free.get(b)
+            if lst:
+                self.cached -= b
+                return C.c_void_p(lst.pop()), b
         p = C.c_void_p()
         rc = _lib.load().lspiv_dev_malloc(C.byref(p), b)
         if rc == _lib.LSPIV_ENOMEM and self.cached:   # give the cache back and retry once
@@ -60,18 +64,20 @@ class _Pool:
         return p, b
 
     def give(self, ptr: C.c_void_p, b: int):
-        if self.cached + b <= self.limit:
-            self.free.setdefault(b, []).append(ptr.value)
-            self.cached += b
-        else:
-            _lib.load().lspiv_dev_free(ptr)
+        with self._lock:
+            if self.cached + b <= self.limit:
+                self.free.setdefault(b, []).append(ptr.value)
+                self.cached += b
+                return
+        _lib.load().lspiv_dev_free(ptr)
 
     def release(self):
         lib = _lib.load()
-        for lst in self.free.values():
+        with self._lock:
+            free, self.free, self.cached = self.free, {}, 0
+        for lst in free.values():
             for v in lst:
                 lib.lspiv_dev_free(C.c_void_p(v))
-        self.free, self.cached = {}, 0
 
 
 _pool = _Pool()

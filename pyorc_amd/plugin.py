@@ -351,8 +351,12 @@ def install(pyorc_module=None) -> bool:
 
 
 def uninstall() -> None:
-    """Put pyorc's own ``get_ffpiv`` / ``Frames.get_piv`` back."""
+    """Put pyorc's own ``get_ffpiv`` / ``Frames.get_piv`` back; drop the cached projection plans and the registered graph nodes."""
     if not _installed:
+        with _PLANS_LOCK:
+            _PLANS.clear()
+            _PROJECTIONS.clear()
+        _remove_hook()
         return
     _installed["ffpiv_mod"].get_ffpiv = _installed["orig_ffpiv"]
     if _installed["reexported"]:

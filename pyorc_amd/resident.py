@@ -25,13 +25,14 @@ Stacks beyond the HBM budget run as consecutive windows of this kind, cut on the
 from __future__ import annotations
 
 import math
+import threading
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
 from .device import DeviceFrames
 
-MIN_LOADS = 4     # a stack with at least this many anchors is cut into at least this many loads: something to run ahead of
+MIN_LOADS = 8     # a stack with at least this many anchors is cut into at least this many loads: something to run ahead of, and a short first load
 
 
 def time_blocks(frames) -> Optional[List[int]]:
@@ -108,21 +109,20 @@ class ResidentStack:
         self.launched = self.first      # pairs [run_start, launched) have been issued
         self.upload_s = 0.0
         self.launch_s = 0.0
+        self._lock = threading.Lock()
 
     # pair p = frames p, p + 1 (absolute indices)
-    def push(self, f0: int, frames) -> None:
-        """The next piece: host frames ``[f0, f0 + n)``.  ``f0`` beyond what has arrived (a loader dropped trailing frames,
-        ``load_frame_chunk``'s TypeError retry) closes the current run -- its last pairs are launched -- and starts a new one at ``f0``."""
+    def stage(self, f0: int, frames) -> int:
+        """Bring host frames ``[f0, f0 + n)`` into their place in the stack (upload, or upload + orthoprojection); returns ``n``.  Touches
+        nothing but that slice: pieces may be staged by several threads at once and in any order (the chunk executor's loaders stage
+        what they loaded -- uploads queue on the library's host lock, i.e. on PCIe, while the consumer's thread only launches)."""
         import time as _time
 
         n = len(frames)
         if n == 0:
-            return
-        if f0 < self.have or f0 + n > self.first + self.capacity:
-            raise ValueError(f"piece [{f0}, {f0 + n}) does not follow frame {self.have} inside [{self.first}, {self.first + self.capacity})")
-        if f0 > self.have:
-            self._launch_ready(final=True)
-            self.run_start = self.have = self.launched = f0
+            return 0
+        if f0 < self.first or f0 + n > self.first + self.capacity:
+            raise ValueError(f"piece [{f0}, {f0 + n}) is outside [{self.first}, {self.first + self.capacity})")
         t0 = _time.perf_counter()
         if self.projection is None:
             self.stack.upload(f0 - self.first, frames, self.signal_threshold)
@@ -130,9 +130,29 @@ class ResidentStack:
             cam = DeviceFrames.from_host(frames)
             self.projection.project_into(cam, self.stack, f0 - self.first)
             del cam      # stream-ordered: the block goes back to the pool, the next upload waits for the library's stream first
-        self.upload_s += _time.perf_counter() - t0
+        with self._lock:
+            self.upload_s += _time.perf_counter() - t0
+        return n
+
+    def commit(self, f0: int, n: int) -> None:
+        """Frames ``[f0, f0 + n)`` have been staged: in time order, from ONE thread.  Launches what has become computable.  ``f0`` beyond
+        what has arrived (a loader dropped trailing frames, ``load_frame_chunk``'s TypeError retry) closes the current run -- its last
+        pairs are launched -- and starts a new one at ``f0``."""
+        if n == 0:
+            return
+        if f0 < self.have:
+            raise ValueError(f"piece [{f0}, {f0 + n}) does not follow frame {self.have}")
+        if f0 > self.have:
+            self._launch_ready(final=True)
+            self.run_start = self.have = self.launched = f0
         self.have = f0 + n
         self._launch_ready(final=False)
+
+    def push(self, f0: int, frames) -> None:
+        """``stage`` + ``commit`` on the calling thread."""
+        if f0 < self.have:
+            raise ValueError(f"piece [{f0}, {f0 + len(frames)}) does not follow frame {self.have}")
+        self.commit(f0, self.stage(f0, frames))
 
     def finish(self) -> None:
         self._launch_ready(final=True)

@@ -490,23 +490,30 @@ def _get_ffpiv_lazy(frames, plan, y, x, dt, time, res_y, res_x, n_cols, n_rows, 
             done.append((p0, p1))
 
     stats = {"plan": {k: plan[k] for k in ("windows", "load_frames", "align", "depth", "max_depth", "source", "peak_host_bytes", "host_budget")},
-             "load_s": 0.0, "waited_s": 0.0, "upload_s": 0.0, "launch_s": 0.0, "chunks": 0, "depth_per_chunk": []}
+             "load_s": 0.0, "waited_s": 0.0, "upload_s": 0.0, "launch_s": 0.0, "chunks": 0, "depth_per_chunk": [], "load_s_per_chunk": [],
+             "waited_s_per_chunk": []}
     try:
         for (w0, w1), loads in zip(plan["windows"], plan["loads"]):
             stack = resident.ResidentStack(w0, w1 - w0, dim_size, frames.dtype, plan["align"], launch, signal_threshold, projection)
-            pieces = [lazy[f0:f1] for f0, f1 in loads]
-            with executor.ChunkPrefetcher(pieces, load_frame_chunk, depth=plan["depth"]) as loader:
+            pieces = [(f0, lazy[f0:f1]) for f0, f1 in loads]
+
+            def load_and_stage(piece, stack=stack):
+                # on a loader thread: materialise the piece AND bring it to the device (upload -- or upload + projection -- into its place:
+                # PCIe and the host's page handling stay off the thread that launches; the loaded array is released here as well)
+                f0, da = piece
+                return stack.stage(f0, _values(load_frame_chunk(da)))
+
+            with executor.ChunkPrefetcher(pieces, load_and_stage, depth=plan["depth"]) as loader:
                 try:
-                    for n, da in loader:
+                    for n, n_staged in loader:
                         pieces[n] = None
-                        if len(da):
-                            stack.push(loads[n][0], _values(da))
-                        del da
+                        stack.commit(loads[n][0], n_staged)
                 finally:
                     loader.close()
                     st = loader.stats
                     stats["load_s"] += st["load_s"]; stats["waited_s"] += st["waited_s"]; stats["chunks"] += st["chunks"]
                     stats["depth_per_chunk"] += st["depth_per_chunk"]
+                    stats["load_s_per_chunk"] += st["load_s_per_chunk"]; stats["waited_s_per_chunk"] += st["waited_s_per_chunk"]
                     stats["depth"], stats["workers"], stats["adaptive"] = st["depth"], st["workers"], st["adaptive"]
             stack.finish()
             stats["upload_s"] += stack.upload_s; stats["launch_s"] += stack.launch_s

@@ -29,6 +29,16 @@ def _name(prefix):
     return f"{prefix}-{next(_token):032x}"
 
 
+_POOL = None
+
+
+def _shared_pool():
+    global _POOL
+    if _POOL is None:
+        _POOL = ThreadPoolExecutor(max_workers=8, thread_name_prefix="fake-dask")
+    return _POOL
+
+
 class Graph:
     def __init__(self, dependencies):
         self.dependencies = dependencies        # layer name -> set of layer names (dask.highlevelgraph.HighLevelGraph.dependencies)
@@ -114,12 +124,9 @@ class LazyDataArray:
 
     def load(self):
         idx = [i for i in range(len(self._blocks) - 1) if self._blocks[i] < self._hi and self._blocks[i + 1] > self._lo]
-        if self._pool is not None:
-            parts = list(self._pool.map(self._block, idx))
-        else:
-            with ThreadPoolExecutor(max_workers=4) as ex:      # dask's threaded scheduler: blocks on worker threads
-                parts = list(ex.map(self._block, idx))
-        whole = np.concatenate(parts) if parts else np.zeros((0,) + self._tail, self._dtype)
+        parts = list((self._pool or _shared_pool()).map(self._block, idx))      # dask's threaded scheduler: blocks on worker threads
+        # one block: its array as it is (dask hands a single chunk over without a copy); several: concatenated into a fresh array
+        whole = parts[0] if len(parts) == 1 else (np.concatenate(parts) if parts else np.zeros((0,) + self._tail, self._dtype))
         first = self._blocks[idx[0]] if idx else self._lo
         vals = whole[self._lo - first:self._hi - first]
         coords = {k: (v[self._lo:self._hi] if v.dims == (self.dims[0],) and len(v) == self._blocks[-1] else v) for k, v in self.coords.items()}

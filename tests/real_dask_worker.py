@@ -109,7 +109,7 @@ def main():
     assert st["plan"]["source"] == "camera" and st["plan"]["load_frames"] == 10 and st["chunks"] == 5, st
     assert decoded == {k: 1 for k in range(5)}, decoded
     plan = OraclePlan.made[0]
-    assert plan.blocks == [] and plan.into == [(0, 10), (10, 10), (20, 10), (30, 10), (40, 7)] and stacks.uploads == []
+    assert plan.blocks == [] and sorted(plan.into) == [(0, 10), (10, 10), (20, 10), (30, 10), (40, 7)] and stacks.uploads == []
     assert any(n != threading.current_thread().name for n in threads)                     # dask's worker threads ran the blocks
 
     # (2) anything else after project -> the generic path under the threaded scheduler: every block decoded + projected ONCE
@@ -121,7 +121,7 @@ def main():
         results[depth] = F.get_piv(Lazy(other), 32, prefetch=depth, **kw)
         assert executor.LAST_STATS["plan"]["source"] == "frames"
         assert decoded == {k: 1 for k in range(5)} and sorted(plan.blocks) == [7, 10, 10, 10, 10] and plan.into == [], (depth, decoded, plan.blocks)
-        assert stacks.uploads == [(0, 10), (10, 10), (20, 10), (30, 10), (40, 7)]
+        assert sorted(stacks.uploads) == [(0, 10), (10, 10), (20, 10), (30, 10), (40, 7)]
     for k in ("v_x", "v_y", "corr", "s2n"):
         assert np.array_equal(results[0][k], results[None][k], equal_nan=True) and np.array_equal(results[0][k], results[2][k], equal_nan=True), k
         assert np.array_equal(results[0][k], got[k], equal_nan=True), k                      # the hand-off computes the same bits

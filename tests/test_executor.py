@@ -238,7 +238,7 @@ def test_get_ffpiv_gives_the_same_dataset_with_and_without_prefetch(monkeypatch)
                 for k, ref in results[0].items():
                     assert np.array_equal(results[depth][k], ref, equal_nan=True), (ens, depth, k)
             # serial: 6 x (load + compute); prefetched: load + 6 x compute (+ the oracle's own time in both)
-            assert walls[1] <= walls[0] - 4 * load_s, (ens, walls)
+            assert walls[1] <= walls[0] - 3 * load_s, (ens, walls)       # five of the six loads hide behind the launches (give one for scheduling noise)
         # an already materialised stack has nothing to prefetch: no thread is started
         loads.clear()
         F.get_piv(fr, 32, time=t, resolution=0.02, chunksize=6)

@@ -531,8 +531,8 @@ def test_chunks_cut_on_anchors_reproduce_the_whole_stack(gpu, ws, dtype):
     ov = (ws // 2, ws // 2)
     fr = particle_stack(64, 2 * ws + 11, 3 * ws + 2, seed=77 + ws, density=0.05)
     fr = fr if dtype == np.uint8 else fr.astype(dtype) - 11.5
-    A = window.chunk_alignment(W)
-    assert A == 25
+    A = window.chunk_alignment(W, fr.shape[1:], ov)          # the grid's own anchor length (a small grid: the family's base)
+    assert A == 25 and window.chunk_alignment(W) == 75         # without a grid: the any-grid alignment (ABI 5)
     whole = np.stack(pyorc_amd.piv_pairs(fr, W, ov))
     for bounds in ([0, 25, 63], [0, 50, 63], [0, 25, 50, 63]):
         parts = [np.stack(pyorc_amd.piv_pairs(fr[a:b + 1], W, ov, pair_offset=a)) for a, b in zip(bounds, bounds[1:])]

@@ -188,6 +188,7 @@ def test_project_hip_blocks_on_the_gpu(gpu, monkeypatch):
     from tests import fake_xarray
 
     monkeypatch.setitem(sys.modules, "xarray", fake_xarray)
+    plugin.uninstall()       # no plans left over from other tests
     src, dst = (270, 480), (200, 360)
     maps = projection_maps(src, dst, tilt=0.15, seed=6)
 
@@ -205,17 +206,20 @@ def test_project_hip_blocks_on_the_gpu(gpu, monkeypatch):
     ref = pro.project_frames(cam, dst, *maps)
     assert out.values.dtype == np.float32 and np.array_equal(out.values.astype(np.float64), ref)
     assert len(plugin._PLANS) == 1
-    # the blocks of ONE graph from four threads
-    plan_args = (maps[0], maps[1], maps[2], maps[3], maps[4])
+    # the blocks of ONE graph from four threads, each handed ANOTHER tuple around the same index maps (a real dask re-creates the
+    # kwargs tuple per task): still the one plan of the graph (round 6: keyed by the arrays, not by the tuple)
+    from pyorc_amd import executor
+
+    dev = executor.current_device()
     res = [None] * 4
     def work(k):
-        res[k] = plugin._project_block(cam[6 * k:6 * k + 6], plan_args=plan_args, dst_shape=dst)
+        res[k] = plugin._project_block(cam[6 * k:6 * k + 6], plan_args=(maps[0], maps[1], maps[2], maps[3], maps[4]), dst_shape=dst, device=dev)
     ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
     for t in ts:
         t.start()
     for t in ts:
         t.join()
-    assert np.array_equal(np.concatenate(res).astype(np.float64), ref) and len(plugin._PLANS) == 2
+    assert np.array_equal(np.concatenate(res).astype(np.float64), ref) and len(plugin._PLANS) == 1
     plugin.uninstall()
 
 

@@ -67,7 +67,7 @@ def test_long_anchors_on_the_full_1080p_grid(gpu, ws, ov, ens):
 
     lib = _lib.load()
     H, W, P = 1080, 1920, 290
-    assert window.chunk_alignment((ws, ws), (H, W), (ov, ov)) == 75 and window.chunk_alignment((ws, ws)) == 25
+    assert window.chunk_alignment((ws, ws), (H, W), (ov, ov)) == 75 and window.chunk_alignment((ws, ws), (128, 160), (ws // 2, ws // 2)) == 25
     nr, nc = window.get_array_shape((H, W), (ws, ws), (ov, ov))
     n_win = nr * nc
     d_f, d_o = C.c_void_p(), C.c_void_p()
