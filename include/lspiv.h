@@ -516,6 +516,11 @@ int lspiv_kernel_times(float* ms, int cap, int* n);
 int lspiv_trace(int enable);
 int lspiv_trace_read(int64_t cap, int32_t* kind, double* start_ms, double* end_ms, int64_t* n);
 
+/* Test hook (round 6): the orthoprojection kernel for plans with group means computes float(sum) / float(count) as q = RN(s y),
+ * q' = RN(q + (s - q c) y) with y = RN(1 / c) instead of the division sequence; *mismatches = the number of (s, c), 0 <= s <= 255 c,
+ * 1 <= c <= 255 -- every sum of c uint8 samples --, for which that differs from s / c on the device (must be 0). */
+int lspiv_debug_project_division(int* mismatches);
+
 /* Test hook (host only, no HIP call): hold one of device `device`'s locks -- 0 the host-pointer PIV entry points' workspaces, 1 a launch
  * and its rescue kernels, 2 the rescue lists, 3 / 4 the two slots of the host-pointer projection entry points -- for `milliseconds`.  The locks are per device (round 5; process-wide before): two
  * threads holding the same lock of two devices overlap, of one device queue.  tests/test_host.py times exactly that. */

@@ -159,6 +159,7 @@ SIGNATURES = {
     "lspiv_debug_hold_lock": (_i32, [_i32, _i32, _i32]),
     "lspiv_kernel_times": (_i32, [_vp, _i32, C.POINTER(_i32)]),
     "lspiv_upload_frames": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _f32]),
+    "lspiv_debug_project_division": (_i32, [C.POINTER(_i32)]),
     "lspiv_trace": (_i32, [_i32]),
     "lspiv_trace_read": (_i32, [_i64, _vp, _vp, _vp, C.POINTER(_i64)]),
 }

@@ -25,6 +25,25 @@ __global__ __launch_bounds__(256) void time_diff_kernel(const T* __restrict__ f,
   }
 }
 
+// uint8 frames, four pixels per thread (round 6): two 4-byte loads and one 16-byte store per lane instead of two byte loads and a 4-byte
+// store -- the byte-per-lane form moved 64 B per load instruction and ran at 3.8 TB/s of the 5.4 TB/s this traffic mix streams at
+// (tools/ubench/stream.hip).  Same float32 arithmetic per pixel.
+__global__ __launch_bounds__(256) void time_diff_u8x4_kernel(const uint32_t* __restrict__ f, int64_t frame_quads, int64_t n_quads,
+                                                             float thres, int use_abs, f32x4* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_quads; i += stride) {
+    const uint32_t a = f[i], b = f[i + frame_quads];
+    f32x4 v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float d = (float)((b >> (8 * k)) & 0xffu) - (float)((a >> (8 * k)) & 0xffu);
+      d = (d > thres) ? d : 0.0f;
+      v[k] = use_abs ? fabsf(d) : d;
+    }
+    out[i] = v;
+  }
+}
+
 // Frames.range (pyorc/api/frames.py:364-379): (max over time - min over time).astype(input dtype), one thread per pixel
 // column walking the frames; xarray's max / min skip NaN for float frames (nanmax / nanmin; an all-NaN pixel stays NaN).
 template <typename T>
@@ -476,6 +495,12 @@ hipError_t launch_time_diff(const void* frames, int dtype, int64_t frame_elems, 
   const int64_t n_out = (n_frames - 1) * frame_elems;
   if (n_out <= 0) return hipSuccess;
   const unsigned blocks = (unsigned)std::min<int64_t>((n_out + 255) / 256, 256 * 16);
+  if (dtype == 0 && frame_elems % 4 == 0 && (reinterpret_cast<uintptr_t>(frames) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    const unsigned qb = (unsigned)std::min<int64_t>((n_out / 4 + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(time_diff_u8x4_kernel, dim3(qb), dim3(256), 0, s, (const uint32_t*)frames, frame_elems / 4, n_out / 4, thres, use_abs,
+                       reinterpret_cast<f32x4*>(out));
+    return hipGetLastError();
+  }
   switch (dtype) {
     case 0: hipLaunchKernelGGL(time_diff_kernel<uint8_t>, dim3(blocks), dim3(256), 0, s, (const uint8_t*)frames, frame_elems, n_out, thres, use_abs, out); break;
     case 1: hipLaunchKernelGGL(time_diff_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)frames, frame_elems, n_out, thres, use_abs, out); break;

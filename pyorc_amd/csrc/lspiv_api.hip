@@ -525,6 +525,10 @@ struct lspiv_projection {
   int *d_qlo1 = nullptr, *d_qlo2 = nullptr;   // quad-window plan for uint8 frames (project.hip), nullptr: not built
   uint32_t* d_qdesc = nullptr;
   int* d_slow_q = nullptr; int n_slow = 0;    // the quads that plan leaves to the per-cell kernel
+  // mixed plan for uint8 frames when the plan has group means (round 6, project.hip: project_mix_kernel): per quad mix_nw 8-byte
+  // windows, per cell one byte mask per window and the sample count; nullptr: not built
+  int* d_mwin = nullptr; uint32_t* d_mcell = nullptr; int mix_nw = 0;
+  int* d_mslow = nullptr; int n_mslow = 0;
   int64_t n_groups = 0;                       // 0: nearest neighbour only -- uint8 frames may stay uint8 (lspiv_project_frames_u8)
 };
 
@@ -1688,6 +1692,93 @@ int lspiv_projection_create(int64_t src_h, int64_t src_w, int64_t dst_h, int64_t
       h->n_slow = (int)slow.size();
     }
   }
+  // mixed plan (round 6): a plan with group means, uint8 frames.  Every cell is a set of samples (its group in the reference's
+  // order, else its nearest-neighbour byte, else nothing); the samples of a quad are covered greedily with 8-byte windows over
+  // the FLAT source index; a quad fits with at most NW windows and at most 255 samples per cell.
+  if (e == hipSuccess && G > 0 && n_out % 4 == 0 && n_src >= 16 && !getenv("LSPIV_PROJECT_ONE_CELL") && !getenv("LSPIV_PROJECT_NO_MIX")) {
+    const size_t nq = (size_t)n_out / 4;
+    std::vector<int> need(nq, 0);
+    std::vector<int> px;
+    auto samples_of = [&](size_t o, const int** first, int* n) {
+      const int g = grp_of[o];
+      if (g >= 0) { *first = &members[(size_t)off[(size_t)g]]; *n = off[(size_t)g + 1] - off[(size_t)g]; }
+      else if (nn[o] >= 0) { *first = &nn[o]; *n = 1; }
+      else { *first = nullptr; *n = 0; }
+    };
+    auto windows_of = [&](size_t q, int* starts, int cap) -> int {     // greedy cover of the quad's sample set; returns the number of windows
+      px.clear();
+      for (int k = 0; k < 4; ++k) {
+        const int* f; int n;
+        samples_of(4 * q + k, &f, &n);
+        px.insert(px.end(), f, f + n);
+      }
+      std::sort(px.begin(), px.end());
+      int nw = 0;
+      int64_t end = -1;
+      for (int v : px) {
+        if (v < end) continue;
+        int64_t st = std::min<int64_t>(v, n_src - 8);
+        // the kernel reads the three aligned dwords around a window in one 12-byte load: they must lie inside the frame
+        if ((st & ~(int64_t)3) + 12 > n_src) st = std::min<int64_t>(st, (n_src - 12) & ~(int64_t)3);
+        if (v >= st + 8) return cap + 1;                     // the frame's last bytes cannot be reached that way: the slow kernel's quad
+        if (nw < cap) starts[nw] = (int)st;
+        ++nw;
+        end = st + 8;
+      }
+      return nw;
+    };
+    size_t over2 = 0, over4 = 0;
+    int tmp[4];
+    for (size_t q = 0; q < nq; ++q) {
+      need[q] = windows_of(q, tmp, 4);
+      over2 += need[q] > 2;
+      over4 += need[q] > 4;
+    }
+    const int NW = over2 * 50 <= nq ? 2 : 4;                 // at most 2 % of the quads left to the slow kernel: two windows will do
+    const size_t left = NW == 2 ? over2 : over4;
+    if (left * 10 <= nq) {                                   // otherwise the geometry is too scattered for windows: the one-cell kernel
+      const int CW = NW / 2;
+      std::vector<int> mwin(nq * NW, 0), mslow;
+      std::vector<int> mcell(nq * 4 * CW, 0);
+      for (size_t q = 0; q < nq; ++q) {
+        int st[4] = {0, 0, 0, 0};
+        bool ok = need[q] <= NW;
+        const int nw = ok ? windows_of(q, st, NW) : 0;
+        uint32_t words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < 4 && ok; ++k) {
+          const int* f; int n;
+          samples_of(4 * q + k, &f, &n);
+          if (n > 255) { ok = false; break; }            // the kernel's division-free quotient is checked for counts up to 255
+          uint32_t masks = 0;
+          for (int i = 0; i < n; ++i) {
+            int wsel = -1;
+            for (int j = 0; j < nw; ++j)
+              if (f[i] >= st[j] && f[i] < st[j] + 8) { wsel = j; break; }
+            if (wsel < 0) { ok = false; break; }
+            masks |= 1u << (8 * wsel + (f[i] - st[wsel]));
+          }
+          const uint32_t cnt = (uint32_t)std::max(n, 1);     // a cell without samples: 0 / 1
+          if (NW == 2) words[k] = masks | (cnt << 16);
+          else { words[2 * k] = masks; words[2 * k + 1] = cnt; }
+        }
+        if (!ok) {
+          mwin[q * NW] = -1;
+          mslow.push_back((int)q);
+          continue;
+        }
+        for (int j = 0; j < NW; ++j) mwin[q * NW + j] = st[j < nw ? j : 0];    // unused windows repeat the first (masks 0)
+        if (nw == 0) for (int j = 0; j < NW; ++j) mwin[q * NW + j] = 0;
+        for (int j = 0; j < 4 * CW; ++j) mcell[q * 4 * CW + j] = (int)words[j];
+      }
+      e = up(&h->d_mwin, mwin);
+      int* dc = nullptr;
+      if (e == hipSuccess) e = up(&dc, mcell);
+      h->d_mcell = reinterpret_cast<uint32_t*>(dc);
+      if (e == hipSuccess) e = up(&h->d_mslow, mslow);
+      h->n_mslow = (int)mslow.size();
+      h->mix_nw = NW;
+    }
+  }
   if (e != hipSuccess) {
     lspiv_projection_destroy(h);
     return fail(e == hipErrorOutOfMemory ? LSPIV_ENOMEM : LSPIV_EHIP, "projection plan upload: %s", hipGetErrorString(e));
@@ -1705,7 +1796,10 @@ int lspiv_project_frames_dev(lspiv_projection* h, const void* d_frames, int dtyp
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   const bool win = dtype == 0 && h->d_qdesc && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
-  hipError_t e = win ? lspiv::launch_project_win((const uint8_t*)d_frames, h->src_h * h->src_w, (int)T, h->d_qlo1, h->d_qlo2, h->d_qdesc,
+  const bool mix = dtype == 0 && !win && h->d_mcell && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
+  hipError_t e = mix ? lspiv::launch_project_mix((const uint8_t*)d_frames, h->src_h * h->src_w, (int)T, h->mix_nw, h->d_mwin, h->d_mcell, h->d_mslow,
+                                                  h->n_mslow, h->d_nn, h->d_grp_of, h->d_grp_off, h->d_grp_src, d_out, (int)(h->dst_h * h->dst_w), s)
+               : win ? lspiv::launch_project_win((const uint8_t*)d_frames, h->src_h * h->src_w, (int)T, h->d_qlo1, h->d_qlo2, h->d_qdesc,
                                                   h->d_slow_q, h->n_slow, h->d_nn, h->d_grp_of, h->d_grp_off, h->d_grp_src, d_out, (int)(h->dst_h * h->dst_w), s)
                      : lspiv::launch_project(d_frames, dtype, h->src_h * h->src_w, (int)T, h->d_nn, h->d_grp_of, h->d_grp_off,
                                              h->d_grp_src, d_out, (int)(h->dst_h * h->dst_w), s);
@@ -1759,6 +1853,9 @@ int lspiv_projection_destroy(lspiv_projection* h) {
   if (h->d_qlo2) hipFree(h->d_qlo2);
   if (h->d_qdesc) hipFree(h->d_qdesc);
   if (h->d_slow_q) hipFree(h->d_slow_q);
+  if (h->d_mwin) hipFree(h->d_mwin);
+  if (h->d_mcell) hipFree(h->d_mcell);
+  if (h->d_mslow) hipFree(h->d_mslow);
   delete h;
   return LSPIV_OK;
 }
@@ -2741,6 +2838,21 @@ int lspiv_debug_narrow(const double* frames, int64_t frame_elems, int64_t n_fram
   lspiv_host::staged_narrow(out, frames, (size_t)frame_elems, (size_t)n_frames, off.data());
   if (offsets) memcpy(offsets, off.data(), off.size() * sizeof(double));
   return lspiv_host::stage_threads();
+}
+int lspiv_debug_project_division(int* mismatches) {
+  // test hook: project_mix_kernel's division-free quotient against the division, every sum 0 .. 255 c for every count c = 1 .. 255
+  if (!mismatches) return fail(LSPIV_EINVAL, "NULL argument");
+  DeviceCtx* c;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  rc = ensure(&c->d_scratch, &c->scratch_cap, sizeof(int));
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(c->d_scratch, 0, sizeof(int), c->stream));
+  const hipError_t e = lspiv::launch_division_check((int*)c->d_scratch, c->stream);
+  if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+  HIP_TRY(hipMemcpyAsync(mismatches, c->d_scratch, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LSPIV_OK;
 }
 int lspiv_debug_hold_lock(int device, int which, int milliseconds) {
   if (device < 0 || device >= kMaxDevices || which < 0 || which > 2 + DeviceCtx::kProjSlots || milliseconds < 0 || milliseconds > 10000)

@@ -181,6 +181,155 @@ hipError_t launch_project_win(const uint8_t* frames, int64_t src_elems, int n_fr
   return hipGetLastError();
 }
 
+// Plans WITH group means (reducer = "mean", the default: pyorc/project.py:196-199) on uint8 frames (round 6).  The quad-window kernel
+// above serves nearest-neighbour cells only; with a fifth of the cells averaged (a camera at 4/3 of the grid's resolution) fewer
+// than 90 % of the quads fit it and every frame went through the one-cell kernel: 64 B per load instruction, and -- because the
+// lanes of a wave that hold a group take another branch than their neighbours -- every 128-byte line of the output written in
+// two partial stores (WRITE_SIZE 1.8 x the output; profiles/r06_rows_project_before).  This kernel treats EVERY cell as a
+// group: its samples (the group's, or the one nearest-neighbour byte, or none) lie in at most NW 8-byte windows per quad, the
+// host plan gives per cell one byte MASK per window and the sample count.  uint8 samples add up to an integer below 2^24, so
+// the float32 sum of the reference's loop is exact whatever the order: sum = sum over windows of dot4(window word, mask
+// bytes) (v_dot4_u32_u8), value = float(sum) / float(count) -- the reference's one rounding.  Uniform code, one float4 store
+// per quad and frame, 8-byte loads; quads whose samples need more windows go to project_slow_kernel as before.
+// blockIdx.x -> quads: hardware block ids go round the 8 XCDs, so XCD x owns a contiguous eighth of the quads -- its share of
+// the plan (24 or 48 B per quad) stays in its L2 from one frame group to the next, and neighbouring quads' camera lines are its own.
+__device__ __forceinline__ uint32_t mask_bytes(uint32_t nibble) { return (nibble * 0x00204081u) & 0x01010101u; }   // bit i -> byte i
+
+// float(sum) / float(count) without the division sequence: y = RN(1 / c) once per cell, then per frame q = RN(s y),
+// r = s - q c (exact in one fma: s, c small integers), q' = RN(q + r y) -- the correctly rounded quotient for every
+// 0 <= s <= 255 c, 1 <= c <= 255 (checked exhaustively against the division on the device: lspiv_debug_project_division,
+// tests/test_project.py); plans with larger groups send those quads to project_slow_kernel.
+__device__ __forceinline__ float quotient(float s, float c, float y) {
+  const float q = s * y;
+  const float r = __builtin_fmaf(-q, c, s);
+  return __builtin_fmaf(r, y, q);
+}
+__global__ void division_check_kernel(int* __restrict__ mismatches) {
+  const int c = blockIdx.x + 1;                            // 1 .. 255
+  const float cf = (float)c, y = 1.0f / cf;
+  int bad = 0;
+  for (int s = threadIdx.x; s <= 255 * c; s += blockDim.x) {
+    const float sf = (float)s;
+    bad += (quotient(sf, cf, y) != sf / cf);
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+hipError_t launch_division_check(int* d_mismatches, hipStream_t s) {
+  hipLaunchKernelGGL(division_check_kernel, dim3(255), dim3(256), 0, s, d_mismatches);
+  return hipGetLastError();
+}
+
+template <int F, int NW, bool DWORDS>
+__global__ __launch_bounds__(256) void project_mix_kernel(const uint8_t* __restrict__ frames, int64_t src_elems, int n_frames,
+                                                          const int* __restrict__ qwin, const uint32_t* __restrict__ qcell,
+                                                          float* __restrict__ out, int n_out, int blocks_per_xcd) {
+  constexpr int CW = NW / 2;                               // descriptor words per cell: NW = 2: masks | count << 16; NW = 4: masks, count
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  typedef uint64_t u64_u __attribute__((aligned(1)));
+  typedef uint32_t u32x3 __attribute__((ext_vector_type(3), aligned(4)));
+  const int t0 = blockIdx.y * F;
+  const int nt = min(n_frames - t0, F);                    // block-uniform
+  const uint8_t* img = frames + (int64_t)t0 * src_elems;
+  const int nq = n_out >> 2;
+  const int q = (((int)blockIdx.x & 7) * blocks_per_xcd + ((int)blockIdx.x >> 3)) * 256 + (int)threadIdx.x;
+  if (q >= nq) return;
+  int w[NW];
+#pragma unroll
+  for (int k = 0; k < NW; k += 2) {
+    const i32x2 v = *reinterpret_cast<const i32x2*>(qwin + NW * (int64_t)q + k);
+    w[k] = v[0]; w[k + 1] = v[1];
+  }
+  if (w[0] < 0) return;                                    // project_slow_kernel's quad
+  uint32_t mlo[4][NW], mhi[4][NW];
+  float cnt[4], rcp[4];
+  {
+    uint32_t d[4 * CW];
+#pragma unroll
+    for (int k = 0; k < CW; ++k) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(qcell + 4 * CW * (int64_t)q + 4 * k);
+      d[4 * k] = v[0]; d[4 * k + 1] = v[1]; d[4 * k + 2] = v[2]; d[4 * k + 3] = v[3];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t m = d[CW * e];
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        mlo[e][k] = mask_bytes((m >> (8 * k)) & 15u);
+        mhi[e][k] = mask_bytes((m >> (8 * k + 4)) & 15u);
+      }
+      cnt[e] = (float)(NW == 2 ? (m >> 16) : d[CW * e + 1]);
+      rcp[e] = 1.0f / cnt[e];
+    }
+  }
+  // The 8 bytes of a window start at any byte.  One unaligned 8-byte load per lane is what the hardware handles worst in a
+  // gather (a wave's 64 windows lie ~5 bytes apart: every line is looked up for several lanes, and windows that straddle two
+  // dwords cost twice): the three ALIGNED dwords around it in one 12-byte load and two v_alignbyte are 8-10 % faster (measured,
+  // DESIGN.md section 3.5).
+  uint32_t lo[F][NW], hi[F][NW];
+  // (every frame's loads sit with their v_alignbyte under the frame's own `t < nt`: the compiler then waits for one frame after the
+  // other.  Issuing all F frames' gathers back to back -- whole groups without guards -- measured 8 % SLOWER: the limit is the
+  // request pattern of the gather in the L1 / TA, not latency)
+#pragma unroll
+  for (int t = 0; t < F; ++t)
+    if (t < nt) {
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        const uint8_t* p = img + (int64_t)t * src_elems + w[k];
+        if (DWORDS) {
+          // ONE aligned 12-byte load (global_load_dwordx3) of the three dwords the window touches (the plan keeps them inside the
+          // frame: a window whose third dword would leave it sends its quad to project_slow_kernel)
+          const u32x3 d = *reinterpret_cast<const u32x3*>(img + (int64_t)t * src_elems + (w[k] & ~3));
+          const uint32_t sh = (uint32_t)w[k] & 3u;
+          lo[t][k] = __builtin_amdgcn_alignbyte(d[1], d[0], sh);
+          hi[t][k] = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
+        } else {
+          const uint64_t v = *reinterpret_cast<const u64_u*>(p);
+          lo[t][k] = (uint32_t)v; hi[t][k] = (uint32_t)(v >> 32);
+        }
+      }
+    }
+  float* dst = out + (int64_t)t0 * n_out + 4 * (int64_t)q;
+#pragma unroll
+  for (int t = 0; t < F; ++t)
+    if (t < nt) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+          sum = __builtin_amdgcn_udot4(lo[t][k], mlo[e][k], sum, false);
+          sum = __builtin_amdgcn_udot4(hi[t][k], mhi[e][k], sum, false);
+        }
+        v[e] = quotient((float)sum, cnt[e], rcp[e]);       // the reference's acc / count (a cell without samples: 0 / 1)
+      }
+      *reinterpret_cast<f32x4*>(dst + (int64_t)t * n_out) = v;
+    }
+}
+
+hipError_t launch_project_mix(const uint8_t* frames, int64_t src_elems, int n_frames, int nw, const int* qwin, const uint32_t* qcell,
+                              const int* slow_q, int n_slow, const int* nn_src, const int* grp_of, const int* grp_off,
+                              const int* grp_src, float* out, int n_out, hipStream_t s) {
+  if (n_frames <= 0 || n_out <= 0) return hipSuccess;
+  constexpr int F = 8;
+  static const bool unaligned = getenv("LSPIV_PROJECT_MIX_UNALIGNED") && atoi(getenv("LSPIV_PROJECT_MIX_UNALIGNED")) != 0;   // A/B: one unaligned 8-byte load per window
+  const bool dwords = !unaligned && src_elems >= 12 && (src_elems & 3) == 0 && (reinterpret_cast<uintptr_t>(frames) & 3) == 0;
+  const int nq = n_out / 4;
+  const int per_xcd = ((nq + 255) / 256 + 7) / 8;
+#define LSPIV_MIX(NN, DD)                                                                                                            \
+  hipLaunchKernelGGL((project_mix_kernel<F, NN, DD>), dim3((unsigned)(8 * per_xcd), (unsigned)((n_frames + F - 1) / F)), dim3(256), 0, s, \
+                     frames, src_elems, n_frames, qwin, qcell, out, n_out, per_xcd)
+  if (nw == 2) { if (dwords) LSPIV_MIX(2, true); else LSPIV_MIX(2, false); }
+  else { if (dwords) LSPIV_MIX(4, true); else LSPIV_MIX(4, false); }
+#undef LSPIV_MIX
+  if (n_slow > 0)
+    hipLaunchKernelGGL((project_slow_kernel<F>), dim3((unsigned)((4 * n_slow + 255) / 256), (n_frames + F - 1) / F), dim3(256), 0, s, frames,
+                       src_elems, n_frames, slow_q, n_slow, nn_src, grp_of, grp_off, grp_src, out, n_out);
+  return hipGetLastError();
+}
+
 // Nearest-neighbour-only plans (Frames.project with a reducer other than "mean", pyorc/project.py:196-199) on uint8 frames:
 // every cell is a source byte or 0, so the stack may stay uint8 -- a quarter of the float32 bytes to write here and for the
 // PIV kernels to read, and get_piv runs its uint8 kernels on the same values.  Quads of the window plan as above (one

@@ -300,3 +300,41 @@ def test_gpu_project_cv_matches_oracle(gpu, dtype):
     p.close()
     with pytest.raises(_lib.LspivError):
         ProjectionCV((480, 640), (10, 10), Kc, [0.1, 0.2, 0.3], M)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src,dst,tilt", [((270, 480), (200, 360), 0.1),      # ~4/3 oversampling: a fifth of the cells are means, two windows per quad
+                                          ((540, 960), (200, 360), 0.3),      # > 2 : 1: most cells are means of 2 .. 9 pixels in 2 .. 3 rows: four windows
+                                          ((270, 480), (200, 360), 0.9)])     # strong perspective: both regimes in one plan
+def test_gpu_projection_with_group_means_through_the_mixed_plan(gpu, src, dst, tilt):
+    """Round 6: uint8 frames through a plan WITH group means run project_mix_kernel (every cell a masked sum over at most NW 8-byte
+    windows, integer sums, one IEEE division) + project_slow_kernel for the quads that need more windows.  Bit-exact against the
+    oracle's literal loops, for frame counts around the kernel's 8-frame groups, and equal to the one-cell kernel (float32 frames
+    holding the same values take that one)."""
+    from pyorc_amd.project import Projection
+
+    idx_img, mask, src_idx, uidx, norm_idx = projection_maps(src, dst, tilt=tilt, seed=3)
+    assert len(uidx) > 0.05 * dst[0] * dst[1]
+    rng = np.random.default_rng(7)
+    p = Projection(src, dst, idx_img, mask, src_idx, uidx, norm_idx)
+    for T in (1, 7, 8, 9, 17):
+        fr = (rng.random((T,) + src) * 256).astype(np.uint8)
+        fr[0, :3] = 255                                                   # saturated rows: the largest sums
+        got = p.project_frames(fr)
+        ref = pro.project_frames(fr, dst, idx_img, mask, src_idx, uidx, norm_idx)
+        assert got.dtype == np.float32 and np.array_equal(got.astype(np.float64), ref), T
+        assert np.array_equal(p.project_frames(fr.astype(np.float32)), got)   # the one-cell kernel on the same values
+    p.close()
+
+
+@pytest.mark.gpu
+def test_gpu_division_free_quotient_is_the_division(gpu):
+    """project_mix_kernel replaces float(sum) / float(count) by a reciprocal and two fused multiply-adds: exhaustively equal to the
+    division for every sum of c uint8 samples, c = 1 .. 255 (8.3 million cases, on the device)."""
+    import ctypes as C
+
+    from pyorc_amd import _lib
+
+    bad = C.c_int(-1)
+    _lib.check(gpu.lspiv_debug_project_division(C.byref(bad)))
+    assert bad.value == 0
