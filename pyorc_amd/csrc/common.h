@@ -457,9 +457,10 @@ inline WalkSegments walk_segments(uint32_t n_pairs, int64_t pair_offset, uint32_
 // concurrent lane groups of a kernel that runs `waves_per_simd` waves with `groups` jobs per wave (CU count queried once)
 uint32_t job_slots(int waves_per_simd, int groups);
 // lane_major_n: 0 = the partial sums are fft-shifted row-major planes like corr_sum; N = the N x N slots of the 64 x 64 walking
-// ensemble kernel, element (row y, column x) at slot[(x / 4) * 4 N + y * 4 + x % 4], un-shifted (piv_fft_impl.h, slot_accumulate)
+// ensemble kernel, element (row y, column x) at slot[(x / 4) * 4 N + y * 4 + x % 4], un-shifted (piv_fft_impl.h, slot_accumulate);
+// split_halves: the first and the second half of every slot live in two arrays, all first halves, then all second halves (kEnsSplitHalves)
 hipError_t launch_ensemble_merge(const float* part_sum, const float* part_cnt, uint32_t n_seg, uint32_t n_win, int plane_elems,
-                                 float* corr_sum, float* corr_count, hipStream_t s, int lane_major_n = 0);
+                                 float* corr_sum, float* corr_count, hipStream_t s, int lane_major_n = 0, bool split_halves = false);
 hipError_t launch_ensemble_mean(const float* sum, const float* count, float min_count, uint32_t n_win,
                                 int plane_elems, float* mean, hipStream_t s);
 // orthoprojection gather (project.hip) and int16 result packing

@@ -154,6 +154,12 @@ __device__ __forceinline__ float tree_sum(const float (&x)[N]) {
   return s[0];
 }
 
+#ifndef LSPIV_ENS64_NT
+#define LSPIV_ENS64_NT 0   // 1: non-temporal frame loads in the 64 x 64 ensemble kernel (RowRaw::fetch<NT>).  Measured and left OFF (round 6):
+                           // written bytes 26.9 -> 21.4 GB only, fetched 3.3 -> 15.4 GB (the 75 % overlap of the windows lives on L2 hits
+                           // of the frame lines, which non-temporal loads give up), 28.7 -> 31.5 ms.  What evicts the slots is their own
+                           // address pattern, not the frames: see kEnsSplitHalves below
+#endif
 // ---- one tile row as fetched from HBM -----------------------------------------------------------
 // uint8 rows are N/4 dwords, cheap enough to prefetch for BOTH windows of a job before any arithmetic
 // starts; float rows are N..2N dwords, so only their address is kept and the load is issued where the
@@ -168,10 +174,13 @@ template <int N>
 struct RowRaw<uint8_t, N> {
   static constexpr int W = (N + 3) / 4;   // N % 4 == 2: the last word holds two samples and two zero bytes
   uint32_t w[W];
+  // NT: non-temporal loads -- the frame bytes stream through the L2 without displacing what lives there (an A/B switch of the 64 x 64
+  // ensemble kernel, LSPIV_ENS64_NT; off: it costs the frame lines' own reuse more than it saves)
+  template <bool NT = false>
   __device__ __forceinline__ void fetch(const uint8_t* q) {
 #pragma unroll
     for (int k = 0; k < N / 16; ++k) {
-      const u32x4 v = *reinterpret_cast<const u32x4_u*>(q + 16 * k);
+      const u32x4 v = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_u*>(q + 16 * k)) : *reinterpret_cast<const u32x4_u*>(q + 16 * k);
       w[4 * k] = v[0]; w[4 * k + 1] = v[1]; w[4 * k + 2] = v[2]; w[4 * k + 3] = v[3];
     }
     constexpr int done = N / 16 * 16;
@@ -1174,6 +1183,23 @@ template <int N> constexpr bool kEnsLdsRmw = LSPIV_ENS_LDS_RMW && N == 64;
 #define LSPIV_ENS_HALF_ACC 1
 #endif
 template <int N> constexpr bool kEnsHalfAcc = LSPIV_ENS_HALF_ACC && kEnsLdsRmw<N>;
+// Round 6: why do ~27 GB of stores per 1000 pairs reach HBM when the hot halves of an XCD's ~256 live slots are
+// 2 MB in a 4 MB L2?  What was established (tools/ubench/l2_rmw.hip + rocprofv3 WRITE_SIZE; A/B builds of this kernel):
+//   * the L2 IS write-back: 2 MB per XCD re-written 500 times reach HBM once (0.017 GB for 8.4 GB stored), also with 55 us between
+//     two passes (no ageing of dirty lines) and also when the read is a global_load_lds_dwordx4 like here;
+//   * a stream of plain loads next to the slots evicts them (7.0 GB written back at 2 stream bytes per slot byte, 0.018 GB at 1/8),
+//     non-temporal loads do not (0.35 GB) -- but in THIS kernel non-temporal frame loads (LSPIV_ENS64_NT) save 20 % of the written
+//     bytes and quintuple the fetched ones (26.9 -> 21.4 GB, 3.3 -> 15.4 GB, 28.7 -> 31.5 ms): the frames are not what evicts;
+//   * hot bytes that are the upper 8 KB of every 16 KB (address bit 13 set: half the sets) are written back 78 x as often in the
+//     micro-benchmark as contiguous ones -- but the split layout below (all cold halves, then all hot halves) moves nothing here:
+//     27.26 vs 27.48 GB written, 30.18 vs 30.19 ms, same bits (tools/sessions_ens64_ab.sh).
+// So: neither a write-through L2, nor the frame stream, nor the slots' address pattern, nor the LDS-direct loads.  Every store of the
+// hot half still reaches the fabric although its line is re-read from the L2 an iteration later (hit rate 95 %); the kernel does not
+// wait for those bytes (VALU-bound).  Dead end recorded; both switches stay for whoever looks next.
+#ifndef LSPIV_ENS_SPLIT_HALVES
+#define LSPIV_ENS_SPLIT_HALVES 0
+#endif
+template <int N> constexpr bool kEnsSplitHalves = LSPIV_ENS_SPLIT_HALVES && kEnsHalfAcc<N>;
 constexpr int kEnsHalfAccWaveDwords = kHalfTileDwords + 2048;   // tile | half accumulator (lane-ordered: (j / 4) * 256 + lane * 4 + j % 4, j < 32)
 typedef float __attribute__((address_space(1))) * GlobalF32;
 typedef float __attribute__((address_space(3))) * LdsF32;
@@ -1206,13 +1232,14 @@ __device__ __forceinline__ void slot_prefetch_lds(GlobalF32 slot, float* buf) { 
   }
 }
 // the half-accumulator variant: only the slot's second 8 KB (columns 32 .. 63) come in, to the start of the (half) tile
+// (`slot`: the address of the slot's UPPER half -- slot + 8 KB in the interleaved layout, the slot's entry of the hot array in the split one)
 __device__ __forceinline__ void slot_prefetch_lds_upper(GlobalF32 slot, float* buf) {
   const uint32_t voff = (threadIdx.x & 63u) * 16u;
   const uint32_t lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uintptr_t)(LdsF32)buf);
   __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the transpose's own reads of the tile have returned
 #pragma unroll
   for (int qq = 0; qq < 2; ++qq) {
-    const uint64_t base = reinterpret_cast<uint64_t>(slot) + 8192u + (uint64_t)qq * 4096u;
+    const uint64_t base = reinterpret_cast<uint64_t>(slot) + (uint64_t)qq * 4096u;
     const uint32_t l = lds + qq * 4096u;
     uint32_t m0_saved;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
@@ -1258,6 +1285,7 @@ __device__ __forceinline__ void slot_accumulate(GlobalF32 slot, const float* buf
 
 // the half-accumulator variant of slot_accumulate: columns 0 .. 31 read-modify-write `hacc` (LDS, stays), columns 32 .. 63 take the
 // prefetched upper half of the slot from the tile and go back to HBM
+// (`slot`: the slot's UPPER half, as for slot_prefetch_lds_upper)
 __device__ __forceinline__ void slot_accumulate_half(GlobalF32 slot, const float* buf, float* hacc, const float (&c0)[64], bool keep0,
                                                      const float (&c1)[64], bool keep1, bool init_) {
   const int lane = threadIdx.x & 63;
@@ -1287,7 +1315,7 @@ __device__ __forceinline__ void slot_accumulate_half(GlobalF32 slot, const float
 #pragma unroll
       for (int e = 0; e < 4; ++e) a[k][e] = fmaf(c1[4 * q + e], m1, fmaf(c0[4 * q + e], m0, a[k][e]));
     }
-    slot_store4(reinterpret_cast<uint64_t>(slot) + (uint64_t)qq * 4096u, voff, a);
+    slot_store4(reinterpret_cast<uint64_t>(slot) + (uint64_t)(qq - 2) * 4096u, voff, a);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -1416,8 +1444,13 @@ __device__ __forceinline__ void walk_iteration(const PivParams& p, const T* row,
     dead1 = inv1 == 0.0f;
   } else {
     RowRaw<T, N> raw0, raw1;
-    raw0.fetch(row);
-    raw1.fetch(has2 ? row + p.frame_elems : row);
+    if constexpr (sizeof(T) == 1 && HALF_TILE && LSPIV_ENS64_NT) {   // the 64 x 64 ensemble kernel: frames past the L2-resident slots
+      raw0.template fetch<true>(row);
+      raw1.template fetch<true>(has2 ? row + p.frame_elems : row);
+    } else {
+      raw0.fetch(row);
+      raw1.fetch(has2 ? row + p.frame_elems : row);
+    }
     prepare_one<T, N, WANT_NZ>(raw0, xr, p.nz_positive != 0, p.std_gain, nz0, fin0, dead0);
     LSPIV_WALK_SB;
     prepare_one<T, N, WANT_NZ>(raw1, xi, p.nz_positive != 0, p.std_gain, nz1, fin1, dead1);
@@ -1974,8 +2007,11 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsBound<T, N, WANT_NZ>)) void piv_fft
   // the job's partial-sum slot is that of its (segment, WINDOW): ensemble_merge_kernel adds the segments' slots of a window in
   // segment order, whatever order the jobs ran in (strip_order permutes the windows of a segment)
   const uint32_t pslot = seg * p.n_win + win;
-  float* part = p.part_sum + (size_t)pslot * G::NN;
+  float* part = p.part_sum + (size_t)pslot * (kEnsSplitHalves<N> ? G::NN / 2 : G::NN);      // split: the slot's entry of the cold array
   const GlobalF32 part_u = kEnsLdsRmw<N> ? uniform_global_ptr(part) : nullptr;   // one job per wave: the slot pointer lives in SGPRs
+  // the half that is re-written every iteration: the slot's entry of the hot array (split layout), or its second 8 KB
+  const GlobalF32 part_hi = !kEnsHalfAcc<N> ? part_u
+                            : uniform_global_ptr(kEnsSplitHalves<N> ? p.part_sum + ((size_t)p.n_seg * p.n_win + pslot) * (G::NN / 2) : part + G::NN / 2);
   const bool win_dropped = WANT_NZ && p.win_keep && !p.win_keep[win];
   float cnt = 0.0f;
   float acc[kEnsRegAcc<N> ? N : 1];
@@ -1991,7 +2027,7 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsBound<T, N, WANT_NZ>)) void piv_fft
     float xr[N], xi[N], mean[2];
     bool skip[2], keep[2], dead[2];
     walk_iteration<T, N, WANT_NZ, kEnsRelax<T, N>, kEnsHalfAcc<N>>(p, row, has2, buf, lg, partner_byte, lane0_byte, carry, xr, xi, mean[0], mean[1], skip[0], skip[1],
-                                                   dead[0], dead[1], (kEnsLdsRmw<N> && !first) ? part_u : nullptr, kEnsLdsRmw<N>);
+                                                   dead[0], dead[1], (kEnsLdsRmw<N> && !first) ? part_hi : nullptr, kEnsLdsRmw<N>);
     if (WANT_NZ && win_dropped) skip[0] = skip[1] = true;
     const bool valid[2] = {job_valid && f > p0, job_valid && has2};
     float vmaxs[2];
@@ -2032,7 +2068,7 @@ __global__ __launch_bounds__(BLOCK, (kWalkEnsBound<T, N, WANT_NZ>)) void piv_fft
       }
     } else if constexpr (kEnsLdsRmw<N>) {
       if constexpr (kEnsHalfAcc<N>) {
-        if (job_valid) slot_accumulate_half(part_u, buf, hacc, xr, keep[0], xi, keep[1], first);
+        if (job_valid) slot_accumulate_half(part_hi, buf, hacc, xr, keep[0], xi, keep[1], first);
         else __builtin_amdgcn_s_waitcnt(0x0F70);
       } else if (job_valid) slot_accumulate<N>(part_u, buf, xr, keep[0], xi, keep[1], first);
       else __builtin_amdgcn_s_waitcnt(0x0F70);   // (a job past the end stores nothing, but its prefetch still has to land before the tile is reused)
@@ -2074,7 +2110,7 @@ static hipError_t launch_t(const PivParams& p, bool ensemble, hipStream_t s) {
                        dim3(BLOCK), ens_lds, s, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_ensemble_merge(p.part_sum, p.part_cnt, p.n_seg, p.n_win, G::NN, p.corr_sum, p.corr_count, s, kEnsLdsRmw<N> ? N : 0);
+    return launch_ensemble_merge(p.part_sum, p.part_cnt, p.n_seg, p.n_win, G::NN, p.corr_sum, p.corr_count, s, kEnsLdsRmw<N> ? N : 0, kEnsSplitHalves<N>);
   }
   if (ensemble) {
     const uint32_t jobs = p.n_win;

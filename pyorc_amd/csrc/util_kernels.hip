@@ -24,7 +24,7 @@ __global__ void ensemble_mean_kernel(const float* sum, const float* count, float
 template <bool LANE_MAJOR>
 __global__ __launch_bounds__(256) void ensemble_merge_kernel(const float* __restrict__ part_sum, const float* __restrict__ part_cnt,
                                                              uint32_t n_seg, int64_t n_elems, uint32_t n_win, int n,
-                                                             float* __restrict__ corr_sum, float* __restrict__ corr_count) {
+                                                             float* __restrict__ corr_sum, float* __restrict__ corr_count, int split) {
   // four consecutive elements per thread (the planes of the even window sizes hold a multiple of four samples): 16-byte loads of
   // every segment's slot
   const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -38,7 +38,14 @@ __global__ __launch_bounds__(256) void ensemble_merge_kernel(const float* __rest
       const int ip = y + h >= n ? y + h - n : y + h, jp = x + h >= n ? x + h - n : x + h;   // (x + 3 stays in the same half: h is a multiple of 4)
       float* dst = corr_sum + win * nn + ip * n + jp;
       f4 acc = *reinterpret_cast<const f4*>(dst);
-      for (uint32_t sg = 0; sg < n_seg; ++sg) acc += *reinterpret_cast<const f4*>(part_sum + (int64_t)sg * n_elems + i);
+      if (split) {
+        // slot (segment, window) = two entries of nn / 2 floats: the cold array (elements below nn / 2), then the hot array
+        const int half = nn / 2, eh = e >= half ? e - half : e;
+        const float* arr = part_sum + (e >= half ? (int64_t)n_seg * n_win * half : 0) + win * half + eh;
+        for (uint32_t sg = 0; sg < n_seg; ++sg) acc += *reinterpret_cast<const f4*>(arr + (int64_t)sg * n_win * half);
+      } else {
+        for (uint32_t sg = 0; sg < n_seg; ++sg) acc += *reinterpret_cast<const f4*>(part_sum + (int64_t)sg * n_elems + i);
+      }
       *reinterpret_cast<f4*>(dst) = acc;
     } else {
       f4 acc = *reinterpret_cast<const f4*>(corr_sum + i);
@@ -55,15 +62,15 @@ __global__ __launch_bounds__(256) void ensemble_merge_kernel(const float* __rest
 }
 
 hipError_t launch_ensemble_merge(const float* part_sum, const float* part_cnt, uint32_t n_seg, uint32_t n_win, int plane_elems,
-                                 float* corr_sum, float* corr_count, hipStream_t s, int lane_major_n) {
+                                 float* corr_sum, float* corr_count, hipStream_t s, int lane_major_n, bool split_halves) {
   const int64_t n_elems = (int64_t)n_win * plane_elems;
   if (n_elems == 0) return hipSuccess;
   if (plane_elems % 4 != 0) return hipErrorInvalidValue;   // (walking kernels: even window sizes only)
   const dim3 grid((unsigned)std::max<int64_t>((n_elems / 4 + 255) / 256, ((int64_t)n_win + 255) / 256));
   if (lane_major_n)
-    hipLaunchKernelGGL(ensemble_merge_kernel<true>, grid, dim3(256), 0, s, part_sum, part_cnt, n_seg, n_elems, n_win, lane_major_n, corr_sum, corr_count);
+    hipLaunchKernelGGL(ensemble_merge_kernel<true>, grid, dim3(256), 0, s, part_sum, part_cnt, n_seg, n_elems, n_win, lane_major_n, corr_sum, corr_count, split_halves ? 1 : 0);
   else
-    hipLaunchKernelGGL(ensemble_merge_kernel<false>, grid, dim3(256), 0, s, part_sum, part_cnt, n_seg, n_elems, n_win, 0, corr_sum, corr_count);
+    hipLaunchKernelGGL(ensemble_merge_kernel<false>, grid, dim3(256), 0, s, part_sum, part_cnt, n_seg, n_elems, n_win, 0, corr_sum, corr_count, 0);
   return hipGetLastError();
 }
 
