@@ -56,6 +56,8 @@ def build_rows(lib, T: int):
     rows = {
         "project": (lambda: p_mean.project_frames_dev(d_cam.value, np.uint8, T, d_f32.value), T * (n + 4 * no), T, "project_",
                     f"Frames.project(method='numpy', reducer='mean'): {H}x{W} uint8 camera -> {HO}x{WO} float32 ortho, quad-window plan + group means"),
+        "project_nn": (lambda: p_nn.project_frames_dev(d_cam.value, np.uint8, T, d_f32.value), T * (n + 4 * no), T, "project_",
+                       "Frames.project(method='numpy') with a reducer other than 'mean': nearest neighbour only, the uint8 quad-window plan, float32 out"),
         "project_u8": (lambda: p_nn.project_frames_dev(d_cam.value, np.uint8, T, d_u8.value, keep_uint8=True), T * (n + no), T, "project_",
                        "nearest-neighbour-only plan (reducer other than 'mean'), uint8 in -> uint8 out"),
         "project_cv": (lambda: _lib.check(lib.lspiv_project_cv_frames_dev(p_cv._h, d_cam, 0, T, d_u8, None)), T * (n + no), T, "remap_",
@@ -75,6 +77,12 @@ def build_rows(lib, T: int):
             lib.lspiv_dev_free(p)
 
     return rows, cleanup
+
+
+def row_read_bytes(name: str, T: int) -> int:
+    """Input bytes a launch of this row cannot avoid reading (every input sample once): what FETCH_SIZE is calibrated against."""
+    n = H * W
+    return T * n
 
 
 def time_launches(lib, launch, reps: int) -> float:
