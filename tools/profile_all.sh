@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 4 / 5: the committed profile sets (per-timestep C2 / C3 / C4 / float32, the two ensemble kernels), the rescue cost of the
-# ensemble finish, and the bench line -- usage: gpu_round5_profiles.sh <tag>   (tag r05 -> profiles/r05_*)
+# the committed profile sets (rounds 4 - 6) (per-timestep C2 / C3 / C4 / float32, the two ensemble kernels), the rescue cost of the
+# ensemble finish, and the bench line -- usage: profile_all.sh <tag>   (tag r06 -> profiles/r06_*)
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd $R
 mkdir -p gpurun_out/${TAG}_out
 python tools/ens_rescue_cost.py 1000 2>&1 | tail -4 | tee gpurun_out/${TAG}_out/ens_rescue_cost.log

@@ -25,5 +25,10 @@ case $NAME in
       cp profiles/r06_rows_${row}_summary.json $OUT/ 2>/dev/null
       for f in gpurun_out/prof_r06_rows_$row/trace_kernel_stats.csv; do cp $f $OUT/r06_rows_${row}_trace_kernel_stats.csv 2>/dev/null; done
     done;;
+  profiles)     # the whole committed profile set of a round: PIV configs + ensemble kernels (tools/profile_all.sh), then the rows
+    bash tools/profile_all.sh ${TAG:-r06} > $OUT/profile_all.log 2>&1; tail -25 $OUT/profile_all.log
+    mkdir -p $OUT/profiles; cp profiles/${TAG:-r06}_* $OUT/profiles/ 2>/dev/null
+    for d in gpurun_out/prof_${TAG:-r06}_*; do t=$(basename $d | sed 's/^prof_//'); for f in $d/*counter_collection.csv $d/trace_kernel_stats.csv; do [ -f $f ] && cp $f $OUT/profiles/${t}_$(basename $f | sed 's/_counter_collection/_counter_collection/'); done; done
+    NAME=rows bash tools/session.sh rows > $OUT/rows.log 2>&1; tail -8 gpurun_out/rows/rows.log;;
   *) echo "unknown session $NAME"; exit 2;;
 esac
