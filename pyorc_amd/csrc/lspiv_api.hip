@@ -100,7 +100,12 @@ struct DeviceCtx {
   // its own lock (DeviceLocks::project), none of them shared with the PIV host entry points -- a project_hip block that dask runs
   // on a worker thread neither waits for the `host` lock a PIV call holds for its whole upload + kernels + download, nor for the
   // other block in flight: block k + 1 crosses PCIe while block k's kernel runs and its result goes back
-  struct ProjWs { hipStream_t stream = nullptr; void* d_in = nullptr; size_t in_cap = 0; void* d_out = nullptr; size_t out_cap = 0; };
+  // pin[2]: pinned bounce buffers of kProjPinBytes each -- the frames of a block go up and its result comes down in slices through
+  // them (staging threads on one slice, DMA on the other): a pageable hipMemcpyAsync moved a block's 93 MB of float32 result at a
+  // few GB/s, which WAS the time of the generic project_hip -> get_piv path (bench.py: dropin_generic_path)
+  struct ProjWs { hipStream_t stream = nullptr; void* d_in = nullptr; size_t in_cap = 0; void* d_out = nullptr; size_t out_cap = 0;
+                  void* pin[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; };
+  static constexpr size_t kProjPinBytes = (size_t)16 << 20;
   static constexpr int kProjSlots = 2;
   ProjWs proj[kProjSlots];
   bool arch_ok = false;
@@ -493,14 +498,49 @@ static int project_host(size_t ib, size_t ob, const void* frames, void* out, Lau
   if (rc) return rc;
   rc = ensure(&w->d_out, &w->out_cap, ob);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(w->d_in, frames, ib, hipMemcpyHostToDevice, w->stream));
+  for (int k = 0; k < 2; ++k) {
+    if (!w->pin[k]) HIP_TRY(hipHostMalloc(&w->pin[k], DeviceCtx::kProjPinBytes, hipHostMallocDefault));
+    if (!w->ev[k]) HIP_TRY(hipEventCreateWithFlags(&w->ev[k], hipEventDisableTiming));
+  }
+  const size_t slice = DeviceCtx::kProjPinBytes;
+  const bool in_pinned = is_pinned(frames), out_pinned = is_pinned(out);
+  // up: staging threads copy slice k into one pinned buffer while the DMA of slice k - 1 drains the other
+  if (in_pinned) {
+    HIP_TRY(hipMemcpyAsync(w->d_in, frames, ib, hipMemcpyHostToDevice, w->stream));
+  } else {
+    int k = 0;
+    for (size_t off = 0; off < ib; off += slice, ++k) {
+      const size_t nb = std::min(slice, ib - off);
+      if (k >= 2) HIP_TRY(hipEventSynchronize(w->ev[k & 1]));
+      staged_copy(w->pin[k & 1], (const char*)frames + off, nb);
+      HIP_TRY(hipMemcpyAsync((char*)w->d_in + off, w->pin[k & 1], nb, hipMemcpyHostToDevice, w->stream));
+      HIP_TRY(hipEventRecord(w->ev[k & 1], w->stream));
+    }
+  }
   TraceSpan span;
   trace_begin(&span, LSPIV_TRACE_PROJECT_HOST, w->stream);
   rc = launch(w->d_in, w->d_out, w->stream);
   if (rc) return rc;
   trace_end(&span, w->stream);
-  HIP_TRY(hipMemcpyAsync(out, w->d_out, ob, hipMemcpyDeviceToHost, w->stream));
-  HIP_TRY(hipStreamSynchronize(w->stream));
+  // down: the DMA of slice k fills one pinned buffer while the staging threads copy slice k - 1 out of the other
+  if (out_pinned) {
+    HIP_TRY(hipMemcpyAsync(out, w->d_out, ob, hipMemcpyDeviceToHost, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    return LSPIV_OK;
+  }
+  const size_t n_slices = (ob + slice - 1) / slice;
+  for (size_t k = 0; k <= n_slices; ++k) {
+    if (k < n_slices) {
+      const size_t off = k * slice, nb = std::min(slice, ob - off);
+      HIP_TRY(hipMemcpyAsync(w->pin[k & 1], (const char*)w->d_out + off, nb, hipMemcpyDeviceToHost, w->stream));
+      HIP_TRY(hipEventRecord(w->ev[k & 1], w->stream));
+    }
+    if (k >= 1) {
+      const size_t off = (k - 1) * slice, nb = std::min(slice, ob - off);
+      HIP_TRY(hipEventSynchronize(w->ev[(k - 1) & 1]));
+      staged_copy((char*)out + off, w->pin[(k - 1) & 1], nb);
+    }
+  }
   return LSPIV_OK;
 }
 

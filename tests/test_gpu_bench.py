@@ -45,7 +45,7 @@ def test_bench_json_contract_single_gpu(gpu):
 def test_bench_launches_its_own_ranks_and_gathers_over_the_native_comm(gpu):
     """`python bench.py --gpus 2` starts two ranks itself; on a 1-GPU box they share the device over the shared-memory
     transport (LSPIV_BENCH_SAME_DEVICE): sharding, pipelined all-gather, max-over-ranks timing and the bit check."""
-    d = run_bench(SMALL + ["--gpus", "2"], {"LSPIV_BENCH_SAME_DEVICE": "1"})
+    d = run_bench(SMALL + ["--gpus", "2", "--strong-pairs", "300"], {"LSPIV_BENCH_SAME_DEVICE": "1"})
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
     comm = d["config"]["comm"]
     assert comm["transport"] == "shm" and comm["ranks_reported_by_transport"] == 2
@@ -59,6 +59,10 @@ def test_bench_launches_its_own_ranks_and_gathers_over_the_native_comm(gpu):
     assert comm["kernel_ms_while_gather_in_flight"] > 0 and comm["gather_ms_overlapped"] > 0 and comm["gather_stream_priority"] == "high"
     assert abs(comm["exposed_comm_ms"] - (d["ms_per_step"] - comm["kernel_ms_while_gather_in_flight"])) < 1e-3
     assert d["config"]["binary"]["binary_hash_matches"] is True
+    # round 6: the weak line also carries ONE strong pass -- north_star's reading -- timed after the weak region:
+    # a fixed total cut over the ranks on the anchors (300 pairs of this small grid, anchors of 25: 150 + 150)
+    assert comm["strong_pairs_total"] == 300 and comm["strong_pairs_rank0"] == 150 and comm["strong_ms_per_step"] > 0
+    assert abs(comm["strong_pairs_per_s"] - 300 / (comm["strong_ms_per_step"] * 1e-3)) / comm["strong_pairs_per_s"] < 1e-3
 
 
 @pytest.mark.gpu
