@@ -569,6 +569,11 @@ struct lspiv_projection {
   // windows, per cell one byte mask per window and the sample count; nullptr: not built
   int* d_mwin = nullptr; uint32_t* d_mcell = nullptr; int mix_nw = 0;
   int* d_mslow = nullptr; int n_mslow = 0;
+  // tiled form of the mixed plan (project_tile_kernel): per wave -- a block of 2^tile_lg x 64 / 2^tile_lg quads -- the sorted list of
+  // the 8-byte chunks of the camera frame its windows touch (64 * tile_rmax entries, lane l loads entry l), parked in LDS; the windows
+  // of its quads as byte offsets into that tile; nullptr: not built
+  int* d_wchunk = nullptr; int* d_twin = nullptr; int tile_rmax = 0, tile_lg = 6, tile_wq = 0, tile_rows = 0;
+  int* d_tslow = nullptr; int n_tslow = 0;
   int64_t n_groups = 0;                       // 0: nearest neighbour only -- uint8 frames may stay uint8 (lspiv_project_frames_u8)
 };
 
@@ -1735,7 +1740,8 @@ int lspiv_projection_create(int64_t src_h, int64_t src_w, int64_t dst_h, int64_t
   // mixed plan (round 6): a plan with group means, uint8 frames.  Every cell is a set of samples (its group in the reference's
   // order, else its nearest-neighbour byte, else nothing); the samples of a quad are covered greedily with 8-byte windows over
   // the FLAT source index; a quad fits with at most NW windows and at most 255 samples per cell.
-  if (e == hipSuccess && G > 0 && n_out % 4 == 0 && n_src >= 16 && !getenv("LSPIV_PROJECT_ONE_CELL") && !getenv("LSPIV_PROJECT_NO_MIX")) {
+  // (nearest-neighbour-only plans too: a group of one sample -- their float32 output goes through the same tiled kernel)
+  if (e == hipSuccess && n_out % 4 == 0 && n_src >= 16 && !getenv("LSPIV_PROJECT_ONE_CELL") && !getenv("LSPIV_PROJECT_NO_MIX")) {
     const size_t nq = (size_t)n_out / 4;
     std::vector<int> need(nq, 0);
     std::vector<int> px;
@@ -1776,6 +1782,9 @@ int lspiv_projection_create(int64_t src_h, int64_t src_w, int64_t dst_h, int64_t
     }
     const int NW = over2 * 50 <= nq ? 2 : 4;                 // at most 2 % of the quads left to the slow kernel: two windows will do
     const size_t left = NW == 2 ? over2 : over4;
+    if (getenv("LSPIV_PROJECT_DEBUG"))
+      fprintf(stderr, "lspiv projection: %zu quads, %zu need more than two 8-byte windows, %zu more than four: %s\n", nq, over2, over4,
+              left * 10 <= nq ? (NW == 2 ? "mixed plan, two windows" : "mixed plan, four windows") : "no mixed plan");
     if (left * 10 <= nq) {                                   // otherwise the geometry is too scattered for windows: the one-cell kernel
       const int CW = NW / 2;
       std::vector<int> mwin(nq * NW, 0), mslow;
@@ -1817,6 +1826,118 @@ int lspiv_projection_create(int64_t src_h, int64_t src_w, int64_t dst_h, int64_t
       if (e == hipSuccess) e = up(&h->d_mslow, mslow);
       h->n_mslow = (int)mslow.size();
       h->mix_nw = NW;
+      // tiled form (project_tile_kernel): a wave owns a block of 64 quads, BQX = 2^lg quads wide and 64 / BQX rows high (grids whose
+      // rows are not whole quads: 64 consecutive quads of the flat index), and loads the sorted list of the 8-byte chunks its
+      // windows touch -- the three dwords around a window lie in chunk c0 = (start & ~3) >> 3 and c0 + 1, neighbours in the list.
+      // One list row (64 chunks) when all but 1 in 100 waves fit, else two, else four (2 : 1 oversampling and beyond); among the
+      // shapes with the shortest lists the one with the fewest chunks wins; waves beyond the list hand their quads to the slow
+      // kernel; more than 1 in 100 beyond four rows: no tiles (project_mix_kernel serves the plan).
+      if (e == hipSuccess && n_src % 8 == 0 && n_src / 8 < (int64_t)1 << 31 && !getenv("LSPIV_PROJECT_NO_TILE")) {
+        std::vector<int> qch(nq * NW, -1);                   // per quad and window: c0, or -1 (window unused / quad not served)
+        for (size_t q = 0; q < nq; ++q) {
+          if (mwin[q * NW] < 0) continue;
+          for (int j = 0; j < NW; ++j) {
+            uint32_t m = 0;                                  // window j's masks of the four cells: none set = the window is not read
+            for (int k = 0; k < 4; ++k) m |= ((uint32_t)mcell[q * 4 * CW + (size_t)k * CW] >> (8 * j)) & 0xffu;
+            if (m) qch[q * NW + j] = (mwin[q * NW + j] & ~3) >> 3;
+          }
+        }
+        struct Shape { int lg; int64_t wq, rows; };
+        std::vector<Shape> shapes;
+        if (dst_w % 4 == 0) for (int lg : {5, 4, 6, 3}) shapes.push_back({lg, dst_w / 4, dst_h});
+        else shapes.push_back({6, (int64_t)nq, 1});
+        if (const char* f = getenv("LSPIV_PROJECT_TILE_LG")) {       // A/B: force a block width
+          const int lg = atoi(f);
+          if (dst_w % 4 == 0 && lg >= 0 && lg <= 6) { shapes.clear(); shapes.push_back({lg, dst_w / 4, dst_h}); }
+        }
+        std::vector<int> lst;
+        auto wave_chunks = [&](const Shape& sh, int64_t wv, int64_t tiles_x) {   // the sorted chunk list of wave wv into lst; false: no quad of its own
+          lst.clear();
+          const int64_t bqx = (int64_t)1 << sh.lg, bqy = 64 >> sh.lg, ty = wv / tiles_x, tx = wv % tiles_x;
+          bool any = false;
+          for (int64_t r = ty * bqy; r < std::min(sh.rows, (ty + 1) * bqy); ++r)
+            for (int64_t c = tx * bqx; c < std::min(sh.wq, (tx + 1) * bqx); ++c) {
+              const size_t q = (size_t)(r * sh.wq + c);
+              if (mwin[q * NW] < 0) continue;
+              any = true;
+              for (int j = 0; j < NW; ++j)
+                if (qch[q * NW + j] >= 0) { lst.push_back(qch[q * NW + j]); lst.push_back(qch[q * NW + j] + 1); }
+            }
+          std::sort(lst.begin(), lst.end());
+          lst.erase(std::unique(lst.begin(), lst.end()), lst.end());
+          return any;
+        };
+        int best = -1, best_rmax = 0;
+        int64_t best_total = 0;
+        size_t best_failed = 0;
+        for (size_t i = 0; i < shapes.size(); ++i) {
+          const Shape& sh = shapes[i];
+          const int64_t bqx = (int64_t)1 << sh.lg, bqy = 64 >> sh.lg;
+          const int64_t tiles_x = (sh.wq + bqx - 1) / bqx, n_waves = tiles_x * ((sh.rows + bqy - 1) / bqy);
+          size_t over1 = 0, over2 = 0, over4 = 0;
+          int64_t total = 0;
+          for (int64_t wv = 0; wv < n_waves; ++wv) {
+            wave_chunks(sh, wv, tiles_x);
+            over1 += lst.size() > 64; over2 += lst.size() > 128; over4 += lst.size() > 256;
+            total += (int64_t)lst.size();
+          }
+          const size_t few = (size_t)n_waves / 100;          // waves a shape may leave to the slow kernel
+          const int rmax = over1 <= few ? 1 : over2 <= few ? 2 : over4 <= few ? 4 : 0;
+          if (getenv("LSPIV_PROJECT_DEBUG"))
+            fprintf(stderr, "lspiv projection: blocks of %lld x %lld quads: %.1f chunks per wave, %zu of %lld waves need more than 64, %zu more than 128, %zu more than 256\n",
+                    (long long)bqx, (long long)bqy, (double)total / (double)n_waves, over1, (long long)n_waves, over2, over4);
+          if (!rmax) continue;
+          if (best < 0 || rmax < best_rmax || (rmax == best_rmax && total < best_total)) {
+            best = (int)i; best_rmax = rmax; best_total = total;
+          }
+        }
+        if (const char* f = getenv("LSPIV_PROJECT_TILE_RMAX"))   // A/B: more list rows than the plan needs
+          if (best >= 0 && (atoi(f) == 2 || atoi(f) == 4)) best_rmax = std::max(best_rmax, atoi(f));
+        int cap_limit = 256;
+        if (const char* f = getenv("LSPIV_PROJECT_TILE_CAP")) {   // test hook: waves with longer lists go to the slow kernel, whatever their share
+          cap_limit = std::max(2, atoi(f));
+          if (best < 0) { best = 0; best_rmax = 1; }
+        }
+        if (best >= 0) {
+          const Shape& sh = shapes[(size_t)best];
+          const int64_t bqx = (int64_t)1 << sh.lg, bqy = 64 >> sh.lg;
+          const int64_t tiles_x = (sh.wq + bqx - 1) / bqx, n_waves = tiles_x * ((sh.rows + bqy - 1) / bqy);
+          const int cap = 64 * best_rmax;
+          best_failed = 0;
+          std::vector<int> wchunk((size_t)n_waves * cap, -1), twin(mwin.size(), 0), tslow(mslow);
+          for (size_t q = 0; q < nq; ++q) if (mwin[q * NW] < 0) twin[q * NW] = -1;
+          for (int64_t wv = 0; wv < n_waves; ++wv) {
+            if (!wave_chunks(sh, wv, tiles_x)) continue;      // (all -1: the wave returns at once)
+            const int64_t ty = wv / tiles_x, tx = wv % tiles_x;
+            const bool fits = (int)lst.size() <= std::min(cap, cap_limit);
+            best_failed += !fits;
+            if (fits) {
+              if (lst.empty()) lst.push_back(0);             // cells without a source only: the wave still runs and writes their zeros
+              for (int i = 0; i < cap; ++i) wchunk[(size_t)wv * cap + i] = lst[std::min<size_t>((size_t)i, lst.size() - 1)];
+            }
+            for (int64_t r = ty * bqy; r < std::min(sh.rows, (ty + 1) * bqy); ++r)
+              for (int64_t c = tx * bqx; c < std::min(sh.wq, (tx + 1) * bqx); ++c) {
+                const size_t q = (size_t)(r * sh.wq + c);
+                if (mwin[q * NW] < 0) continue;
+                if (!fits) { twin[q * NW] = -1; tslow.push_back((int)q); continue; }
+                for (int j = 0; j < NW; ++j) {
+                  const int c0 = qch[q * NW + j];
+                  if (c0 < 0) continue;                       // (offset 0: any resident bytes do under a zero mask)
+                  const int pos = (int)(std::lower_bound(lst.begin(), lst.end(), c0) - lst.begin());
+                  twin[q * NW + j] = 8 * pos + (mwin[q * NW + j] - 8 * c0);
+                }
+              }
+          }
+          if (getenv("LSPIV_PROJECT_DEBUG"))
+            fprintf(stderr, "lspiv projection: tiles of %lld x %lld quads, %d list row(s), %zu waves to the slow kernel (%zu slow quads in all)\n",
+                    (long long)bqx, (long long)bqy, best_rmax, best_failed, tslow.size());
+          e = up(&h->d_wchunk, wchunk);
+          if (e == hipSuccess) e = up(&h->d_twin, twin);
+          if (e == hipSuccess) e = up(&h->d_tslow, tslow);
+          h->n_tslow = (int)tslow.size();
+          h->tile_rmax = best_rmax; h->tile_lg = sh.lg; h->tile_wq = (int)sh.wq; h->tile_rows = (int)sh.rows;
+        }
+      }
     }
   }
   if (e != hipSuccess) {
@@ -1835,9 +1956,13 @@ int lspiv_project_frames_dev(lspiv_projection* h, const void* d_frames, int dtyp
   int rc = get_ctx(&c);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-  const bool win = dtype == 0 && h->d_qdesc && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
-  const bool mix = dtype == 0 && !win && h->d_mcell && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
-  hipError_t e = mix ? lspiv::launch_project_mix((const uint8_t*)d_frames, h->src_h * h->src_w, (int)T, h->mix_nw, h->d_mwin, h->d_mcell, h->d_mslow,
+  const bool tile = dtype == 0 && h->d_mcell && h->d_twin && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_frames) & 7) == 0;
+  const bool win = dtype == 0 && !tile && h->d_qdesc && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
+  const bool mix = dtype == 0 && !tile && !win && h->d_mcell && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
+  hipError_t e = tile ? lspiv::launch_project_tile((const uint8_t*)d_frames, h->src_h * h->src_w, (int)T, h->mix_nw, h->tile_rmax, h->d_wchunk, h->d_twin,
+                                                    h->d_mcell, h->tile_wq, h->tile_rows, h->tile_lg, h->d_tslow, h->n_tslow, h->d_nn, h->d_grp_of, h->d_grp_off, h->d_grp_src, d_out,
+                                                    (int)(h->dst_h * h->dst_w), s)
+               : mix ? lspiv::launch_project_mix((const uint8_t*)d_frames, h->src_h * h->src_w, (int)T, h->mix_nw, h->d_mwin, h->d_mcell, h->d_mslow,
                                                   h->n_mslow, h->d_nn, h->d_grp_of, h->d_grp_off, h->d_grp_src, d_out, (int)(h->dst_h * h->dst_w), s)
                : win ? lspiv::launch_project_win((const uint8_t*)d_frames, h->src_h * h->src_w, (int)T, h->d_qlo1, h->d_qlo2, h->d_qdesc,
                                                   h->d_slow_q, h->n_slow, h->d_nn, h->d_grp_of, h->d_grp_off, h->d_grp_src, d_out, (int)(h->dst_h * h->dst_w), s)
@@ -1896,6 +2021,9 @@ int lspiv_projection_destroy(lspiv_projection* h) {
   if (h->d_mwin) hipFree(h->d_mwin);
   if (h->d_mcell) hipFree(h->d_mcell);
   if (h->d_mslow) hipFree(h->d_mslow);
+  if (h->d_wchunk) hipFree(h->d_wchunk);
+  if (h->d_twin) hipFree(h->d_twin);
+  if (h->d_tslow) hipFree(h->d_tslow);
   delete h;
   return LSPIV_OK;
 }

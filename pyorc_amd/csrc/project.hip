@@ -330,6 +330,162 @@ hipError_t launch_project_mix(const uint8_t* frames, int64_t src_elems, int n_fr
   return hipGetLastError();
 }
 
+// project_mix_kernel with the gather taken out of the vector-memory path (round 6).  What held that kernel at half the streaming rate
+// is the request pattern of its loads -- 64 lanes asking for 12 bytes every ~5 bytes: gather loads and stores did not overlap (0.153 +
+// 0.171 ms = the 0.35 measured), the same byte count loaded coalesced took 0.277 ms.  Here a WAVE owns a block of 64 quads of the ortho
+// grid (BQX quads wide, 64 / BQX rows high: the host picks the shape whose camera footprint is smallest) and the plan lists the 8-byte
+// aligned CHUNKS of the camera frame that block's windows touch, sorted: at 4/3 oversampling 45 - 50 of them, a handful of runs along
+// camera rows.  Lane l loads chunk l of the list (RMAX = 2: and chunk 64 + l) -- every camera byte the wave needs is asked for ONCE, 8
+// bytes per lane, neighbouring lanes neighbouring addresses -- and parks it in the wave's own slice of LDS (no block barrier: the LDS
+// operations of one wave execute in order, the wave_barrier only pins the compiler); a window is then the three dwords at its offset
+// into that tile (chunks c and c + 1 of the frame are neighbours in the sorted list, so a window that straddles them reads on).  Same
+// masks, same integer sums, same quotient as project_mix_kernel: same bits.  Waves whose footprint needs more chunks than RMAX * 64
+// (wild geometry) give their quads to project_slow_kernel; too many of them: the plan is not built and project_mix_kernel runs.
+#ifndef LSPIV_TILE_F
+#define LSPIV_TILE_F 8          // frames per thread
+#endif
+#ifndef LSPIV_TILE_WAVES
+#define LSPIV_TILE_WAVES 4      // waves per block
+#endif
+#ifndef LSPIV_TILE_NT
+#define LSPIV_TILE_NT 0         // 1: non-temporal stores of the ortho frames
+#endif
+template <int F, int NW, int RMAX>
+__global__ __launch_bounds__(64 * LSPIV_TILE_WAVES) void project_tile_kernel(const uint8_t* __restrict__ frames, int64_t src_elems, int n_frames,
+                                                           const int* __restrict__ wchunk, const int* __restrict__ twin,
+                                                           const uint32_t* __restrict__ qcell, float* __restrict__ out, int n_out,
+                                                           int wq, int rows, int lg_bqx, int tiles_x, int n_waves, int blocks_per_xcd) {
+  constexpr int CW = NW / 2;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  __shared__ uint64_t tile_all[LSPIV_TILE_WAVES][RMAX * 64 + 2];          // (+ 2: a window in the list's last chunk reads one dword past it)
+  const int lane = threadIdx.x & 63;
+  uint64_t* tile = tile_all[threadIdx.x >> 6];
+  const uint32_t* tile32 = reinterpret_cast<const uint32_t*>(tile);
+  const int t0 = blockIdx.y * F;
+  const int nt = min(n_frames - t0, F);                    // block-uniform
+  const uint8_t* img = frames + (int64_t)t0 * src_elems;
+  // hardware block ids go round the 8 XCDs: XCD x owns a contiguous eighth of the waves (a band of the grid; its plan stays in its L2)
+  const int gw = __builtin_amdgcn_readfirstlane((((int)blockIdx.x & 7) * blocks_per_xcd + ((int)blockIdx.x >> 3)) * LSPIV_TILE_WAVES + ((int)threadIdx.x >> 6));
+  if (gw >= n_waves) return;                               // wave-uniform
+  int64_t coff[RMAX];
+  {
+    int c0 = 0;
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      const int c = wchunk[((int64_t)gw * RMAX + r) * 64 + lane];
+      if (r == 0) c0 = c;
+      coff[r] = 8 * (int64_t)c;
+    }
+    if (__builtin_amdgcn_readfirstlane(c0) < 0) return;    // nothing of this wave is served here (its quads are project_slow_kernel's)
+  }
+  // the wave's block of quads: ty, tx its position among the blocks, lane -> (row, quad column) inside it
+  const int ty = gw / tiles_x, tx = gw - ty * tiles_x;
+  const int row = (ty << (6 - lg_bqx)) + (lane >> lg_bqx), qx = (tx << lg_bqx) + (lane & ((1 << lg_bqx) - 1));
+  const int q = row * wq + qx;
+  // every lane takes part in the loads; only lanes with a quad of their own compute and store
+  int w[NW];
+  bool active = row < rows && qx < wq;
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < NW; k += 2) {
+      const i32x2 v = *reinterpret_cast<const i32x2*>(twin + NW * (int64_t)q + k);
+      w[k] = v[0]; w[k + 1] = v[1];
+    }
+    active = w[0] >= 0;
+  }
+  if (!active) {
+#pragma unroll
+    for (int k = 0; k < NW; ++k) w[k] = 0;
+  }
+  uint32_t mlo[4][NW], mhi[4][NW];
+  float cnt[4], rcp[4];
+  {
+    uint32_t d[4 * CW];
+#pragma unroll
+    for (int k = 0; k < CW; ++k) {
+      const u32x4 v = active ? *reinterpret_cast<const u32x4*>(qcell + 4 * CW * (int64_t)q + 4 * k) : u32x4{0u, 0u, 0u, 0u};
+      d[4 * k] = v[0]; d[4 * k + 1] = v[1]; d[4 * k + 2] = v[2]; d[4 * k + 3] = v[3];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t m = d[CW * e];
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        mlo[e][k] = mask_bytes((m >> (8 * k)) & 15u);
+        mhi[e][k] = mask_bytes((m >> (8 * k + 4)) & 15u);
+      }
+      const uint32_t c = NW == 2 ? (m >> 16) : d[CW * e + 1];
+      cnt[e] = (float)(c ? c : 1u);
+      rcp[e] = 1.0f / cnt[e];
+    }
+  }
+  // the chunks of all F frames in registers first (F independent loads in flight per lane and list row)
+  uint64_t sv[F][RMAX];
+#pragma unroll
+  for (int t = 0; t < F; ++t)
+    if (t < nt) {
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) sv[t][r] = *reinterpret_cast<const uint64_t*>(img + (int64_t)t * src_elems + coff[r]);
+    }
+  float* dst = out + (int64_t)t0 * n_out + 4 * (int64_t)q;
+#pragma unroll
+  for (int t = 0; t < F; ++t)
+    if (t < nt) {
+      __builtin_amdgcn_wave_barrier();                     // the previous frame's reads of the tile are issued before it is overwritten
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) tile[r * 64 + lane] = sv[t][r];
+      __builtin_amdgcn_wave_barrier();
+      uint32_t lo[NW], hi[NW];
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        const int a = w[k] >> 2;
+        const uint32_t d0 = tile32[a], d1 = tile32[a + 1], d2 = tile32[a + 2];
+        const uint32_t sh = (uint32_t)w[k] & 3u;
+        lo[k] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+        hi[k] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+      }
+      if (active) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          uint32_t sum = 0;
+#pragma unroll
+          for (int k = 0; k < NW; ++k) {
+            sum = __builtin_amdgcn_udot4(lo[k], mlo[e][k], sum, false);
+            sum = __builtin_amdgcn_udot4(hi[k], mhi[e][k], sum, false);
+          }
+          v[e] = quotient((float)sum, cnt[e], rcp[e]);
+        }
+        if (LSPIV_TILE_NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst + (int64_t)t * n_out));
+        else *reinterpret_cast<f32x4*>(dst + (int64_t)t * n_out) = v;
+      }
+    }
+}
+
+hipError_t launch_project_tile(const uint8_t* frames, int64_t src_elems, int n_frames, int nw, int rmax, const int* wchunk, const int* twin,
+                               const uint32_t* qcell, int wq, int rows, int lg_bqx, const int* slow_q, int n_slow, const int* nn_src,
+                               const int* grp_of, const int* grp_off, const int* grp_src, float* out, int n_out, hipStream_t s) {
+  if (n_frames <= 0 || n_out <= 0) return hipSuccess;
+  constexpr int F = LSPIV_TILE_F, F4 = LSPIV_TILE_F / 2;  // four list rows: half the frames per thread (the chunks of all of them wait in registers)
+  const int bqx = 1 << lg_bqx, bqy = 64 >> lg_bqx;
+  const int tiles_x = (wq + bqx - 1) / bqx, n_waves = tiles_x * ((rows + bqy - 1) / bqy);
+  const int per_xcd = ((n_waves + LSPIV_TILE_WAVES - 1) / LSPIV_TILE_WAVES + 7) / 8;
+  const int f = rmax > 2 ? F4 : F;
+  const dim3 grid((unsigned)(8 * per_xcd), (unsigned)((n_frames + f - 1) / f));
+#define LSPIV_TILE(FF, NN, RR)                                                                                                              \
+  hipLaunchKernelGGL((project_tile_kernel<FF, NN, RR>), grid, dim3(64 * LSPIV_TILE_WAVES), 0, s, frames, src_elems, n_frames, wchunk, twin, \
+                     qcell, out, n_out, wq, rows, lg_bqx, tiles_x, n_waves, per_xcd)
+  if (nw == 2) { if (rmax <= 1) LSPIV_TILE(F, 2, 1); else if (rmax == 2) LSPIV_TILE(F, 2, 2); else LSPIV_TILE(F4, 2, 4); }
+  else { if (rmax <= 1) LSPIV_TILE(F, 4, 1); else if (rmax == 2) LSPIV_TILE(F, 4, 2); else LSPIV_TILE(F4, 4, 4); }
+#undef LSPIV_TILE
+  if (n_slow > 0)
+    hipLaunchKernelGGL((project_slow_kernel<F>), dim3((unsigned)((4 * n_slow + 255) / 256), (n_frames + F - 1) / F), dim3(256), 0, s, frames,
+                       src_elems, n_frames, slow_q, n_slow, nn_src, grp_of, grp_off, grp_src, out, n_out);
+  return hipGetLastError();
+}
+
 // Nearest-neighbour-only plans (Frames.project with a reducer other than "mean", pyorc/project.py:196-199) on uint8 frames:
 // every cell is a source byte or 0, so the stack may stay uint8 -- a quarter of the float32 bytes to write here and for the
 // PIV kernels to read, and get_piv runs its uint8 kernels on the same values.  Quads of the window plan as above (one

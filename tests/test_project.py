@@ -304,7 +304,8 @@ def test_gpu_project_cv_matches_oracle(gpu, dtype):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("src,dst,tilt", [((270, 480), (200, 360), 0.1),      # ~4/3 oversampling: a fifth of the cells are means, two windows per quad
-                                          ((540, 960), (200, 360), 0.3),      # > 2 : 1: most cells are means of 2 .. 9 pixels in 2 .. 3 rows: four windows
+                                          ((405, 720), (200, 360), 0.3),      # ~2 : 1: most cells are means of 2 .. 6 pixels in 2 .. 3 rows: four windows
+                                          ((540, 960), (200, 360), 0.3),      # > 2.5 : 1: too scattered for windows -- the one-cell kernel
                                           ((270, 480), (200, 360), 0.9)])     # strong perspective: both regimes in one plan
 def test_gpu_projection_with_group_means_through_the_mixed_plan(gpu, src, dst, tilt):
     """Round 6: uint8 frames through a plan WITH group means run project_mix_kernel (every cell a masked sum over at most NW 8-byte
@@ -338,3 +339,59 @@ def test_gpu_division_free_quotient_is_the_division(gpu):
     bad = C.c_int(-1)
     _lib.check(gpu.lspiv_debug_project_division(C.byref(bad)))
     assert bad.value == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src,dst,tilt,groups", [((270, 480), (200, 360), 0.1, True),     # 4/3 oversampling, two windows per quad
+                                                 ((405, 720), (200, 360), 0.3, True),     # ~2 : 1: four windows per quad, four list rows
+                                                 ((270, 480), (200, 360), 0.9, True),     # strong perspective: two list rows
+                                                 ((270, 480), (200, 358), 0.35, True),    # rows that are not whole quads: 64 consecutive quads of the flat index
+                                                 ((270, 480), (200, 360), 0.35, False),   # nearest neighbour only (a reducer other than "mean")
+                                                 ((272, 488), (120, 520), 0.2, True)])    # a partial last block of quads in both directions
+def test_gpu_projection_through_the_tiled_plan(gpu, monkeypatch, capfd, src, dst, tilt, groups):
+    """Round 6: project_tile_kernel -- a wave owns a block of 64 quads, loads the sorted list of the 8-byte chunks its windows touch (one
+    chunk per lane; one, two or four list rows) into LDS and reads its windows from there.  Every block shape, both list lengths, waves
+    handed to the slow kernel (the LSPIV_PROJECT_TILE_CAP test hook), and project_mix_kernel on the same plan: all bit-exact against
+    the oracle's literal loops, for frame counts around the kernel's 8-frame groups, from host arrays and from a stack resident in HBM."""
+    from pyorc_amd.device import DeviceFrames
+    from pyorc_amd.project import Projection
+
+    idx_img, mask, src_idx, uidx, norm_idx = projection_maps(src, dst, tilt=tilt, seed=5)
+    maps = (idx_img, mask, src_idx, uidx, norm_idx) if groups else (idx_img, mask)
+    rng = np.random.default_rng(11)
+    stacks = []
+    for T in (1, 8, 9, 19):
+        fr = (rng.random((T,) + src) * 256).astype(np.uint8)
+        fr[0, :3] = 255
+        fr[-1, -3:] = 255                                                # the frame's last bytes
+        stacks.append((fr, pro.project_frames(fr, dst, *maps) if groups else pro.project_frames(fr, dst, idx_img, mask)))
+    flat = dst[1] % 4 != 0
+    settings = [{}] + [{"LSPIV_PROJECT_TILE_LG": str(lg)} for lg in ((6,) if flat else (3, 4, 5, 6))]
+    settings += [{"LSPIV_PROJECT_TILE_RMAX": "2"}, {"LSPIV_PROJECT_TILE_RMAX": "4"}, {"LSPIV_PROJECT_TILE_CAP": "40"},
+                 {"LSPIV_PROJECT_TILE_CAP": "40", "LSPIV_PROJECT_TILE_RMAX": "2"}, {"LSPIV_PROJECT_NO_TILE": "1"}]
+    for env in settings:
+        for k in ("LSPIV_PROJECT_TILE_LG", "LSPIV_PROJECT_TILE_RMAX", "LSPIV_PROJECT_TILE_CAP", "LSPIV_PROJECT_NO_TILE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        monkeypatch.setenv("LSPIV_PROJECT_DEBUG", "1")
+        capfd.readouterr()
+        p = Projection(src, dst, *maps)
+        said = capfd.readouterr().err
+        if "LSPIV_PROJECT_NO_TILE" in env:
+            assert "tiles of" not in said
+        else:
+            assert "tiles of" in said, said                              # the tiled plan was built ...
+            if "LSPIV_PROJECT_TILE_LG" in env and not flat:
+                assert f"tiles of {1 << int(env['LSPIV_PROJECT_TILE_LG'])} x" in said
+            if "LSPIV_PROJECT_TILE_RMAX" in env:
+                assert int(said.split(" list row(s)")[0].split()[-1]) >= int(env["LSPIV_PROJECT_TILE_RMAX"])
+            slow_waves = int(said.split("list row(s), ")[1].split(" waves")[0])
+            assert (slow_waves > 0) == ("LSPIV_PROJECT_TILE_CAP" in env), said   # ... and the hook (only the hook) sends waves to the slow kernel
+        for fr, ref in stacks:
+            got = p.project_frames(fr)
+            assert got.dtype == np.float32 and np.array_equal(got.astype(np.float64), ref), (env, len(fr))
+            d = DeviceFrames.from_host(fr)
+            dv = p.project_frames(d, keep_uint8=False).to_host()
+            assert dv.dtype == np.float32 and np.array_equal(dv, got), (env, len(fr))
+        p.close()

@@ -20,6 +20,8 @@ from pyorc_amd import _lib  # noqa: E402
 
 H, W = 1080, 1920
 HO, WO = 810, 1440          # the ortho grid of bench.py's camera -> velocity legs (3/4 of the camera's resolution)
+if os.environ.get("ROWS_ORTHO"):   # another ortho grid for the projection rows (A/B sessions): ROWS_ORTHO=540x960
+    HO, WO = (int(v) for v in os.environ["ROWS_ORTHO"].split("x"))
 HBM_PEAK_GBS = 8000.0
 
 
