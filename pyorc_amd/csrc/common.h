@@ -468,11 +468,6 @@ hipError_t launch_project(const void* frames, int dtype, int64_t src_elems, int 
                           const int* grp_of, const int* grp_off, const int* grp_src, float* out, int n_out,
                           hipStream_t s);
 // uint8 frames through the quad-window plan (two 8-byte source windows per four output cells, project.hip)
-// the same plan in tiles: a wave = a block of 2^lg_bqx x 64 / 2^lg_bqx quads; the sorted 8-byte chunks its windows touch (rmax * 64 per
-// wave) loaded one per lane and parked in LDS, windows = byte offsets into that tile (project.hip: project_tile_kernel)
-hipError_t launch_project_tile(const uint8_t* frames, int64_t src_elems, int n_frames, int nw, int rmax, const int* wchunk, const int* twin,
-                               const uint32_t* qcell, int wq, int rows, int lg_bqx, const int* slow_q, int n_slow, const int* nn_src,
-                               const int* grp_of, const int* grp_off, const int* grp_src, float* out, int n_out, hipStream_t s);
 hipError_t launch_division_check(int* d_mismatches, hipStream_t s);   // test hook of project_mix_kernel's quotient
 // uint8 frames through a plan WITH group means: per quad NW (2 or 4) 8-byte windows, per cell one byte mask per window + the count
 hipError_t launch_project_mix(const uint8_t* frames, int64_t src_elems, int n_frames, int nw, const int* qwin, const uint32_t* qcell,

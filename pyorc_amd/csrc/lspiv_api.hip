@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "common.h"
+#include "project_tile.h"
 #include "host_stage.h"
 
 namespace lspiv {   // project.hip

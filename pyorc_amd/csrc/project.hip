@@ -14,6 +14,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "project_tile.h"
 
 namespace lspiv {
 

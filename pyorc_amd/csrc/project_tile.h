@@ -1,0 +1,13 @@
+// Declaration of the tiled orthoprojection launch (project.hip), kept out of common.h: that header is one of the four sources the
+// committed PIV profile summaries are keyed to (Makefile: KERNEL_HASH), and this kernel is not on the PIV path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace lspiv {
+// the mixed plan in tiles: a wave = a block of 2^lg_bqx x 64 / 2^lg_bqx quads; the sorted 8-byte chunks its windows touch (rmax * 64 per
+// wave) loaded one per lane and parked in LDS, windows = byte offsets into that tile (project.hip: project_tile_kernel)
+hipError_t launch_project_tile(const uint8_t* frames, int64_t src_elems, int n_frames, int nw, int rmax, const int* wchunk, const int* twin,
+                               const uint32_t* qcell, int wq, int rows, int lg_bqx, const int* slow_q, int n_slow, const int* nn_src,
+                               const int* grp_of, const int* grp_off, const int* grp_src, float* out, int n_out, hipStream_t s);
+}  // namespace lspiv
