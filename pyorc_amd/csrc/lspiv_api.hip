@@ -575,6 +575,10 @@ struct lspiv_projection {
   // of its quads as byte offsets into that tile; nullptr: not built
   int* d_wchunk = nullptr; int* d_twin = nullptr; int tile_rmax = 0, tile_lg = 6, tile_wq = 0, tile_rows = 0;
   int* d_tslow = nullptr; int n_tslow = 0;
+  // tiles for float32 frames (project_tile_f32_kernel): chunk lists of four pixels, per cell f_dw descriptor words (tile positions of
+  // its samples in the reference's order, count, group flag); nullptr: not built
+  int* d_fchunk = nullptr; uint32_t* d_fdesc = nullptr; int f_dw = 0, f_rmax = 0, f_lg = 6, f_wq = 0, f_rows = 0;
+  int* d_fslow = nullptr; int n_fslow = 0;
   int64_t n_groups = 0;                       // 0: nearest neighbour only -- uint8 frames may stay uint8 (lspiv_project_frames_u8)
 };
 
@@ -1640,6 +1644,83 @@ int lspiv_ensemble_destroy(lspiv_ensemble* h) {
   return LSPIV_OK;
 }
 
+// ---- tiles of the orthoprojection plans (project.hip: project_tile_kernel, project_tile_f32_kernel) ------------------------------
+// A wave owns a block of 64 quads of the ortho grid, 2^lg quads wide and 64 / 2^lg rows high (grids whose rows are not whole quads: 64
+// consecutive quads of the flat index), and loads the sorted list of the aligned CHUNKS of the camera frame its cells read (8 bytes of a
+// uint8 frame, four pixels of a float32 frame), one chunk per lane and list row.
+extern "C++" {
+namespace {
+struct TileShape {
+  int lg = 6, rmax = 0;                                     // block width 2^lg quads; list rows of 64 chunks (1, 2 or 4)
+  int64_t wq = 0, rows = 0;                                 // quads per grid row, grid rows (flat: all quads in one row)
+  int64_t bqx() const { return (int64_t)1 << lg; }
+  int64_t bqy() const { return 64 >> lg; }
+  int64_t tiles_x() const { return (wq + bqx() - 1) / bqx(); }
+  int64_t n_waves() const { return tiles_x() * ((rows + bqy() - 1) / bqy()); }
+};
+
+// the sorted chunk list of wave wv into lst; QC: bool(size_t quad, std::vector<int>& lst) appends the chunks a quad reads, false: the
+// quad is not served by the tiles.  Returns whether the wave has a quad of its own.
+template <class QC>
+bool tile_wave_list(const TileShape& sh, int64_t wv, QC& quad_chunks, std::vector<int>& lst) {
+  lst.clear();
+  const int64_t ty = wv / sh.tiles_x(), tx = wv % sh.tiles_x();
+  bool any = false;
+  for (int64_t r = ty * sh.bqy(); r < std::min(sh.rows, (ty + 1) * sh.bqy()); ++r)
+    for (int64_t c = tx * sh.bqx(); c < std::min(sh.wq, (tx + 1) * sh.bqx()); ++c) any = quad_chunks((size_t)(r * sh.wq + c), lst) || any;
+  std::sort(lst.begin(), lst.end());
+  lst.erase(std::unique(lst.begin(), lst.end()), lst.end());
+  return any;
+}
+
+// One list row (64 chunks) when all but 1 in 100 waves fit, else two, else four (2 : 1 oversampling and beyond); among the shapes with
+// the shortest lists the one with the fewest chunks wins; waves beyond the list hand their quads to a slow kernel; more than 1 in 100
+// beyond four rows: no tiles.  *cap_limit: the list length beyond which a wave goes to the slow kernel (the LSPIV_PROJECT_TILE_CAP hook).
+template <class QC>
+bool tile_pick_shape(int64_t dst_h, int64_t dst_w, size_t nq, QC& quad_chunks, const char* what, TileShape* out, int* cap_limit) {
+  std::vector<TileShape> shapes;
+  auto shape = [&](int lg, int64_t wq, int64_t rows) { TileShape t; t.lg = lg; t.wq = wq; t.rows = rows; return t; };
+  if (dst_w % 4 == 0) for (int lg : {5, 4, 6, 3}) shapes.push_back(shape(lg, dst_w / 4, dst_h));
+  else shapes.push_back(shape(6, (int64_t)nq, 1));
+  if (const char* f = getenv("LSPIV_PROJECT_TILE_LG")) {       // A/B: force a block width
+    const int lg = atoi(f);
+    if (dst_w % 4 == 0 && lg >= 0 && lg <= 6) { shapes.clear(); shapes.push_back(shape(lg, dst_w / 4, dst_h)); }
+  }
+  const bool say = getenv("LSPIV_PROJECT_DEBUG") != nullptr;
+  std::vector<int> lst;
+  int best = -1;
+  int64_t best_total = 0;
+  for (size_t i = 0; i < shapes.size(); ++i) {
+    TileShape& sh = shapes[i];
+    size_t over1 = 0, over2 = 0, over4 = 0;
+    int64_t total = 0;
+    for (int64_t wv = 0; wv < sh.n_waves(); ++wv) {
+      tile_wave_list(sh, wv, quad_chunks, lst);
+      over1 += lst.size() > 64; over2 += lst.size() > 128; over4 += lst.size() > 256;
+      total += (int64_t)lst.size();
+    }
+    const size_t few = (size_t)sh.n_waves() / 100;            // waves a shape may leave to the slow kernel
+    sh.rmax = over1 <= few ? 1 : over2 <= few ? 2 : over4 <= few ? 4 : 0;
+    if (say)
+      fprintf(stderr, "lspiv projection (%s): blocks of %lld x %lld quads: %.1f chunks per wave, %zu of %lld waves need more than 64, %zu more than 128, %zu more than 256\n",
+              what, (long long)sh.bqx(), (long long)sh.bqy(), (double)total / (double)sh.n_waves(), over1, (long long)sh.n_waves(), over2, over4);
+    if (!sh.rmax) continue;
+    if (best < 0 || sh.rmax < shapes[(size_t)best].rmax || (sh.rmax == shapes[(size_t)best].rmax && total < best_total)) { best = (int)i; best_total = total; }
+  }
+  if (const char* f = getenv("LSPIV_PROJECT_TILE_RMAX"))       // A/B: more list rows than the plan needs
+    if (best >= 0 && (atoi(f) == 2 || atoi(f) == 4)) shapes[(size_t)best].rmax = std::max(shapes[(size_t)best].rmax, atoi(f));
+  *cap_limit = 256;
+  if (const char* f = getenv("LSPIV_PROJECT_TILE_CAP")) {      // test hook: waves with longer lists go to the slow kernel, whatever their share
+    *cap_limit = std::max(2, atoi(f));
+    if (best < 0) { best = 0; shapes[0].rmax = 1; }
+  }
+  if (best < 0) return false;
+  *out = shapes[(size_t)best];
+  return true;
+}
+}  // namespace
+}  // extern "C++"
+
 // ---- orthoprojection (N1) and int16 packing (N4) -------------------------------------------------
 int lspiv_projection_create(int64_t src_h, int64_t src_w, int64_t dst_h, int64_t dst_w, const int64_t* idx_img,
                             const int64_t* idx_ortho, int64_t K, const int64_t* src_idx, const int64_t* norm_idx,
@@ -1827,13 +1908,9 @@ int lspiv_projection_create(int64_t src_h, int64_t src_w, int64_t dst_h, int64_t
       if (e == hipSuccess) e = up(&h->d_mslow, mslow);
       h->n_mslow = (int)mslow.size();
       h->mix_nw = NW;
-      // tiled form (project_tile_kernel): a wave owns a block of 64 quads, BQX = 2^lg quads wide and 64 / BQX rows high (grids whose
-      // rows are not whole quads: 64 consecutive quads of the flat index), and loads the sorted list of the 8-byte chunks its
-      // windows touch -- the three dwords around a window lie in chunk c0 = (start & ~3) >> 3 and c0 + 1, neighbours in the list.
-      // One list row (64 chunks) when all but 1 in 100 waves fit, else two, else four (2 : 1 oversampling and beyond); among the
-      // shapes with the shortest lists the one with the fewest chunks wins; waves beyond the list hand their quads to the slow
-      // kernel; more than 1 in 100 beyond four rows: no tiles (project_mix_kernel serves the plan).
-      if (e == hipSuccess && n_src % 8 == 0 && n_src / 8 < (int64_t)1 << 31 && !getenv("LSPIV_PROJECT_NO_TILE")) {
+      // tiled form (project_tile_kernel): chunks of 8 bytes; the three dwords around a window lie in chunk c0 = (start & ~3) >> 3 and
+      // c0 + 1, neighbours in the wave's sorted list; a window becomes its byte offset into the wave's tile.
+      if (e == hipSuccess && n_src % 8 == 0 && !getenv("LSPIV_PROJECT_NO_TILE")) {
         std::vector<int> qch(nq * NW, -1);                   // per quad and window: c0, or -1 (window unused / quad not served)
         for (size_t q = 0; q < nq; ++q) {
           if (mwin[q * NW] < 0) continue;
@@ -1843,81 +1920,30 @@ int lspiv_projection_create(int64_t src_h, int64_t src_w, int64_t dst_h, int64_t
             if (m) qch[q * NW + j] = (mwin[q * NW + j] & ~3) >> 3;
           }
         }
-        struct Shape { int lg; int64_t wq, rows; };
-        std::vector<Shape> shapes;
-        if (dst_w % 4 == 0) for (int lg : {5, 4, 6, 3}) shapes.push_back({lg, dst_w / 4, dst_h});
-        else shapes.push_back({6, (int64_t)nq, 1});
-        if (const char* f = getenv("LSPIV_PROJECT_TILE_LG")) {       // A/B: force a block width
-          const int lg = atoi(f);
-          if (dst_w % 4 == 0 && lg >= 0 && lg <= 6) { shapes.clear(); shapes.push_back({lg, dst_w / 4, dst_h}); }
-        }
-        std::vector<int> lst;
-        auto wave_chunks = [&](const Shape& sh, int64_t wv, int64_t tiles_x) {   // the sorted chunk list of wave wv into lst; false: no quad of its own
-          lst.clear();
-          const int64_t bqx = (int64_t)1 << sh.lg, bqy = 64 >> sh.lg, ty = wv / tiles_x, tx = wv % tiles_x;
-          bool any = false;
-          for (int64_t r = ty * bqy; r < std::min(sh.rows, (ty + 1) * bqy); ++r)
-            for (int64_t c = tx * bqx; c < std::min(sh.wq, (tx + 1) * bqx); ++c) {
-              const size_t q = (size_t)(r * sh.wq + c);
-              if (mwin[q * NW] < 0) continue;
-              any = true;
-              for (int j = 0; j < NW; ++j)
-                if (qch[q * NW + j] >= 0) { lst.push_back(qch[q * NW + j]); lst.push_back(qch[q * NW + j] + 1); }
-            }
-          std::sort(lst.begin(), lst.end());
-          lst.erase(std::unique(lst.begin(), lst.end()), lst.end());
-          return any;
+        auto quad_chunks = [&](size_t q, std::vector<int>& l) {
+          if (mwin[q * NW] < 0) return false;
+          for (int j = 0; j < NW; ++j)
+            if (qch[q * NW + j] >= 0) { l.push_back(qch[q * NW + j]); l.push_back(qch[q * NW + j] + 1); }
+          return true;
         };
-        int best = -1, best_rmax = 0;
-        int64_t best_total = 0;
-        size_t best_failed = 0;
-        for (size_t i = 0; i < shapes.size(); ++i) {
-          const Shape& sh = shapes[i];
-          const int64_t bqx = (int64_t)1 << sh.lg, bqy = 64 >> sh.lg;
-          const int64_t tiles_x = (sh.wq + bqx - 1) / bqx, n_waves = tiles_x * ((sh.rows + bqy - 1) / bqy);
-          size_t over1 = 0, over2 = 0, over4 = 0;
-          int64_t total = 0;
-          for (int64_t wv = 0; wv < n_waves; ++wv) {
-            wave_chunks(sh, wv, tiles_x);
-            over1 += lst.size() > 64; over2 += lst.size() > 128; over4 += lst.size() > 256;
-            total += (int64_t)lst.size();
-          }
-          const size_t few = (size_t)n_waves / 100;          // waves a shape may leave to the slow kernel
-          const int rmax = over1 <= few ? 1 : over2 <= few ? 2 : over4 <= few ? 4 : 0;
-          if (getenv("LSPIV_PROJECT_DEBUG"))
-            fprintf(stderr, "lspiv projection: blocks of %lld x %lld quads: %.1f chunks per wave, %zu of %lld waves need more than 64, %zu more than 128, %zu more than 256\n",
-                    (long long)bqx, (long long)bqy, (double)total / (double)n_waves, over1, (long long)n_waves, over2, over4);
-          if (!rmax) continue;
-          if (best < 0 || rmax < best_rmax || (rmax == best_rmax && total < best_total)) {
-            best = (int)i; best_rmax = rmax; best_total = total;
-          }
-        }
-        if (const char* f = getenv("LSPIV_PROJECT_TILE_RMAX"))   // A/B: more list rows than the plan needs
-          if (best >= 0 && (atoi(f) == 2 || atoi(f) == 4)) best_rmax = std::max(best_rmax, atoi(f));
-        int cap_limit = 256;
-        if (const char* f = getenv("LSPIV_PROJECT_TILE_CAP")) {   // test hook: waves with longer lists go to the slow kernel, whatever their share
-          cap_limit = std::max(2, atoi(f));
-          if (best < 0) { best = 0; best_rmax = 1; }
-        }
-        if (best >= 0) {
-          const Shape& sh = shapes[(size_t)best];
-          const int64_t bqx = (int64_t)1 << sh.lg, bqy = 64 >> sh.lg;
-          const int64_t tiles_x = (sh.wq + bqx - 1) / bqx, n_waves = tiles_x * ((sh.rows + bqy - 1) / bqy);
-          const int cap = 64 * best_rmax;
-          best_failed = 0;
-          std::vector<int> wchunk((size_t)n_waves * cap, -1), twin(mwin.size(), 0), tslow(mslow);
+        TileShape sh;
+        int cap_limit = 0;
+        if (tile_pick_shape(dst_h, dst_w, nq, quad_chunks, "uint8", &sh, &cap_limit)) {
+          const int cap = 64 * sh.rmax;
+          size_t failed = 0;
+          std::vector<int> lst, wchunk((size_t)sh.n_waves() * cap, -1), twin(mwin.size(), 0), tslow(mslow);
           for (size_t q = 0; q < nq; ++q) if (mwin[q * NW] < 0) twin[q * NW] = -1;
-          for (int64_t wv = 0; wv < n_waves; ++wv) {
-            if (!wave_chunks(sh, wv, tiles_x)) continue;      // (all -1: the wave returns at once)
-            const int64_t ty = wv / tiles_x, tx = wv % tiles_x;
+          for (int64_t wv = 0; wv < sh.n_waves(); ++wv) {
+            if (!tile_wave_list(sh, wv, quad_chunks, lst)) continue;      // (all -1: the wave returns at once)
+            const int64_t ty = wv / sh.tiles_x(), tx = wv % sh.tiles_x();
             const bool fits = (int)lst.size() <= std::min(cap, cap_limit);
-            best_failed += !fits;
+            failed += !fits;
             if (fits) {
               if (lst.empty()) lst.push_back(0);             // cells without a source only: the wave still runs and writes their zeros
               for (int i = 0; i < cap; ++i) wchunk[(size_t)wv * cap + i] = lst[std::min<size_t>((size_t)i, lst.size() - 1)];
             }
-            for (int64_t r = ty * bqy; r < std::min(sh.rows, (ty + 1) * bqy); ++r)
-              for (int64_t c = tx * bqx; c < std::min(sh.wq, (tx + 1) * bqx); ++c) {
+            for (int64_t r = ty * sh.bqy(); r < std::min(sh.rows, (ty + 1) * sh.bqy()); ++r)
+              for (int64_t c = tx * sh.bqx(); c < std::min(sh.wq, (tx + 1) * sh.bqx()); ++c) {
                 const size_t q = (size_t)(r * sh.wq + c);
                 if (mwin[q * NW] < 0) continue;
                 if (!fits) { twin[q * NW] = -1; tslow.push_back((int)q); continue; }
@@ -1930,14 +1956,99 @@ int lspiv_projection_create(int64_t src_h, int64_t src_w, int64_t dst_h, int64_t
               }
           }
           if (getenv("LSPIV_PROJECT_DEBUG"))
-            fprintf(stderr, "lspiv projection: tiles of %lld x %lld quads, %d list row(s), %zu waves to the slow kernel (%zu slow quads in all)\n",
-                    (long long)bqx, (long long)bqy, best_rmax, best_failed, tslow.size());
+            fprintf(stderr, "lspiv projection (uint8): tiles of %lld x %lld quads, %d list row(s), %zu waves to the slow kernel (%zu slow quads in all)\n",
+                    (long long)sh.bqx(), (long long)sh.bqy(), sh.rmax, failed, tslow.size());
           e = up(&h->d_wchunk, wchunk);
           if (e == hipSuccess) e = up(&h->d_twin, twin);
           if (e == hipSuccess) e = up(&h->d_tslow, tslow);
           h->n_tslow = (int)tslow.size();
-          h->tile_rmax = best_rmax; h->tile_lg = sh.lg; h->tile_wq = (int)sh.wq; h->tile_rows = (int)sh.rows;
+          h->tile_rmax = sh.rmax; h->tile_lg = sh.lg; h->tile_wq = (int)sh.wq; h->tile_rows = (int)sh.rows;
         }
+      }
+    }
+  }
+  // float32 frames in tiles (project_tile_f32_kernel): chunks of four pixels; a cell = the tile positions of its samples in the
+  // reference's order (the group's members, or the one nearest neighbour), at most 6 (two descriptor words per cell) or 9 (three).
+  if (e == hipSuccess && n_out % 4 == 0 && n_src % 4 == 0 && !getenv("LSPIV_PROJECT_ONE_CELL") && !getenv("LSPIV_PROJECT_NO_TILE")) {
+    const size_t nq = (size_t)n_out / 4;
+    auto count_of = [&](size_t o) { const int g = grp_of[o]; return g >= 0 ? off[(size_t)g + 1] - off[(size_t)g] : nn[o] >= 0 ? 1 : 0; };
+    size_t over6 = 0, over9 = 0;
+    for (size_t q = 0; q < nq; ++q) {
+      int m = 0;
+      for (int k = 0; k < 4; ++k) m = std::max(m, count_of(4 * q + k));
+      over6 += m > 6; over9 += m > 9;
+    }
+    const int DW = over6 * 100 <= nq ? 2 : 3, maxs = 3 * DW;
+    if (getenv("LSPIV_PROJECT_DEBUG"))
+      fprintf(stderr, "lspiv projection (float32): %zu quads, %zu with a cell of more than 6 samples, %zu of more than 9: %s\n", nq, over6, over9,
+              (DW == 2 ? over6 : over9) * 10 <= nq ? (DW == 2 ? "two descriptor words per cell" : "three descriptor words per cell") : "no tiles");
+    if ((DW == 2 ? over6 : over9) * 10 <= nq) {
+      auto served = [&](size_t q) {
+        for (int k = 0; k < 4; ++k) if (count_of(4 * q + k) > maxs) return false;
+        return true;
+      };
+      auto samples_of = [&](size_t o, const int** first, int* n) {
+        const int g = grp_of[o];
+        if (g >= 0) { *first = &members[(size_t)off[(size_t)g]]; *n = off[(size_t)g + 1] - off[(size_t)g]; }
+        else if (nn[o] >= 0) { *first = &nn[o]; *n = 1; }
+        else { *first = nullptr; *n = 0; }
+      };
+      auto quad_chunks = [&](size_t q, std::vector<int>& l) {
+        if (!served(q)) return false;
+        for (int k = 0; k < 4; ++k) {
+          const int* f; int n;
+          samples_of(4 * q + k, &f, &n);
+          for (int i = 0; i < n; ++i) l.push_back(f[i] >> 2);
+        }
+        return true;
+      };
+      TileShape sh;
+      int cap_limit = 0;
+      if (tile_pick_shape(dst_h, dst_w, nq, quad_chunks, "float32", &sh, &cap_limit)) {
+        const int cap = 64 * sh.rmax;
+        size_t failed = 0;
+        std::vector<int> lst, wchunk((size_t)sh.n_waves() * cap, -1), fdesc(nq * 4 * DW, 0), fslow;
+        for (size_t q = 0; q < nq; ++q) if (!served(q)) { fdesc[q * 4 * DW] = -1; fslow.push_back((int)q); }
+        for (int64_t wv = 0; wv < sh.n_waves(); ++wv) {
+          if (!tile_wave_list(sh, wv, quad_chunks, lst)) continue;
+          const int64_t ty = wv / sh.tiles_x(), tx = wv % sh.tiles_x();
+          const bool fits = (int)lst.size() <= std::min(cap, cap_limit);
+          failed += !fits;
+          if (fits) {
+            if (lst.empty()) lst.push_back(0);
+            for (int i = 0; i < cap; ++i) wchunk[(size_t)wv * cap + i] = lst[std::min<size_t>((size_t)i, lst.size() - 1)];
+          }
+          for (int64_t r = ty * sh.bqy(); r < std::min(sh.rows, (ty + 1) * sh.bqy()); ++r)
+            for (int64_t c = tx * sh.bqx(); c < std::min(sh.wq, (tx + 1) * sh.bqx()); ++c) {
+              const size_t q = (size_t)(r * sh.wq + c);
+              if (!served(q)) continue;
+              if (!fits) { fdesc[q * 4 * DW] = -1; fslow.push_back((int)q); continue; }
+              for (int k = 0; k < 4; ++k) {
+                const int* f; int n;
+                samples_of(4 * q + k, &f, &n);
+                uint32_t w[3] = {0, 0, 0};
+                for (int i = 0; i < n; ++i) {
+                  const int pos = 4 * (int)(std::lower_bound(lst.begin(), lst.end(), f[i] >> 2) - lst.begin()) + (f[i] & 3);
+                  w[i / 3] |= (uint32_t)pos << (10 * (i % 3));
+                }
+                const uint32_t grp = grp_of[4 * q + k] >= 0;
+                w[0] |= ((uint32_t)n & 3u) << 30;
+                if (DW == 2) w[1] |= (((uint32_t)n >> 2) & 1u) << 30 | grp << 31;
+                else { w[1] |= (((uint32_t)n >> 2) & 3u) << 30; w[2] |= grp << 30; }
+                for (int j = 0; j < DW; ++j) fdesc[(q * 4 + (size_t)k) * DW + j] = (int)w[j];
+              }
+            }
+        }
+        if (getenv("LSPIV_PROJECT_DEBUG"))
+          fprintf(stderr, "lspiv projection (float32): tiles of %lld x %lld quads, %d list row(s), %zu waves to the slow kernel (%zu slow quads in all)\n",
+                  (long long)sh.bqx(), (long long)sh.bqy(), sh.rmax, failed, fslow.size());
+        e = up(&h->d_fchunk, wchunk);
+        int* dd = nullptr;
+        if (e == hipSuccess) e = up(&dd, fdesc);
+        h->d_fdesc = reinterpret_cast<uint32_t*>(dd);
+        if (e == hipSuccess) e = up(&h->d_fslow, fslow);
+        h->n_fslow = (int)fslow.size();
+        h->f_dw = DW; h->f_rmax = sh.rmax; h->f_lg = sh.lg; h->f_wq = (int)sh.wq; h->f_rows = (int)sh.rows;
       }
     }
   }
@@ -1960,7 +2071,11 @@ int lspiv_project_frames_dev(lspiv_projection* h, const void* d_frames, int dtyp
   const bool tile = dtype == 0 && h->d_mcell && h->d_twin && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_frames) & 7) == 0;
   const bool win = dtype == 0 && !tile && h->d_qdesc && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
   const bool mix = dtype == 0 && !tile && !win && h->d_mcell && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
-  hipError_t e = tile ? lspiv::launch_project_tile((const uint8_t*)d_frames, h->src_h * h->src_w, (int)T, h->mix_nw, h->tile_rmax, h->d_wchunk, h->d_twin,
+  const bool tile_f = dtype == 1 && h->d_fdesc && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_frames) & 15) == 0;
+  hipError_t e = tile_f ? lspiv::launch_project_tile_f32((const float*)d_frames, h->src_h * h->src_w, (int)T, h->f_dw, h->f_rmax, h->d_fchunk, h->d_fdesc,
+                                                          h->f_wq, h->f_rows, h->f_lg, h->d_fslow, h->n_fslow, h->d_nn, h->d_grp_of, h->d_grp_off, h->d_grp_src,
+                                                          d_out, (int)(h->dst_h * h->dst_w), s)
+               : tile ? lspiv::launch_project_tile((const uint8_t*)d_frames, h->src_h * h->src_w, (int)T, h->mix_nw, h->tile_rmax, h->d_wchunk, h->d_twin,
                                                     h->d_mcell, h->tile_wq, h->tile_rows, h->tile_lg, h->d_tslow, h->n_tslow, h->d_nn, h->d_grp_of, h->d_grp_off, h->d_grp_src, d_out,
                                                     (int)(h->dst_h * h->dst_w), s)
                : mix ? lspiv::launch_project_mix((const uint8_t*)d_frames, h->src_h * h->src_w, (int)T, h->mix_nw, h->d_mwin, h->d_mcell, h->d_mslow,
@@ -2025,6 +2140,9 @@ int lspiv_projection_destroy(lspiv_projection* h) {
   if (h->d_wchunk) hipFree(h->d_wchunk);
   if (h->d_twin) hipFree(h->d_twin);
   if (h->d_tslow) hipFree(h->d_tslow);
+  if (h->d_fchunk) hipFree(h->d_fchunk);
+  if (h->d_fdesc) hipFree(h->d_fdesc);
+  if (h->d_fslow) hipFree(h->d_fslow);
   delete h;
   return LSPIV_OK;
 }

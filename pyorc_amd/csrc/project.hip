@@ -487,6 +487,145 @@ hipError_t launch_project_tile(const uint8_t* frames, int64_t src_elems, int n_f
   return hipGetLastError();
 }
 
+// FLOAT32 camera frames through tiles (round 6): what the reference's own recipe projects -- Frames.normalize -> edge_detect -> minmax
+// come BEFORE project (examples/ngwerere/ngwerere.yml:5-11, pyorc/service/velocimetry.py:537-538), so project_numpy sees float32
+// frames, and those went through the one-cell kernel (4-byte gathers, 0.37 of 8 TB/s).  Same idea as project_tile_kernel with pixels
+// instead of bytes: a wave owns a block of 64 quads, the plan lists the 16-byte CHUNKS (four pixels) of the camera frame its samples lie
+// in, sorted; lane l loads chunk l (and 64 + l ...: RMAX list rows) of every frame of its group -- each camera pixel is asked for once,
+// 16 bytes per lane -- and parks them in the wave's slice of LDS.  A cell is then a short list of tile positions (10 bits each; up to
+// 6 samples with DW = 2 descriptor words per cell, 9 with DW = 3) read from LDS and added IN THE REFERENCE'S ORDER
+// (float32 sums are not associative: pyorc/project.py:19-53 adds a group's samples in index order), then the one IEEE division and
+// fillna(0).  A nearest-neighbour cell is a "group" of one sample whose sum starts at -0.0f (x + -0.0f == x for every x, signed zeros
+// and NaN payloads included) and is divided by 1.0f: the bits of the one-cell kernel.  Cells with more samples, waves with longer
+// lists: project_slow_f32_kernel (the one-cell arithmetic).
+template <int F, int DW, int RMAX>
+__global__ __launch_bounds__(256) void project_tile_f32_kernel(const float* __restrict__ frames, int64_t src_elems, int n_frames,
+                                                               const int* __restrict__ wchunk, const uint32_t* __restrict__ qdesc,
+                                                               float* __restrict__ out, int n_out, int wq, int rows, int lg_bqx,
+                                                               int tiles_x, int n_waves, int blocks_per_xcd) {
+  constexpr int MAXS = 3 * DW;                             // samples per cell the descriptor holds
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  __shared__ f32x4 tile_all[4][RMAX * 64];
+  const int lane = threadIdx.x & 63;
+  f32x4* tile = tile_all[threadIdx.x >> 6];
+  const float* tile_f = reinterpret_cast<const float*>(tile);
+  const int t0 = blockIdx.y * F;
+  const int nt = min(n_frames - t0, F);                    // block-uniform
+  const float* img = frames + (int64_t)t0 * src_elems;
+  const int gw = __builtin_amdgcn_readfirstlane((((int)blockIdx.x & 7) * blocks_per_xcd + ((int)blockIdx.x >> 3)) * 4 + ((int)threadIdx.x >> 6));
+  if (gw >= n_waves) return;                               // wave-uniform
+  int64_t coff[RMAX];
+  {
+    int c0 = 0;
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      const int c = wchunk[((int64_t)gw * RMAX + r) * 64 + lane];
+      if (r == 0) c0 = c;
+      coff[r] = 4 * (int64_t)c;                            // in pixels
+    }
+    if (__builtin_amdgcn_readfirstlane(c0) < 0) return;    // nothing of this wave is served here
+  }
+  const int ty = gw / tiles_x, tx = gw - ty * tiles_x;
+  const int row = (ty << (6 - lg_bqx)) + (lane >> lg_bqx), qx = (tx << lg_bqx) + (lane & ((1 << lg_bqx) - 1));
+  const int q = row * wq + qx;
+  bool active = row < rows && qx < wq;
+  // descriptor of cell e = words d[DW e ...]: three 10-bit tile positions per word; the count in bits 30-31 of word 0 (low two bits) and
+  // bit 30 (DW = 2) / bits 30-31 (DW = 3) of word 1; "is a group" (the sum starts at +0) in bit 31 of word 1 (DW = 2) / bit 30 of word 2
+  uint32_t d[4 * DW];
+#pragma unroll
+  for (int k = 0; k < DW; ++k) {
+    const u32x4 v = active ? *reinterpret_cast<const u32x4*>(qdesc + 4 * DW * (int64_t)q + 4 * k) : u32x4{0xffffffffu, 0u, 0u, 0u};
+    d[4 * k] = v[0]; d[4 * k + 1] = v[1]; d[4 * k + 2] = v[2]; d[4 * k + 3] = v[3];
+  }
+  active = active && d[0] != 0xffffffffu;                  // (a slow quad's first word: no cell has the same position three times)
+  int cnt[4];
+  float fcnt[4], init[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const uint32_t w0 = active ? d[DW * e] : 0u, w1 = active ? d[DW * e + 1] : 0u;
+    cnt[e] = (int)((w0 >> 30) | (DW == 2 ? ((w1 >> 30) & 1u) << 2 : (w1 >> 30) << 2));
+    fcnt[e] = (float)max(cnt[e], 1);
+    const uint32_t grp = DW == 2 ? w1 >> 31 : (d[DW * e + 2] >> 30) & 1u;
+    // a group's sum starts at +0 (the reference's accumulator); a nearest-neighbour sample is taken as it is: -0 + x == x
+    init[e] = grp ? 0.0f : -0.0f;
+  }
+  f32x4 sv[F][RMAX];
+#pragma unroll
+  for (int t = 0; t < F; ++t)
+    if (t < nt) {
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) sv[t][r] = *reinterpret_cast<const f32x4*>(img + (int64_t)t * src_elems + coff[r]);
+    }
+  float* dst = out + (int64_t)t0 * n_out + 4 * (int64_t)q;
+#pragma unroll
+  for (int t = 0; t < F; ++t)
+    if (t < nt) {
+      __builtin_amdgcn_wave_barrier();                     // the previous frame's reads of the tile are issued before it is overwritten
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) tile[r * 64 + lane] = sv[t][r];
+      __builtin_amdgcn_wave_barrier();
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float acc = init[e];
+#pragma unroll
+        for (int k = 0; k < MAXS; ++k)
+          if (k < cnt[e]) acc += tile_f[(d[DW * e + k / 3] >> (10 * (k % 3))) & 1023u];
+        const float val = cnt[e] > 1 ? acc / fcnt[e] : (cnt[e] == 1 ? acc : 0.0f);   // IEEE division == the reference's, rounded once
+        v[e] = (val != val) ? 0.0f : val;                  // fillna(0.0)
+      }
+      if (active) *reinterpret_cast<f32x4*>(dst + (int64_t)t * n_out) = v;
+    }
+}
+
+// the cells of the quads the float32 tiles leave out: project_kernel's arithmetic, one thread per cell and F frames
+template <int F>
+__global__ __launch_bounds__(256) void project_slow_f32_kernel(const float* __restrict__ frames, int64_t src_elems, int n_frames,
+                                                               const int* __restrict__ slow_q, int n_slow, const int* __restrict__ nn_src,
+                                                               const int* __restrict__ grp_of, const int* __restrict__ grp_off,
+                                                               const int* __restrict__ grp_src, float* __restrict__ out, int n_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * n_slow) return;
+  const int o = 4 * slow_q[i >> 2] + (i & 3), nn = nn_src[o], g = grp_of[o];
+  int k0 = 0, k1 = 0;
+  if (g >= 0) { k0 = grp_off[g]; k1 = grp_off[g + 1]; }
+  const float cnt = (float)(k1 - k0);
+  const int t0 = blockIdx.y * F, nt = min(n_frames - t0, F);
+  const float* im = frames + (int64_t)t0 * src_elems;
+  float* dst = out + (int64_t)t0 * n_out + o;
+  for (int t = 0; t < nt; ++t, im += src_elems) {
+    float val = 0.0f;
+    if (nn >= 0) val = im[nn];
+    if (g >= 0) {
+      float sacc = 0.0f;
+      for (int k = k0; k < k1; ++k) sacc += im[grp_src[k]];
+      val = sacc / cnt;
+    }
+    dst[(int64_t)t * n_out] = (val != val) ? 0.0f : val;
+  }
+}
+
+hipError_t launch_project_tile_f32(const float* frames, int64_t src_elems, int n_frames, int dw, int rmax, const int* wchunk,
+                                   const uint32_t* qdesc, int wq, int rows, int lg_bqx, const int* slow_q, int n_slow, const int* nn_src,
+                                   const int* grp_of, const int* grp_off, const int* grp_src, float* out, int n_out, hipStream_t s) {
+  if (n_frames <= 0 || n_out <= 0) return hipSuccess;
+  const int bqx = 1 << lg_bqx, bqy = 64 >> lg_bqx;
+  const int tiles_x = (wq + bqx - 1) / bqx, n_waves = tiles_x * ((rows + bqy - 1) / bqy);
+  const int per_xcd = ((n_waves + 3) / 4 + 7) / 8;
+  // frames per thread: the chunks of all of them wait in registers (16 bytes per lane, list row and frame)
+#define LSPIV_TILE(FF, DD, RR)                                                                                                               \
+  hipLaunchKernelGGL((project_tile_f32_kernel<FF, DD, RR>), dim3((unsigned)(8 * per_xcd), (unsigned)((n_frames + FF - 1) / FF)), dim3(256), 0, s, \
+                     frames, src_elems, n_frames, wchunk, qdesc, out, n_out, wq, rows, lg_bqx, tiles_x, n_waves, per_xcd)
+  if (dw == 2) { if (rmax <= 1) LSPIV_TILE(4, 2, 1); else if (rmax == 2) LSPIV_TILE(4, 2, 2); else LSPIV_TILE(2, 2, 4); }
+  else { if (rmax <= 1) LSPIV_TILE(4, 3, 1); else if (rmax == 2) LSPIV_TILE(4, 3, 2); else LSPIV_TILE(2, 3, 4); }
+#undef LSPIV_TILE
+  if (n_slow > 0)
+    hipLaunchKernelGGL((project_slow_f32_kernel<8>), dim3((unsigned)((4 * n_slow + 255) / 256), (n_frames + 7) / 8), dim3(256), 0, s, frames,
+                       src_elems, n_frames, slow_q, n_slow, nn_src, grp_of, grp_off, grp_src, out, n_out);
+  return hipGetLastError();
+}
+
 // Nearest-neighbour-only plans (Frames.project with a reducer other than "mean", pyorc/project.py:196-199) on uint8 frames:
 // every cell is a source byte or 0, so the stack may stay uint8 -- a quarter of the float32 bytes to write here and for the
 // PIV kernels to read, and get_piv runs its uint8 kernels on the same values.  Quads of the window plan as above (one

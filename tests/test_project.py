@@ -352,19 +352,34 @@ def test_gpu_projection_through_the_tiled_plan(gpu, monkeypatch, capfd, src, dst
     """Round 6: project_tile_kernel -- a wave owns a block of 64 quads, loads the sorted list of the 8-byte chunks its windows touch (one
     chunk per lane; one, two or four list rows) into LDS and reads its windows from there.  Every block shape, both list lengths, waves
     handed to the slow kernel (the LSPIV_PROJECT_TILE_CAP test hook), and project_mix_kernel on the same plan: all bit-exact against
-    the oracle's literal loops, for frame counts around the kernel's 8-frame groups, from host arrays and from a stack resident in HBM."""
+    the oracle's literal loops, for frame counts around the kernel's 8-frame groups, from host arrays and from a stack resident in HBM.
+    The same for FLOAT32 frames (project_tile_f32_kernel: chunks of four pixels, a cell = the tile positions of its samples added in
+    the reference's order) -- signed values, NaN samples, sums whose value depends on the order -- against the oracle and against
+    the one-cell kernel's bits."""
     from pyorc_amd.device import DeviceFrames
     from pyorc_amd.project import Projection
 
     idx_img, mask, src_idx, uidx, norm_idx = projection_maps(src, dst, tilt=tilt, seed=5)
     maps = (idx_img, mask, src_idx, uidx, norm_idx) if groups else (idx_img, mask)
+    import re
+
     rng = np.random.default_rng(11)
     stacks = []
     for T in (1, 8, 9, 19):
         fr = (rng.random((T,) + src) * 256).astype(np.uint8)
         fr[0, :3] = 255
         fr[-1, -3:] = 255                                                # the frame's last bytes
-        stacks.append((fr, pro.project_frames(fr, dst, *maps) if groups else pro.project_frames(fr, dst, idx_img, mask)))
+        ff = ((rng.random((T,) + src) - 0.5) * 10).astype(np.float32)    # the recipe's edge-detected frames: signed float32
+        ff[0, ::7, ::5] = np.nan                                         # NaN samples: fillna(0) of the cell (of the whole mean)
+        ff[-1, ::3, ::4] = -0.0
+        ff[-1, 1::3, ::4] = 1e30                                         # sums that depend on the order of the additions
+        ff[-1, 2::3, ::4] = -1e30
+        refs = [pro.project_frames(f, dst, *maps) if groups else pro.project_frames(f, dst, idx_img, mask) for f in (fr, ff)]
+        stacks.append((fr, refs[0], ff, refs[1]))
+    monkeypatch.setenv("LSPIV_PROJECT_NO_TILE", "1")
+    p = Projection(src, dst, *maps)
+    one_cell_bits = [p.project_frames(ff).view(np.uint32) for _, _, ff, _ in stacks]   # the one-cell kernel's bits (signed zeros included)
+    p.close()
     flat = dst[1] % 4 != 0
     settings = [{}] + [{"LSPIV_PROJECT_TILE_LG": str(lg)} for lg in ((6,) if flat else (3, 4, 5, 6))]
     settings += [{"LSPIV_PROJECT_TILE_RMAX": "2"}, {"LSPIV_PROJECT_TILE_RMAX": "4"}, {"LSPIV_PROJECT_TILE_CAP": "40"},
@@ -378,20 +393,27 @@ def test_gpu_projection_through_the_tiled_plan(gpu, monkeypatch, capfd, src, dst
         capfd.readouterr()
         p = Projection(src, dst, *maps)
         said = capfd.readouterr().err
+        built = {m[0]: tuple(int(v) for v in m[1:]) for m in
+                 re.findall(r"\((uint8|float32)\): tiles of (\d+) x (\d+) quads, (\d+) list row\(s\), (\d+) waves to the slow kernel", said)}
         if "LSPIV_PROJECT_NO_TILE" in env:
-            assert "tiles of" not in said
+            assert not built
         else:
-            assert "tiles of" in said, said                              # the tiled plan was built ...
-            if "LSPIV_PROJECT_TILE_LG" in env and not flat:
-                assert f"tiles of {1 << int(env['LSPIV_PROJECT_TILE_LG'])} x" in said
-            if "LSPIV_PROJECT_TILE_RMAX" in env:
-                assert int(said.split(" list row(s)")[0].split()[-1]) >= int(env["LSPIV_PROJECT_TILE_RMAX"])
-            slow_waves = int(said.split("list row(s), ")[1].split(" waves")[0])
-            assert (slow_waves > 0) == ("LSPIV_PROJECT_TILE_CAP" in env), said   # ... and the hook (only the hook) sends waves to the slow kernel
-        for fr, ref in stacks:
+            assert set(built) == {"uint8", "float32"}, said              # both tiled plans were built ...
+            for kind, (bqx, bqy, list_rows, slow_waves) in built.items():
+                assert bqx * bqy == 64
+                if "LSPIV_PROJECT_TILE_LG" in env and not flat:
+                    assert bqx == 1 << int(env["LSPIV_PROJECT_TILE_LG"])
+                assert list_rows >= int(env.get("LSPIV_PROJECT_TILE_RMAX", 1))
+                if "LSPIV_PROJECT_TILE_CAP" in env:                       # ... and the hook sends waves to the slow kernels (a plan's own choice
+                    assert slow_waves > 0, said                          # leaves them at most 1 wave in 100)
+        for (fr, ref, ff, reff), bits in zip(stacks, one_cell_bits):
             got = p.project_frames(fr)
             assert got.dtype == np.float32 and np.array_equal(got.astype(np.float64), ref), (env, len(fr))
             d = DeviceFrames.from_host(fr)
             dv = p.project_frames(d, keep_uint8=False).to_host()
             assert dv.dtype == np.float32 and np.array_equal(dv, got), (env, len(fr))
+            gotf = p.project_frames(ff)
+            assert gotf.dtype == np.float32 and np.array_equal(gotf.astype(np.float64), reff), (env, len(ff))
+            assert np.array_equal(gotf.view(np.uint32), bits), (env, len(ff))
+            assert np.array_equal(p.project_frames(DeviceFrames.from_host(ff)).to_host().view(np.uint32), bits), (env, len(ff))
         p.close()

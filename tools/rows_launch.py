@@ -51,6 +51,8 @@ def build_rows(lib, T: int):
     _lib.check(lib.lspiv_synth_particles_dev(d_cam, T, H, W, 3, 0.02))
     d_f32 = _alloc(lib, T * max(n, no) * 4)
     d_u8 = _alloc(lib, T * n)
+    d_camf = _alloc(lib, T * n * 4)                          # float32 camera frames: the edge-detected stack the Ngwerere recipe projects
+    _lib.check(lib.lspiv_edge_detect_dev(d_cam, 0, T, H, W, 3, 5, d_camf, None))
     maps = projection_maps((H, W), (HO, WO), tilt=0.1, seed=1)
     p_mean = Projection((H, W), (HO, WO), *maps)
     p_nn = Projection((H, W), (HO, WO), maps[0], maps[1])
@@ -62,6 +64,10 @@ def build_rows(lib, T: int):
                        "Frames.project(method='numpy') with a reducer other than 'mean': nearest neighbour only, the uint8 quad-window plan, float32 out"),
         "project_u8": (lambda: p_nn.project_frames_dev(d_cam.value, np.uint8, T, d_u8.value, keep_uint8=True), T * (n + no), T, "project_",
                        "nearest-neighbour-only plan (reducer other than 'mean'), uint8 in -> uint8 out"),
+        "project_f32": (lambda: p_mean.project_frames_dev(d_camf.value, np.float32, T, d_f32.value), T * (4 * n + 4 * no), T, "project_",
+                        f"Frames.project(method='numpy', reducer='mean') of FLOAT32 camera frames (after edge_detect / minmax, the Ngwerere recipe's order): {H}x{W} -> {HO}x{WO}"),
+        "edge_detect": (lambda: _lib.check(lib.lspiv_edge_detect_dev(d_cam, 0, T, H, W, 3, 5, d_f32, None)), T * n * 5, T, "blur_|edge_",
+                        "Frames.edge_detect(wdw_1=1, wdw_2=2): difference of two Gaussian blurs (3x3, 5x5), uint8 -> float32"),
         "project_cv": (lambda: _lib.check(lib.lspiv_project_cv_frames_dev(p_cv._h, d_cam, 0, T, d_u8, None)), T * (n + no), T, "remap_",
                        "Frames.project(method='cv'): undistort + warpPerspective as two fixed-point bilinear remaps, uint8"),
         "time_diff": (lambda: _lib.check(lib.lspiv_time_diff_dev(d_cam, 0, T, H, W, 0.0, 0, d_f32, None)), T * n + (T - 1) * n * 4, T - 1, "time_diff_",
@@ -75,7 +81,7 @@ def build_rows(lib, T: int):
     def cleanup():
         for pl in (p_mean, p_nn, p_cv):
             pl.close()
-        for p in (d_cam, d_f32, d_u8):
+        for p in (d_cam, d_f32, d_u8, d_camf):
             lib.lspiv_dev_free(p)
 
     return rows, cleanup
