@@ -92,8 +92,8 @@ def _ortho_lazy(cam, maps, dst, block=20, extra_layer=False, xarray_mod=None):
     return (ortho.map_time(lambda blk: blk, "astype") if extra_layer else ortho), video
 
 
-@pytest.mark.parametrize("reducer_mean", [True, False])
-def test_project_hip_product_stays_in_hbm_for_get_piv(gpu, monkeypatch, reducer_mean):
+@pytest.mark.parametrize("reducer_mean,recipe_frames", [(True, False), (False, False), (True, True)])
+def test_project_hip_product_stays_in_hbm_for_get_piv(gpu, monkeypatch, reducer_mean, recipe_frames):
     """frames.project(method="hip") -> [fillna] -> get_piv(engine="hip"): the camera blocks are uploaded and projected into the
     resident stack on the device; one more layer in between and the projected blocks come back to the host and go up again.  Same bits
     both ways, and those of Projection.project_frames + get_piv on a numpy stack."""
@@ -108,6 +108,12 @@ def test_project_hip_product_stays_in_hbm_for_get_piv(gpu, monkeypatch, reducer_
     if not reducer_mean:
         maps = (maps[0], maps[1], None, None, None)
     cam = particle_stack(91, src[0], src[1], seed=8)
+    if recipe_frames:
+        # what the reference's recipe hands to project: normalize -> edge_detect -> minmax come first (examples/ngwerere/ngwerere.yml:5-11),
+        # signed float32 camera frames -- uploaded as they are and projected through the float32 tiles
+        from pyorc_amd import filters
+        cam = filters.minmax(filters.edge_detect(filters.normalize(cam, 15), 1, 2), -5, 5)
+        assert cam.dtype == np.float32 and cam.min() < 0
     t = np.arange(91) / 30.0
     kw = dict(time=t, resolution=0.01)
     try:
