@@ -295,24 +295,49 @@ __global__ __launch_bounds__(256) void norm_fold_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void norm_stretch_space_kernel(const uint8_t* __restrict__ f, const float* __restrict__ mean,
                                                                  int64_t frame_elems, int n_frames, int seg_len,
                                                                  const float* __restrict__ lo_in, const float* __restrict__ hi_in,
-                                                                 uint8_t* __restrict__ out) {
+                                                                 uint8_t* __restrict__ out, int mode) {
   NormLane L;
   L.init(mean, frame_elems);
   const int t0 = blockIdx.y * seg_len, t1 = min(t0 + seg_len, n_frames);
-#pragma unroll 4
+  // The reference's  a / span * 255  costs an IEEE division per pixel (ten instructions: this pass ran at the VALU's rate, 0.22 of its
+  // 0.25 ms, profiles/r06_rows_normalize) -- but only the INTEGER PART of the result is kept.  With y = RN(1 / span) once per frame,
+  // (a y) 255 is within 5 roundings (3e-7 relative) of RN(RN(a / span) 255), so wherever it is further than that from an integer its
+  // integer part is the reference's; the few pixels nearer to one (about 1 instruction in 100 has such a lane) take the division
+  // under a wave-uniform branch.  Frames whose span has no usable reciprocal (0: a constant frame, 0 / 0 -> 0) divide everywhere.
+  // (the ballot is a convergent operation: the compiler does not unroll this loop, so the next frame's loads are issued by hand)
+  u32x4n wn[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) wn[k] = L.v[k] && t0 < t1 ? *reinterpret_cast<const u32x4n*>(f + (int64_t)t0 * frame_elems + L.c[k]) : u32x4n{0u, 0u, 0u, 0u};
   for (int t = t0; t < t1; ++t) {
     const float lo = lo_in[t], span = hi_in[t] - lo;
-    const uint8_t* img = f + (int64_t)t * frame_elems;
+    const float y = 1.0f / span;
+    const bool fast = mode == 0 && span > 1e-30f && span < 1e30f;     // wave-uniform
     uint8_t* dst = out + (int64_t)t * frame_elems;
+    u32x4n wc[2] = {wn[0], wn[1]};
+    if (t + 1 < t1) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) if (L.v[k]) wn[k] = *reinterpret_cast<const u32x4n*>(f + (int64_t)(t + 1) * frame_elems + L.c[k]);
+    }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       if (L.v[k]) {
-        const u32x4n w = *reinterpret_cast<const u32x4n*>(img + L.c[k]);
+        const u32x4n w = wc[k];
         u32x4n o = {0u, 0u, 0u, 0u};
+        if (fast) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float q = (((float)((w[e >> 2] >> (8 * (e & 3))) & 0xffu) - L.m[k][e]) - lo) / span * 255.0f;
-          o[e >> 2] |= (uint32_t)((q != q) ? (uint8_t)0 : (uint8_t)(int)q) << (8 * (e & 3));
+          for (int e = 0; e < 16; ++e) {
+            const float a = ((float)((w[e >> 2] >> (8 * (e & 3))) & 0xffu) - L.m[k][e]) - lo;
+            float q = (a * y) * 255.0f;
+            const bool near = !(fabsf(q - rintf(q)) > 6.0e-7f * q + 1.0e-30f);   // (NaN: near)
+            if (__builtin_amdgcn_ballot_w64(near) != 0) q = near ? a / span * 255.0f : q;
+            o[e >> 2] |= (uint32_t)((q != q) ? (uint8_t)0 : (uint8_t)(int)q) << (8 * (e & 3));
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float q = (((float)((w[e >> 2] >> (8 * (e & 3))) & 0xffu) - L.m[k][e]) - lo) / span * 255.0f;
+            o[e >> 2] |= (uint32_t)((q != q) ? (uint8_t)0 : (uint8_t)(int)q) << (8 * (e & 3));
+          }
         }
         *reinterpret_cast<u32x4n*>(dst + L.c[k]) = o;
       }
@@ -580,7 +605,8 @@ hipError_t launch_normalize_apply(const uint8_t* frames, int64_t frame_elems, in
     float* hi = reinterpret_cast<float*>(d_mx);
     hipLaunchKernelGGL(norm_minmax_space_kernel, dim3(n_slices, n_seg), dim3(256), 0, s, frames, d_mean, frame_elems, n_frames, seg_len, d_part, n_ws);
     hipLaunchKernelGGL(norm_fold_kernel, dim3(n_frames), dim3(256), 0, s, d_part, n_ws, lo, hi);
-    hipLaunchKernelGGL(norm_stretch_space_kernel, dim3(n_slices, n_seg), dim3(256), 0, s, frames, d_mean, frame_elems, n_frames, seg_len, lo, hi, out);
+    static const int divide = getenv("LSPIV_NORM_DIVIDE") != nullptr;   // A/B: the division for every pixel (the round-5 pass)
+    hipLaunchKernelGGL(norm_stretch_space_kernel, dim3(n_slices, n_seg), dim3(256), 0, s, frames, d_mean, frame_elems, n_frames, seg_len, lo, hi, out, divide);
     return hipGetLastError();
   }
   const bool vec = frame_elems % 4 == 0 && (reinterpret_cast<uintptr_t>(frames) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;

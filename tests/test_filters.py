@@ -1,9 +1,13 @@
 """N2 element-wise filters: oracle behaviour on CPU, bit-exact parity on the GPU."""
+import os
+
 import numpy as np
 import pytest
 
 from oracle import filters_oracle as fo
 from pyorc_amd.synth import particle_stack
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_oracle_filters_follow_reference_arithmetic():
@@ -298,3 +302,40 @@ def test_gpu_smooth_and_edge_detect(gpu, dtype):
     assert np.abs(filters.smooth(fr[0], 1) - fo.gaussian_blur(fr[0], 3)).max() < 1e-4
     tiny = fr[:, :5, :3]                                                          # smaller than the halo: reflect101 wraps
     assert np.abs(filters.smooth(tiny, 3) - fo.smooth(tiny, 3)).max() <= 2e-6 * max(1.0, float(np.abs(tiny).max()))
+
+
+@pytest.mark.gpu
+def test_gpu_normalize_without_the_division_keeps_the_reference_integers(gpu, monkeypatch):
+    """Round 6: the stretch pass multiplies by RN(1 / span) and divides only where the product lies within rounding distance of an
+    integer.  Frames of every span 1 .. 255 around a constant mean (the quotient times 255 is then an exact integer for many pixels:
+    every one of them must take the division), random means, a constant frame (0 / 0) -- the bytes of the reference's float32
+    expression (oracle), and of the all-division pass the library ran before."""
+    import subprocess
+    import sys as _sys
+
+    from pyorc_amd import filters
+
+    rng = np.random.default_rng(12)
+    T, H, W = 45, 48, 256
+    const_mean = np.empty((T, H, W), np.uint8)
+    for t in range(T):
+        span = 1 + (t * 6) % 255
+        lo = int(rng.integers(0, 256 - span))
+        const_mean[t] = rng.integers(lo, lo + span + 1, (H, W))
+        const_mean[t, 0, 0], const_mean[t, 0, 1] = lo, lo + span       # the frame's range is exactly `span`
+    const_mean[::3] = 100                                              # the sampled frames (interval 3 for 15 samples): mean plane = 100
+    rnd = (rng.random((T, H, W)) * rng.integers(2, 256, (T, 1, 1))).astype(np.uint8)
+    rnd[7] = 31                                                        # a constant frame away from the mean
+    for fr in (const_mean, rnd):
+        got = filters.normalize(fr, 15)
+        assert np.array_equal(got, fo.normalize(fr, 15))
+    # the same stacks through the all-division pass (the switch is read once per process)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from pyorc_amd import filters; a = np.load(sys.argv[1]);"
+            "np.save(sys.argv[2], np.stack([filters.normalize(f, 15) for f in a]))" % ROOT)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "in.npy"), np.stack([const_mean, rnd]))
+        subprocess.check_call([_sys.executable, "-c", code, os.path.join(d, "in.npy"), os.path.join(d, "out.npy")],
+                              env=dict(os.environ, LSPIV_NORM_DIVIDE="1"))
+        old = np.load(os.path.join(d, "out.npy"))
+    assert np.array_equal(old[0], filters.normalize(const_mean, 15)) and np.array_equal(old[1], filters.normalize(rnd, 15))
