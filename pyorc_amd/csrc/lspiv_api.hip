@@ -2109,8 +2109,12 @@ int lspiv_project_frames_u8_dev(lspiv_projection* h, const uint8_t* d_frames, in
   int rc = get_ctx(&c);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-  hipError_t e = lspiv::launch_project_u8(d_frames, h->src_h * h->src_w, (int)T, h->d_qlo1, h->d_qlo2, h->d_qdesc, h->d_nn, d_out,
-                                          (int)(h->dst_h * h->dst_w), s);
+  const bool tile = h->d_mcell && h->d_twin && (reinterpret_cast<uintptr_t>(d_out) & 3) == 0 && (reinterpret_cast<uintptr_t>(d_frames) & 7) == 0;
+  hipError_t e = tile ? lspiv::launch_project_tile_u8(d_frames, h->src_h * h->src_w, (int)T, h->mix_nw, h->tile_rmax, h->d_wchunk, h->d_twin, h->d_mcell,
+                                                       h->tile_wq, h->tile_rows, h->tile_lg, h->d_tslow, h->n_tslow, h->d_nn, d_out,
+                                                       (int)(h->dst_h * h->dst_w), s)
+                      : lspiv::launch_project_u8(d_frames, h->src_h * h->src_w, (int)T, h->d_qlo1, h->d_qlo2, h->d_qdesc, h->d_nn, d_out,
+                                                 (int)(h->dst_h * h->dst_w), s);
   if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
   return LSPIV_OK;
 }

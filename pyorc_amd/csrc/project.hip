@@ -351,10 +351,10 @@ hipError_t launch_project_mix(const uint8_t* frames, int64_t src_elems, int n_fr
 #ifndef LSPIV_TILE_NT
 #define LSPIV_TILE_NT 0         // 1: non-temporal stores of the ortho frames
 #endif
-template <int F, int NW, int RMAX>
+template <int F, int NW, int RMAX, typename OUT>      // OUT float: the reference's float32 cells; uint8_t: a nearest-neighbour-only plan's bytes as they are
 __global__ __launch_bounds__(64 * LSPIV_TILE_WAVES) void project_tile_kernel(const uint8_t* __restrict__ frames, int64_t src_elems, int n_frames,
                                                            const int* __restrict__ wchunk, const int* __restrict__ twin,
-                                                           const uint32_t* __restrict__ qcell, float* __restrict__ out, int n_out,
+                                                           const uint32_t* __restrict__ qcell, OUT* __restrict__ out, int n_out,
                                                            int wq, int rows, int lg_bqx, int tiles_x, int n_waves, int blocks_per_xcd) {
   constexpr int CW = NW / 2;
   typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(64 * LSPIV_TILE_WAVES) void project_tile_kernel(con
 #pragma unroll
       for (int r = 0; r < RMAX; ++r) sv[t][r] = *reinterpret_cast<const uint64_t*>(img + (int64_t)t * src_elems + coff[r]);
     }
-  float* dst = out + (int64_t)t0 * n_out + 4 * (int64_t)q;
+  OUT* dst = out + (int64_t)t0 * n_out + 4 * (int64_t)q;
 #pragma unroll
   for (int t = 0; t < F; ++t)
     if (t < nt) {
@@ -449,6 +449,7 @@ __global__ __launch_bounds__(64 * LSPIV_TILE_WAVES) void project_tile_kernel(con
       }
       if (active) {
         f32x4 v;
+        uint32_t bytes = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           uint32_t sum = 0;
@@ -457,17 +458,34 @@ __global__ __launch_bounds__(64 * LSPIV_TILE_WAVES) void project_tile_kernel(con
             sum = __builtin_amdgcn_udot4(lo[k], mlo[e][k], sum, false);
             sum = __builtin_amdgcn_udot4(hi[k], mhi[e][k], sum, false);
           }
-          v[e] = quotient((float)sum, cnt[e], rcp[e]);
+          if (sizeof(OUT) == 1) bytes |= sum << (8 * e);   // one sample (or none) per cell: the sum is the byte
+          else v[e] = quotient((float)sum, cnt[e], rcp[e]);
         }
-        if (LSPIV_TILE_NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst + (int64_t)t * n_out));
+        if (sizeof(OUT) == 1) *reinterpret_cast<uint32_t*>(dst + (int64_t)t * n_out) = bytes;
+        else if (LSPIV_TILE_NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst + (int64_t)t * n_out));
         else *reinterpret_cast<f32x4*>(dst + (int64_t)t * n_out) = v;
       }
     }
 }
 
-hipError_t launch_project_tile(const uint8_t* frames, int64_t src_elems, int n_frames, int nw, int rmax, const int* wchunk, const int* twin,
-                               const uint32_t* qcell, int wq, int rows, int lg_bqx, const int* slow_q, int n_slow, const int* nn_src,
-                               const int* grp_of, const int* grp_off, const int* grp_src, float* out, int n_out, hipStream_t s) {
+// the quads the tiles leave out, uint8 output: a cell is its nearest-neighbour byte or 0
+template <int F>
+__global__ __launch_bounds__(256) void project_slow_u8_kernel(const uint8_t* __restrict__ frames, int64_t src_elems, int n_frames,
+                                                              const int* __restrict__ slow_q, int n_slow, const int* __restrict__ nn_src,
+                                                              uint8_t* __restrict__ out, int n_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * n_slow) return;
+  const int o = 4 * slow_q[i >> 2] + (i & 3), nn = nn_src[o];
+  const int t0 = blockIdx.y * F, nt = min(n_frames - t0, F);
+  const uint8_t* im = frames + (int64_t)t0 * src_elems;
+  uint8_t* dst = out + (int64_t)t0 * n_out + o;
+  for (int t = 0; t < nt; ++t, im += src_elems) dst[(int64_t)t * n_out] = nn >= 0 ? im[nn] : (uint8_t)0;
+}
+
+template <typename OUT>
+static hipError_t launch_project_tile_t(const uint8_t* frames, int64_t src_elems, int n_frames, int nw, int rmax, const int* wchunk, const int* twin,
+                                        const uint32_t* qcell, int wq, int rows, int lg_bqx, const int* slow_q, int n_slow, const int* nn_src,
+                                        const int* grp_of, const int* grp_off, const int* grp_src, OUT* out, int n_out, hipStream_t s) {
   if (n_frames <= 0 || n_out <= 0) return hipSuccess;
   constexpr int F = LSPIV_TILE_F, F4 = LSPIV_TILE_F / 2;  // four list rows: half the frames per thread (the chunks of all of them wait in registers)
   const int bqx = 1 << lg_bqx, bqy = 64 >> lg_bqx;
@@ -476,15 +494,34 @@ hipError_t launch_project_tile(const uint8_t* frames, int64_t src_elems, int n_f
   const int f = rmax > 2 ? F4 : F;
   const dim3 grid((unsigned)(8 * per_xcd), (unsigned)((n_frames + f - 1) / f));
 #define LSPIV_TILE(FF, NN, RR)                                                                                                              \
-  hipLaunchKernelGGL((project_tile_kernel<FF, NN, RR>), grid, dim3(64 * LSPIV_TILE_WAVES), 0, s, frames, src_elems, n_frames, wchunk, twin, \
+  hipLaunchKernelGGL((project_tile_kernel<FF, NN, RR, OUT>), grid, dim3(64 * LSPIV_TILE_WAVES), 0, s, frames, src_elems, n_frames, wchunk, twin, \
                      qcell, out, n_out, wq, rows, lg_bqx, tiles_x, n_waves, per_xcd)
   if (nw == 2) { if (rmax <= 1) LSPIV_TILE(F, 2, 1); else if (rmax == 2) LSPIV_TILE(F, 2, 2); else LSPIV_TILE(F4, 2, 4); }
   else { if (rmax <= 1) LSPIV_TILE(F, 4, 1); else if (rmax == 2) LSPIV_TILE(F, 4, 2); else LSPIV_TILE(F4, 4, 4); }
 #undef LSPIV_TILE
-  if (n_slow > 0)
-    hipLaunchKernelGGL((project_slow_kernel<F>), dim3((unsigned)((4 * n_slow + 255) / 256), (n_frames + F - 1) / F), dim3(256), 0, s, frames,
-                       src_elems, n_frames, slow_q, n_slow, nn_src, grp_of, grp_off, grp_src, out, n_out);
+  if (n_slow > 0) {
+    const dim3 sgrid((unsigned)((4 * n_slow + 255) / 256), (n_frames + F - 1) / F);
+    if constexpr (sizeof(OUT) == 1)
+      hipLaunchKernelGGL((project_slow_u8_kernel<F>), sgrid, dim3(256), 0, s, frames, src_elems, n_frames, slow_q, n_slow, nn_src, out, n_out);
+    else
+      hipLaunchKernelGGL((project_slow_kernel<F>), sgrid, dim3(256), 0, s, frames, src_elems, n_frames, slow_q, n_slow, nn_src, grp_of, grp_off,
+                         grp_src, out, n_out);
+  }
   return hipGetLastError();
+}
+
+hipError_t launch_project_tile(const uint8_t* frames, int64_t src_elems, int n_frames, int nw, int rmax, const int* wchunk, const int* twin,
+                               const uint32_t* qcell, int wq, int rows, int lg_bqx, const int* slow_q, int n_slow, const int* nn_src,
+                               const int* grp_of, const int* grp_off, const int* grp_src, float* out, int n_out, hipStream_t s) {
+  return launch_project_tile_t<float>(frames, src_elems, n_frames, nw, rmax, wchunk, twin, qcell, wq, rows, lg_bqx, slow_q, n_slow, nn_src, grp_of,
+                                      grp_off, grp_src, out, n_out, s);
+}
+
+hipError_t launch_project_tile_u8(const uint8_t* frames, int64_t src_elems, int n_frames, int nw, int rmax, const int* wchunk, const int* twin,
+                                  const uint32_t* qcell, int wq, int rows, int lg_bqx, const int* slow_q, int n_slow, const int* nn_src,
+                                  uint8_t* out, int n_out, hipStream_t s) {
+  return launch_project_tile_t<uint8_t>(frames, src_elems, n_frames, nw, rmax, wchunk, twin, qcell, wq, rows, lg_bqx, slow_q, n_slow, nn_src, nullptr,
+                                        nullptr, nullptr, out, n_out, s);
 }
 
 // FLOAT32 camera frames through tiles (round 6): what the reference's own recipe projects -- Frames.normalize -> edge_detect -> minmax

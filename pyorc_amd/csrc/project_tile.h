@@ -10,6 +10,10 @@ namespace lspiv {
 hipError_t launch_project_tile(const uint8_t* frames, int64_t src_elems, int n_frames, int nw, int rmax, const int* wchunk, const int* twin,
                                const uint32_t* qcell, int wq, int rows, int lg_bqx, const int* slow_q, int n_slow, const int* nn_src,
                                const int* grp_of, const int* grp_off, const int* grp_src, float* out, int n_out, hipStream_t s);
+// the same tiles with uint8 output: a nearest-neighbour-only plan (every cell one source byte or 0) keeps uint8 frames uint8
+hipError_t launch_project_tile_u8(const uint8_t* frames, int64_t src_elems, int n_frames, int nw, int rmax, const int* wchunk, const int* twin,
+                                  const uint32_t* qcell, int wq, int rows, int lg_bqx, const int* slow_q, int n_slow, const int* nn_src,
+                                  uint8_t* out, int n_out, hipStream_t s);
 // float32 frames in tiles: 16-byte chunks (four pixels), per cell a descriptor of dw words holding up to 3 * dw tile positions, the
 // count and the group flag (project.hip: project_tile_f32_kernel)
 hipError_t launch_project_tile_f32(const float* frames, int64_t src_elems, int n_frames, int dw, int rmax, const int* wchunk,

@@ -412,6 +412,10 @@ def test_gpu_projection_through_the_tiled_plan(gpu, monkeypatch, capfd, src, dst
             d = DeviceFrames.from_host(fr)
             dv = p.project_frames(d, keep_uint8=False).to_host()
             assert dv.dtype == np.float32 and np.array_equal(dv, got), (env, len(fr))
+            if not groups:                                                # a nearest-neighbour-only plan keeps uint8 frames uint8: the same tiles, bytes out
+                du = p.project_frames(d).to_host()
+                assert du.dtype == np.uint8 and np.array_equal(du, got), (env, len(fr))
+                assert np.array_equal(p.project_frames(fr, keep_uint8=True), du), (env, len(fr))
             gotf = p.project_frames(ff)
             assert gotf.dtype == np.float32 and np.array_equal(gotf.astype(np.float64), reff), (env, len(ff))
             assert np.array_equal(gotf.view(np.uint32), bits), (env, len(ff))
