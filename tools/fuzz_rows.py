@@ -1,7 +1,7 @@
 """Randomised differential test of the rows around the hot path: filters, both projections, the
 post-PIV masks and the int16 packing against their numpy oracles, over random shapes (odd widths, single frames, tiny
 frames), dtypes and parameters.  Bit-exact except the Gaussian filters (4e-6 of the value range) and `angle` (atan2f).
-usage: fuzz_rows.py <seed> <cases>"""
+usage: fuzz_rows.py <seed> <cases>        FUZZ_KINDS=project,normalize restricts the kinds drawn"""
 import os, sys, time, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -17,7 +17,8 @@ eq = lambda a, b: a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
 bad = 0
 t_start = time.time()
 for case in range(n_cases):
-    kind = str(rng.choice(["time_diff", "range", "minmax", "normalize", "reduce_rolling", "blur", "project", "project_cv", "masks", "pack"]))
+    kind = str(rng.choice(os.environ["FUZZ_KINDS"].split(",") if os.environ.get("FUZZ_KINDS") else
+                          ["time_diff", "range", "minmax", "normalize", "reduce_rolling", "blur", "project", "project_cv", "masks", "pack"]))
     T = int(rng.integers(1, 6)) if rng.random() < 0.3 else int(rng.integers(6, 40))
     H = int(rng.integers(3, 40)) if rng.random() < 0.3 else int(rng.integers(40, 200))
     W = int(rng.integers(3, 40)) if rng.random() < 0.3 else int(rng.integers(40, 260))
@@ -69,6 +70,8 @@ for case in range(n_cases):
             maps = projection_maps(src, dst, tilt=float(rng.uniform(0.05, 0.5)), seed=int(rng.integers(1000)))
             fr = (rng.random((max(T, 1),) + src) * 255).astype(np.uint8)
             fr = fr if dtype == np.uint8 else fr.astype(dtype) * 0.731 - 40.5
+            if dtype != np.uint8 and rng.random() < 0.5:                         # NaN samples: fillna(0) of the cell (a group's whole mean)
+                fr[rng.integers(fr.shape[0]), ::int(rng.integers(1, 9)), ::int(rng.integers(1, 9))] = np.nan
             full = rng.random() < 0.7
             args = maps if full else maps[:2]
             p = Projection(src, dst, *args)
