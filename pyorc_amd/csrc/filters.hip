@@ -44,6 +44,35 @@ __global__ __launch_bounds__(256) void time_diff_u8x4_kernel(const uint32_t* __r
   }
 }
 
+// The same per pixel, walking through time (round 6): a lane owns four pixels and S + 1 consecutive frames -- S + 1 four-byte loads, S
+// 16-byte stores.  The flat kernel above asks for every frame twice (as `a` and as `b`; the second request is an L2 / Infinity-Cache hit,
+// HBM fetch = the frames once) and ran at 4.2 TB/s where one load per store streams at 5.2 - 5.5 (tools/ubench/stream.hip: expand).
+template <int S>
+__global__ __launch_bounds__(256) void time_diff_u8x4_walk_kernel(const uint32_t* __restrict__ f, int64_t frame_quads, int n_out_frames,
+                                                                  float thres, int use_abs, f32x4* __restrict__ out) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= frame_quads) return;
+  const int t0 = blockIdx.y * S, nt = min(n_out_frames - t0, S);      // block-uniform
+  const uint32_t* src = f + (int64_t)t0 * frame_quads + q;
+  f32x4* dst = out + (int64_t)t0 * frame_quads + q;
+  uint32_t w[S + 1];
+#pragma unroll
+  for (int t = 0; t <= S; ++t)
+    if (t <= nt) w[t] = src[(int64_t)t * frame_quads];
+#pragma unroll
+  for (int t = 0; t < S; ++t)
+    if (t < nt) {
+      f32x4 v;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float d = (float)((w[t + 1] >> (8 * k)) & 0xffu) - (float)((w[t] >> (8 * k)) & 0xffu);
+        d = (d > thres) ? d : 0.0f;
+        v[k] = use_abs ? fabsf(d) : d;
+      }
+      dst[(int64_t)t * frame_quads] = v;
+    }
+}
+
 // Frames.range (pyorc/api/frames.py:364-379): (max over time - min over time).astype(input dtype), one thread per pixel
 // column walking the frames; xarray's max / min skip NaN for float frames (nanmax / nanmin; an all-NaN pixel stays NaN).
 template <typename T>
@@ -521,6 +550,14 @@ hipError_t launch_time_diff(const void* frames, int dtype, int64_t frame_elems, 
   if (n_out <= 0) return hipSuccess;
   const unsigned blocks = (unsigned)std::min<int64_t>((n_out + 255) / 256, 256 * 16);
   if (dtype == 0 && frame_elems % 4 == 0 && (reinterpret_cast<uintptr_t>(frames) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    static const bool flat = getenv("LSPIV_TIME_DIFF_FLAT") != nullptr;   // A/B: the flat kernel (two loads per store)
+    if (!flat) {
+      constexpr int S = 8;
+      const int64_t fq = frame_elems / 4;
+      hipLaunchKernelGGL(time_diff_u8x4_walk_kernel<S>, dim3((unsigned)((fq + 255) / 256), (unsigned)((n_frames - 1 + S - 1) / S)), dim3(256), 0, s,
+                         (const uint32_t*)frames, fq, (int)(n_frames - 1), thres, use_abs, reinterpret_cast<f32x4*>(out));
+      return hipGetLastError();
+    }
     const unsigned qb = (unsigned)std::min<int64_t>((n_out / 4 + 255) / 256, 256 * 32);
     hipLaunchKernelGGL(time_diff_u8x4_kernel, dim3(qb), dim3(256), 0, s, (const uint32_t*)frames, frame_elems / 4, n_out / 4, thres, use_abs,
                        reinterpret_cast<f32x4*>(out));
