@@ -514,6 +514,7 @@ def camera_to_velocity_rates(cam: np.ndarray, ws, ov) -> dict:
         del d_ortho
     del d_res
     out["hbm_resident_project_then_piv"] = res
+    out["ngwerere_recipe"] = recipe_rates(cam, maps, (Ho, Wo), ws, ov)
     out.update(dropin)
     pn.close()
     del d_norm
@@ -521,6 +522,64 @@ def camera_to_velocity_rates(cam: np.ndarray, ws, ov) -> dict:
     out["note"] = (f"{T - 1} pairs of {H}x{W} uint8 camera frames in pageable host memory -> normalize(15) -> orthoprojection "
                    f"to a {Ho}x{Wo} grid (synthetic homography; {averaged_cells} of its {Ho * Wo} cells are group means of 2+ camera pixels, the rest "
                    f"nearest neighbour) -> get_piv {ws[0]}x{ws[1]}; PCIe-inclusive, never `value`")
+    return out
+
+
+def recipe_rates(cam: np.ndarray, maps, ortho_shape, ws, ov) -> dict:
+    """The `frames:` section of the reference's own recipe in its own order (examples/ngwerere/ngwerere.yml:5-11; the service appends
+    `project` last, pyorc/service/velocimetry.py:537-538): normalize -> edge_detect(1, 2) -> minmax(-5, 5) -> project -> get_piv.  What
+    project sees is then a FLOAT32 camera stack (the float32 tiles of round 6).  (a) the fixed chain from uint8 camera frames in host
+    memory to velocities in host memory, upload streamed under the kernels; (b) the stages once the camera stack is in HBM, each timed
+    by HIP events, results left in HBM (minmax rides in edge_detect's store: lspiv_edge_detect_clip_dev; as a pass of its own it
+    cost 0.73 ms of the chain's 3.4)."""
+    import ctypes as C
+
+    from pyorc_amd import DeviceFrames, _lib, filters, window
+    from pyorc_amd.pipeline import CameraToVelocity
+    from pyorc_amd.project import Projection
+
+    T, H, W = cam.shape
+    Ho, Wo = ortho_shape
+    lib = _lib.load()
+    out = {}
+    with CameraToVelocity((H, W), (Ho, Wo), *maps, window_size=ws, overlap=ov, normalize_samples=15, edge_detect=(1, 2), minmax=(-5, 5)) as chain:
+        chain.run(cam)
+        t0 = time.perf_counter()
+        chain.run(cam)
+        out["host_to_host_pairs_per_s"] = round((T - 1) / (time.perf_counter() - t0), 1)
+    p = Projection((H, W), (Ho, Wo), *maps)
+    nr, nc = window.get_array_shape((Ho, Wo), ws, ov)
+    d_cam = DeviceFrames.from_host(cam)
+    d_edge = DeviceFrames.empty((T, H, W), np.float32)
+    d_ortho = DeviceFrames.empty((T, Ho, Wo), np.float32)
+    d_res = DeviceFrames.empty((4 * (T - 1), nr, nc), np.float32)
+    d_n = DeviceFrames.empty((T, H, W), np.uint8)
+    stages = (("normalize", lambda: _lib.check(lib.lspiv_normalize_dev(d_cam.c_ptr, T, H, W, 15, d_n.c_ptr, None))),
+              ("edge_detect_minmax", lambda: _lib.check(lib.lspiv_edge_detect_clip_dev(d_n.c_ptr, 0, T, H, W, 3, 5, -5.0, 5.0, d_edge.c_ptr, None))),
+              ("project_float32", lambda: p.project_frames_dev(d_edge.ptr, np.float32, T, d_ortho.ptr)),
+              ("get_piv", lambda: _lib.check(lib.lspiv_piv_pairs_dev(d_ortho.c_ptr, 1, T, Ho, Wo, ws[0], ws[1], ov[0], ov[1], -1.0, d_res.c_ptr, None, None))))
+    ev = [C.c_void_p() for _ in range(len(stages) + 1)]
+    for e in ev:
+        _lib.check(lib.lspiv_event_create(C.byref(e)))
+    for _ in range(2):                                  # the second pass is the one read
+        _lib.check(lib.lspiv_synchronize())
+        _lib.check(lib.lspiv_event_record(ev[0]))
+        for i, (_, fn) in enumerate(stages):
+            fn()
+            _lib.check(lib.lspiv_event_record(ev[i + 1]))
+        _lib.check(lib.lspiv_synchronize())
+    ms = {}
+    for i, (name, _) in enumerate(stages):
+        v = C.c_float()
+        _lib.check(lib.lspiv_event_elapsed_ms(ev[i], ev[i + 1], C.byref(v)))
+        ms[name] = round(v.value, 3)
+    for e in ev:
+        _lib.check(lib.lspiv_event_destroy(e))
+    p.close()
+    out["hbm_resident_stage_ms"] = ms
+    out["hbm_resident_pairs_per_s"] = round((T - 1) / (sum(ms.values()) * 1e-3), 1)
+    out["note"] = (f"{T - 1} pairs; the reference's recipe order: normalize(15) -> edge_detect(1, 2) -> minmax(-5, 5) -> project (float32 in, "
+                   f"{Ho}x{Wo} float32 out) -> get_piv {ws[0]}x{ws[1]}; PCIe-inclusive / host-inclusive, never `value`")
     return out
 
 

@@ -344,6 +344,11 @@ int lspiv_gaussian_blur_dev(const void* d_frames, int dtype, int64_t T, int64_t 
 int lspiv_edge_detect(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, int ksize_1, int ksize_2, float* out);
 int lspiv_edge_detect_dev(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, int ksize_1, int ksize_2,
                           float* d_out, void* stream);
+/* Frames.edge_detect followed by Frames.minmax (the reference's recipe order, examples/ngwerere/ngwerere.yml:6-11; pyorc/api/frames.py:308-362)
+ * in one pass: np.maximum(np.minimum(x, hi), lo) applied as the band-filtered value is stored -- the bits of lspiv_edge_detect_dev +
+ * lspiv_minmax_dev without the second trip over the float32 stack.  -INFINITY / INFINITY switch a limit off. */
+int lspiv_edge_detect_clip_dev(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, int ksize_1, int ksize_2, float lo,
+                               float hi, float* d_out, void* stream);
 int lspiv_time_diff(const void* frames, int dtype, int64_t T, int64_t H, int64_t W, float thres, int use_abs, float* out);
 int lspiv_time_diff_dev(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, float thres, int use_abs,
                         float* d_out, void* stream);

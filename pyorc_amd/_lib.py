@@ -114,6 +114,7 @@ SIGNATURES = {
     "lspiv_gaussian_blur_dev": (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _vp, _vp]),
     "lspiv_edge_detect": (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp]),
     "lspiv_edge_detect_dev": (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp, _vp]),
+    "lspiv_edge_detect_clip_dev": (_i32, [_vp, _i32, _i64, _i64, _i64, _i32, _i32, _f32, _f32, _vp, _vp]),
     "lspiv_mask": (_i32, [_vp, _i64, _i64, _i64, _i32, _vp, _i32, _vp]),
     "lspiv_mask_dev": (_i32, [_vp, _i64, _i64, _i64, _i32, _vp, _i32, _vp, _vp]),
     "lspiv_mask_apply": (_i32, [_vp, _i64, _i64, _i64, _vp, _i32]),

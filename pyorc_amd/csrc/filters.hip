@@ -9,6 +9,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "project_tile.h"
 
 namespace lspiv {
 
@@ -684,6 +685,18 @@ __device__ __forceinline__ int reflect101(int i, int n) {
   return i;
 }
 
+// Frames.minmax fused into the filter's store (round 6: the recipe's edge_detect -> minmax, a pass over a float32 stack of its own
+// otherwise): np.maximum(np.minimum(x, hi), lo), NaN propagates -- minmax_kernel's expression.  Without limits (-inf, +inf) nothing is done.
+struct BlurClip {
+  float lo, hi;
+  bool on;
+};
+__device__ __forceinline__ float blur_clip(float x, const BlurClip& c) {
+  if (!c.on) return x;                                   // (uniform)
+  const float a = (x != x) ? x : (x < c.hi ? x : c.hi);
+  return (a != a) ? a : (a > c.lo ? a : c.lo);
+}
+
 // symmetric taps around c with element stride S; R > 0: compile-time radius (unrolled), R == 0: run-time radius
 template <int R, int S>
 __device__ __forceinline__ float taps(const float* c, const BlurTaps& k) {
@@ -699,7 +712,7 @@ __device__ __forceinline__ float taps(const float* c, const BlurTaps& k) {
 
 template <typename T, bool EDGE, int RA, int RB, int BLUR_TH>
 __global__ __launch_bounds__(256) void blur_kernel(const T* __restrict__ frames, int H, int W, BlurTaps ka, BlurTaps kb,
-                                                   float* __restrict__ out) {
+                                                   float* __restrict__ out, BlurClip clip) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int R = EDGE ? (RB > 0 ? RB : kb.r) : (RA > 0 ? RA : ka.r);   // halo = the larger radius
   const int tw = BLUR_TW + 2 * R, th = BLUR_TH + 2 * R;
@@ -735,7 +748,7 @@ __global__ __launch_bounds__(256) void blur_kernel(const T* __restrict__ frames,
     if (y >= H) break;
     float res = taps<RA, BLUR_TW>(rowa + (ty + R) * BLUR_TW + lane, ka);
     if (EDGE) res = taps<RB, BLUR_TW>(rowb + (ty + R) * BLUR_TW + lane, kb) - res;
-    dst[(int64_t)y * W] = res;
+    dst[(int64_t)y * W] = blur_clip(res, clip);
   }
 }
 
@@ -747,7 +760,7 @@ constexpr int BLUR_TS = 32;
 
 template <typename T, bool EDGE, int RA, int RB>
 __global__ __launch_bounds__(256) void blur_strip_kernel(const T* __restrict__ frames, int H, int W, BlurTaps ka,
-                                                         BlurTaps kb, float* __restrict__ out) {
+                                                         BlurTaps kb, float* __restrict__ out, BlurClip clip) {
   constexpr int R = EDGE ? RB : RA;
   constexpr int TWW = BLUR_TW + 2 * R;
   __shared__ float rowbuf[4][TWW + 2];
@@ -789,7 +802,7 @@ __global__ __launch_bounds__(256) void blur_strip_kernel(const T* __restrict__ f
         for (int j = 1; j <= RB; ++j) sb += kb.k[j] * (wb[R - j] + wb[R + j]);
         res = sb - res;
       }
-      if (y < H && x < W) dst[(int64_t)y * W] = res;
+      if (y < H && x < W) dst[(int64_t)y * W] = blur_clip(res, clip);
     }
   }
 }
@@ -799,7 +812,7 @@ __global__ __launch_bounds__(256) void blur_strip_kernel(const T* __restrict__ f
 // traffic besides the staged input row).  One row of loads is kept in flight ahead of the row being filtered.
 template <typename T, bool EDGE>
 __global__ __launch_bounds__(256) void blur_ring_kernel(const T* __restrict__ frames, int H, int W, BlurTaps ka, BlurTaps kb,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, BlurClip clip) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int R = EDGE ? kb.r : ka.r, M = 2 * R + 1;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -847,7 +860,7 @@ __global__ __launch_bounds__(256) void blur_ring_kernel(const T* __restrict__ fr
       };
       float res = column(ring_a, ka);
       if (EDGE) res = column(ring_b, kb) - res;
-      if (y < H && x < W) dst[(int64_t)y * W] = res;
+      if (y < H && x < W) dst[(int64_t)y * W] = blur_clip(res, clip);
     }
     slot = slot == M - 1 ? 0 : slot + 1;
   }
@@ -874,7 +887,13 @@ static BlurTaps make_taps(int ksize) {
 
 hipError_t launch_blur(const void* frames, int dtype, int n_frames, int H, int W, int ksize_a, int ksize_b, float* out,
                        hipStream_t s) {
+  return launch_blur_clip(frames, dtype, n_frames, H, W, ksize_a, ksize_b, -INFINITY, INFINITY, out, s);
+}
+
+hipError_t launch_blur_clip(const void* frames, int dtype, int n_frames, int H, int W, int ksize_a, int ksize_b, float lo, float hi,
+                            float* out, hipStream_t s) {
   if (n_frames <= 0) return hipSuccess;
+  const BlurClip clip{lo, hi, !(lo == -INFINITY && hi == INFINITY)};
   const bool edge = ksize_b > 0;
   const BlurTaps ka = make_taps(ksize_a), kb = edge ? make_taps(ksize_b) : ka;
   const int R = edge ? kb.r : ka.r;
@@ -882,7 +901,7 @@ hipError_t launch_blur(const void* frames, int dtype, int n_frames, int H, int W
   if (unrolled) {
     const int strips = (H + BLUR_TS - 1) / BLUR_TS;
     const dim3 grid((W + BLUR_TW - 1) / BLUR_TW, (strips + 3) / 4, n_frames);
-#define LSPIV_STRIP4(T, E, A, B) hipLaunchKernelGGL((blur_strip_kernel<T, E, A, B>), grid, dim3(256), 0, s, (const T*)frames, H, W, ka, kb, out)
+#define LSPIV_STRIP4(T, E, A, B) hipLaunchKernelGGL((blur_strip_kernel<T, E, A, B>), grid, dim3(256), 0, s, (const T*)frames, H, W, ka, kb, out, clip)
 #define LSPIV_STRIP(T)                                                                     \
   if (!edge) {                                                                             \
     if (ka.r == 1) LSPIV_STRIP4(T, false, 1, 0); else if (ka.r == 2) LSPIV_STRIP4(T, false, 2, 0); else LSPIV_STRIP4(T, false, 3, 0); \
@@ -905,7 +924,7 @@ hipError_t launch_blur(const void* frames, int dtype, int n_frames, int H, int W
     const int strips = (H + BLUR_TS - 1) / BLUR_TS;
     const dim3 grid((W + BLUR_TW - 1) / BLUR_TW, (strips + 3) / 4, n_frames);
     const size_t lds = (size_t)4 * ((BLUR_TW + 2 * R) + (edge ? 2 : 1) * (2 * R + 1) * 64) * sizeof(float);
-#define LSPIV_RING(T, E) hipLaunchKernelGGL((blur_ring_kernel<T, E>), grid, dim3(256), lds, s, (const T*)frames, H, W, ka, kb, out)
+#define LSPIV_RING(T, E) hipLaunchKernelGGL((blur_ring_kernel<T, E>), grid, dim3(256), lds, s, (const T*)frames, H, W, ka, kb, out, clip)
     switch (dtype) {
       case 0: if (edge) LSPIV_RING(uint8_t, true); else LSPIV_RING(uint8_t, false); break;
       case 1: if (edge) LSPIV_RING(float, true); else LSPIV_RING(float, false); break;
@@ -918,7 +937,7 @@ hipError_t launch_blur(const void* frames, int dtype, int n_frames, int H, int W
   const int TH = 16;
   const size_t lds = ((size_t)(TH + 2 * R) * (BLUR_TW + 2 * R) + (size_t)(edge ? 2 : 1) * (TH + 2 * R) * BLUR_TW) * sizeof(float);
   const dim3 grid((W + BLUR_TW - 1) / BLUR_TW, (H + TH - 1) / TH, n_frames);
-#define LSPIV_BLUR(T, E) hipLaunchKernelGGL((blur_kernel<T, E, 0, 0, 16>), grid, dim3(256), lds, s, (const T*)frames, H, W, ka, kb, out)
+#define LSPIV_BLUR(T, E) hipLaunchKernelGGL((blur_kernel<T, E, 0, 0, 16>), grid, dim3(256), lds, s, (const T*)frames, H, W, ka, kb, out, clip)
   switch (dtype) {
     case 0: if (edge) LSPIV_BLUR(uint8_t, true); else LSPIV_BLUR(uint8_t, false); break;
     case 1: if (edge) LSPIV_BLUR(float, true); else LSPIV_BLUR(float, false); break;

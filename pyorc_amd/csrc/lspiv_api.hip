@@ -2797,7 +2797,7 @@ int lspiv_reduce_rolling(const uint8_t* frames, int64_t T, int64_t H, int64_t W,
 }
 
 static int blur_common_dev(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, int k1, int k2, float* d_out,
-                           void* stream) {
+                           void* stream, float lo = -INFINITY, float hi = INFINITY) {
   if (!d_frames || !d_out) return fail(LSPIV_EINVAL, "NULL argument");
   if (dtype < 0 || dtype > 2) return fail(LSPIV_EINVAL, "dtype %d not in {0:u8, 1:f32, 2:f64}", dtype);
   if (T < 1 || H <= 0 || W <= 0 || T > 65535 || H >= (1 << 30) || W >= (1 << 30)) return fail(LSPIV_ESHAPE, "bad shape");
@@ -2807,7 +2807,7 @@ static int blur_common_dev(const void* d_frames, int dtype, int64_t T, int64_t H
   DeviceCtx* c;
   int rc = get_ctx(&c);
   if (rc) return rc;
-  hipError_t e = lspiv::launch_blur(d_frames, dtype, (int)T, (int)H, (int)W, k1, k2, d_out, stream ? (hipStream_t)stream : c->stream);
+  hipError_t e = lspiv::launch_blur_clip(d_frames, dtype, (int)T, (int)H, (int)W, k1, k2, lo, hi, d_out, stream ? (hipStream_t)stream : c->stream);
   if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
   return LSPIV_OK;
 }
@@ -2847,6 +2847,13 @@ int lspiv_edge_detect_dev(const void* d_frames, int dtype, int64_t T, int64_t H,
                           float* d_out, void* stream) {
   if (ksize_2 < ksize_1) return fail(LSPIV_EINVAL, "edge_detect expects ksize_2 >= ksize_1");
   return blur_common_dev(d_frames, dtype, T, H, W, ksize_1, ksize_2, d_out, stream);
+}
+
+int lspiv_edge_detect_clip_dev(const void* d_frames, int dtype, int64_t T, int64_t H, int64_t W, int ksize_1, int ksize_2, float lo,
+                               float hi, float* d_out, void* stream) {
+  if (ksize_2 < ksize_1) return fail(LSPIV_EINVAL, "edge_detect expects ksize_2 >= ksize_1");
+  if (lo != lo || hi != hi) return fail(LSPIV_EINVAL, "NaN limit");
+  return blur_common_dev(d_frames, dtype, T, H, W, ksize_1, ksize_2, d_out, stream, lo, hi);
 }
 
 // ---- device-resident helpers ------------------------------------------------------------------

@@ -6,7 +6,7 @@ x4..x8 the bytes of the camera stack) -> ``get_piv()`` (window stack x3.9, corre
 ``to_netcdf`` (int16).  ``CameraToVelocity`` keeps everything between the raw uint8 camera frames and the result
 block in HBM and calls only ``*_dev`` entry points of the C ABI:
 
-    H2D uint8 frames -> lspiv_normalize_dev -> lspiv_edge_detect_dev -> lspiv_minmax_dev   (each optional)
+    H2D uint8 frames -> lspiv_normalize_dev -> lspiv_edge_detect_clip_dev (edge_detect + minmax in one pass)   (each optional)
                      -> lspiv_project_frames_dev (lspiv_project_frames_u8_dev: nearest-neighbour-only plan, uint8 in) -> lspiv_piv_pairs_dev
                      -> lspiv_pack_int16_dev (optional) -> D2H (16 B or 8 B per vector)
 
@@ -118,13 +118,11 @@ class CameraToVelocity:
         src_dtype = np.uint8
         if self.edge_detect:
             d_edge = self._edge.ensure(T * n_cam * 4)
-            _lib.check(lib.lspiv_edge_detect_dev(src, 0, T, self.cam_shape[0], self.cam_shape[1], self.edge_detect[0],
-                                                 self.edge_detect[1], d_edge, None))
+            # the recipe's minmax rides in the filter's store (lspiv_edge_detect_clip_dev: the bits of edge_detect + minmax, one pass)
+            lo, hi = self.minmax if self.minmax else (float("-inf"), float("inf"))
+            _lib.check(lib.lspiv_edge_detect_clip_dev(src, 0, T, self.cam_shape[0], self.cam_shape[1], self.edge_detect[0],
+                                                      self.edge_detect[1], lo, hi, d_edge, None))
             src, src_dtype = d_edge, np.float32
-        if self.minmax:
-            if src_dtype is np.uint8:
-                raise ValueError("minmax in the chain follows edge_detect (float32 frames); uint8 frames are not thresholded")
-            _lib.check(lib.lspiv_minmax_dev(src, T * n_cam, self.minmax[0], self.minmax[1], src, None))   # in place
         osz = 1 if self.ortho_uint8 else 4
         d_ortho = self._ortho.ensure(T * n_ortho * osz)
         self.projection.project_frames_dev(src.value, src_dtype, T, d_ortho.value, keep_uint8=self.ortho_uint8)
@@ -216,10 +214,9 @@ class CameraToVelocity:
                 src = dst
             if self.edge_detect:
                 dst = at(d_edge, f0 * n_cam * 4)
-                _lib.check(lib.lspiv_edge_detect_dev(src, 0, n_new, Hc, Wc, self.edge_detect[0], self.edge_detect[1], dst, comp))
+                lo, hi = self.minmax if self.minmax else (float("-inf"), float("inf"))
+                _lib.check(lib.lspiv_edge_detect_clip_dev(src, 0, n_new, Hc, Wc, self.edge_detect[0], self.edge_detect[1], lo, hi, dst, comp))
                 src, src_dtype, esz = dst, np.float32, 4
-                if self.minmax:
-                    _lib.check(lib.lspiv_minmax_dev(src, n_new * n_cam, self.minmax[0], self.minmax[1], src, comp))
             osz = 1 if self.ortho_uint8 else 4
             self.projection.project_frames_dev(src.value, src_dtype, n_new, d_ortho.value + f0 * n_ortho * osz, comp.value,
                                                keep_uint8=self.ortho_uint8)

@@ -339,3 +339,37 @@ def test_gpu_normalize_without_the_division_keeps_the_reference_integers(gpu, mo
                               env=dict(os.environ, LSPIV_NORM_DIVIDE="1"))
         old = np.load(os.path.join(d, "out.npy"))
     assert np.array_equal(old[0], filters.normalize(const_mean, 15)) and np.array_equal(old[1], filters.normalize(rnd, 15))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32, np.float64])
+def test_gpu_edge_detect_with_the_clip_in_its_store_is_edge_detect_then_minmax(gpu, dtype):
+    """Round 6: lspiv_edge_detect_clip_dev = Frames.edge_detect followed by Frames.minmax (the recipe's order) in one pass.  The bits of the
+    two calls, for every kernel family (unrolled radii, run-time radii), NaN samples (they propagate through both) and one-sided limits;
+    without limits it is lspiv_edge_detect_dev."""
+    import ctypes as C
+
+    from pyorc_amd import _lib, filters
+    from pyorc_amd.device import DeviceFrames
+
+    fr = particle_stack(4, 70, 132, seed=23, density=0.05)
+    if dtype != np.uint8:
+        fr = fr.astype(dtype) * 0.41 - 7.0
+        fr[1, 5, 7] = np.nan
+    d = DeviceFrames.from_host(fr) if dtype != np.float64 else None
+    T, H, W = fr.shape
+    inf = float("inf")
+    for w1, w2 in ((1, 2), (1, 3), (2, 3), (2, 7), (4, 5)):
+        edge = filters.edge_detect(fr, w1, w2)
+        for lo, hi in ((-5.0, 5.0), (-inf, 0.25), (0.0, inf), (-inf, inf)):
+            ref = filters.minmax(edge, lo, hi)
+            if d is None:
+                continue                                              # float64 stacks have no device-resident form: the host mirror below
+            out = DeviceFrames.empty((T, H, W), np.float32)
+            _lib.check(gpu.lspiv_edge_detect_clip_dev(d.c_ptr, _lib.DTYPE_CODES[np.dtype(d.dtype)], T, H, W, 2 * w1 + 1, 2 * w2 + 1, lo, hi, out.c_ptr, None))
+            got = out.to_host()
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (w1, w2, lo, hi)
+    with pytest.raises(_lib.LspivError):
+        d8 = DeviceFrames.from_host(particle_stack(2, 16, 16, seed=1))
+        out = DeviceFrames.empty((2, 16, 16), np.float32)
+        _lib.check(gpu.lspiv_edge_detect_clip_dev(d8.c_ptr, 0, 2, 16, 16, 3, 5, float("nan"), 1.0, out.c_ptr, None))
