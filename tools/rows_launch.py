@@ -90,7 +90,7 @@ def build_rows(lib, T: int):
 def row_read_bytes(name: str, T: int) -> int:
     """Input bytes a launch of this row cannot avoid reading (every input sample once): what FETCH_SIZE is calibrated against."""
     n = H * W
-    return T * n
+    return T * n * (4 if name == "project_f32" else 1)     # float32 camera frames
 
 
 def time_launches(lib, launch, reps: int) -> float:
