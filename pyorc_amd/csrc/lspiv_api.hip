@@ -1693,17 +1693,21 @@ bool tile_pick_shape(int64_t dst_h, int64_t dst_w, size_t nq, QC& quad_chunks, c
   for (size_t i = 0; i < shapes.size(); ++i) {
     TileShape& sh = shapes[i];
     size_t over1 = 0, over2 = 0, over4 = 0;
-    int64_t total = 0;
-    for (int64_t wv = 0; wv < sh.n_waves(); ++wv) {
+    int64_t total = 0, seen = 0;
+    // the shapes are compared on a sample of their waves (every k-th, about a thousand: a 1080p grid has 4 600 per shape and four shapes
+    // per plan; the builder of the chosen shape then visits every wave and sends whatever does not fit to the slow kernel)
+    const int64_t step = std::max<int64_t>(1, sh.n_waves() / 1024);
+    for (int64_t wv = 0; wv < sh.n_waves(); wv += step, ++seen) {
       tile_wave_list(sh, wv, quad_chunks, lst);
       over1 += lst.size() > 64; over2 += lst.size() > 128; over4 += lst.size() > 256;
       total += (int64_t)lst.size();
     }
-    const size_t few = (size_t)sh.n_waves() / 100;            // waves a shape may leave to the slow kernel
+    const size_t few = (size_t)seen / 100;                    // waves a shape may leave to the slow kernel
     sh.rmax = over1 <= few ? 1 : over2 <= few ? 2 : over4 <= few ? 4 : 0;
+    total = total * sh.n_waves() / std::max<int64_t>(seen, 1);   // (shapes differ in their number of waves: compare chunks per grid)
     if (say)
-      fprintf(stderr, "lspiv projection (%s): blocks of %lld x %lld quads: %.1f chunks per wave, %zu of %lld waves need more than 64, %zu more than 128, %zu more than 256\n",
-              what, (long long)sh.bqx(), (long long)sh.bqy(), (double)total / (double)sh.n_waves(), over1, (long long)sh.n_waves(), over2, over4);
+      fprintf(stderr, "lspiv projection (%s): blocks of %lld x %lld quads: %.1f chunks per wave, of %lld sampled waves (%lld in all) %zu need more than 64, %zu more than 128, %zu more than 256\n",
+              what, (long long)sh.bqx(), (long long)sh.bqy(), (double)total / (double)sh.n_waves(), (long long)seen, (long long)sh.n_waves(), over1, over2, over4);
     if (!sh.rmax) continue;
     if (best < 0 || sh.rmax < shapes[(size_t)best].rmax || (sh.rmax == shapes[(size_t)best].rmax && total < best_total)) { best = (int)i; best_total = total; }
   }
