@@ -602,6 +602,72 @@ def rows_block(lib) -> list:
     return mod.measure_rows(lib)
 
 
+def open_comm(rank: int, world: int):
+    """The communicator of the run: RCCL unless LSPIV_COMM says otherwise.  RCCL has never met two ranks on the boxes this was built on, so
+    a node on which it cannot be brought up (no librccl, an IPC mode the driver refuses, ...) must still yield a line that SAYS so: every
+    rank tries ncclCommInitRank plus one tiny device all-gather, the ranks then vote through files next to the id file (the rendezvous
+    they already share), and unless all of them succeeded all of them fall back to the shared-memory transport.  Returns (comm, None) or
+    (comm over shm, the first error message)."""
+    import ctypes as C
+
+    from pyorc_amd import comm as cm
+
+    want = os.environ.get("LSPIV_COMM", "rccl")
+    if want != "rccl" or world == 1:
+        return cm.Comm(rank, world), None
+    base = cm.default_id_file()
+    nonce = cm._job_nonce().hex()
+    c, err = None, None
+    try:
+        c = cm.Comm(rank, world, "rccl", id_file=base, timeout=180.0)
+        lib = _lib.load()
+        d = C.c_void_p()
+        _lib.check(lib.lspiv_dev_malloc(C.byref(d), 4 * (world + 1)))
+        try:
+            c.allgather_dev(d.value, d.value + 4, 1, np.float32)      # what fails here would fail in the first step
+            _lib.check(lib.lspiv_synchronize())
+        finally:
+            lib.lspiv_dev_free(d)
+    except Exception as e:                                            # noqa: BLE001 -- any failure is a vote
+        err = f"rank {rank}: {type(e).__name__}: {e}"
+    mine = f"{base}.vote.{rank}"
+    with open(mine, "w") as fh:
+        fh.write(f"{nonce}\n{err or 'ok'}\n")
+    votes, t0 = {}, time.time()
+    while len(votes) < world:
+        for r in range(world):
+            if r in votes:
+                continue
+            try:
+                txt = open(f"{base}.vote.{r}").read().split("\n")
+                if len(txt) >= 2 and txt[0] == nonce:
+                    votes[r] = txt[1]
+            except OSError:
+                pass
+        if len(votes) < world:
+            if time.time() - t0 > 240.0:
+                raise TimeoutError(f"rank {rank}: only {sorted(votes)} of {world} ranks reported on their communicator" + (f"; own error: {err}" if err else ""))
+            time.sleep(0.02)
+    bad = [v for _, v in sorted(votes.items()) if v != "ok"]
+    if not bad:
+        c.barrier()                                                   # every rank has read every vote
+        try:
+            os.unlink(mine)
+        except OSError:
+            pass
+        return c, None
+    if c is not None:
+        c.close()
+    print(f"[bench] rank {rank}: RCCL is not usable on every rank ({bad[0]}); falling back to the shared-memory transport", file=sys.stderr, flush=True)
+    c = cm.Comm(rank, world, "shm", id_file=base + ".shm")
+    c.barrier()
+    try:
+        os.unlink(mine)
+    except OSError:
+        pass
+    return c, bad[0]
+
+
 def spawn_ranks(a) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) and wait for them."""
     tmp = tempfile.mkdtemp(prefix="lspiv_bench_")
@@ -658,11 +724,10 @@ def main():
     _lib.require_device()
     _lib.check(lib.lspiv_set_device(local_rank))
     comm = None
+    rccl_error = None
     use_comm = world > 1 or bool(os.environ.get("LSPIV_BENCH_FORCE_COMM"))  # FORCE_COMM: 1-rank RCCL plumbing test
     if use_comm:
-        from pyorc_amd.comm import Comm
-
-        comm = Comm(rank, world)
+        comm, rccl_error = open_comm(rank, world)
 
     H, W = a.height, a.width
     ws, ov = (a.window, a.window), (a.overlap, a.overlap)
@@ -887,6 +952,8 @@ def main():
         mean = lambda x: round(float(np.mean(x)), 4) if len(x) else None   # noqa: E731
         out["config"]["comm"] = {
             "transport": comm.transport, "ranks_reported_by_transport": comm.backend_ranks,
+            **({"rccl_error": rccl_error, "note": "RCCL could not be brought up on every rank: this line ran over the shared-memory transport "
+                                                  "(results cross the host) -- a diagnosis, not the xGMI figure"} if rccl_error else {}),
             "path": "pyorc_amd.shard.ShardedPivDev (the library's device-resident sharded path; bench.py only times it)",
             "mode": "strong" if a.strong else "weak", "pairs_total": total_pairs, "pairs_rank0": my_pairs,
             "allgather_matches_single_launch": dist_check,

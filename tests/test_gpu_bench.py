@@ -98,3 +98,15 @@ def test_bench_over_rccl_with_one_rank(gpu):
     assert comm["transport"] == "rccl" and comm["ranks_reported_by_transport"] == 1
     assert comm["allgather_matches_single_launch"] is True
     assert comm["rccl_env"].get("NCCL_MAX_NCHANNELS") == "16"       # the default cap on RCCL's CU take is in force and recorded
+
+
+@pytest.mark.gpu
+def test_bench_falls_back_to_shared_memory_when_rccl_cannot_be_brought_up(gpu):
+    """Round 6: RCCL has never met two ranks on the boxes this was built on.  A node on which it cannot be brought up must still yield a
+    line that says so: the ranks vote on their communicator and, unless all of them succeeded, all of them fall back to the shared-memory
+    transport and the line carries the error.  Provoked here with two ranks on ONE device, which RCCL refuses ("Duplicate GPU")."""
+    d = run_bench(SMALL + ["--gpus", "2", "--strong-pairs", "300"], {"LSPIV_BENCH_SAME_DEVICE": "1", "LSPIV_COMM": "rccl"})
+    comm = d["config"]["comm"]
+    assert d["n_gpus"] == 2 and comm["transport"] == "shm" and comm["ranks_reported_by_transport"] == 2
+    assert "rccl_error" in comm and "rank" in comm["rccl_error"] and "diagnosis" in comm["note"]
+    assert comm["allgather_matches_single_launch"] is True and d["value"] > 0
