@@ -807,6 +807,147 @@ __global__ __launch_bounds__(256) void blur_strip_kernel(const T* __restrict__ f
   }
 }
 
+// uint8 frames, unrolled radii, FOUR columns per lane with an INTEGER row pass (round 6).  What holds blur_strip_kernel at 0.42 of the
+// roofline is neither its arithmetic (smooth and edge_detect take the same 0.61 ms) nor HBM: 14.7 M one-byte-per-lane loads and 6.5 M
+// 256-byte stores per 201 frames -- the vector-memory path takes a wave instruction every ~16 cycles whatever its width.  Four columns per
+// lane cut the instructions by four, but then the float arithmetic (25 instructions per pixel) paces the stores of a wave and, with 100+
+// registers, too few waves are resident to keep the store stream fed (measured: every float variant of this layout is slower, docs/
+// history.md).  Here the arithmetic shrinks to 11 per pixel and there is no cross-lane traffic:
+//  * OpenCV's fixed kernels for k = 3, 5, 7 are (1 2 1) / 4, (1 4 6 4 1) / 16, (2 7 14 18 14 7 2) / 64, and EVERY float32 operation of
+//    either pass on a uint8 frame is exact (integers below 2^24 times a power of two): the result is the exact rational, whatever the
+//    order or the arithmetic.  The row pass is therefore done on the packed bytes: the lane loads the 12 bytes around its four columns
+//    (its neighbours load the same cache lines: no extra HBM traffic), v_alignbyte cuts the shifted dwords out of that string,
+//    v_dot4_u32_u8 applies the integer taps: 2 dot4 per output of a 5- or 7-tap kernel, 1 of the 3-tap one.
+//  * the column pass runs on integer-valued floats with the taps scaled by 1 / (row divisor x column divisor) -- exact again --, two
+//    columns per instruction (v_pk_*_f32 on float2 pairs).
+// Same bits as blur_strip_kernel (tests/test_filters.py).  A wave covers 256 columns (eight whole 128-byte lines per stored row) and
+// BLUR4_TS rows; EVERY load of the strip is issued before its first store (LSPIV_BLUR4_AHEAD >= the rows of a strip): vmcnt counts
+// stores as well, a load issued after a store is only known to have arrived when the store has been acknowledged -- a rolling window
+// of 6 rows of loads costs 8 % at 16 rows per strip.  The row-filtered rows sit in a ring of registers (the fully unrolled row loop
+// makes every ring index a constant: no moves).  Measured on 201 1080p frames, ms per launch (one-column kernel | this one): k = 3
+// 0.589 | 0.426, k = 5 0.592 | 0.421, k = 7 0.676 | 0.410, edge 3 / 5 0.593 | 0.417, 3 / 7 0.689 | 0.426, 5 / 7 0.704 | 0.434; rows
+// per strip 4 / 8 / 16 / 24 / 32 / 48 / 64: 0.49 / 0.46 / 0.44 / 0.43 / 0.41 / 0.44 / 0.49 (tools/sessions/r06_ab_blur4.sh).
+#ifndef LSPIV_BLUR4_AHEAD
+#define LSPIV_BLUR4_AHEAD 64
+#endif
+#ifndef LSPIV_BLUR4_TS
+#define LSPIV_BLUR4_TS 32
+#endif
+constexpr int BLUR4_TS = LSPIV_BLUR4_TS;                               // rows per strip of the four-column kernel
+typedef float f32x2b __attribute__((ext_vector_type(2)));
+
+// integer taps of the kernel of radius R as dot4 weight words: w0 covers the bytes [centre - R, centre - R + 3], w1 the next four
+template <int R> struct IntTaps;
+template <> struct IntTaps<1> { static constexpr uint32_t w0 = 0x00010201u, w1 = 0u; static constexpr float div = 4.0f; };
+template <> struct IntTaps<2> { static constexpr uint32_t w0 = 0x04060401u, w1 = 0x00000001u; static constexpr float div = 16.0f; };
+template <> struct IntTaps<3> { static constexpr uint32_t w0 = 0x120e0702u, w1 = 0x0002070eu; static constexpr float div = 64.0f; };
+
+// bytes [o, o + 3] of the 12-byte string pl | pc | pr (o = 0 .. 9; bytes beyond 11 are whatever: their tap weight is 0)
+template <int O>
+__device__ __forceinline__ uint32_t str_dword(uint32_t pl, uint32_t pc, uint32_t pr) {
+  if (O == 0) return pl;
+  if (O < 4) return __builtin_amdgcn_alignbyte(pc, pl, O);
+  if (O == 4) return pc;
+  if (O < 8) return __builtin_amdgcn_alignbyte(pr, pc, O - 4);
+  if (O == 8) return pr;
+  return __builtin_amdgcn_alignbyte(pr, pr, O - 8);
+}
+// the row-filtered value (an integer: the taps' divisor is applied by the column pass) of output column E of the lane
+template <int R, int E>
+__device__ __forceinline__ uint32_t row_taps_int(uint32_t pl, uint32_t pc, uint32_t pr) {
+  uint32_t s = __builtin_amdgcn_udot4(str_dword<4 + E - R>(pl, pc, pr), IntTaps<R>::w0, 0u, false);
+  if (R > 1) s = __builtin_amdgcn_udot4(str_dword<8 + E - R>(pl, pc, pr), IntTaps<R>::w1, s, false);
+  return s;
+}
+
+// the rows of one strip.  INTERIOR (wave-uniform): every lane's 12 bytes [xl - 4, xl + 8) lie inside the frame -- one 12-byte load per
+// lane and row (neighbouring lanes overlap by 8 bytes: the same cache lines, no extra HBM traffic, and no cross-lane operation at all);
+// otherwise (the first and the last strip of a row) the loads are clamped into the row and the lane at the edge mirrors the dword beyond it.
+template <bool EDGE, int RA, int RB, bool INTERIOR>
+__device__ __forceinline__ void blur4_strip(const uint8_t* __restrict__ img, int H, int W, int y0, int xl, float* __restrict__ dst,
+                                            const BlurClip& clip) {
+  constexpr int R = EDGE ? RB : RA;
+  constexpr int M = 2 * R + 1;
+  constexpr int NR = BLUR4_TS + 2 * R;
+  constexpr int K = LSPIV_BLUR4_AHEAD < NR ? LSPIV_BLUR4_AHEAD : NR;
+  typedef uint32_t u32x3b __attribute__((ext_vector_type(3), aligned(4)));
+  // the first and the last strip of a row: every lane loads 12 bytes INSIDE the row (its window shifted by a dword where it reaches over
+  // an edge), the lane at the edge rebuilds the dword beyond it by BORDER_REFLECT_101 from the bytes it has: left of column 0 the columns
+  // 4 3 2 1, right of column W - 1 the columns W-2 W-3 W-4 W-5 (v_perm_b32) -- W % 4 == 0 and W >= 12, lanes with xl >= W do not write
+  const int xc = INTERIOR ? xl - 4 : min(max(xl - 4, 0), W - 12);
+  const int sh = xl - 4 - xc;                                          // -4: the lane at the left edge, +4: at the right edge
+  u32x3b p[K];                                                         // a rolling window of K rows of loads in flight
+  auto load_row = [&](int i, u32x3b& d) {
+    const uint8_t* row = img + (int64_t)reflect101(y0 - R + i, H) * W;   // (scalar: the row is wave-uniform)
+    d = *reinterpret_cast<const u32x3b*>(row + xc);
+  };
+  auto fix_edges = [&](uint32_t& pl, uint32_t& pc, uint32_t& pr) {
+    if (INTERIOR) return;
+    const uint32_t d0 = pl, d1 = pc, d2 = pr;
+    pl = sh < 0 ? __builtin_amdgcn_perm(d1, d0, 0x01020304u) : (sh > 0 ? d1 : d0);
+    pc = sh < 0 ? d0 : (sh > 0 ? d2 : d1);
+    pr = sh < 0 ? d1 : (sh > 0 ? __builtin_amdgcn_perm(d2, d1, 0x03040506u) : d2);
+  };
+#pragma unroll
+  for (int i = 0; i < K; ++i) load_row(i, p[i]);
+  // column taps as exact floats: kernel weight / (row divisor x column divisor)
+  constexpr float da = IntTaps<RA>::div * IntTaps<RA>::div, db = IntTaps<R>::div * IntTaps<R>::div;
+  float ca[RA + 1], cb[R + 1];
+#pragma unroll
+  for (int j = 0; j <= RA; ++j) ca[j] = (float)((IntTaps<RA>::w0 >> (8 * (RA - j))) & 0xffu) / da;     // tap at distance j: byte RA - j of w0
+#pragma unroll
+  for (int j = 0; j <= R; ++j) cb[j] = (float)((IntTaps<R>::w0 >> (8 * (R - j))) & 0xffu) / db;
+  const bool writes = xl < W;                                          // (W % 4 == 0: then all four columns are inside)
+  f32x2b wa[2][M], wb[2][M];                                           // a ring of the last M row-filtered rows, columns (0, 1) and (2, 3): row i sits in slot i % M
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    uint32_t pl = p[i % K][0], pc = p[i % K][1], pr = p[i % K][2];
+    fix_edges(pl, pc, pr);
+    if (i + K < NR) load_row(i + K, p[i % K]);                         // the slot is free: the row K ahead goes out
+    wa[0][i % M] = f32x2b{(float)row_taps_int<RA, 0>(pl, pc, pr), (float)row_taps_int<RA, 1>(pl, pc, pr)};
+    wa[1][i % M] = f32x2b{(float)row_taps_int<RA, 2>(pl, pc, pr), (float)row_taps_int<RA, 3>(pl, pc, pr)};
+    if (EDGE) {
+      wb[0][i % M] = f32x2b{(float)row_taps_int<R, 0>(pl, pc, pr), (float)row_taps_int<R, 1>(pl, pc, pr)};
+      wb[1][i % M] = f32x2b{(float)row_taps_int<R, 2>(pl, pc, pr), (float)row_taps_int<R, 3>(pl, pc, pr)};
+    }
+    if (i >= 2 * R) {
+      const int y = y0 + i - 2 * R, c = i - R;                         // the centre row of this output
+      f32x4 v;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        f32x2b res = wa[q][c % M] * ca[0];
+#pragma unroll
+        for (int j = 1; j <= RA; ++j) res += ca[j] * (wa[q][(c - j) % M] + wa[q][(c + j) % M]);
+        if (EDGE) {
+          f32x2b sb = wb[q][c % M] * cb[0];
+#pragma unroll
+          for (int j = 1; j <= R; ++j) sb += cb[j] * (wb[q][(c - j) % M] + wb[q][(c + j) % M]);
+          res = sb - res;
+        }
+        v[2 * q] = res[0]; v[2 * q + 1] = res[1];
+      }
+      if (clip.on) {                                                   // (uniform)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = blur_clip(v[e], clip);
+      }
+      if (writes && y < H) *reinterpret_cast<f32x4*>(dst + (int64_t)y * W) = v;      // (non-temporal stores: no difference)
+    }
+  }
+}
+
+template <bool EDGE, int RA, int RB>
+__global__ __launch_bounds__(256) void blur_strip4_kernel(const uint8_t* __restrict__ frames, int H, int W, float* __restrict__ out,
+                                                          BlurClip clip) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int y0 = (blockIdx.y * 4 + wv) * BLUR4_TS;
+  if (y0 >= H) return;
+  const uint8_t* img = frames + (int64_t)blockIdx.z * H * W;
+  const int x0 = (int)blockIdx.x * 256, xl = x0 + 4 * lane;            // this lane's first column
+  float* dst = out + (int64_t)blockIdx.z * H * W + xl;
+  if (x0 - 4 >= 0 && x0 + 260 <= W) blur4_strip<EDGE, RA, RB, true>(img, H, W, y0, xl, dst, clip);
+  else blur4_strip<EDGE, RA, RB, false>(img, H, W, y0, xl, dst, clip);
+}
+
 // Run-time radii (> 3): the same streaming structure, with the last 2R+1 row-filtered values of every column kept
 // in a wave-private LDS ring instead of registers (the ring slot is wave-uniform, the column is the lane: no cross-lane
 // traffic besides the staged input row).  One row of loads is kept in flight ahead of the row being filtered.
@@ -898,6 +1039,21 @@ hipError_t launch_blur_clip(const void* frames, int dtype, int n_frames, int H, 
   const BlurTaps ka = make_taps(ksize_a), kb = edge ? make_taps(ksize_b) : ka;
   const int R = edge ? kb.r : ka.r;
   const bool unrolled = edge ? (kb.r <= 3 && ka.r >= 1 && ka.r < kb.r) : (ka.r >= 1 && ka.r <= 3);
+  // uint8 frames under OpenCV's fixed kernels (k = 3, 5, 7): four columns per lane, integer row pass (blur_strip4_kernel);
+  // LSPIV_BLUR_ONE_COLUMN=1 keeps the one-column float kernel for A/B
+  if (unrolled && dtype == 0 && W % 4 == 0 && W >= 12 && (reinterpret_cast<uintptr_t>(frames) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+      !getenv("LSPIV_BLUR_ONE_COLUMN")) {
+    const int strips = (H + BLUR4_TS - 1) / BLUR4_TS;
+    const dim3 grid((W + 255) / 256, (strips + 3) / 4, n_frames);
+#define LSPIV_S4(E, A, B) hipLaunchKernelGGL((blur_strip4_kernel<E, A, B>), grid, dim3(256), 0, s, (const uint8_t*)frames, H, W, out, clip)
+    if (!edge) {
+      if (ka.r == 1) LSPIV_S4(false, 1, 1); else if (ka.r == 2) LSPIV_S4(false, 2, 2); else LSPIV_S4(false, 3, 3);
+    } else {
+      if (kb.r == 2) LSPIV_S4(true, 1, 2); else if (ka.r == 1) LSPIV_S4(true, 1, 3); else LSPIV_S4(true, 2, 3);
+    }
+#undef LSPIV_S4
+    return hipGetLastError();
+  }
   if (unrolled) {
     const int strips = (H + BLUR_TS - 1) / BLUR_TS;
     const dim3 grid((W + BLUR_TW - 1) / BLUR_TW, (strips + 3) / 4, n_frames);

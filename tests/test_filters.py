@@ -373,3 +373,37 @@ def test_gpu_edge_detect_with_the_clip_in_its_store_is_edge_detect_then_minmax(g
         d8 = DeviceFrames.from_host(particle_stack(2, 16, 16, seed=1))
         out = DeviceFrames.empty((2, 16, 16), np.float32)
         _lib.check(gpu.lspiv_edge_detect_clip_dev(d8.c_ptr, 0, 2, 16, 16, 3, 5, float("nan"), 1.0, out.c_ptr, None))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(70, 500), (33, 256), (64, 252), (5, 8), (3, 4), (9, 12), (20, 16), (130, 1028), (40, 260), (31, 264)])
+def test_gpu_four_column_integer_blur_equals_the_one_column_float_kernel(gpu, monkeypatch, shape):
+    """Round 6: uint8 frames whose width is a multiple of four go through blur_strip4_kernel -- four columns per lane, the row pass on the
+    packed bytes (v_alignbyte + v_dot4 with OpenCV's integer taps 1 2 1 / 1 4 6 4 1 / 2 7 14 18 14 7 2), the column pass on integer-valued
+    floats two columns per instruction.  Every float operation of the one-column kernel is exact on uint8 input, so both give the exact
+    rational: the same bits, for every unrolled radius, on widths with a partial last strip (the lane at an edge mirrors the dword beyond it
+    with v_perm_b32 from the bytes it loaded), frames of one strip whose first lane is the left and third lane the right edge (12 columns),
+    narrower ones (they stay with the one-column kernel), heights around the 32-row strips and below the halo (BORDER_REFLECT_101 wraps);
+    and within the oracle's tolerance."""
+    from pyorc_amd import filters
+
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    fr = (rng.random((3,) + shape) * 256).astype(np.uint8)
+    fr[0, 0, :] = 255
+    fr[1, :, -1] = 255
+    fr[2] = 255                                                            # the largest sums everywhere
+    for wdw in (1, 2, 3):
+        monkeypatch.delenv("LSPIV_BLUR_ONE_COLUMN", raising=False)
+        got = filters.smooth(fr, wdw)
+        monkeypatch.setenv("LSPIV_BLUR_ONE_COLUMN", "1")
+        one = filters.smooth(fr, wdw)
+        assert np.array_equal(got.view(np.uint32), one.view(np.uint32)), ("smooth", wdw)
+        assert np.abs(got - fo.smooth(fr, wdw)).max() <= 2e-6 * 255
+        assert np.array_equal(got[2], np.full(shape, 255.0, np.float32))   # the taps sum to one, exactly
+    for w1, w2 in ((1, 2), (1, 3), (2, 3)):
+        monkeypatch.delenv("LSPIV_BLUR_ONE_COLUMN", raising=False)
+        got = filters.edge_detect(fr, w1, w2)
+        monkeypatch.setenv("LSPIV_BLUR_ONE_COLUMN", "1")
+        one = filters.edge_detect(fr, w1, w2)
+        assert np.array_equal(got.view(np.uint32), one.view(np.uint32)), ("edge_detect", w1, w2)
+        assert np.abs(got - fo.edge_detect(fr, w1, w2)).max() <= 4e-6 * 255
