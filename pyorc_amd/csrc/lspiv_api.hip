@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -2166,6 +2167,10 @@ struct lspiv_remap {
   int *d_qb1, *d_qb2, *d_slow1, *d_slow2;
   uint64_t *d_qd1, *d_qd2;
   int n_slow1, n_slow2;
+  // both remaps in one kernel for uint8 frames (project.hip, remap_fused_kernel): tiles' boxes, destination pixel descriptors, the
+  // undistortion map's quads with the row step; nullptr: not built (the two passes run)
+  void* d_ft; uint32_t* d_fpx; int* d_fqb; uint64_t* d_fqd;
+  int f_tiles, f_tiles_x, f_cap;
   std::mutex host_mu;                      // host-pointer calls on ONE handle queue: they share d_tmp (two handles run side by side)
 };
 
@@ -2244,6 +2249,88 @@ int build_remap_quads(const std::vector<int>& mx, const std::vector<int>& my, co
   *n_slow = (int)slow.size();
   return LSPIV_OK;
 }
+
+// Plan of remap_fused_kernel (project.hip): undistortion and warp of uint8 frames in one kernel.  Built when both widths are multiples of
+// four and every 64 x 16 destination tile's box of undistorted pixels fits 16 KB; LSPIV_PROJECT_CV_TWO_PASS=1 skips it (A/B, tests).
+int build_remap_fused(lspiv_remap* h, const std::vector<int>& mx1, const std::vector<int>& my1, const std::vector<uint16_t>& mf1,
+                      const std::vector<int>& mx2, const std::vector<int>& my2, const std::vector<uint16_t>& mf2) {
+  const int64_t Hs = h->src_h, Ws = h->src_w, Hd = h->dst_h, Wd = h->dst_w;
+  if (Ws % 4 != 0 || Wd % 4 != 0 || Hs * Ws < 64 || getenv("LSPIV_PROJECT_CV_TWO_PASS")) return LSPIV_OK;
+  // the undistortion map by quads: two or three 8-byte windows of the camera frame per four undistorted pixels
+  const size_t nq = (size_t)(Hs * Ws / 4);
+  std::vector<int> qb(nq, 0);
+  std::vector<uint64_t> qd(nq, 0);
+  size_t n_slow = 0;
+  for (size_t q = 0; q < nq; ++q) {
+    const size_t o = 4 * q;
+    bool ok = true, outside = true;
+    int lo = mx1[o], hi = mx1[o], ylo = my1[o], yhi = my1[o];
+    for (int k = 0; k < 4; ++k) {
+      const int ix = mx1[o + k], iy = my1[o + k];
+      ok = ok && ix >= 0 && ix + 1 < Ws && iy >= 0 && iy + 1 < Hs;
+      outside = outside && !((ix >= -1 && ix < Ws) && (iy >= -1 && iy < Hs));
+      lo = std::min(lo, ix); hi = std::max(hi, ix); ylo = std::min(ylo, iy); yhi = std::max(yhi, iy);
+    }
+    if (outside) { qd[q] = (uint64_t)1 << 62; continue; }
+    const int64_t base = ok ? (int64_t)ylo * Ws + lo : 0;
+    ok = ok && hi - lo <= 6 && yhi - ylo <= 1 && (base & ~(int64_t)3) + (int64_t)(yhi - ylo + 1) * Ws + 12 <= Hs * Ws;   // every 12-byte load (from the dword below the window) ends inside the frame
+    if (!ok) { qd[q] = (uint64_t)1 << 63; ++n_slow; continue; }
+    uint64_t d = yhi > ylo ? (uint64_t)1 << 15 : 0;
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t fr = mf1[o + k], fx = fr & 31u, fy = fr >> 5;
+      d |= (uint64_t)((uint32_t)(mx1[o + k] - lo) | (fx << 3) | (fy << 8) | ((uint32_t)(my1[o + k] - ylo) << 13)) << (16 * k);
+    }
+    qb[q] = (int)base; qd[q] = d;
+  }
+  if (n_slow * 5 > nq) return LSPIV_OK;                       // a map this folded: the per-pixel path would pace every wave
+  // the warp by tiles
+  constexpr int TW = 64, TH = 16;
+  const int tiles_x = (int)((Wd + TW - 1) / TW), tiles_y = (int)((Hd + TH - 1) / TH);
+  std::vector<int> tiles((size_t)tiles_x * tiles_y * 4, 0);
+  std::vector<uint32_t> pxd((size_t)(Hd * Wd), 0x80000000u);
+  int cap = 16;
+  auto inside = [&](int ix, int iy) { return (ix >= -1 && ix < Ws) && (iy >= -1 && iy < Hs); };
+  for (int ty = 0; ty < tiles_y; ++ty)
+    for (int tx = 0; tx < tiles_x; ++tx) {
+      int xlo = INT_MAX, xhi = INT_MIN, ylo = INT_MAX, yhi = INT_MIN;
+      const int64_t y1 = std::min<int64_t>(Hd, (int64_t)(ty + 1) * TH), x1 = std::min<int64_t>(Wd, (int64_t)(tx + 1) * TW);
+      for (int64_t y = (int64_t)ty * TH; y < y1; ++y)
+        for (int64_t x = (int64_t)tx * TW; x < x1; ++x) {
+          const int ix = mx2[(size_t)(y * Wd + x)], iy = my2[(size_t)(y * Wd + x)];
+          if (!inside(ix, iy)) continue;
+          xlo = std::min(xlo, ix); xhi = std::max(xhi, ix + 1); ylo = std::min(ylo, iy); yhi = std::max(yhi, iy + 1);
+        }
+      if (xlo > xhi) continue;                                // nothing of the tile inside the image: an empty box
+      const int bx0 = xlo >= 0 ? xlo / 4 * 4 : -4, bw = (xhi - bx0 + 1 + 3) / 4 * 4, bh = yhi - ylo + 1;
+      if ((int64_t)bw * bh > 16384) return LSPIV_OK;          // this tile reads too wide a piece of the image: two passes
+      cap = std::max(cap, bw * bh);
+      int* t = &tiles[((size_t)ty * tiles_x + tx) * 4];
+      t[0] = bx0; t[1] = ylo; t[2] = bw; t[3] = bh;
+      for (int64_t y = (int64_t)ty * TH; y < y1; ++y)
+        for (int64_t x = (int64_t)tx * TW; x < x1; ++x) {
+          const size_t o = (size_t)(y * Wd + x);
+          const int ix = mx2[o], iy = my2[o];
+          if (!inside(ix, iy)) continue;
+          const uint32_t fr = mf2[o], fx = fr & 31u, fy = fr >> 5;
+          pxd[o] = (uint32_t)((iy - ylo) * bw + (ix - bx0)) | (fx << 16) | (fy << 21);
+        }
+    }
+  cap = (cap + 15) / 16 * 16;
+  if (getenv("LSPIV_PROJECT_DEBUG"))
+    fprintf(stderr, "lspiv project_cv fused plan: %d x %d tiles, largest box %d bytes, %zu of %zu undistortion quads per pixel\n", tiles_x,
+            tiles_y, cap, n_slow, nq);
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, nq * sizeof(int))); h->d_fqb = (int*)p;
+  HIP_TRY(hipMalloc(&p, nq * sizeof(uint64_t))); h->d_fqd = (uint64_t*)p;
+  HIP_TRY(hipMalloc(&p, pxd.size() * sizeof(uint32_t))); h->d_fpx = (uint32_t*)p;
+  HIP_TRY(hipMalloc(&p, tiles.size() * sizeof(int))); h->d_ft = p;
+  HIP_TRY(hipMemcpy(h->d_fqb, qb.data(), nq * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_fqd, qd.data(), nq * sizeof(uint64_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_fpx, pxd.data(), pxd.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_ft, tiles.data(), tiles.size() * sizeof(int), hipMemcpyHostToDevice));
+  h->f_tiles = tiles_x * tiles_y; h->f_tiles_x = tiles_x; h->f_cap = cap;
+  return LSPIV_OK;
+}
 }  // namespace
 
 int lspiv_project_cv_create(int64_t src_h, int64_t src_w, int64_t dst_h, int64_t dst_w, const double* camera_matrix,
@@ -2261,6 +2348,8 @@ int lspiv_project_cv_create(int64_t src_h, int64_t src_w, int64_t dst_h, int64_t
   memset(h, 0, sizeof(*h));
   h->src_h = src_h; h->src_w = src_w; h->dst_h = dst_h; h->dst_w = dst_w;
   h->undistort = camera_matrix != nullptr;
+  std::vector<int> mx1, my1;                 // the undistortion map, kept for the fused plan
+  std::vector<uint16_t> mf1;
   if (h->undistort) {
     // initUndistortRectifyMap(K, dist, R = I, newK = K, size, CV_16SC2): the row walk _x += ir[0] included
     double ir[9];
@@ -2288,6 +2377,7 @@ int lspiv_project_cv_create(int64_t src_h, int64_t src_w, int64_t dst_h, int64_t
     rc = upload_map(mx, my, mf, &h->d_mx1, &h->d_my1, &h->d_mf1);
     if (!rc) rc = build_remap_quads(mx, my, mf, src_h, src_w, &h->d_qb1, &h->d_qd1, &h->d_slow1, &h->n_slow1);
     if (rc) { lspiv_project_cv_destroy(h); return rc; }
+    mx1.swap(mx); my1.swap(my); mf1.swap(mf);
   }
   {
     // cv2.warpPerspective(src, M, (dst_w, dst_h), INTER_AREA -> INTER_LINEAR): M is inverted, 64-pixel column blocks
@@ -2312,6 +2402,7 @@ int lspiv_project_cv_create(int64_t src_h, int64_t src_w, int64_t dst_h, int64_t
       }
     rc = upload_map(mx, my, mf, &h->d_mx2, &h->d_my2, &h->d_mf2);
     if (!rc) rc = build_remap_quads(mx, my, mf, src_h, src_w, &h->d_qb2, &h->d_qd2, &h->d_slow2, &h->n_slow2);
+    if (!rc && h->undistort) rc = build_remap_fused(h, mx1, my1, mf1, mx, my, mf);
     if (rc) { lspiv_project_cv_destroy(h); return rc; }
   }
   *handle = h;
@@ -2329,6 +2420,13 @@ int lspiv_project_cv_frames_dev(lspiv_remap* h, const void* d_frames, int dtype,
   const int64_t n_src = h->src_h * h->src_w, n_dst = h->dst_h * h->dst_w;
   const void* src = d_frames;
   hipError_t e;
+  if (dtype == LSPIV_U8 && h->undistort && h->d_ft && ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_frames)) & 3) == 0) {   // both remaps in one kernel
+    e = lspiv::launch_remap_fused((const uint8_t*)d_frames, n_src, (int)h->src_h, (int)h->src_w, (int)T, h->d_ft, h->f_tiles, h->f_tiles_x,
+                                  h->f_cap, h->d_fpx, h->d_fqb, h->d_fqd, h->d_mx1, h->d_my1, h->d_mf1, (uint8_t*)d_out, (int)h->dst_h,
+                                  (int)h->dst_w, s);
+    if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return LSPIV_OK;
+  }
   if (h->undistort) {
     rc = ensure(&h->d_tmp, &h->tmp_cap, (size_t)T * n_src * elem_size(dtype));
     if (rc) return rc;
@@ -2363,7 +2461,8 @@ int lspiv_project_cv_frames(lspiv_remap* h, const void* frames, int dtype, int64
 int lspiv_project_cv_destroy(lspiv_remap* h) {
   if (!h) return LSPIV_OK;
   for (void* p : {(void*)h->d_mx1, (void*)h->d_my1, (void*)h->d_mf1, (void*)h->d_mx2, (void*)h->d_my2, (void*)h->d_mf2, h->d_tmp,
-                  (void*)h->d_qb1, (void*)h->d_qb2, (void*)h->d_qd1, (void*)h->d_qd2, (void*)h->d_slow1, (void*)h->d_slow2})
+                  (void*)h->d_qb1, (void*)h->d_qb2, (void*)h->d_qd1, (void*)h->d_qd2, (void*)h->d_slow1, (void*)h->d_slow2,
+                  h->d_ft, (void*)h->d_fpx, (void*)h->d_fqb, (void*)h->d_fqd})
     if (p) hipFree(p);
   delete h;
   return LSPIV_OK;

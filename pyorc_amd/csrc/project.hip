@@ -920,6 +920,208 @@ hipError_t launch_remap(const void* frames, int dtype, int64_t src_elems, int Hs
   return hipGetLastError();
 }
 
+// ---- project_cv, both remaps in ONE kernel (round 6) ----------------------------------------------------------------------------------
+// cv2.undistort followed by cv2.warpPerspective writes and re-reads an undistorted uint8 stack the size of the camera stack: 5 x the
+// algorithmic bytes (profiles/r06_rows_project_cv), and a fifth of the quads of either pass went through the per-pixel kernel.  Here a
+// block owns a TILE of 64 x 16 destination pixels and a run of frames:
+//   stage A  the bounding box of the undistorted pixels the tile's warp reads (plus a border of the constant 0 where it leaves the
+//            image) is computed into LDS, four pixels per lane from two or THREE 8-byte windows of the camera frame (a quad of the
+//            undistortion map may step into the next row pair: one `dy` bit per pixel), blended with OpenCV's integer weights and rounded
+//            to uint8 exactly as the first pass stores them;
+//   stage B  a lane warps four destination pixels from those bytes and stores one packed dword.
+// Same integers as the two kernels in a row (tests/test_project.py); the camera frame is read once (+ the boxes' overlap, L2 hits), the
+// undistorted stack never exists.  Plan (lspiv_api.hip, build_remap_fused): per tile the box {x0, y0, width, height} (x0 and width
+// multiples of 4), per destination pixel `offset in the box (16) | fx (5) | fy (5) | bit 31: wholly outside`, per quad of the undistorted
+// image the windows' base and `xoff (3) | fx (5) | fy (5) | dy (1)` per pixel, bit 15: three rows, bit 62: all outside, bit 63: per pixel.
+// Measured on 201 1080p frames -> 810 x 1440 (tools/sessions/r06_cv_fused*.sh): the two passes 0.80 - 0.85 ms; this kernel 0.505 with the
+// blend as four multiply-adds per pixel and byte reads from LDS; 0.86 with ds_read_u16 at odd addresses (~30 cycles per wave
+// instruction); 0.47 with v_perm_b32 + v_dot4_u32_u8 row sums, ds_read2_b32 of the aligned dwords in stage B, 24-bit multiplies and no
+// 64-bit index arithmetic (the arithmetic alone, every memory operation knocked out: 0.275 -> 0.154); 0.41 with the camera windows
+// taken as dword-ALIGNED 12-byte loads + v_alignbyte_b32 (byte-aligned 8-byte loads: a third more).  What is left is the stage A loads
+// (0.15 ms next to 0.15 of arithmetic, additive): not their number (without the third row: - 5 %), not occupancy (4 / 6 / 8 waves per SIMD:
+// 0.49 / 0.47 / 0.52), not the lines a wave touches (8 x 8 quads per wave-round instead of 64 x 1: 0.49), frames per group 2 / 4 / 6 / 8:
+// 0.52 / 0.47 / 0.475 / 0.48.
+#ifndef LSPIV_RF_F
+#define LSPIV_RF_F 4
+#endif
+constexpr int RF_TW = 64, RF_TH = 16, RF_F = LSPIV_RF_F;
+
+__device__ __forceinline__ uint32_t rf_blend(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, int fx, int fy) {
+  const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+  const int acc = (int)p00 * w00 + (int)p01 * w01 + (int)p10 * w10 + (int)p11 * w11;
+  return (uint32_t)(uint8_t)((acc + (1 << 14)) >> 15);
+}
+// The same integer with a third of the instructions: the weights factor, w_rc = 32 (32 - fx | fx)_c (32 - fy | fy)_r, so with the row
+// sums h_r = p_r0 (32 - fx) + p_r1 fx -- ONE v_dot4_u32_u8 on the two bytes as they lie next to each other (v_perm_b32 puts them into
+// the low half of a dword, zeros above) -- (acc + 2^14) >> 15 = (h_0 (32 - fy) + h_1 fy + 2^9) >> 10; with the row weights scaled by
+// 64 that byte is byte 2 of the sum (< 2^24: v_mad_u32_u24), and two more v_perm_b32 pack the four pixels of a lane.
+__device__ __forceinline__ uint32_t rf_wx(uint32_t fx) { return (32u - fx) | fx << 8; }
+__device__ __forceinline__ uint32_t rf_pack(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3) {      // byte 2 of each
+  return __builtin_amdgcn_perm(a1, a0, 0x0c0c0602u) | __builtin_amdgcn_perm(a3, a2, 0x06020c0cu);
+}
+
+// one group of F consecutive frames of a tile: stage A (the box of undistorted pixels into LDS), stage B (the warp from LDS)
+template <int F>
+__device__ __forceinline__ void rf_group(const uint8_t* __restrict__ img, int64_t src_elems, int Hs, int Ws, int bx0, int by0, int bw, int bq,
+                                         int n_bq, float inv_bq, int rot, const int* __restrict__ qbase, const uint64_t* __restrict__ qdesc,
+                                         const int* __restrict__ mx1, const int* __restrict__ my1, const uint16_t* __restrict__ mf1,
+                                         uint8_t* __restrict__ lds, int box_cap, bool writes, const int (&b_off)[4], const uint32_t (&b_sel)[4],
+                                         const uint32_t (&b_wx)[4], const uint32_t (&b_w0)[4], const uint32_t (&b_w1)[4],
+                                         uint8_t* __restrict__ dst, int64_t n_out) {
+  typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(1)));
+  // ---- stage A.  (The wave that takes the last, partial round changes from group to group: the waves of a block sit on different SIMDs.)
+  for (int j = (int)((threadIdx.x + 64u * (unsigned)rot) & 255u); j < n_bq; j += 256) {
+    const int r = (int)(((float)j + 0.5f) * inv_bq), c = j - __mul24(r, bq);   // (exact: bq bh <= 4096)
+    const int qy = by0 + r, qx = bx0 + 4 * c;
+    uint32_t res[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) res[f] = 0u;
+    if (qy >= 0 && qy < Hs && qx >= 0 && qx < Ws) {                          // (Ws % 4 == 0: a quad is inside or outside as a whole)
+      const int qi = __mul24(qy, Ws >> 2) + (qx >> 2);
+      const uint64_t d = qdesc[qi];
+      if (!(d >> 62)) {
+        // 12 bytes per row from the dword-aligned address below the window (a byte-aligned 8-byte load costs a third more: 0.47
+        // against 0.39 ms per 201 frames with the addresses rounded down), v_alignbyte_b32 shifts the window into place
+        const int qb = qbase[qi];
+        const uint8_t* p = img + (qb & ~3);
+        const uint32_t ph = (uint32_t)qb & 3u;
+        const bool three = (d >> 15) & 1u;
+        typedef uint32_t u32x3_a __attribute__((ext_vector_type(3), aligned(4)));
+        u32x2_u r0[F], r1[F], r2[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          const u32x3_a a = *reinterpret_cast<const u32x3_a*>(p + f * src_elems);
+          const u32x3_a b = *reinterpret_cast<const u32x3_a*>(p + f * src_elems + Ws);
+          const u32x3_a c3 = three ? *reinterpret_cast<const u32x3_a*>(p + f * src_elems + 2 * Ws) : u32x3_a{0u, 0u, 0u};
+          r0[f] = u32x2_u{__builtin_amdgcn_alignbyte(a[1], a[0], ph), __builtin_amdgcn_alignbyte(a[2], a[1], ph)};
+          r1[f] = u32x2_u{__builtin_amdgcn_alignbyte(b[1], b[0], ph), __builtin_amdgcn_alignbyte(b[2], b[1], ph)};
+          r2[f] = u32x2_u{__builtin_amdgcn_alignbyte(c3[1], c3[0], ph), __builtin_amdgcn_alignbyte(c3[2], c3[1], ph)};
+        }
+        uint32_t acc[F][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t cd = (uint32_t)(d >> (16 * e)) & 0xffffu;
+          const uint32_t xo = cd & 7u, fx = (cd >> 3) & 31u, fy = (cd >> 8) & 31u;
+          const bool dy = (cd >> 13) & 1u;                                   // the pixel's row pair starts at the middle row
+          const uint32_t sel = 0x0c0c0000u | (xo + 1u) << 8 | xo;            // v_perm_b32: the two neighbouring bytes, zeros above them
+          const uint32_t wx = rf_wx(fx);
+          const uint32_t wo = dy ? 64u * fy : 64u * (32u - fy), wm = dy ? 64u * (32u - fy) : 64u * fy;   // weight of the other row, of the middle row
+#pragma unroll
+          for (int f = 0; f < F; ++f) {
+            const uint32_t olo = dy ? r2[f][0] : r0[f][0], ohi = dy ? r2[f][1] : r0[f][1];
+            const uint32_t ho = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(ohi, olo, sel), wx, 0u, false);
+            const uint32_t hm = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(r1[f][1], r1[f][0], sel), wx, 0u, false);
+            acc[f][e] = __umul24(ho, wo) + (__umul24(hm, wm) + (512u << 6));
+          }
+        }
+#pragma unroll
+        for (int f = 0; f < F; ++f) res[f] = rf_pack(acc[f][0], acc[f][1], acc[f][2], acc[f][3]);
+      } else if (d >> 63) {                                                  // a quad outside the plan (the image's border, a fold of the map): per pixel
+#pragma unroll 1
+        for (int e = 0; e < 4; ++e) {
+          const int o = __mul24(qy, Ws) + qx + e;
+          const int ix = mx1[o], iy = my1[o], fr = mf1[o], fx = fr & 31, fy = fr >> 5;
+          const bool x0 = ix >= 0 && ix < Ws, x1 = ix + 1 >= 0 && ix + 1 < Ws, y0 = iy >= 0 && iy < Hs, y1 = iy + 1 >= 0 && iy + 1 < Hs;
+          if (!((x0 || x1) && (y0 || y1))) continue;
+          const int b = __mul24(iy, Ws) + ix;
+#pragma unroll 1
+          for (int f = 0; f < F; ++f) {
+            const uint8_t* p = img + f * src_elems;
+            const uint32_t p00 = (x0 && y0) ? p[b] : 0u, p01 = (x1 && y0) ? p[b + 1] : 0u;
+            const uint32_t p10 = (x0 && y1) ? p[b + Ws] : 0u, p11 = (x1 && y1) ? p[b + Ws + 1] : 0u;
+            res[f] |= rf_blend(p00, p01, p10, p11, fx, fy) << (8 * e);
+          }
+        }
+      }
+    }
+    uint32_t* w = reinterpret_cast<uint32_t*>(lds + __mul24(r, bw) + 4 * c);
+#pragma unroll
+    for (int f = 0; f < F; ++f) w[f * (box_cap >> 2)] = res[f];
+  }
+  __syncthreads();
+  // ---- stage B: per pixel and row the two ALIGNED dwords around its two bytes (one ds_read2_b32; byte reads take twice the LDS
+  // instructions, a ds_read_u16 at an odd address ~30 cycles), v_perm_b32 picks the bytes
+  if (writes) {
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      const uint8_t* bx = lds + f * box_cap;
+      uint32_t acc[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t* qa = reinterpret_cast<const uint32_t*>(bx + b_off[e]);
+        const uint32_t* qb = reinterpret_cast<const uint32_t*>(bx + b_off[e] + bw);
+        const uint2 a = {qa[0], qa[1]}, b = {qb[0], qb[1]};                  // (ds_read2_b32: the pair is only 4-byte aligned)
+        const uint32_t h0 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(a.y, a.x, b_sel[e]), b_wx[e], 0u, false);
+        const uint32_t h1 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(b.y, b.x, b_sel[e]), b_wx[e], 0u, false);
+        acc[e] = __umul24(h0, b_w0[e]) + (__umul24(h1, b_w1[e]) + (512u << 6));
+      }
+      *reinterpret_cast<uint32_t*>(dst + f * n_out) = rf_pack(acc[0], acc[1], acc[2], acc[3]);
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void remap_fused_kernel(const uint8_t* __restrict__ frames, int64_t src_elems, int Hs, int Ws, int n_frames,
+                                                          int seg_len, const int4* __restrict__ tiles, const uint32_t* __restrict__ pxd,
+                                                          const int* __restrict__ qbase, const uint64_t* __restrict__ qdesc,
+                                                          const int* __restrict__ mx1, const int* __restrict__ my1,
+                                                          const uint16_t* __restrict__ mf1, uint8_t* __restrict__ out, int Hd, int Wd,
+                                                          int tiles_x, int box_cap, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t rf_lds[];          // RF_F boxes of box_cap bytes (+ 8: stage B reads whole dwords)
+  // consecutive tiles (row-major: neighbours whose boxes overlap) to ONE XCD's L2: workgroups go round the eight XCDs
+  const int per_xcd = (n_tiles + 7) >> 3;
+  const int tile = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+  if (tile >= n_tiles) return;
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
+  const int4 box = tiles[tile];
+  const int bx0 = box.x, by0 = box.y, bw = box.z, bh = box.w, bq = bw >> 2, n_bq = bq * bh;
+  const float inv_bq = 1.0f / (float)max(bq, 1);
+  const int t0 = blockIdx.y * seg_len, t1 = min(t0 + seg_len, n_frames);
+  // stage B: this lane's four destination pixels -- the aligned dword under the pixel's first byte, the byte selector, the weight
+  // words of the columns and the (x 64) weights of the rows
+  const int oy = ty * RF_TH + (threadIdx.x >> 4), ox = tx * RF_TW + 4 * (threadIdx.x & 15);
+  const bool writes = oy < Hd && ox < Wd;                                    // (Wd % 4 == 0)
+  const int64_t n_out = (int64_t)Hd * Wd;
+  int b_off[4]; uint32_t b_sel[4], b_wx[4], b_w0[4], b_w1[4];
+  {
+    uint4 d = {0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u};
+    if (writes) d = *reinterpret_cast<const uint4*>(pxd + (int64_t)oy * Wd + ox);
+    const uint32_t pd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool zero = pd[e] >> 31;                                         // wholly outside: weights 0 on the box's first bytes
+      const uint32_t off = zero ? 0u : pd[e] & 0xffffu, fx = (pd[e] >> 16) & 31u, fy = (pd[e] >> 21) & 31u, lo = off & 3u;
+      b_off[e] = (int)(off & ~3u);
+      b_sel[e] = 0x0c0c0000u | (lo + 1u) << 8 | lo;
+      b_wx[e] = zero ? 0u : rf_wx(fx);
+      b_w0[e] = 64u * (32u - fy); b_w1[e] = 64u * fy;
+    }
+  }
+  uint8_t* dst = out + (int64_t)t0 * n_out + (int64_t)oy * Wd + ox;
+  const uint8_t* img = frames + (int64_t)t0 * src_elems;
+  int t = t0, rot = tile;
+  for (; t + RF_F <= t1; t += RF_F, ++rot, img += RF_F * src_elems, dst += RF_F * n_out)
+    rf_group<RF_F>(img, src_elems, Hs, Ws, bx0, by0, bw, bq, n_bq, inv_bq, rot, qbase, qdesc, mx1, my1, mf1, rf_lds, box_cap, writes, b_off,
+                   b_sel, b_wx, b_w0, b_w1, dst, n_out);
+  for (; t < t1; ++t, img += src_elems, dst += n_out)
+    rf_group<1>(img, src_elems, Hs, Ws, bx0, by0, bw, bq, n_bq, inv_bq, rot, qbase, qdesc, mx1, my1, mf1, rf_lds, box_cap, writes, b_off,
+                b_sel, b_wx, b_w0, b_w1, dst, n_out);
+}
+
+hipError_t launch_remap_fused(const uint8_t* frames, int64_t src_elems, int Hs, int Ws, int n_frames, const void* tiles, int n_tiles,
+                              int tiles_x, int box_cap, const uint32_t* pxd, const int* qbase, const uint64_t* qdesc, const int* mx1,
+                              const int* my1, const uint16_t* mf1, uint8_t* out, int Hd, int Wd, hipStream_t s) {
+  if (n_frames <= 0 || n_tiles <= 0) return hipSuccess;
+  // enough blocks to fill the chip a few times over, segments of whole groups of RF_F frames
+  int n_seg = std::max(1, std::min((n_frames + RF_F - 1) / RF_F, (8192 + n_tiles - 1) / n_tiles));
+  int seg_len = ((n_frames + n_seg - 1) / n_seg + RF_F - 1) / RF_F * RF_F;
+  n_seg = (n_frames + seg_len - 1) / seg_len;
+  hipLaunchKernelGGL(remap_fused_kernel, dim3((unsigned)((n_tiles + 7) / 8 * 8), (unsigned)n_seg), dim3(256), (size_t)RF_F * box_cap + 16, s, frames,
+                     src_elems, Hs, Ws, n_frames, seg_len, (const int4*)tiles, pxd, qbase, qdesc, mx1, my1, mf1, out, Hd, Wd, tiles_x, box_cap,
+                     n_tiles);
+  return hipGetLastError();
+}
+
 // int16 packing of result variables (pyorc/const.py:80: dtype int16, scale_factor 0.01, _FillValue -9999), the
 // arithmetic xarray applies on to_netcdf: float32 data / float32(scale) -> NaN -> fill -> np.around -> int16.
 __global__ void pack_int16_kernel(const float* __restrict__ in, int64_t n, float scale, int fill, int16_t* __restrict__ out) {

@@ -303,6 +303,59 @@ def test_gpu_project_cv_matches_oracle(gpu, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["mild", "strong_lens", "tilted", "mostly_outside", "zoom_in", "zoom_out", "too_wide", "small"])
+def test_gpu_project_cv_in_one_kernel_is_the_two_passes(gpu, monkeypatch, case):
+    """Round 6: uint8 frames go through remap_fused_kernel -- a block computes the box of UNDISTORTED pixels its 64 x 16 tile of the
+    destination reads into LDS (two or three 8-byte windows of the camera frame per four pixels, rounded to uint8 as the first pass
+    stores them) and warps from there; the undistorted stack never reaches HBM.  Same integers as the two passes in a row
+    (LSPIV_PROJECT_CV_TWO_PASS=1 at plan creation) and as the oracle: lens distortion strong enough that quads of the undistortion map
+    step rows, tilted homographies, destinations mostly outside the image (empty boxes, the constant border), magnification either way,
+    a warp whose tiles read more than a box may hold (the plan declines: two passes), sizes that are no multiples of the tile, frame
+    counts around the groups of four and the frame segments."""
+    from oracle import project_oracle as pj
+    from pyorc_amd import DeviceFrames
+    from pyorc_amd.project import ProjectionCV
+
+    Kc, dist, M = _cv_case()
+    src, n_frames = (480, 640), 7
+    if case == "mild":
+        K_, d_, M_, shape = Kc, dist, M, (300, 400)
+    elif case == "strong_lens":
+        K_, d_, M_, shape = Kc, [-0.45, 0.18, 0.004, -0.003, -0.02], M, (300, 400)
+    elif case == "tilted":
+        K_, d_, M_, shape = Kc, dist, np.array([[0.61, -0.22, 60.0], [0.19, 0.58, -20.0], [2.0e-4, 3.0e-4, 1.0]]), (310, 404)
+    elif case == "mostly_outside":
+        K_, d_, M_, shape = Kc, dist, np.array([[0.5, 0.02, 250.0], [0.01, 0.5, 190.0], [0.0, 0.0, 1.0]]), (300, 400)
+    elif case == "zoom_in":                      # the destination is finer than the camera: small boxes
+        K_, d_, M_, shape = Kc, dist, np.array([[2.6, 0.1, -300.0], [0.05, 2.4, -200.0], [1e-5, 2e-5, 1.0]]), (333, 420)
+    elif case == "zoom_out":                     # 2.5 camera pixels per destination pixel: boxes of ~170 x 45
+        K_, d_, M_, shape = Kc, dist, np.array([[0.4, 0.01, 3.0], [0.005, 0.4, 2.0], [0.0, 0.0, 1.0]]), (190, 252)
+    elif case == "too_wide":                     # 8 camera pixels per destination pixel: a tile's box would exceed 16 KB
+        K_, d_, M_, shape, n_frames = Kc, dist, np.array([[0.125, 0.0, 0.0], [0.0, 0.125, 0.0], [0.0, 0.0, 1.0]]), (60, 80), 3
+    else:                                        # a frame smaller than a tile, one frame
+        src, n_frames = (20, 24), 1
+        K_ = np.array([[30.0, 0.0, 12.0], [0.0, 30.0, 10.0], [0.0, 0.0, 1.0]])
+        d_, M_, shape = [-0.1, 0.02, 0.0, 0.0], np.array([[0.9, 0.05, 1.0], [0.02, 0.95, 0.5], [0.0, 0.0, 1.0]]), (12, 16)
+    rng = np.random.default_rng(sum(map(ord, case)))
+    fr = (rng.random((n_frames,) + src) * 256).astype(np.uint8)
+    ref = pj.project_cv(fr, K_, d_, M_, shape)
+    monkeypatch.setenv("LSPIV_PROJECT_CV_TWO_PASS", "1")
+    two = ProjectionCV(src, shape, K_, d_, M_)
+    monkeypatch.delenv("LSPIV_PROJECT_CV_TWO_PASS")
+    one = ProjectionCV(src, shape, K_, d_, M_)
+    try:
+        got2, got1 = two.project_frames(fr), one.project_frames(fr)
+        assert np.array_equal(got2, ref)
+        assert np.array_equal(got1, ref), np.argwhere(got1 != ref)[:5]
+        assert np.array_equal(one.project_frames(DeviceFrames.from_host(fr)).to_host(), ref)
+        if case == "mild":                       # more frames than a block's segment, and a count that is no multiple of four
+            many = np.concatenate([fr] * 19 + [fr[:2]])
+            assert np.array_equal(one.project_frames(DeviceFrames.from_host(many)).to_host(), np.concatenate([ref] * 19 + [ref[:2]]))
+    finally:
+        two.close(); one.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("src,dst,tilt", [((270, 480), (200, 360), 0.1),      # ~4/3 oversampling: a fifth of the cells are means, two windows per quad
                                           ((405, 720), (200, 360), 0.3),      # ~2 : 1: most cells are means of 2 .. 6 pixels in 2 .. 3 rows: four windows
                                           ((540, 960), (200, 360), 0.3),      # > 2.5 : 1: too scattered for windows -- the one-cell kernel
