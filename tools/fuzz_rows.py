@@ -1,7 +1,8 @@
 """Randomised differential test of the rows around the hot path: filters, both projections, the
 post-PIV masks and the int16 packing against their numpy oracles, over random shapes (odd widths, single frames, tiny
 frames), dtypes and parameters.  Bit-exact except the Gaussian filters (4e-6 of the value range) and `angle` (atan2f).
-usage: fuzz_rows.py <seed> <cases>        FUZZ_KINDS=project,normalize restricts the kinds drawn"""
+usage: fuzz_rows.py <seed> <cases>        FUZZ_KINDS=project,normalize restricts the kinds drawn; FUZZ_W4=1: widths that are multiples of
+four (the four-column blur, project_cv in one kernel); FUZZ_DIST=0.3: amplitude of the lens coefficients of project_cv (default 0.05)"""
 import os, sys, time, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -23,6 +24,9 @@ for case in range(n_cases):
     H = int(rng.integers(3, 40)) if rng.random() < 0.3 else int(rng.integers(40, 200))
     W = int(rng.integers(3, 40)) if rng.random() < 0.3 else int(rng.integers(40, 260))
     dtype = rng.choice([np.uint8, np.float32, np.float64])
+    if os.environ.get("FUZZ_W4"):            # widths the four-column blur / the one-kernel project_cv take (multiples of four), uint8 more often
+        W = max(W // 4 * 4, 4)
+        dtype = np.uint8 if rng.random() < 0.6 else dtype
     note, ok = "", True
     try:
         if kind in ("time_diff", "range", "blur"):
@@ -79,9 +83,11 @@ for case in range(n_cases):
             p.close(); note = f"dst {dst} groups {full}"
         elif kind == "project_cv":
             src = (max(H, 32), max(W, 32)); dst = (int(rng.integers(8, 150)), int(rng.integers(8, 200)))
+            if os.environ.get("FUZZ_W4"):
+                dst = (dst[0], dst[1] // 4 * 4)
             K = np.array([[rng.uniform(300, 900), 0, src[1] / 2 + rng.uniform(-5, 5)], [0, rng.uniform(300, 900), src[0] / 2 + rng.uniform(-5, 5)], [0, 0, 1.0]])
             nd = int(rng.choice([0, 4, 5, 8]))
-            dist = list(rng.uniform(-0.05, 0.05, nd) * ([1, 1, 0.02, 0.02, 1, 1, 1, 1][:nd] if nd else []))
+            dist = list(rng.uniform(-1, 1, nd) * float(os.environ.get("FUZZ_DIST", 0.05)) * ([1, 1, 0.02, 0.02, 1, 1, 1, 1][:nd] if nd else []))
             M = np.array([[rng.uniform(0.4, 1.5), rng.uniform(-0.1, 0.1), rng.uniform(-20, 20)], [rng.uniform(-0.1, 0.1), rng.uniform(0.4, 1.5), rng.uniform(-20, 20)],
                           [rng.uniform(-2e-4, 2e-4), rng.uniform(-2e-4, 2e-4), 1.0]])
             d2 = np.uint8 if dtype == np.uint8 else np.float32
