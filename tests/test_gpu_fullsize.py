@@ -309,3 +309,43 @@ def test_device_chain_on_a_stack_beyond_2_31_elements(gpu):
         assert np.array_equal(np.isnan(ds["corr"][k]), np.isnan(cmo[0])) and rel_err(ds["corr"][k], cmo[0].astype(np.float64)) <= TOL
         assert rel_err(ds["v_x"][k][ok[0]], (uo[0].astype(np.float64) * 0.3)[ok[0]], floor=0.05 * 0.3) <= TOL, k
         assert rel_err(ds["v_y"][k][ok[0]], (vo[0].astype(np.float64) * 0.3)[ok[0]], floor=0.05 * 0.3) <= TOL, k
+
+
+def test_rows_at_1080p_new_kernels_equal_the_ones_they_replace(gpu, monkeypatch):
+    """The two row kernels that came last in round 6, at the size the bench line quotes them on (1080 x 1920 camera frames, the 810 x 1440
+    ortho grid of the bench's lens + perspective), through their size-independent property: the SAME bits as the kernels they replace --
+    `blur_strip4_kernel` (four columns per lane, integer row pass; 7.5 strips of 256 columns per row, 33.75 strips of 32 rows) against the
+    one-column float kernel for every unrolled radius, `remap_fused_kernel` (undistortion + warp in one kernel, 23 x 51 tiles) against the
+    two remap passes -- and a sample of frames against the oracles."""
+    from oracle import filters_oracle as fo
+    from oracle import project_oracle as pj
+    from pyorc_amd import DeviceFrames, filters
+    from pyorc_amd.project import ProjectionCV
+    from pyorc_amd.synth import particle_stack
+
+    fr = particle_stack(9, 1080, 1920, seed=77)
+    fr[3, 500:600, 900:1100] = 255                                     # a saturated patch: the largest sums of the integer row pass
+    dev = DeviceFrames.from_host(fr)
+    for name, args in (("smooth", (1,)), ("smooth", (2,)), ("smooth", (3,)), ("edge_detect", (1, 2)), ("edge_detect", (1, 3)), ("edge_detect", (2, 3))):
+        monkeypatch.delenv("LSPIV_BLUR_ONE_COLUMN", raising=False)
+        four = getattr(filters, name)(dev, *args).to_host()
+        monkeypatch.setenv("LSPIV_BLUR_ONE_COLUMN", "1")
+        one = getattr(filters, name)(dev, *args).to_host()
+        assert np.array_equal(four.view(np.uint32), one.view(np.uint32)), (name, args)
+        ref = getattr(fo, name)(fr[3:4], *args)
+        assert np.abs(four[3:4] - ref).max() <= 4e-6 * 255, (name, args)
+    monkeypatch.delenv("LSPIV_BLUR_ONE_COLUMN", raising=False)
+
+    K = np.array([[1500.0, 0, 960.0], [0, 1500.0, 540.0], [0, 0, 1]])
+    dist = np.array([-0.12, 0.03, 0.001, -0.0005, 0.0])
+    M = np.array([[0.78, 0.05, -20.0], [0.01, 0.80, -15.0], [1.5e-5, 4.0e-5, 1.0]])
+    monkeypatch.setenv("LSPIV_PROJECT_CV_TWO_PASS", "1")
+    two = ProjectionCV((1080, 1920), (810, 1440), K, dist, M)
+    monkeypatch.delenv("LSPIV_PROJECT_CV_TWO_PASS")
+    one = ProjectionCV((1080, 1920), (810, 1440), K, dist, M)
+    try:
+        a, b = one.project_frames(dev).to_host(), two.project_frames(dev).to_host()
+        assert a.dtype == np.uint8 and np.array_equal(a, b)
+        assert np.array_equal(a[3], pj.project_cv(fr[3:4], K, dist, M, (810, 1440))[0])
+    finally:
+        one.close(); two.close()
