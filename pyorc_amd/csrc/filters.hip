@@ -255,7 +255,8 @@ struct NormLane {
 
 __global__ __launch_bounds__(256) void norm_minmax_space_kernel(const uint8_t* __restrict__ f, const float* __restrict__ mean,
                                                                 int64_t frame_elems, int n_frames, int seg_len,
-                                                                float* __restrict__ part, int n_ws) {
+                                                                float* __restrict__ part, int n_ws, const int* __restrict__ guard) {
+  if (guard && *guard == 0) return;
   NormLane L;
   L.init(mean, frame_elems);
   const int t0 = blockIdx.y * seg_len, t1 = min(t0 + seg_len, n_frames);
@@ -304,7 +305,8 @@ __global__ __launch_bounds__(256) void norm_minmax_space_kernel(const uint8_t* _
 }
 
 __global__ __launch_bounds__(256) void norm_fold_kernel(const float* __restrict__ part, int n_ws, float* __restrict__ lo_out,
-                                                        float* __restrict__ hi_out) {
+                                                        float* __restrict__ hi_out, const int* __restrict__ guard) {
+  if (guard && *guard == 0) return;
   const int t = blockIdx.x;
   float lo = 3.0e38f, hi = -3.0e38f;
   for (int i = threadIdx.x; i < n_ws; i += 256) {
@@ -322,56 +324,191 @@ __global__ __launch_bounds__(256) void norm_fold_kernel(const float* __restrict_
   }
 }
 
+// The stretch of one frame of a lane's 32 pixels.
+// The reference's  a / span * 255  costs an IEEE division per pixel (ten instructions: this pass ran at the VALU's rate, 0.22 of its
+// 0.25 ms, profiles/r06_rows_normalize) -- but only the INTEGER PART of the result is kept.  With y = RN(1 / span) once per frame,
+// (a y) 255 is within 5 roundings (3e-7 relative) of RN(RN(a / span) 255), so wherever it is further than that from an integer its
+// integer part is the reference's; the few pixels nearer to one (about 1 instruction in 100 has such a lane) take the division
+// under a wave-uniform branch.  Frames whose span has no usable reciprocal (0: a constant frame, 0 / 0 -> 0) divide everywhere.
+__device__ __forceinline__ void norm_stretch_frame(const NormLane& L, const u32x4n (&wc)[2], float lo, float span, int mode, uint8_t* __restrict__ dst) {
+  const float y = 1.0f / span;
+  const bool fast = mode == 0 && span > 1e-30f && span < 1e30f;     // wave-uniform
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (L.v[k]) {
+      const u32x4n w = wc[k];
+      u32x4n o = {0u, 0u, 0u, 0u};
+      if (fast) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float a = ((float)((w[e >> 2] >> (8 * (e & 3))) & 0xffu) - L.m[k][e]) - lo;
+          float q = (a * y) * 255.0f;
+          const bool near = !(fabsf(q - rintf(q)) > 6.0e-7f * q + 1.0e-30f);   // (NaN: near)
+          if (__builtin_amdgcn_ballot_w64(near) != 0) q = near ? a / span * 255.0f : q;
+          o[e >> 2] |= (uint32_t)((q != q) ? (uint8_t)0 : (uint8_t)(int)q) << (8 * (e & 3));
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float q = (((float)((w[e >> 2] >> (8 * (e & 3))) & 0xffu) - L.m[k][e]) - lo) / span * 255.0f;
+          o[e >> 2] |= (uint32_t)((q != q) ? (uint8_t)0 : (uint8_t)(int)q) << (8 * (e & 3));
+        }
+      }
+      *reinterpret_cast<u32x4n*>(dst + L.c[k]) = o;
+    }
+  }
+}
+
+// `guard` (all three space-major kernels): nullptr, or a flag of the one-pass kernel below -- 0: it finished, nothing to do here
 __global__ __launch_bounds__(256) void norm_stretch_space_kernel(const uint8_t* __restrict__ f, const float* __restrict__ mean,
                                                                  int64_t frame_elems, int n_frames, int seg_len,
                                                                  const float* __restrict__ lo_in, const float* __restrict__ hi_in,
-                                                                 uint8_t* __restrict__ out, int mode) {
+                                                                 uint8_t* __restrict__ out, int mode, const int* __restrict__ guard) {
+  if (guard && *guard == 0) return;
   NormLane L;
   L.init(mean, frame_elems);
   const int t0 = blockIdx.y * seg_len, t1 = min(t0 + seg_len, n_frames);
-  // The reference's  a / span * 255  costs an IEEE division per pixel (ten instructions: this pass ran at the VALU's rate, 0.22 of its
-  // 0.25 ms, profiles/r06_rows_normalize) -- but only the INTEGER PART of the result is kept.  With y = RN(1 / span) once per frame,
-  // (a y) 255 is within 5 roundings (3e-7 relative) of RN(RN(a / span) 255), so wherever it is further than that from an integer its
-  // integer part is the reference's; the few pixels nearer to one (about 1 instruction in 100 has such a lane) take the division
-  // under a wave-uniform branch.  Frames whose span has no usable reciprocal (0: a constant frame, 0 / 0 -> 0) divide everywhere.
-  // (the ballot is a convergent operation: the compiler does not unroll this loop, so the next frame's loads are issued by hand)
+  // (the ballot in the stretch is a convergent operation: the compiler does not unroll this loop, so the next frame's loads are issued by hand)
   u32x4n wn[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) wn[k] = L.v[k] && t0 < t1 ? *reinterpret_cast<const u32x4n*>(f + (int64_t)t0 * frame_elems + L.c[k]) : u32x4n{0u, 0u, 0u, 0u};
   for (int t = t0; t < t1; ++t) {
     const float lo = lo_in[t], span = hi_in[t] - lo;
-    const float y = 1.0f / span;
-    const bool fast = mode == 0 && span > 1e-30f && span < 1e30f;     // wave-uniform
-    uint8_t* dst = out + (int64_t)t * frame_elems;
-    u32x4n wc[2] = {wn[0], wn[1]};
+    const u32x4n wc[2] = {wn[0], wn[1]};
     if (t + 1 < t1) {
 #pragma unroll
       for (int k = 0; k < 2; ++k) if (L.v[k]) wn[k] = *reinterpret_cast<const u32x4n*>(f + (int64_t)(t + 1) * frame_elems + L.c[k]);
     }
+    norm_stretch_frame(L, wc, lo, span, mode, out + (int64_t)t * frame_elems);
+  }
+}
+
+// ---- normalize in ONE pass over the frames (round 6) -----------------------------------------------------------------------------------
+// The two passes above read every frame twice: 3 bytes of HBM traffic per pixel where the row needs 2.  Here the blocks that own the
+// slices of a frame EXCHANGE their minima while they hold the frame in registers: one block per slice of 8192 pixels (253 at 1080p: all
+// resident at once, the launcher checks it against the device's capacity), every block walks ALL frames in groups of NORM1_D -- load
+// the group, reduce it, publish the block's (min, max) per frame (device-coherent stores, then an increment of one of the frame's counters),
+// issue the NEXT group's loads, wait until the counters of the group have reached the number of blocks, fold the other
+// blocks' pairs, stretch from the registers, store.  No block waits for anything another block does AFTER that block's own wait, so
+// resident blocks cannot deadlock; a block that does not see a counter complete within NORM1_SPIN polls (blocks not resident together:
+// the device shared with another long kernel) raises `fail` and leaves, every other block follows, and the three guarded kernels
+// above redo the call.  Same float32 arithmetic, minimum and maximum do not depend on the order: the same bits.
+// MEASURED, and therefore opt-in (LSPIV_NORM_ONE_PASS=1): with release / acquire fences at device scope around the exchange 1.67 ms per
+// 201 1080p frames (a device-scope release writes back every dirty line of the XCD's L2 -- the stretched frames: ~30 us per group); with
+// device-coherent (sc1) stores and loads of the pairs, a workgroup-scope fence for the acknowledgement and 16 counters per frame 0.94 ms
+// -- ~18 us per group of four frames for store -> counter -> poll -> fold of 253 pairs -> stretch, one group in flight per block -- against
+// 0.32 ms of the two passes.  Hiding that latency needs ~14 frames in flight per block, and then one wave per SIMD has to issue the 450
+// VALU instructions a frame costs it (min / max + stretch) in the 0.85 us the frame may take: no slack at all for 0.08 ms at best.
+constexpr int NORM1_D = 4, NORM1_SLOTS = 16;   // frames per group; counters per frame (block b counts on slot b % 16: 16 same-address increments in a row instead of 253)
+constexpr unsigned NORM1_SPIN = 1u << 21;
+
+__global__ __launch_bounds__(256) void norm_onepass_kernel(const uint8_t* __restrict__ f, const float* __restrict__ mean, int64_t frame_elems,
+                                                           int n_frames, float* __restrict__ part, unsigned* __restrict__ ready,
+                                                           int* __restrict__ fail, float* __restrict__ lo_out, float* __restrict__ hi_out,
+                                                           uint8_t* __restrict__ out, int mode) {
+  constexpr int D = NORM1_D;
+  if (mode & 2) {                                                      // (test hook: as if the exchange had timed out)
+    if (threadIdx.x == 0) __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  NormLane L;
+  L.init(mean, frame_elems);
+  const int nb = gridDim.x, b = blockIdx.x, wv = threadIdx.x >> 6;
+  __shared__ float red[2][D][4];
+  __shared__ float bc[2][D];
+  __shared__ int gave_up;
+  if (threadIdx.x == 0) gave_up = 0;
+  auto load_group = [&](int g, u32x4n (&w)[D][2]) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      if (L.v[k]) {
-        const u32x4n w = wc[k];
-        u32x4n o = {0u, 0u, 0u, 0u};
-        if (fast) {
+    for (int j = 0; j < D; ++j) {
+      const uint8_t* img = f + (int64_t)min(g + j, n_frames - 1) * frame_elems;   // (beyond the last frame: the last one again, unused)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) w[j][k] = L.v[k] ? *reinterpret_cast<const u32x4n*>(img + L.c[k]) : u32x4n{0u, 0u, 0u, 0u};
+    }
+  };
+  // this block's (min, max) of every frame of the group -> part, the frames' counters + 1
+  auto publish_group = [&](int g, const u32x4n (&w)[D][2]) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      float lo = 3.0e38f, hi = -3.0e38f;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (L.v[k]) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            const float a = ((float)((w[e >> 2] >> (8 * (e & 3))) & 0xffu) - L.m[k][e]) - lo;
-            float q = (a * y) * 255.0f;
-            const bool near = !(fabsf(q - rintf(q)) > 6.0e-7f * q + 1.0e-30f);   // (NaN: near)
-            if (__builtin_amdgcn_ballot_w64(near) != 0) q = near ? a / span * 255.0f : q;
-            o[e >> 2] |= (uint32_t)((q != q) ? (uint8_t)0 : (uint8_t)(int)q) << (8 * (e & 3));
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const float q = (((float)((w[e >> 2] >> (8 * (e & 3))) & 0xffu) - L.m[k][e]) - lo) / span * 255.0f;
-            o[e >> 2] |= (uint32_t)((q != q) ? (uint8_t)0 : (uint8_t)(int)q) << (8 * (e & 3));
+            const float d = (float)((w[j][k][e >> 2] >> (8 * (e & 3))) & 0xffu) - L.m[k][e];
+            lo = fminf(lo, d);
+            hi = fmaxf(hi, d);
           }
         }
-        *reinterpret_cast<u32x4n*>(dst + L.c[k]) = o;
+      }
+      lo = -half_max(-lo); hi = half_max(hi);
+      lo = fminf(lo, __shfl_xor(lo, 32, 64)); hi = fmaxf(hi, __shfl_xor(hi, 32, 64));
+      if ((threadIdx.x & 63) == 0) { red[0][j][wv] = lo; red[1][j][wv] = hi; }
+    }
+    __syncthreads();
+    if (threadIdx.x < D && g + (int)threadIdx.x < n_frames) {
+      const int j = threadIdx.x, t = g + j;
+      // device-coherent stores (they go past this XCD's L2), acknowledged before the counter moves; NO release fence at device scope:
+      // that one writes back every dirty line of the L2 -- the stretched frames -- and cost 30 us per group (1.67 ms per 201 frames)
+      __hip_atomic_store(&part[((int64_t)t * nb + b) * 2], fminf(fminf(red[0][j][0], red[0][j][1]), fminf(red[0][j][2], red[0][j][3])),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&part[((int64_t)t * nb + b) * 2 + 1], fmaxf(fmaxf(red[1][j][0], red[1][j][1]), fmaxf(red[1][j][2], red[1][j][3])),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");           // s_waitcnt vmcnt(0): the two stores have been acknowledged
+      __hip_atomic_fetch_add(&ready[(int64_t)t * NORM1_SLOTS + (b & (NORM1_SLOTS - 1))], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  // false: the exchange timed out somewhere (block-uniform)
+  auto finish_group = [&](int g, const u32x4n (&w)[D][2]) -> bool {
+    if (wv == 0) {                                                     // lane = (frame of the group, counter slot): D x NORM1_SLOTS = 64
+      const int j = (threadIdx.x & 63) / NORM1_SLOTS, slot = threadIdx.x & (NORM1_SLOTS - 1);
+      const unsigned expected = g + j < n_frames && slot < nb ? (unsigned)((nb - 1 - slot) / NORM1_SLOTS + 1) : 0u;   // blocks with b % SLOTS == slot
+      const unsigned* ctr = &ready[(int64_t)min(g + j, n_frames - 1) * NORM1_SLOTS + slot];
+      unsigned polls = 0;
+      while (__builtin_amdgcn_ballot_w64(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) != 0) {
+        if (++polls > NORM1_SPIN || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {   // (wave-uniform)
+          __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          gave_up = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
       }
     }
+    __syncthreads();                                                   // (also: red[] may be written again)
+    if (gave_up) return false;
+    // fold the blocks' pairs: wave j takes frame j of the group
+    if (wv < D && g + wv < n_frames) {
+      const int t = g + wv;
+      float lo = 3.0e38f, hi = -3.0e38f;
+      for (int i = threadIdx.x & 63; i < nb; i += 64) {
+        lo = fminf(lo, __hip_atomic_load(&part[((int64_t)t * nb + i) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        hi = fmaxf(hi, __hip_atomic_load(&part[((int64_t)t * nb + i) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      }
+      lo = -half_max(-lo); hi = half_max(hi);
+      lo = fminf(lo, __shfl_xor(lo, 32, 64)); hi = fmaxf(hi, __shfl_xor(hi, 32, 64));
+      if ((threadIdx.x & 63) == 0) {
+        bc[0][wv] = lo; bc[1][wv] = hi;
+        if (b == 0) { lo_out[t] = lo; hi_out[t] = hi; }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+      if (g + j < n_frames) norm_stretch_frame(L, w[j], bc[0][j], bc[1][j] - bc[0][j], mode & 1, out + (int64_t)(g + j) * frame_elems);
+    return true;
+  };
+  static_assert(D <= 4 && D * NORM1_SLOTS == 64, "one wave folds one frame of a group; one lane polls one counter");
+  u32x4n wa[D][2], wb[D][2];
+  load_group(0, wa);
+  for (int g = 0; g < n_frames; g += 2 * D) {                          // two groups per trip: the buffers swap without moves
+    publish_group(g, wa);
+    if (g + D < n_frames) load_group(g + D, wb);
+    if (!finish_group(g, wa)) return;
+    if (g + D >= n_frames) break;
+    publish_group(g + D, wb);
+    if (g + 2 * D < n_frames) load_group(g + 2 * D, wa);
+    if (!finish_group(g + D, wb)) return;
   }
 }
 
@@ -604,7 +741,8 @@ hipError_t launch_minmax(const float* in, int64_t n, float lo, float hi, float* 
 
 size_t normalize_part_bytes(int64_t frame_elems, int n_frames) {
   const int64_t n_slices = (frame_elems + NORM_SLICE - 1) / NORM_SLICE;
-  return (size_t)n_frames * (size_t)(4 * n_slices) * 2 * sizeof(float);
+  // + the one-pass kernel's counters (one per frame) and its flag, behind the pairs
+  return (size_t)n_frames * (size_t)(4 * n_slices) * 2 * sizeof(float) + ((size_t)n_frames * NORM1_SLOTS + 64) * sizeof(unsigned);
 }
 
 hipError_t launch_sample_mean(const uint8_t* frames, int64_t frame_elems, int n_frames, int interval, float* d_mean, hipStream_t s) {
@@ -619,6 +757,20 @@ hipError_t launch_normalize(const uint8_t* frames, int64_t frame_elems, int n_fr
   const hipError_t e = launch_sample_mean(frames, frame_elems, n_frames, interval, d_mean, s);
   if (e != hipSuccess) return e;
   return launch_normalize_apply(frames, frame_elems, n_frames, d_mean, d_mn, d_mx, d_part, out, s);
+}
+
+// blocks of norm_onepass_kernel the current device holds at once (its blocks wait for each other: all of them must be resident)
+static int onepass_capacity() {
+  static thread_local int cap_dev = -1, cap = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (dev != cap_dev) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, norm_onepass_kernel, 256, 0) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+    cap = per_cu * cus; cap_dev = dev;
+  }
+  return cap;
 }
 
 // passes 2 and 3 on their own: per-frame statistics only, so a stack may be normalised in pieces against one mean plane
@@ -641,10 +793,23 @@ hipError_t launch_normalize_apply(const uint8_t* frames, int64_t frame_elems, in
     n_seg = (n_frames + seg_len - 1) / seg_len;
     float* lo = reinterpret_cast<float*>(d_mn);
     float* hi = reinterpret_cast<float*>(d_mx);
-    hipLaunchKernelGGL(norm_minmax_space_kernel, dim3(n_slices, n_seg), dim3(256), 0, s, frames, d_mean, frame_elems, n_frames, seg_len, d_part, n_ws);
-    hipLaunchKernelGGL(norm_fold_kernel, dim3(n_frames), dim3(256), 0, s, d_part, n_ws, lo, hi);
+    // LSPIV_NORM_ONE_PASS=1 (read per call): one pass over the frames when every slice's block is resident at once
+    // (norm_onepass_kernel), the two passes behind it guarded by its flag.  NOT the default: 0.94 ms per 201 frames against 0.32.
+    const bool one_pass = getenv("LSPIV_NORM_ONE_PASS") != nullptr;
+    const int give_up = getenv("LSPIV_NORM_ONEPASS_FAIL") ? 2 : 0;               // test hook: the exchange "times out" at once
     static const int divide = getenv("LSPIV_NORM_DIVIDE") != nullptr;   // A/B: the division for every pixel (the round-5 pass)
-    hipLaunchKernelGGL(norm_stretch_space_kernel, dim3(n_slices, n_seg), dim3(256), 0, s, frames, d_mean, frame_elems, n_frames, seg_len, lo, hi, out, divide);
+    const int* guard = nullptr;
+    if (one_pass && n_slices <= onepass_capacity()) {
+      unsigned* state = reinterpret_cast<unsigned*>(d_part + (size_t)n_frames * n_ws * 2);
+      e = hipMemsetAsync(state, 0, ((size_t)n_frames * NORM1_SLOTS + 64) * sizeof(unsigned), s);
+      if (e != hipSuccess) return e;
+      int* fail = reinterpret_cast<int*>(state + (size_t)n_frames * NORM1_SLOTS);
+      hipLaunchKernelGGL(norm_onepass_kernel, dim3(n_slices), dim3(256), 0, s, frames, d_mean, frame_elems, n_frames, d_part, state, fail, lo, hi, out, divide | give_up);
+      guard = fail;
+    }
+    hipLaunchKernelGGL(norm_minmax_space_kernel, dim3(n_slices, n_seg), dim3(256), 0, s, frames, d_mean, frame_elems, n_frames, seg_len, d_part, n_ws, guard);
+    hipLaunchKernelGGL(norm_fold_kernel, dim3(n_frames), dim3(256), 0, s, d_part, n_ws, lo, hi, guard);
+    hipLaunchKernelGGL(norm_stretch_space_kernel, dim3(n_slices, n_seg), dim3(256), 0, s, frames, d_mean, frame_elems, n_frames, seg_len, lo, hi, out, divide, guard);
     return hipGetLastError();
   }
   const bool vec = frame_elems % 4 == 0 && (reinterpret_cast<uintptr_t>(frames) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;

@@ -342,6 +342,34 @@ def test_gpu_normalize_without_the_division_keeps_the_reference_integers(gpu, mo
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(45, 48, 256), (9, 270, 480), (4, 1080, 1920), (3, 64, 1024), (1, 16, 16), (13, 100, 176)])
+def test_gpu_normalize_in_one_pass_is_the_two_passes(gpu, monkeypatch, shape):
+    """Round 6, opt-in (LSPIV_NORM_ONE_PASS=1; measured slower, see filters.hip): norm_onepass_kernel reads every frame ONCE -- the blocks
+    that own the slices of a frame exchange their minima (device-coherent stores, counters per frame) while they hold the frame in
+    registers.  The bytes of the default two-pass path and of the oracle: frame counts around the groups of four and the two-group trips,
+    one slice and 253, a constant frame, device-resident and host stacks; and when the exchange gives up (LSPIV_NORM_ONEPASS_FAIL=1 --
+    what a timeout on a device shared with another long kernel does) the guarded passes behind it deliver the same bytes."""
+    from pyorc_amd import DeviceFrames, filters
+
+    rng = np.random.default_rng(shape[0] * 7 + shape[2])
+    T = shape[0]
+    fr = (rng.random(shape) * rng.integers(2, 256, (T, 1, 1))).astype(np.uint8)
+    if T > 2:
+        fr[2] = 77
+    samples = min(15, T)
+    ref = fo.normalize(fr, samples)
+    monkeypatch.delenv("LSPIV_NORM_ONE_PASS", raising=False)
+    monkeypatch.delenv("LSPIV_NORM_ONEPASS_FAIL", raising=False)
+    two = filters.normalize(fr, samples)
+    monkeypatch.setenv("LSPIV_NORM_ONE_PASS", "1")
+    one = filters.normalize(fr, samples)
+    one_dev = filters.normalize(DeviceFrames.from_host(fr), samples).to_host()
+    monkeypatch.setenv("LSPIV_NORM_ONEPASS_FAIL", "1")
+    fell_back = filters.normalize(DeviceFrames.from_host(fr), samples).to_host()
+    assert np.array_equal(two, ref) and np.array_equal(one, ref) and np.array_equal(one_dev, ref) and np.array_equal(fell_back, ref)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.uint8, np.float32, np.float64])
 def test_gpu_edge_detect_with_the_clip_in_its_store_is_edge_detect_then_minmax(gpu, dtype):
     """Round 6: lspiv_edge_detect_clip_dev = Frames.edge_detect followed by Frames.minmax (the recipe's order) in one pass.  The bits of the
