@@ -76,6 +76,10 @@ def build_rows(lib, T: int):
                       "Frames.normalize(samples=15): uint8 -> uint8 (read once + written once credited; the per-frame min / max needs a second look at every frame)"),
         "smooth": (lambda: _lib.check(lib.lspiv_gaussian_blur_dev(d_cam, 0, T, H, W, 5, d_f32, None)), T * n * 5, T, "blur_",
                    "Frames.smooth(wdw=2): cv2.GaussianBlur 5x5, uint8 -> float32"),
+        "smooth_f32": (lambda: _lib.check(lib.lspiv_gaussian_blur_dev(d_camf, 1, T, H, W, 5, d_f32, None)), T * n * 8, T, "blur_",
+                       "Frames.smooth(wdw=2) of FLOAT32 frames (after time_diff / a float video): float32 -> float32"),
+        "edge_detect_f32": (lambda: _lib.check(lib.lspiv_edge_detect_dev(d_camf, 1, T, H, W, 3, 5, d_f32, None)), T * n * 8, T, "blur_|edge_",
+                            "Frames.edge_detect(wdw_1=1, wdw_2=2) of FLOAT32 frames: float32 -> float32"),
     }
 
     def cleanup():
@@ -90,7 +94,7 @@ def build_rows(lib, T: int):
 def row_read_bytes(name: str, T: int) -> int:
     """Input bytes a launch of this row cannot avoid reading (every input sample once): what FETCH_SIZE is calibrated against."""
     n = H * W
-    return T * n * (4 if name == "project_f32" else 1)     # float32 camera frames
+    return T * n * (4 if name in ("project_f32", "smooth_f32", "edge_detect_f32") else 1)     # float32 camera frames
 
 
 def time_launches(lib, launch, reps: int) -> float:
