@@ -2251,11 +2251,12 @@ int build_remap_quads(const std::vector<int>& mx, const std::vector<int>& my, co
 }
 
 // Plan of remap_fused_kernel (project.hip): undistortion and warp of uint8 frames in one kernel.  Built when both widths are multiples of
-// four and every 64 x 16 destination tile's box of undistorted pixels fits 16 KB; LSPIV_PROJECT_CV_TWO_PASS=1 skips it (A/B, tests).
+// four and every 64 x 16 destination tile's box of undistorted pixels fits 16 000 bytes; LSPIV_PROJECT_CV_TWO_PASS=1 skips it (A/B, tests).
 int build_remap_fused(lspiv_remap* h, const std::vector<int>& mx1, const std::vector<int>& my1, const std::vector<uint16_t>& mf1,
                       const std::vector<int>& mx2, const std::vector<int>& my2, const std::vector<uint16_t>& mf2) {
   const int64_t Hs = h->src_h, Ws = h->src_w, Hd = h->dst_h, Wd = h->dst_w;
-  if (Ws % 4 != 0 || Wd % 4 != 0 || Hs * Ws < 64 || getenv("LSPIV_PROJECT_CV_TWO_PASS")) return LSPIV_OK;
+  if (Ws % 4 != 0 || Wd % 4 != 0 || Hs * Ws < 64 || Hs > 32767 || Ws > 32767 || Hd > 32767 || Wd > 32767 ||   // (24-bit index arithmetic in the kernel)
+      getenv("LSPIV_PROJECT_CV_TWO_PASS")) return LSPIV_OK;
   // the undistortion map by quads: two or three 8-byte windows of the camera frame per four undistorted pixels
   const size_t nq = (size_t)(Hs * Ws / 4);
   std::vector<int> qb(nq, 0);
@@ -2302,7 +2303,7 @@ int build_remap_fused(lspiv_remap* h, const std::vector<int>& mx1, const std::ve
         }
       if (xlo > xhi) continue;                                // nothing of the tile inside the image: an empty box
       const int bx0 = xlo >= 0 ? xlo / 4 * 4 : -4, bw = (xhi - bx0 + 1 + 3) / 4 * 4, bh = yhi - ylo + 1;
-      if ((int64_t)bw * bh > 16384) return LSPIV_OK;          // this tile reads too wide a piece of the image: two passes
+      if ((int64_t)bw * bh > 16000) return LSPIV_OK;          // this tile reads too wide a piece of the image (four boxes + 16 bytes must fit 64 KB of LDS): two passes
       cap = std::max(cap, bw * bh);
       int* t = &tiles[((size_t)ty * tiles_x + tx) * 4];
       t[0] = bx0; t[1] = ylo; t[2] = bw; t[3] = bh;

@@ -303,7 +303,7 @@ def test_gpu_project_cv_matches_oracle(gpu, dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["mild", "strong_lens", "tilted", "mostly_outside", "zoom_in", "zoom_out", "too_wide", "small"])
+@pytest.mark.parametrize("case", ["mild", "strong_lens", "tilted", "mostly_outside", "zoom_in", "zoom_out", "near_limit", "too_wide", "small"])
 def test_gpu_project_cv_in_one_kernel_is_the_two_passes(gpu, monkeypatch, case):
     """Round 6: uint8 frames go through remap_fused_kernel -- a block computes the box of UNDISTORTED pixels its 64 x 16 tile of the
     destination reads into LDS (two or three 8-byte windows of the camera frame per four pixels, rounded to uint8 as the first pass
@@ -330,7 +330,9 @@ def test_gpu_project_cv_in_one_kernel_is_the_two_passes(gpu, monkeypatch, case):
         K_, d_, M_, shape = Kc, dist, np.array([[2.6, 0.1, -300.0], [0.05, 2.4, -200.0], [1e-5, 2e-5, 1.0]]), (333, 420)
     elif case == "zoom_out":                     # 2.5 camera pixels per destination pixel: boxes of ~170 x 45
         K_, d_, M_, shape = Kc, dist, np.array([[0.4, 0.01, 3.0], [0.005, 0.4, 2.0], [0.0, 0.0, 1.0]]), (190, 252)
-    elif case == "too_wide":                     # 8 camera pixels per destination pixel: a tile's box would exceed 16 KB
+    elif case == "near_limit":                   # 3.5 camera pixels per destination pixel: boxes of ~232 x 58 = 13 KB, four of them in LDS
+        K_, d_, M_, shape = Kc, dist, np.array([[1 / 3.5, 0.004, 1.0], [0.002, 1 / 3.5, 0.5], [0.0, 0.0, 1.0]]), (136, 180)
+    elif case == "too_wide":                     # 8 camera pixels per destination pixel: a tile's box would exceed the 16 000 bytes
         K_, d_, M_, shape, n_frames = Kc, dist, np.array([[0.125, 0.0, 0.0], [0.0, 0.125, 0.0], [0.0, 0.0, 1.0]]), (60, 80), 3
     else:                                        # a frame smaller than a tile, one frame
         src, n_frames = (20, 24), 1
