@@ -2428,6 +2428,12 @@ int lspiv_project_cv_frames_dev(lspiv_remap* h, const void* d_frames, int dtype,
     if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
     return LSPIV_OK;
   }
+  if (dtype == LSPIV_F32 && h->undistort && h->d_ft && ((reinterpret_cast<uintptr_t>(d_out) & 15) | (reinterpret_cast<uintptr_t>(d_frames) & 3)) == 0) {
+    e = lspiv::launch_remap_fused_f32((const float*)d_frames, n_src, (int)h->src_h, (int)h->src_w, (int)T, h->d_ft, h->f_tiles, h->f_tiles_x,
+                                      h->f_cap, h->d_fpx, h->d_mx1, h->d_my1, h->d_mf1, (float*)d_out, (int)h->dst_h, (int)h->dst_w, s);
+    if (e != hipSuccess) return fail(LSPIV_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return LSPIV_OK;
+  }
   if (h->undistort) {
     rc = ensure(&h->d_tmp, &h->tmp_cap, (size_t)T * n_src * elem_size(dtype));
     if (rc) return rc;

@@ -1108,6 +1108,125 @@ __global__ __launch_bounds__(256) void remap_fused_kernel(const uint8_t* __restr
                 b_sel, b_wx, b_w0, b_w1, dst, n_out);
 }
 
+// The same for FLOAT32 frames (the recipe's edge-detected stack through method "cv"): the box holds floats (F = 4 / 2 / 1 frames per
+// group by its size), stage A works per undistorted PIXEL -- the map entry once per group, two 2-pixel loads per frame, remap_kernel's
+// float32 expression ((p00 w00 + p01 w01) + p10 w10) + p11 w11 with its weights (no contraction: the pragma above) -- and stage B blends
+// four destination pixels per lane from LDS (one ds_read2_b32 per row) into one 16-byte store.  Neighbours outside the image are the
+// +0 of the box's border, exactly what the per-pixel kernel multiplies by.  Two float32 passes: 1.52 ms per 201 1080p frames.
+template <int F>
+__global__ __launch_bounds__(256) void remap_fused_f32_kernel(const float* __restrict__ frames, int64_t src_elems, int Hs, int Ws, int n_frames,
+                                                              int seg_len, const int4* __restrict__ tiles, const uint32_t* __restrict__ pxd,
+                                                              const int* __restrict__ mx1, const int* __restrict__ my1,
+                                                              const uint16_t* __restrict__ mf1, float* __restrict__ out, int Hd, int Wd,
+                                                              int tiles_x, int box_cap, int n_tiles) {
+  typedef float pair_t __attribute__((ext_vector_type(2), aligned(4)));
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float rff_lds[];           // F boxes of box_cap floats
+  const int per_xcd = (n_tiles + 7) >> 3;
+  const int tile = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+  if (tile >= n_tiles) return;
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
+  const int4 box = tiles[tile];
+  const int bx0 = box.x, by0 = box.y, bw = box.z, n_box = box.z * box.w;
+  const float inv_bw = 1.0f / (float)max(bw, 1);
+  const int t0 = blockIdx.y * seg_len, t1 = min(t0 + seg_len, n_frames);
+  const int oy = ty * RF_TH + (threadIdx.x >> 4), ox = tx * RF_TW + 4 * (threadIdx.x & 15);
+  const bool writes = oy < Hd && ox < Wd;                                    // (Wd % 4 == 0)
+  const int64_t n_out = (int64_t)Hd * Wd;
+  int b_off[4]; float b00[4], b01[4], b10[4], b11[4]; bool b_zero[4];
+  {
+    uint4 d = {0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u};
+    if (writes) d = *reinterpret_cast<const uint4*>(pxd + (int64_t)oy * Wd + ox);
+    const uint32_t pd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      b_zero[e] = pd[e] >> 31;
+      b_off[e] = b_zero[e] ? 0 : (int)(pd[e] & 0xffffu);
+      const float a = (float)((pd[e] >> 16) & 31u) / 32.0f, b = (float)((pd[e] >> 21) & 31u) / 32.0f;
+      b00[e] = (1.0f - a) * (1.0f - b); b01[e] = a * (1.0f - b); b10[e] = (1.0f - a) * b; b11[e] = a * b;
+    }
+  }
+  for (int t = t0; t < t1; t += F) {
+    const int nt = min(F, t1 - t);
+    const float* img = frames + (int64_t)t * src_elems;
+    // ---- stage A: the box of undistorted pixels
+    for (int j = threadIdx.x; j < n_box; j += 256) {
+      int r = (int)((float)j * inv_bw);
+      r -= (r * bw > j); r += ((r + 1) * bw <= j);                           // (the float quotient may be off by one)
+      const int c = j - r * bw;
+      const int qy = by0 + r, qx = bx0 + c;
+      float res[F];
+#pragma unroll
+      for (int f = 0; f < F; ++f) res[f] = 0.0f;
+      if (qy >= 0 && qy < Hs && qx >= 0 && qx < Ws) {
+        const int o = __mul24(qy, Ws) + qx;
+        const int ix = mx1[o], iy = my1[o], fr = mf1[o];
+        const bool x0 = ix >= 0 && ix < Ws, x1 = ix + 1 >= 0 && ix + 1 < Ws, y0 = iy >= 0 && iy < Hs, y1 = iy + 1 >= 0 && iy + 1 < Hs;
+        const float a = (float)(fr & 31) / 32.0f, b = (float)(fr >> 5) / 32.0f;
+        const float w00 = (1.0f - a) * (1.0f - b), w01 = a * (1.0f - b), w10 = (1.0f - a) * b, w11 = a * b;
+        const int base = __mul24(iy, Ws) + ix;
+        if (x0 && x1 && y0 && y1) {
+          pair_t top[F], bot[F];
+#pragma unroll
+          for (int f = 0; f < F; ++f)
+            if (f < nt) {
+              top[f] = *reinterpret_cast<const pair_t*>(img + f * src_elems + base);
+              bot[f] = *reinterpret_cast<const pair_t*>(img + f * src_elems + base + Ws);
+            }
+#pragma unroll
+          for (int f = 0; f < F; ++f)
+            if (f < nt) res[f] = ((top[f][0] * w00 + top[f][1] * w01) + bot[f][0] * w10) + bot[f][1] * w11;
+        } else if ((x0 || x1) && (y0 || y1)) {
+          for (int f = 0; f < nt; ++f) {
+            const float* p = img + f * src_elems;
+            const float p00 = (x0 && y0) ? p[base] : 0.0f, p01 = (x1 && y0) ? p[base + 1] : 0.0f;
+            const float p10 = (x0 && y1) ? p[base + Ws] : 0.0f, p11 = (x1 && y1) ? p[base + Ws + 1] : 0.0f;
+            res[f] = ((p00 * w00 + p01 * w01) + p10 * w10) + p11 * w11;
+          }
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < F; ++f)
+        if (f < nt) rff_lds[f * box_cap + j] = res[f];
+    }
+    __syncthreads();
+    // ---- stage B: the warp, from LDS
+    if (writes) {
+#pragma unroll
+      for (int f = 0; f < F; ++f)
+        if (f < nt) {
+          const float* bx = rff_lds + f * box_cap;
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float p00 = bx[b_off[e]], p01 = bx[b_off[e] + 1], p10 = bx[b_off[e] + bw], p11 = bx[b_off[e] + bw + 1];
+            const float v = ((p00 * b00[e] + p01 * b01[e]) + p10 * b10[e]) + p11 * b11[e];
+            o[e] = b_zero[e] ? 0.0f : v;
+          }
+          *reinterpret_cast<f32x4*>(out + (int64_t)(t + f) * n_out + (int64_t)oy * Wd + ox) = o;
+        }
+    }
+    __syncthreads();
+  }
+}
+
+hipError_t launch_remap_fused_f32(const float* frames, int64_t src_elems, int Hs, int Ws, int n_frames, const void* tiles, int n_tiles,
+                                  int tiles_x, int box_cap, const uint32_t* pxd, const int* mx1, const int* my1, const uint16_t* mf1,
+                                  float* out, int Hd, int Wd, hipStream_t s) {
+  if (n_frames <= 0 || n_tiles <= 0) return hipSuccess;
+  const int F = 4 * 4 * box_cap <= 65000 ? 4 : 2 * 4 * box_cap <= 65000 ? 2 : 1;     // frames per group: F float boxes within 64 KB of LDS
+  int n_seg = std::max(1, std::min((n_frames + F - 1) / F, (8192 + n_tiles - 1) / n_tiles));
+  int seg_len = ((n_frames + n_seg - 1) / n_seg + F - 1) / F * F;
+  n_seg = (n_frames + seg_len - 1) / seg_len;
+  const dim3 grid((unsigned)((n_tiles + 7) / 8 * 8), (unsigned)n_seg);
+  const size_t lds = (size_t)F * box_cap * sizeof(float);
+#define LSPIV_RFF(FF) hipLaunchKernelGGL((remap_fused_f32_kernel<FF>), grid, dim3(256), lds, s, frames, src_elems, Hs, Ws, n_frames, seg_len, \
+                                         (const int4*)tiles, pxd, mx1, my1, mf1, out, Hd, Wd, tiles_x, box_cap, n_tiles)
+  if (F == 4) LSPIV_RFF(4); else if (F == 2) LSPIV_RFF(2); else LSPIV_RFF(1);
+#undef LSPIV_RFF
+  return hipGetLastError();
+}
+
 hipError_t launch_remap_fused(const uint8_t* frames, int64_t src_elems, int Hs, int Ws, int n_frames, const void* tiles, int n_tiles,
                               int tiles_x, int box_cap, const uint32_t* pxd, const int* qbase, const uint64_t* qdesc, const int* mx1,
                               const int* my1, const uint16_t* mf1, uint8_t* out, int Hd, int Wd, hipStream_t s) {

@@ -303,15 +303,17 @@ def test_gpu_project_cv_matches_oracle(gpu, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
 @pytest.mark.parametrize("case", ["mild", "strong_lens", "tilted", "mostly_outside", "zoom_in", "zoom_out", "near_limit", "too_wide", "small"])
-def test_gpu_project_cv_in_one_kernel_is_the_two_passes(gpu, monkeypatch, case):
+def test_gpu_project_cv_in_one_kernel_is_the_two_passes(gpu, monkeypatch, case, dtype):
     """Round 6: uint8 frames go through remap_fused_kernel -- a block computes the box of UNDISTORTED pixels its 64 x 16 tile of the
     destination reads into LDS (two or three 8-byte windows of the camera frame per four pixels, rounded to uint8 as the first pass
     stores them) and warps from there; the undistorted stack never reaches HBM.  Same integers as the two passes in a row
     (LSPIV_PROJECT_CV_TWO_PASS=1 at plan creation) and as the oracle: lens distortion strong enough that quads of the undistortion map
     step rows, tilted homographies, destinations mostly outside the image (empty boxes, the constant border), magnification either way,
     a warp whose tiles read more than a box may hold (the plan declines: two passes), sizes that are no multiples of the tile, frame
-    counts around the groups of four and the frame segments."""
+    counts around the groups of four and the frame segments.  float32 frames (remap_fused_f32_kernel: a box of floats, the per-pixel
+    kernel's float32 expression in both stages; four, two or one frame per group by the size of the box) likewise, NaN samples included."""
     from oracle import project_oracle as pj
     from pyorc_amd import DeviceFrames
     from pyorc_amd.project import ProjectionCV
@@ -340,6 +342,9 @@ def test_gpu_project_cv_in_one_kernel_is_the_two_passes(gpu, monkeypatch, case):
         d_, M_, shape = [-0.1, 0.02, 0.0, 0.0], np.array([[0.9, 0.05, 1.0], [0.02, 0.95, 0.5], [0.0, 0.0, 1.0]]), (12, 16)
     rng = np.random.default_rng(sum(map(ord, case)))
     fr = (rng.random((n_frames,) + src) * 256).astype(np.uint8)
+    if dtype == np.float32:
+        fr = (fr.astype(np.float32) - 100.5) * 0.25
+        fr[0, src[0] // 2, src[1] // 3] = np.nan
     ref = pj.project_cv(fr, K_, d_, M_, shape)
     monkeypatch.setenv("LSPIV_PROJECT_CV_TWO_PASS", "1")
     two = ProjectionCV(src, shape, K_, d_, M_)
@@ -347,12 +352,12 @@ def test_gpu_project_cv_in_one_kernel_is_the_two_passes(gpu, monkeypatch, case):
     one = ProjectionCV(src, shape, K_, d_, M_)
     try:
         got2, got1 = two.project_frames(fr), one.project_frames(fr)
-        assert np.array_equal(got2, ref)
-        assert np.array_equal(got1, ref), np.argwhere(got1 != ref)[:5]
-        assert np.array_equal(one.project_frames(DeviceFrames.from_host(fr)).to_host(), ref)
+        assert got1.dtype == dtype and np.array_equal(got2, ref, equal_nan=True)
+        assert np.array_equal(got1, ref, equal_nan=True), np.argwhere(got1 != ref)[:5]
+        assert np.array_equal(one.project_frames(DeviceFrames.from_host(fr)).to_host(), ref, equal_nan=True)
         if case == "mild":                       # more frames than a block's segment, and a count that is no multiple of four
             many = np.concatenate([fr] * 19 + [fr[:2]])
-            assert np.array_equal(one.project_frames(DeviceFrames.from_host(many)).to_host(), np.concatenate([ref] * 19 + [ref[:2]]))
+            assert np.array_equal(one.project_frames(DeviceFrames.from_host(many)).to_host(), np.concatenate([ref] * 19 + [ref[:2]]), equal_nan=True)
     finally:
         two.close(); one.close()
 

@@ -70,6 +70,8 @@ def build_rows(lib, T: int):
                         "Frames.edge_detect(wdw_1=1, wdw_2=2): difference of two Gaussian blurs (3x3, 5x5), uint8 -> float32"),
         "project_cv": (lambda: _lib.check(lib.lspiv_project_cv_frames_dev(p_cv._h, d_cam, 0, T, d_u8, None)), T * (n + no), T, "remap_",
                        "Frames.project(method='cv'): undistort + warpPerspective as two fixed-point bilinear remaps, uint8"),
+        "project_cv_f32": (lambda: _lib.check(lib.lspiv_project_cv_frames_dev(p_cv._h, d_camf, 1, T, d_f32, None)), T * (4 * n + 4 * no), T, "remap_",
+                           "Frames.project(method='cv') of FLOAT32 frames (after edge_detect): two float32 bilinear remaps"),
         "time_diff": (lambda: _lib.check(lib.lspiv_time_diff_dev(d_cam, 0, T, H, W, 0.0, 0, d_f32, None)), T * n + (T - 1) * n * 4, T - 1, "time_diff_",
                       "Frames.time_diff: uint8 -> float32 difference of consecutive frames (every frame read once, algorithmically)"),
         "normalize": (lambda: _lib.check(lib.lspiv_normalize_dev(d_cam, T, H, W, 15, d_u8, None)), T * n * 2, T, "norm|sample_mean|frame_minmax",
@@ -94,7 +96,7 @@ def build_rows(lib, T: int):
 def row_read_bytes(name: str, T: int) -> int:
     """Input bytes a launch of this row cannot avoid reading (every input sample once): what FETCH_SIZE is calibrated against."""
     n = H * W
-    return T * n * (4 if name in ("project_f32", "smooth_f32", "edge_detect_f32") else 1)     # float32 camera frames
+    return T * n * (4 if name in ("project_f32", "smooth_f32", "edge_detect_f32", "project_cv_f32") else 1)     # float32 camera frames
 
 
 def time_launches(lib, launch, reps: int) -> float:
