@@ -36,3 +36,7 @@ for name, fn, k in (("smooth k=3", lambda: lib.lspiv_gaussian_blur_dev(d_f, 0, T
     t = timed(lambda: _lib.check(fn()))
     b = (T - 1) * n * (1 + 4)
     print(f"{name} u8->f32: {t*1e3:.2f} ms / {T-1} frames = {(T-1)/t:.0f} frames/s, {b/t/1e9:.0f} GB/s algorithmic (1 u8 read + 1 f32 write per px) = {b/t/8e12*100:.1f}% of 8 TB/s")
+for samples in (5, 25):
+    t = timed(lambda: _lib.check(lib.lspiv_reduce_rolling_dev(d_f, T, H, W, samples, d_n, None)), 3)
+    b = T * n * 2
+    print(f"reduce_rolling(samples={samples}) u8->u8: {t*1e3:.2f} ms / {T} frames, {b/t/1e9:.0f} GB/s algorithmic (read once + written once credited; two passes) = {b/t/8e12*100:.1f}% of 8 TB/s")
