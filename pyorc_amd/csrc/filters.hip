@@ -1172,6 +1172,94 @@ __global__ __launch_bounds__(256) void blur_ring_kernel(const T* __restrict__ fr
   }
 }
 
+// Run-time radii, streaming with a REGISTER ring (round 6; the reference's own user guide filters with wdw 2 | 4 and 6 | 10: k = 5 | 9
+// and 13 | 21): blur_strip_kernel's structure for any radius up to RMAX (template: 5 / 10 / 15) -- a wave walks down a 64-column strip, a row goes global -> wave-private LDS row -> the lane's 2R + 1 neighbours into
+// registers (the row pass of kernel A and of kernel B from the same registers) -> slot i mod (2 RMAX + 1) of a ring of REGISTERS
+// (the row loop is unrolled by the ring's period, so every slot is a compile-time register; outputs trail the rows by RMAX whatever
+// the radius) -> column pass from registers -> HBM.  1 + 2R LDS reads per pixel where the LDS-ring kernel needs 2 (2R + 1) per filter
+// kernel; no block barrier.  Taps beyond the run-time radius are skipped by wave-uniform branches.  The same expressions and order as
+// taps<>: the same bits as blur_ring_kernel (tests/test_filters.py).  Per 200 1080p uint8 frames, LDS-ring kernel | this one: k = 5 | 9
+// 1.90 | 1.06 ms, k = 11 1.47 | 1.03, k = 13 | 21 5.42 | 2.12, k = 5 | 15 2.93 | 2.06 (RMAX = 15: the compiler does not unroll the period
+// of 31 rows and indexes the ring dynamically -- still ahead).  A tile-per-block kernel with four columns per lane in the row pass and
+// four rows per lane in the column pass (1.5 + 5 ... 10 LDS reads per pixel, two block barriers, 40 - 55 KB of LDS) was bit-identical and
+// slower than this one everywhere (2.12 / 1.53 / 3.60 / 3.27 ms): removed.
+constexpr int BLURR_TS = 64;
+
+template <int RMAX>
+__device__ __forceinline__ float ring_taps(const float (&w)[2 * RMAX + 1], int c, const BlurTaps& k) {   // c: compile-time after unrolling
+  constexpr int M = 2 * RMAX + 1;
+  float s = w[c] * k.k[0];
+#pragma unroll
+  for (int j = 1; j <= RMAX; ++j)
+    if (j <= k.r) s += k.k[j] * (w[(c - j + M) % M] + w[(c + j) % M]);     // (earlier row + later row, like the LDS ring)
+  return s;
+}
+
+template <typename T, bool EDGE, int RMAX>
+__global__ __launch_bounds__(256) void blur_stripr_kernel(const T* __restrict__ frames, int H, int W, BlurTaps ka, BlurTaps kb,
+                                                          float* __restrict__ out, BlurClip clip) {
+  constexpr int M = 2 * RMAX + 1;
+  __shared__ float rowbuf[4][BLUR_TW + 2 * RMAX + 2];
+  const int R = EDGE ? kb.r : ka.r;                                     // the columns staged to either side: the larger radius
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int x0 = blockIdx.x * BLUR_TW, y0 = (blockIdx.y * 4 + wv) * BLURR_TS;
+  if (y0 >= H) return;
+  const T* img = frames + (int64_t)blockIdx.z * H * W;
+  const int x = x0 + lane;
+  float* dst = out + (int64_t)blockIdx.z * H * W + x;
+  const int cx0 = reflect101(x - R, W);
+  const int cx1 = lane < 2 * R ? reflect101(x + 64 - R, W) : 0;
+  float* buf = rowbuf[wv];
+  const int n_rows = min(BLURR_TS, H - y0) + 2 * RMAX;                  // rows y0 - RMAX .. : an output row trails its last input row by RMAX
+  const T* row = img + (int64_t)reflect101(y0 - RMAX, H) * W;
+  T n0 = row[cx0], n1 = row[cx1];
+  float wa[M], wb[M];
+  for (int base = 0; base < n_rows; base += M) {
+#pragma unroll
+    for (int ii = 0; ii < M; ++ii) {
+      const int i = base + ii;
+      if (i < n_rows) {                                                  // (wave-uniform)
+        const float v0 = to_f32(n0), v1 = to_f32(n1);
+        if (i + 1 < n_rows) {                                            // next row's loads go out before this row is filtered
+          row = img + (int64_t)reflect101(y0 - RMAX + i + 1, H) * W;
+          n0 = row[cx0];
+          n1 = row[cx1];
+        }
+        __builtin_amdgcn_wave_barrier();
+        buf[lane] = v0;
+        if (lane < 2 * R) buf[lane + 64] = v1;
+        __builtin_amdgcn_wave_barrier();
+        float a[M];                                                      // the lane's neighbours: a[RMAX + d] = column x + d
+        a[RMAX] = buf[lane + R];
+#pragma unroll
+        for (int j = 1; j <= RMAX; ++j)
+          if (j <= R) { a[RMAX - j] = buf[lane + R - j]; a[RMAX + j] = buf[lane + R + j]; }
+        {
+          float sa = a[RMAX] * ka.k[0];
+#pragma unroll
+          for (int j = 1; j <= RMAX; ++j)
+            if (j <= ka.r) sa += ka.k[j] * (a[RMAX - j] + a[RMAX + j]);
+          wa[ii] = sa;
+          if (EDGE) {
+            float sb = a[RMAX] * kb.k[0];
+#pragma unroll
+            for (int j = 1; j <= RMAX; ++j)
+              if (j <= kb.r) sb += kb.k[j] * (a[RMAX - j] + a[RMAX + j]);
+            wb[ii] = sb;
+          }
+        }
+        if (i >= 2 * RMAX) {
+          const int y = y0 + i - 2 * RMAX;
+          const int c = (ii + RMAX + 1) % M;                             // slot of the centre row i - RMAX (compile-time)
+          float res = ring_taps<RMAX>(wa, c, ka);
+          if (EDGE) res = ring_taps<RMAX>(wb, c, kb) - res;
+          if (y < H && x < W) dst[(int64_t)y * W] = blur_clip(res, clip);
+        }
+      }
+    }
+  }
+}
+
 // getGaussianKernel(ksize, sigma <= 0, CV_32F)
 static BlurTaps make_taps(int ksize) {
   BlurTaps t;
@@ -1239,7 +1327,23 @@ hipError_t launch_blur_clip(const void* frames, int dtype, int n_frames, int H, 
 #undef LSPIV_STRIP4
     return hipGetLastError();
   }
-  // run-time radii: streaming ring kernel (LSPIV_BLUR_BLOCK=1: the tile-per-block kernel it replaced, for A/B)
+  // run-time radii up to 15: the streaming kernel with a register ring (LSPIV_BLUR_RING=1, read per call: the LDS-ring kernel it replaces, for A/B)
+  if (R <= 15 && !getenv("LSPIV_BLUR_RING") && !getenv("LSPIV_BLUR_BLOCK")) {   // the streaming kernel with a register ring
+    const int strips = (H + BLURR_TS - 1) / BLURR_TS;
+    const dim3 grid((W + BLUR_TW - 1) / BLUR_TW, (strips + 3) / 4, n_frames);
+#define LSPIV_SR(T, E, RM) hipLaunchKernelGGL((blur_stripr_kernel<T, E, RM>), grid, dim3(256), 0, s, (const T*)frames, H, W, ka, kb, out, clip)
+#define LSPIV_SRR(T, E) do { if (R <= 5) LSPIV_SR(T, E, 5); else if (R <= 10) LSPIV_SR(T, E, 10); else LSPIV_SR(T, E, 15); } while (0)
+    switch (dtype) {
+      case 0: if (edge) LSPIV_SRR(uint8_t, true); else LSPIV_SRR(uint8_t, false); break;
+      case 1: if (edge) LSPIV_SRR(float, true); else LSPIV_SRR(float, false); break;
+      case 2: if (edge) LSPIV_SRR(double, true); else LSPIV_SRR(double, false); break;
+      default: return hipErrorInvalidValue;
+    }
+#undef LSPIV_SRR
+#undef LSPIV_SR
+    return hipGetLastError();
+  }
+  // larger radii: streaming ring kernel (LSPIV_BLUR_BLOCK=1: the tile-per-block kernel it replaced, for A/B)
   static const bool use_block = getenv("LSPIV_BLUR_BLOCK") != nullptr;
   if (!use_block) {
     const int strips = (H + BLUR_TS - 1) / BLUR_TS;

@@ -435,3 +435,41 @@ def test_gpu_four_column_integer_blur_equals_the_one_column_float_kernel(gpu, mo
         one = filters.edge_detect(fr, w1, w2)
         assert np.array_equal(got.view(np.uint32), one.view(np.uint32)), ("edge_detect", w1, w2)
         assert np.abs(got - fo.edge_detect(fr, w1, w2)).max() <= 4e-6 * 255
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32, np.float64])
+def test_gpu_register_ring_blur_of_run_time_radii_equals_the_lds_ring_kernel(gpu, monkeypatch, dtype):
+    """Round 6: windows above 3 (k >= 9; the reference's user guide filters with wdw 2 | 4 and 6 | 10) go through blur_stripr_kernel -- the
+    streaming strip kernel with the ring of row-filtered rows in REGISTERS (the row loop unrolled by the ring's period, laid out for
+    RMAX = 5 / 10 / 15, the taps beyond the run-time radius skipped by uniform branches).  The same expression per pixel as the LDS-ring
+    kernel (LSPIV_BLUR_RING=1): the same bits for every radius class, on frames smaller than a strip and than the halo
+    (BORDER_REFLECT_101 wraps), heights around the 64-row strips, NaN samples (a NaN outside a kernel's support must not reach the
+    sum); and within the oracle's tolerance."""
+    from pyorc_amd import filters
+
+    rng = np.random.default_rng(5)
+    for shape in ((3, 70, 150), (2, 33, 64), (2, 7, 9), (1, 130, 257)):
+        fr = (rng.random(shape) * 256).astype(np.uint8)
+        if dtype != np.uint8:
+            fr = (fr.astype(dtype) - 90.25) * 0.5
+            fr[0, shape[1] // 2, shape[2] // 2] = np.nan
+        scale = 255.0
+        for wdw in (4, 5, 7, 10, 12, 15):
+            monkeypatch.delenv("LSPIV_BLUR_RING", raising=False)
+            got = filters.smooth(fr, wdw)
+            monkeypatch.setenv("LSPIV_BLUR_RING", "1")
+            ring = filters.smooth(fr, wdw)
+            assert np.array_equal(got.view(np.uint32), ring.view(np.uint32)), ("smooth", shape, wdw)
+            ref = fo.smooth(np.nan_to_num(fr), wdw) if dtype == np.uint8 else None
+            if ref is not None:
+                assert np.abs(got - ref).max() <= 4e-6 * scale
+        for w1, w2 in ((2, 4), (6, 10), (1, 5), (3, 8), (11, 15), (4, 4)):
+            monkeypatch.delenv("LSPIV_BLUR_RING", raising=False)
+            got = filters.edge_detect(fr, w1, w2)
+            monkeypatch.setenv("LSPIV_BLUR_RING", "1")
+            ring = filters.edge_detect(fr, w1, w2)
+            assert np.array_equal(got.view(np.uint32), ring.view(np.uint32)), ("edge_detect", shape, w1, w2)
+            if dtype == np.uint8:
+                assert np.abs(got - fo.edge_detect(fr, w1, w2)).max() <= 8e-6 * scale
+    monkeypatch.delenv("LSPIV_BLUR_RING", raising=False)

@@ -78,6 +78,8 @@ def build_rows(lib, T: int):
                       "Frames.normalize(samples=15): uint8 -> uint8 (read once + written once credited; the per-frame min / max needs a second look at every frame)"),
         "smooth": (lambda: _lib.check(lib.lspiv_gaussian_blur_dev(d_cam, 0, T, H, W, 5, d_f32, None)), T * n * 5, T, "blur_",
                    "Frames.smooth(wdw=2): cv2.GaussianBlur 5x5, uint8 -> float32"),
+        "edge_detect_6_10": (lambda: _lib.check(lib.lspiv_edge_detect_dev(d_cam, 0, T, H, W, 13, 21, d_f32, None)), T * n * 5, T, "blur_|edge_",
+                             "Frames.edge_detect(wdw_1=6, wdw_2=10), the reference's user-guide example: Gaussian blurs 13x13 and 21x21 (run-time radii), uint8 -> float32"),
         "smooth_f32": (lambda: _lib.check(lib.lspiv_gaussian_blur_dev(d_camf, 1, T, H, W, 5, d_f32, None)), T * n * 8, T, "blur_",
                        "Frames.smooth(wdw=2) of FLOAT32 frames (after time_diff / a float video): float32 -> float32"),
         "edge_detect_f32": (lambda: _lib.check(lib.lspiv_edge_detect_dev(d_camf, 1, T, H, W, 3, 5, d_f32, None)), T * n * 8, T, "blur_|edge_",

@@ -15,11 +15,11 @@ case $NAME in
   bench)
     timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc $?"; tail -3 $OUT/bench.err; head -c 400 $OUT/bench.json;;
   rows)         # the HBM-bound rows: timings, then rocprofv3 passes per row (tools/profile.sh with another kernel filter)
-    for row in project project_nn project_u8 project_f32 project_cv project_cv_f32 time_diff normalize smooth edge_detect smooth_f32 edge_detect_f32; do
+    for row in project project_nn project_u8 project_f32 project_cv project_cv_f32 time_diff normalize smooth edge_detect edge_detect_6_10 smooth_f32 edge_detect_f32; do
       python tools/rows_launch.py $row 30 201 | tee -a $OUT/rows.log
     done
-    for row in ${ROWS:-project project_nn project_u8 project_f32 project_cv project_cv_f32 time_diff normalize smooth edge_detect smooth_f32 edge_detect_f32}; do
-      case $row in project|project_nn|project_u8|project_f32) re='project_';; project_cv|project_cv_f32) re='remap_';; time_diff) re='time_diff_';; normalize) re='norm|sample_mean|frame_minmax';; smooth|edge_detect|smooth_f32|edge_detect_f32) re='blur_';; esac
+    for row in ${ROWS:-project project_nn project_u8 project_f32 project_cv project_cv_f32 time_diff normalize smooth edge_detect edge_detect_6_10 smooth_f32 edge_detect_f32}; do
+      case $row in project|project_nn|project_u8|project_f32) re='project_';; project_cv|project_cv_f32) re='remap_';; time_diff) re='time_diff_';; normalize) re='norm|sample_mean|frame_minmax';; smooth|edge_detect|edge_detect_6_10|smooth_f32|edge_detect_f32) re='blur_';; esac
       PROFILE_KF="--kernel-include-regex $re" PROFILE_CMD="python $R/tools/rows_launch.py $row 30 201" bash tools/profile.sh r06_rows_$row > $OUT/profile_$row.log 2>&1
       SUMMARY_KERNELS="$re" SUMMARY_ROW=$row SUMMARY_ROW_FRAMES=201 SUMMARY_CALLS=32 python tools/summarize_profile.py gpurun_out/prof_r06_rows_$row r06_rows_$row > $OUT/summary_$row.log 2>&1
       cp profiles/r06_rows_${row}_summary.json $OUT/ 2>/dev/null
