@@ -2,7 +2,7 @@
 post-PIV masks and the int16 packing against their numpy oracles, over random shapes (odd widths, single frames, tiny
 frames), dtypes and parameters.  Bit-exact except the Gaussian filters (4e-6 of the value range) and `angle` (atan2f).
 usage: fuzz_rows.py <seed> <cases>        FUZZ_KINDS=project,normalize restricts the kinds drawn; FUZZ_W4=1: widths that are multiples of
-four (the four-column blur, project_cv in one kernel); FUZZ_DIST=0.3: amplitude of the lens coefficients of project_cv (default 0.05)"""
+four (the four-column blur, project_cv in one kernel); FUZZ_DIST=0.3: amplitude of the lens coefficients of project_cv (default 0.05); FUZZ_BIGWDW=1: filter windows up to 15"""
 import os, sys, time, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -42,7 +42,8 @@ for case in range(n_cases):
                 ok = eq(filters.range(fr), fo.time_range(fr))
             else:
                 fr = np.nan_to_num(fr)
-                k1 = int(rng.integers(0, 7)); k2 = int(rng.integers(k1, 9))
+                big = bool(os.environ.get("FUZZ_BIGWDW"))              # windows up to 15 (the library's limit: k = 31): every radius class of the run-time-radius kernel
+                k1 = int(rng.integers(0, 13 if big else 7)); k2 = int(rng.integers(k1, 16 if big else 9))
                 if rng.random() < 0.5:
                     got, ref = filters.smooth(fr, k2), fo.smooth(fr, k2); note = f"smooth {k2}"
                 else:

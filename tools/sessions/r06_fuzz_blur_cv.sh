@@ -7,3 +7,6 @@ for seed in 641 642; do timeout 900 python tools/fuzz_rows.py $seed 150 2>&1 | g
 # after remap_fused_f32_kernel: project_cv again (uint8 and float32 frames through the one-kernel path)
 for seed in 651 652 653; do FUZZ_W4=1 FUZZ_KINDS=project_cv timeout 600 python tools/fuzz_rows.py $seed 200 2>&1 | grep -v "^ok" | tail -3; done | tee -a $OUT/log.txt
 FUZZ_W4=1 FUZZ_DIST=0.3 FUZZ_KINDS=project_cv timeout 600 python tools/fuzz_rows.py 654 200 2>&1 | grep -v "^ok" | tail -3 | tee -a $OUT/log.txt
+# after blur_stripr_kernel: the filters over every radius class (windows up to 15)
+for seed in 661 662 663 664; do FUZZ_KINDS=blur timeout 600 python tools/fuzz_rows.py $seed 200 2>&1 | grep -v "^ok" | tail -3; done | tee -a $OUT/log.txt
+for seed in 671 672 673; do FUZZ_BIGWDW=1 FUZZ_KINDS=blur timeout 600 python tools/fuzz_rows.py $seed 200 2>&1 | grep -v "^ok" | tail -3; done | tee -a $OUT/log.txt
