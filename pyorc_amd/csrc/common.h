@@ -483,13 +483,6 @@ hipError_t launch_remap(const void* frames, int dtype, int64_t src_elems, int Hs
 hipError_t launch_remap_win(const uint8_t* frames, int64_t src_elems, int Hs, int Ws, int n_frames, const int* qbase, const uint64_t* qdesc,
                             const int* slow_q, int n_slow, const int* mx, const int* my, const uint16_t* mf, uint8_t* out, int n_out,
                             hipStream_t s);
-// both remaps of project_cv in one kernel (uint8 frames; plan: lspiv_api.hip build_remap_fused)
-hipError_t launch_remap_fused(const uint8_t* frames, int64_t src_elems, int Hs, int Ws, int n_frames, const void* tiles, int n_tiles,
-                              int tiles_x, int box_cap, const uint32_t* pxd, const int* qbase, const uint64_t* qdesc, const int* mx1,
-                              const int* my1, const uint16_t* mf1, uint8_t* out, int Hd, int Wd, hipStream_t s);
-hipError_t launch_remap_fused_f32(const float* frames, int64_t src_elems, int Hs, int Ws, int n_frames, const void* tiles, int n_tiles,
-                                  int tiles_x, int box_cap, const uint32_t* pxd, const int* mx1, const int* my1, const uint16_t* mf1,
-                                  float* out, int Hd, int Wd, hipStream_t s);
 // x[i] = -x[i]: the "v_sign" option (a reading of ffpiv nothing in the reference decides), applied after the kernels
 hipError_t launch_negate(float* x, int64_t n, hipStream_t s);
 hipError_t launch_pack_int16(const float* in, int64_t n, float scale, int fill, int16_t* out, hipStream_t s);

@@ -22,6 +22,7 @@
 
 #include "common.h"
 #include "project_tile.h"
+#include "project_fused.h"
 #include "host_stage.h"
 
 namespace lspiv {   // project.hip

@@ -15,6 +15,7 @@
 
 #include "common.h"
 #include "project_tile.h"
+#include "project_fused.h"
 
 namespace lspiv {
 
