@@ -1173,14 +1173,15 @@ __global__ __launch_bounds__(256) void blur_ring_kernel(const T* __restrict__ fr
 }
 
 // Run-time radii, streaming with a REGISTER ring (round 6; the reference's own user guide filters with wdw 2 | 4 and 6 | 10: k = 5 | 9
-// and 13 | 21): blur_strip_kernel's structure for any radius up to RMAX (template: 5 / 10 / 15) -- a wave walks down a 64-column strip, a row goes global -> wave-private LDS row -> the lane's 2R + 1 neighbours into
+// and 13 | 21): blur_strip_kernel's structure for any radius up to RMAX (template: 5 / 10) -- a wave walks down a 64-column strip, a row goes global -> wave-private LDS row -> the lane's 2R + 1 neighbours into
 // registers (the row pass of kernel A and of kernel B from the same registers) -> slot i mod (2 RMAX + 1) of a ring of REGISTERS
 // (the row loop is unrolled by the ring's period, so every slot is a compile-time register; outputs trail the rows by RMAX whatever
 // the radius) -> column pass from registers -> HBM.  1 + 2R LDS reads per pixel where the LDS-ring kernel needs 2 (2R + 1) per filter
 // kernel; no block barrier.  Taps beyond the run-time radius are skipped by wave-uniform branches.  The same expressions and order as
 // taps<>: the same bits as blur_ring_kernel (tests/test_filters.py).  Per 200 1080p uint8 frames, LDS-ring kernel | this one: k = 5 | 9
-// 1.90 | 1.06 ms, k = 11 1.47 | 1.03, k = 13 | 21 5.42 | 2.12, k = 5 | 15 2.93 | 2.06 (RMAX = 15: the compiler does not unroll the period
-// of 31 rows and indexes the ring dynamically -- still ahead).  A tile-per-block kernel with four columns per lane in the row pass and
+// 1.90 | 1.06 ms, k = 11 1.47 | 1.03, k = 13 | 21 5.42 | 2.12, k = 5 | 15 2.93 | 2.06.  (An RMAX = 15 instance: the compiler does not unroll the
+// period of 31 rows and indexes the ring dynamically -- k = 23 / 27 / 31 1.99 / 2.08 / 2.20 ms per 101 frames against 1.30 / 1.60 / 2.16 of the
+// LDS-ring kernel, edge 23 | 31 4.20 against 5.71, 9 | 23 3.61 against 2.67: windows above 10 stay with the LDS ring.)  A tile-per-block kernel with four columns per lane in the row pass and
 // four rows per lane in the column pass (1.5 + 5 ... 10 LDS reads per pixel, two block barriers, 40 - 55 KB of LDS) was bit-identical and
 // slower than this one everywhere (2.12 / 1.53 / 3.60 / 3.27 ms): removed.
 constexpr int BLURR_TS = 64;
@@ -1327,12 +1328,13 @@ hipError_t launch_blur_clip(const void* frames, int dtype, int n_frames, int H, 
 #undef LSPIV_STRIP4
     return hipGetLastError();
   }
-  // run-time radii up to 15: the streaming kernel with a register ring (LSPIV_BLUR_RING=1, read per call: the LDS-ring kernel it replaces, for A/B)
-  if (R <= 15 && !getenv("LSPIV_BLUR_RING") && !getenv("LSPIV_BLUR_BLOCK")) {   // the streaming kernel with a register ring
+  // run-time radii up to 10 (windows 4 .. 10): the streaming kernel with a register ring (LSPIV_BLUR_RING=1, read per call: the LDS-ring
+  // kernel it replaces, for A/B); windows 11 .. 15 stay with the LDS-ring kernel
+  if (R <= 10 && !getenv("LSPIV_BLUR_RING") && !getenv("LSPIV_BLUR_BLOCK")) {   // the streaming kernel with a register ring
     const int strips = (H + BLURR_TS - 1) / BLURR_TS;
     const dim3 grid((W + BLUR_TW - 1) / BLUR_TW, (strips + 3) / 4, n_frames);
 #define LSPIV_SR(T, E, RM) hipLaunchKernelGGL((blur_stripr_kernel<T, E, RM>), grid, dim3(256), 0, s, (const T*)frames, H, W, ka, kb, out, clip)
-#define LSPIV_SRR(T, E) do { if (R <= 5) LSPIV_SR(T, E, 5); else if (R <= 10) LSPIV_SR(T, E, 10); else LSPIV_SR(T, E, 15); } while (0)
+#define LSPIV_SRR(T, E) do { if (R <= 5) LSPIV_SR(T, E, 5); else LSPIV_SR(T, E, 10); } while (0)
     switch (dtype) {
       case 0: if (edge) LSPIV_SRR(uint8_t, true); else LSPIV_SRR(uint8_t, false); break;
       case 1: if (edge) LSPIV_SRR(float, true); else LSPIV_SRR(float, false); break;

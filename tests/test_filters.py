@@ -442,7 +442,7 @@ def test_gpu_four_column_integer_blur_equals_the_one_column_float_kernel(gpu, mo
 def test_gpu_register_ring_blur_of_run_time_radii_equals_the_lds_ring_kernel(gpu, monkeypatch, dtype):
     """Round 6: windows above 3 (k >= 9; the reference's user guide filters with wdw 2 | 4 and 6 | 10) go through blur_stripr_kernel -- the
     streaming strip kernel with the ring of row-filtered rows in REGISTERS (the row loop unrolled by the ring's period, laid out for
-    RMAX = 5 / 10 / 15, the taps beyond the run-time radius skipped by uniform branches).  The same expression per pixel as the LDS-ring
+    RMAX = 5 / 10 -- windows 4 .. 10; 11 .. 15 stay with the LDS ring --, the taps beyond the run-time radius skipped by uniform branches).  The same expression per pixel as the LDS-ring
     kernel (LSPIV_BLUR_RING=1): the same bits for every radius class, on frames smaller than a strip and than the halo
     (BORDER_REFLECT_101 wraps), heights around the 64-row strips, NaN samples (a NaN outside a kernel's support must not reach the
     sum); and within the oracle's tolerance."""
